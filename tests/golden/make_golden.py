@@ -1,0 +1,334 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz by running the REFERENCE's own Python.
+
+Runs only in the build container (needs /root/reference); the fixtures (data: inputs, weights
+and the reference's outputs) are committed, this script is committed, the reference source is
+not.  Third-party packages the reference imports but that are absent here are replaced by empty
+stub modules (recipe: SURVEY.md Appendix B); every stage generated below executes the
+reference's hand-written code unmodified.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# ----------------------------------------------------------------------------- import shims
+class AttrDict(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def wrap(o):
+    if isinstance(o, dict):
+        return AttrDict({k: wrap(v) for k, v in o.items()})
+    if isinstance(o, (list, tuple)):
+        return [wrap(v) for v in o]
+    return o
+
+
+def install_shims():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    mod("torch_scatter")
+    mod("cv2")
+    mod("kornia"); mod("kornia.geometry"); mod("kornia.geometry.transform")
+    mod("kornia.losses", focal_loss=None)
+    mod("pytorch_lightning")
+    tv = mod("torchvision")
+    tvt = mod("torchvision.transforms", GaussianBlur=object)
+    tvt.__path__ = []
+    mod("torchvision.transforms.functional", InterpolationMode=object)
+    mod("torchvision.models"); mod("torchvision.models.resnet")
+    tv.transforms = tvt
+    mod("efficientnet_pytorch", EfficientNet=object, utils=SimpleNamespace())
+    oc = SimpleNamespace(create=wrap, to_object=lambda x: x)
+    mod("omegaconf", DictConfig=AttrDict, OmegaConf=oc, open_dict=None)
+    noop = lambda *a, **k: None
+    sys.path.insert(0, REF)
+    import creste.utils  # noqa: F401  (real package; then stub its visualization sub-module)
+    mod("creste.utils.visualization", numpy_to_pcd=noop, show_bev_map=noop,
+        visualize_bev_policy=noop, visualize_bev_label=noop, save_depth_color_image=noop,
+        save_depth_image=noop, draw_sparse_depth_on_image=noop)
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **out)
+    print(f"  wrote {name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def sd_arrays(module, prefix="sd/"):
+    return {prefix + k: v for k, v in module.state_dict().items()}
+
+
+def randomise_bn(module, gen):
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+            m.weight.data.copy_(torch.rand(m.weight.shape, generator=gen) + 0.5)
+            m.bias.data.copy_(torch.randn(m.bias.shape, generator=gen) * 0.1)
+
+
+def make_p2p(B, hs, ws, full_w=612.0, tz=0.4):
+    """pixel(u*d, v*d, d, 1) at feature resolution -> LiDAR xyz; pinhole + axis swap."""
+    s = full_w / ws
+    fx = fy = 730.0 * (612.0 / 1216.0) / s * 2.0
+    cx, cy = ws / 2.0, hs / 2.0
+    kinv = torch.tensor([[1 / fx, 0, -cx / fx, 0], [0, 1 / fy, -cy / fy, 0], [0, 0, 1, 0],
+                         [0, 0, 0, 1]], dtype=torch.float32)
+    c2l = torch.tensor([[0, 0, 1, 0.1], [-1, 0, 0, 0.05], [0, -1, 0, tz], [0, 0, 0, 1]],
+                       dtype=torch.float32)
+    return (c2l @ kinv).view(1, 1, 4, 4).repeat(B, 1, 1, 1)
+
+
+# ----------------------------------------------------------------------------- generators
+def gen_splat():
+    from creste.models.blocks.splat_projection import Camera2MapMulti
+    from creste_public_amd.config import terrainnet_cfg
+    cfg = wrap(terrainnet_cfg().to_dict()["camera_projector"])
+    g = torch.Generator().manual_seed(1337)
+    torch.manual_seed(1337)
+    m = Camera2MapMulti(cfg, mode="bilinear")
+    randomise_bn(m, g)
+    m.eval()
+    for tag, (B, hs, ws) in {"small": (2, 16, 19), "wide": (1, 24, 40)}.items():
+        depth = torch.rand(B, 1, hs, ws, generator=g) * 16.0 + 0.3
+        depth[:, :, :2, :3] = 30.0          # far points -> out of range (masked, x > 12.8)
+        depth[:, :, -1, :] = 0.05           # near the sensor
+        feats = torch.randn(B, 1, 256, hs, ws, generator=g)
+        p2p = make_p2p(B, hs, ws)
+        p2p[:, :, :3, 3] += torch.randn(B, 1, 3, generator=g) * 0.05
+        with torch.no_grad():
+            out = m([depth, feats, p2p])
+            xyz, mask, fused = m._prepare_features_and_coords([depth, feats, p2p])
+        bf = out["bev_features"]
+        dens = out["bev_densities"]
+        touched = (dens[:, 0] != 0) | (bf != 0).any(dim=1)
+        idx = touched.nonzero()
+        vals = bf.permute(0, 2, 3, 1)[touched]
+        arrs = dict(depth=depth, feats=feats, p2p=p2p, bev_coords=out["bev_coords"],
+                    bev_densities=dens, touched_idx=idx, touched_feats=vals,
+                    bev_features_abs_sum=bf.abs().sum(), xyz=xyz, mask=mask, fused=fused,
+                    grid_size=m.grid_size)
+        if tag == "small":
+            arrs.update(sd_arrays(m))
+        npz(f"splat_{tag}.npz", **arrs)
+
+
+def gen_vin_svf_loss():
+    import creste.models.blocks.vin as vin_mod
+    from creste.models.blocks.vin import VIN
+    import creste.models.lfd as lfd
+    import creste.utils.train_utils as tu
+    from creste.utils.loss_utils import LossManager
+    from creste_public_amd.config import maxent_irl_cfg
+    cfgd = maxent_irl_cfg().to_dict()
+    nk = cfgd["traversability_head"]["net_kwargs"]
+    torch.manual_seed(7)
+    g = torch.Generator().manual_seed(7)
+    vin = VIN(wrap(nk["reward_cfg"]), wrap(nk["qvalue_cfg"]))
+    randomise_bn(vin, g)
+    vin.eval()
+    npz("vin_w.npz", w=vin.w)
+
+    calls = {"n": 0}
+    real_conv = vin_mod.F.conv2d
+
+    def counting_conv(*a, **k):
+        calls["n"] += 1
+        return real_conv(*a, **k)
+
+    # -- value iteration
+    vi = {}
+    for tag, shape in {"a": (3, 1, 16, 32), "b": (2, 1, 64, 128)}.items():
+        r = torch.rand(shape, generator=g)
+        if tag == "a":
+            r[0, 0, 4:9, 10:20] = 0.0       # an obstacle block of zero reward
+            r[2] *= 0.25
+        calls["n"] = 0
+        vin_mod.F.conv2d = counting_conv
+        try:
+            with torch.no_grad():
+                v, pol, q = vin.value_iteration_manual(r, None, threshold=0.001, discount=0.99)
+        finally:
+            vin_mod.F.conv2d = real_conv
+        vi[tag] = (r, v, pol, q)
+        npz(f"vi_{tag}.npz", r=r, v=v, policy=pol, q=q, sweeps=calls["n"] - 1, discount=0.99,
+            threshold=0.001)
+
+    # -- reward net + VIN.forward (solve_mdp False and True) on a small BEV dict
+    fm = {"inpainting_sam_preds": torch.randn(2, 32, 32, 64, generator=g),
+          "inpainting_sam_dynamic_preds": torch.randn(2, 6, 32, 64, generator=g),
+          "elevation_preds": torch.randn(2, 2, 32, 64, generator=g)}
+    S = torch.zeros(2, 50, 2, dtype=torch.long)
+    out = vin(fm, S, solve_mdp=True)
+    npz("vin_forward.npz", **{f"in/{k}": v for k, v in fm.items()},
+        traversability_preds=out["traversability_preds"],
+        traversability_preds_full=out["traversability_preds_full"],
+        input_view=out["input_view"], policy=out["policy"], q_estimate=out["q_estimate"],
+        value_estimate=out["value_estimate"], **sd_arrays(vin))
+    vin.train()
+    out_tr = vin(fm, S, solve_mdp=False)
+    npz("vin_forward_train.npz", traversability_preds=out_tr["traversability_preds"],
+        **{f"sd_after/{k}": v for k, v in vin.state_dict().items() if "running" in k})
+    vin.eval()
+
+    # -- SVF (MaxEntIRL.expected_state_visitation_frequency, unbound)
+    H, W, T = 64, 128, 50
+    fov = tu.create_trapezoidal_fov_mask(H * 2, W, 70, 70, 0, 100).view(1, 1, H * 2, W)[:, :, :H, :W]
+    tp = torch.zeros(8, 1, 3, 3)
+    center = [[2, 2], [2, 1], [2, 0], [1, 2], [1, 0], [0, 2], [0, 1], [0, 0]]
+    for i in range(8):
+        tp[i, :, center[i][0], center[i][1]] = 1.0
+    dyn = torch.tensor([[-1, -1], [-1, 0], [-1, 1], [0, -1], [0, 1], [1, -1], [1, 0], [1, 1]])
+    _, _, pol_b, _ = vi["b"]
+    B = pol_b.shape[0]
+
+    def pose_batch(xy):  # [B,T,2] -> [B,T,3,3]
+        P = torch.eye(3).repeat(xy.shape[0], xy.shape[1], 1, 1)
+        P[:, :, :2, 2] = xy
+        return P
+
+    tt = torch.linspace(0, 1, T).view(1, T, 1)
+    # full-res (256 grid) coordinates; ds=2 -> grid 64x128 rows 0..63
+    e0 = torch.tensor([[120.0, 128.0]]) + tt * torch.tensor([[-100.0, 30.0]])     # in fov, forward
+    e1 = torch.tensor([[126.5, 10.0]]) + tt * torch.tensor([[0.0, 20.0]])         # never in fov
+    experts = pose_batch(torch.cat([e0, e1], dim=0))
+    for ztag, zts in {"": False, "_zts": True}.items():
+        ns = SimpleNamespace(
+            traversability_head_cfg=wrap(cfgd["traversability_head"]), fov_mask=fov,
+            action_horizon=T, policy_cfg=wrap(cfgd["policy_kwargs"]), zero_terminal_state=zts,
+            transition_probs=tp, dynamics=dyn, map_size=[H, W])
+        ns._state_to_coord = lambda s, vectorized=False: lfd.MaxEntIRL._state_to_coord(ns, s, vectorized)
+        ns._coord_to_state = lambda c, vectorized=False: lfd.MaxEntIRL._coord_to_state(ns, c, vectorized)
+        with torch.no_grad():
+            o = lfd.MaxEntIRL.expected_state_visitation_frequency(ns, pol_b.clone(), experts.clone())
+        # policy input = vi_b.npz["policy"] (not stored twice)
+        npz(f"svf{ztag}.npz", expert=experts, fov_mask=fov, exp_svf=o["exp_svf"],
+            state_preds=o["state_preds"], state_preds_grid=o["state_preds_grid"],
+            transition_probs=tp)
+        if not zts:
+            svf_out = o
+
+    # -- MaxEntIRLLoss through LossManager (with and without counterfactuals)
+    lcfg = wrap({"loss": cfgd["loss"]})
+    lm = LossManager(lcfg)
+    fov256 = tu.create_trapezoidal_fov_mask(256, 256, 70, 70, 0, 200).unsqueeze(0).repeat(B, 1, 1)
+    vin.zero_grad()
+    feat40 = torch.randn(B, 40, 64, 128, generator=g, requires_grad=True)
+    r = vin.r(feat40)
+    rng = np.random.RandomState(3)
+    cf = [dict(trajectories=(np.array([[100.0, 128.0]]) +
+                             np.linspace(0, 1, 20)[None, :, None] *
+                             rng.uniform(-80, 80, size=(3, 1, 2))).astype(np.float32),
+               rank=np.array([0, 1, 2])), None]
+    for tag, cfl in {"cf": cf, "nocf": [None, None]}.items():
+        td = {"outputs/exp_svf": svf_out["exp_svf"].clone(), "inputs/traversability_label": experts,
+              "inputs/fov_mask": fov256, "outputs/traversability_preds": r,
+              "outputs/input_view": feat40, "inputs/counterfactuals_label": cfl, "task": "x"}
+        ld, md = lm(td)
+        (wgt, val), = ld.values()
+        vin.zero_grad()
+        (wgt * val).backward(retain_graph=True)
+        grads = {f"grad/{k}": p.grad for k, p in vin.r.named_parameters()}
+        # inputs shared by both cases live in irl_loss_inputs.npz; exp_svf = svf.npz["exp_svf"]
+        npz(f"irl_loss_{tag}.npz", loss_key=list(ld.keys())[0], loss_weight=wgt,
+            loss=val, **{f"meta/{k}": v for k, v in md.items()}, **grads)
+    npz("irl_loss_inputs.npz", expert=experts, fov_mask=fov256, input_view=feat40, reward=r,
+        cf_traj=cf[0]["trajectories"], cf_rank=cf[0]["rank"], **sd_arrays(vin.r, "sd_r/"))
+    pts, cnt = lm.losses[0].compute_expert_visitation(experts, 2, [64, 128])
+    npz("expert_raster.npz", expert=experts, points=pts, counts=cnt)
+
+
+def gen_blocks_and_utils():
+    from creste.models.blocks.conv import MultiLayerConv, ConvEncoder, MultiScaleFCN
+    from creste.models.blocks.effnet import Up
+    from creste.models.blocks.inpainting import DeconvHead
+    import creste.utils.depth_utils as du
+    import creste.utils.train_utils as tu
+    from creste_public_amd.config import terrainnet_cfg, maxent_irl_cfg
+    g = torch.Generator().manual_seed(11)
+    torch.manual_seed(11)
+    arrs = {}
+
+    def run(tag, m, *xs):
+        randomise_bn(m, g)
+        m.eval()
+        with torch.no_grad():
+            y = m(*xs)
+        ys = y if isinstance(y, tuple) else (y,)
+        for i, x in enumerate(xs):
+            arrs[f"{tag}/in{i}"] = x
+        for i, yy in enumerate(ys):
+            arrs[f"{tag}/out{i}"] = yy
+        arrs.update(sd_arrays(m, f"{tag}/sd/"))
+
+    run("mlc", MultiLayerConv(wrap(dict(dims=[8, 12, 6], kernels=[3, 1], paddings=[1, 0],
+                                        norm_type="batch_norm"))),
+        torch.randn(2, 8, 9, 11, generator=g))
+    run("enc", ConvEncoder(wrap(dict(dims=[10, 6], kernels=[1], paddings=[0],
+                                     norm_type="batch_norm"))),
+        torch.randn(2, 10, 5, 7, generator=g))
+    run("up2", Up(8 + 4, 12, scale_factor=2), torch.randn(1, 8, 6, 7, generator=g),
+        torch.randn(1, 4, 12, 14, generator=g))
+    # the odd-width decoder step of the 512x612 config: 64x76 -> 128x153 (effnet.py:64-68)
+    sf = (128 / 64, 153 / 76)
+    run("upodd", Up(3 + 1, 2, scale_factor=sf), torch.randn(1, 3, 64, 76, generator=g),
+        torch.randn(1, 1, 128, 153, generator=g))
+    import torch.nn as nn
+    run("deconv", DeconvHead(16 + 8, 5, nn.BatchNorm2d), torch.randn(1, 16, 4, 4, generator=g),
+        torch.randn(1, 8, 16, 16, generator=g))
+    nk = maxent_irl_cfg().to_dict()["traversability_head"]["net_kwargs"]
+    run("msfcn", MultiScaleFCN(wrap(nk["reward_cfg"]["net_kwargs"])),
+        torch.randn(2, 40, 16, 24, generator=g))
+    npz("blocks.npz", **arrs)
+
+    d = terrainnet_cfg().to_dict()["discretize"]
+    logits = torch.relu(torch.randn(2, 128, 6, 7, generator=g) * 3)
+    depth = du.convert_to_metric_depth_differentiable(logits, d["mode"], d["depth_min"],
+                                                      d["depth_max"], d["num_bins"])
+    dm = torch.rand(4, 9, generator=g) * 30000
+    npz("utils.npz", logits=logits, metric_depth_mm=depth,
+        depth_map=dm, bins=du.bin_depths(dm.clone(), "UD", 300, 25600, 128),
+        bins_target=du.bin_depths(dm.clone(), "UD", 300, 25600, 128, target=True),
+        fov_128=tu.create_trapezoidal_fov_mask(128, 128, 70, 70, 0, 100),
+        fov_default=tu.create_trapezoidal_fov_mask(40, 60),
+        rc_in=torch.arange(2 * 1 * 8 * 8).view(2, 1, 8, 8).byte(),
+        rc_out=tu.resize_and_crop(torch.arange(2 * 1 * 8 * 8).view(2, 1, 8, 8).byte(), (4, 4),
+                                  (0, 2, 0, 4)))
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "reference tree not mounted: fixtures can only be made in the build container"
+    sys.path.insert(0, os.path.abspath(os.path.join(OUT, "..", "..")))
+    install_shims()
+    with torch.no_grad():
+        pass
+    gen_splat()
+    gen_vin_svf_loss()
+    gen_blocks_and_utils()
