@@ -1,0 +1,91 @@
+"""ctypes binding of libcreste_hip.so (include/creste_hip.h).
+
+The product path has NO fallback: if the shared library is missing or fails to load, every op
+raises `HipLibraryError` -- it never silently routes to a PyTorch/CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libcreste_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
+PREC_F32, PREC_BF16 = 0, 1
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("wpk", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
+                ("a_scale", C.c_void_p), ("row_mask", C.c_void_p), ("out", C.c_void_p)] + \
+               [(n, C.c_int32) for n in ("N", "H", "W", "Cin", "in_cs", "Ho", "Wo", "Cout", "out_cs",
+                                         "out_co", "res_cs", "KH", "KW", "stride", "pad_t", "pad_l",
+                                         "act", "prec")]
+
+
+_vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
+SIGNATURES = {
+    "creste_last_error": (C.c_char_p, []),
+    "creste_abi_version": (_i, []),
+    "creste_conv2d_nhwc": (_i, [C.POINTER(ConvDesc), _vp]),
+    "creste_conv_packed_weight_bytes": (_i64, [_i, _i, _i, _i, _i]),
+    "creste_conv_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "creste_dwconv2d_nhwc_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
+    "creste_se_partial_rows": (_i, [_i]),
+    "creste_se_gate_f32": (_i, [_vp] * 7 + [_i] * 4 + [_vp]),
+    "creste_upsample_concat_nhwc_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i,
+                                              _f, _f, _vp]),
+    "creste_maxpool2_nhwc_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "creste_affine_act_nhwc_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
+    "creste_resize_plane_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _f, _f, _vp]),
+    "creste_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "creste_nhwc_to_nchw_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "creste_depth_expectation_f32": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp]),
+    "creste_pixel_geometry_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp,
+                                        _vp, _i, _i, _vp]),
+    "creste_bev_splat_workspace_bytes": (_i64, [_i, _i, _i, _i]),
+    "creste_bev_splat_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _i, _i, _f, _vp, _vp, _vp,
+                                   _vp, _vp]),
+    "creste_value_iteration_workspace_bytes": (_i64, [_i, _i, _i]),
+    "creste_value_iteration_f32": (_i, [_vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "creste_expected_svf_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp,
+                                      _vp]),
+}
+
+_lib = None
+
+
+def load(path: str | None = None):
+    """Load (once) and return the ctypes handle; raises HipLibraryError when unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = path or os.environ.get("CRESTE_HIP_LIB", LIB_PATH)
+    if not os.path.exists(p):
+        raise HipLibraryError(
+            f"{p} not found: build it with `python -m creste_public_amd.build` "
+            "(the HIP path has no PyTorch/CPU fallback)")
+    try:
+        lib = C.CDLL(p)
+    except OSError as e:
+        raise HipLibraryError(f"cannot load {p}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{p} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().creste_last_error()
+        raise HipLibraryError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

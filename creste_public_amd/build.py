@@ -1,0 +1,65 @@
+"""Build libcreste_hip.so (gfx950) in-tree with hipcc.
+
+    python -m creste_public_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  Objects go to creste_public_amd/lib/obj, the shared library
+to creste_public_amd/lib/libcreste_hip.so (git-ignored; it travels to the GPU box with the repo
+snapshot).  `-ffp-contract=off`: the geometry / value-iteration kernels spell out every fma they
+want, so results do not depend on the compiler's contraction choices.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = os.path.join(LIBDIR, "libcreste_hip.so")
+ARCH = "gfx950"
+SOURCES = ["error.cpp", "conv_igemm.hip", "pointwise.hip", "bev_splat.hip", "value_iteration.hip",
+           "svf.hip"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _deps_mtime() -> float:
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(HERE, "..", "include", "creste_hip.h"))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = _hipcc()
+    hdr_m = _deps_mtime()
+    objs, rebuilt = [], False
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+        objs.append(op)
+        if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_m):
+            cmd = [hipcc, *FLAGS, "-x", "hip", "-c", sp, "-o", op]
+            if verbose:
+                print("[creste build]", " ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            rebuilt = True
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]
+        if verbose:
+            print("[creste build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

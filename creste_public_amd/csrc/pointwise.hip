@@ -1,0 +1,468 @@
+// Memory-bound NHWC kernels of the perception path: depthwise conv, squeeze-excite, bilinear
+// upsample+concat, 2x2 max-pool, layout transposes, depth-bin expectation, pixel geometry + z-MLP.
+// All are HBM/L2-bandwidth bound: one thread owns 4 consecutive channels (16-B accesses, lanes run
+// along the channel axis first so a wave touches whole contiguous pixels), grid-stride loops.
+#include "common.h"
+
+namespace creste {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+static inline int grid_for(long work_items, int block = 256, int max_blocks = 256 * 16) {
+  long b = (work_items + block - 1) / block;
+  if (b < 1) b = 1;
+  return (int)(b > max_blocks ? max_blocks : b);
+}
+
+// ------------------------------------------------------------------------------ depthwise conv
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ in,
+                                                     const float* __restrict__ w,
+                                                     const float* __restrict__ bias,
+                                                     float* __restrict__ out, int N, int H, int W,
+                                                     int C, int Ho, int Wo, int stride, int pad_t,
+                                                     int pad_l, int act) {
+  const int cq = C >> 2;
+  const long total = (long)N * Ho * Wo * cq;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cq) * 4;
+    long t = i / cq;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    f32x4 acc = bias ? ld4(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int iy0 = oy * stride - pad_t, ix0 = ox * stride - pad_l;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int iy = iy0 + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const int ix = ix0 + kx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const f32x4 x = ld4(in + (((long)n * H + iy) * W + ix) * C + c);
+        const f32x4 ww = ld4(w + (ky * K + kx) * C + c);
+        acc += x * ww;
+      }
+    }
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = act_apply(acc[j], act);
+    st4(out + i * 4, o);
+  }
+}
+
+// ------------------------------------------------------------------------------ squeeze-excite
+constexpr int SE_ROWS_PER_BLOCK = 2048;   // pixels reduced by one block of the partial pass
+
+// partial[n][chunk][c] = sum over the chunk's pixels of x[n][p][c]   (deterministic order)
+__global__ __launch_bounds__(256) void se_partial_kernel(const float* __restrict__ x,
+                                                         float* __restrict__ partial, int HW, int C,
+                                                         int nchunk) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [slices][C]
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int cq = C >> 2;
+  const int slices = 256 / cq > 0 ? 256 / cq : 1;     // pixel slices processed in parallel
+  const int p0 = chunk * SE_ROWS_PER_BLOCK;
+  const int p1 = min(HW, p0 + SE_ROWS_PER_BLOCK);
+  // thread -> (slice, channel quad); when C/4 > 256 a thread loops over several quads
+  for (int q0 = 0; q0 < cq; q0 += 256) {
+    const int tq = (cq >= 256) ? q0 + threadIdx.x : threadIdx.x % cq;
+    const int sl = (cq >= 256) ? 0 : threadIdx.x / cq;
+    const bool active = tq < cq && sl < slices;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (active)
+      for (int p = p0 + sl; p < p1; p += slices) s += ld4(x + ((long)n * HW + p) * C + tq * 4);
+    if (active) st4(sm + (long)sl * C + tq * 4, s);
+    __syncthreads();
+    if (active && sl == 0) {
+      f32x4 tot = s;
+      for (int k = 1; k < slices; ++k) tot += ld4(sm + (long)k * C + tq * 4);
+      st4(partial + ((long)n * nchunk + chunk) * C + tq * 4, tot);
+    }
+    __syncthreads();
+  }
+}
+
+// one block per sample: mean -> FC1 + swish -> FC2 -> sigmoid
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ partial,
+                                                      const float* __restrict__ w1,
+                                                      const float* __restrict__ b1,
+                                                      const float* __restrict__ w2,
+                                                      const float* __restrict__ b2,
+                                                      float* __restrict__ gate, int HW, int C, int Cse,
+                                                      int nchunk) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // mean[C] + hid[Cse]
+  float* mean = sm;
+  float* hid = sm + C;
+  const int n = blockIdx.x;
+  const float inv = 1.f / (float)HW;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int k = 0; k < nchunk; ++k) s += partial[((long)n * nchunk + k) * C + c];
+    mean[c] = s * inv;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int j = wave; j < Cse; j += 4) {               // one wave per squeezed channel
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += w1[(long)j * C + c] * mean[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) hid[j] = act_apply(s + b1[j], CRESTE_ACT_SWISH);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = b2[c];
+    for (int j = 0; j < Cse; ++j) s += w2[(long)c * Cse + j] * hid[j];
+    gate[(long)n * C + c] = 1.f / (1.f + expf(-s));
+  }
+}
+
+// ------------------------------------------------------------------------------ upsample + concat
+__global__ __launch_bounds__(256) void upsample_concat_kernel(
+    const float* __restrict__ x1, int H1, int W1, int C1, int x1_cs, const float* __restrict__ skip,
+    int C2, int skip_cs, float* __restrict__ out, int N, int Ho, int Wo, int out_cs, int out_co,
+    float rh, float rw) {
+  const int cq = (C1 + C2) >> 2, c2q = C2 >> 2;
+  const long total = (long)N * Ho * Wo * cq;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % cq);
+    long t = i / cq;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const long opix = ((long)n * Ho + oy) * Wo + ox;
+    f32x4 v;
+    if (q < c2q) {
+      v = ld4(skip + opix * skip_cs + q * 4);
+    } else {
+      const int c = (q - c2q) * 4;
+      // PyTorch area_pixel_compute_source_index (align_corners=False): clamp below at 0
+      float sy = rh * ((float)oy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+      float sx = rw * ((float)ox + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
+      const int y0 = (int)sy, x0 = (int)sx;
+      const int y1 = y0 + (y0 < H1 - 1 ? 1 : 0), x1i = x0 + (x0 < W1 - 1 ? 1 : 0);
+      const float ly = sy - (float)y0, lx = sx - (float)x0;
+      const float hy = 1.f - ly, hx = 1.f - lx;
+      const float* b = x1 + (long)n * H1 * W1 * x1_cs + c;
+      const f32x4 v00 = ld4(b + ((long)y0 * W1 + x0) * x1_cs), v01 = ld4(b + ((long)y0 * W1 + x1i) * x1_cs);
+      const f32x4 v10 = ld4(b + ((long)y1 * W1 + x0) * x1_cs), v11 = ld4(b + ((long)y1 * W1 + x1i) * x1_cs);
+      v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    }
+    st4(out + opix * out_cs + out_co + q * 4, v);
+  }
+}
+
+// ------------------------------------------------------------------------------ max-pool 2x2/2
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ in, int H, int W,
+                                                       int C, int in_cs, float* __restrict__ out,
+                                                       int N, int Ho, int Wo, int out_cs) {
+  const int cq = C >> 2;
+  const long total = (long)N * Ho * Wo * cq;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cq) * 4;
+    long t = i / cq;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const float* b = in + (((long)n * H + 2 * oy) * W + 2 * ox) * in_cs + c;
+    const f32x4 a = ld4(b), bb = ld4(b + in_cs), cc = ld4(b + (long)W * in_cs),
+                d = ld4(b + (long)W * in_cs + in_cs);
+    f32x4 m;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(a[j], bb[j]), fmaxf(cc[j], d[j]));
+    st4(out + (((long)n * Ho + oy) * Wo + ox) * out_cs + c, m);
+  }
+}
+
+// ------------------------------------------------------------------------------ layout transposes
+// NCHW -> NHWC through a 32x33 LDS tile: reads coalesced along W, writes coalesced along C.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in,
+                                                           float* __restrict__ out, int C, long HW,
+                                                           int out_cs) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const long p0 = (long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k; const long p = p0 + tx;
+    tile[k][tx] = (c < C && p < HW) ? in[((long)n * C + c) * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const long p = p0 + k; const int c = c0 + tx;
+    if (c < C && p < HW) out[((long)n * HW + p) * out_cs + c] = tile[tx][k];
+  }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, int in_cs,
+                                                           float* __restrict__ out, int C, long HW) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const long p0 = (long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const long p = p0 + k; const int c = c0 + tx;
+    tile[k][tx] = (c < C && p < HW) ? in[((long)n * HW + p) * in_cs + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k; const long p = p0 + tx;
+    if (c < C && p < HW) out[((long)n * C + c) * HW + p] = tile[tx][k];
+  }
+}
+
+// ------------------------------------------------------------------------------ depth expectation
+// One 32-lane half-wave per pixel, 4 logits per lane (nbins = 128).
+__global__ __launch_bounds__(256) void depth_expectation_kernel(const float* __restrict__ logits,
+                                                                int cs, long P,
+                                                                const float* __restrict__ bin_values,
+                                                                float* __restrict__ depth_m,
+                                                                int64_t* __restrict__ bins) {
+  const int sub = threadIdx.x & 31;
+  const long half = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 5;
+  const long nhalf = ((long)gridDim.x * blockDim.x) >> 5;
+  const f32x4 bv = ld4(bin_values + sub * 4);
+  for (long p = half; p < P; p += nhalf) {
+    const f32x4 x = ld4(logits + p * cs + sub * 4);
+    float mx = x[0]; int am = sub * 4;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) if (x[j] > mx) { mx = x[j]; am = sub * 4 + j; }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {      // stays inside the 32-lane half
+      const float om = __shfl_xor(mx, o);
+      const int oa = __shfl_xor(am, o);
+      if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
+    }
+    float se = 0.f, sw = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float e = expf(x[j] - mx); se += e; sw += e * bv[j]; }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { se += __shfl_xor(se, o); sw += __shfl_xor(sw, o); }
+    if (sub == 0) { depth_m[p] = (sw / se) / 1000.f; bins[p] = am; }
+  }
+}
+
+// ------------------------------------------------------------------------------ pixel geometry + z MLP
+// Per pixel: c = [u*d, v*d, d, 1]; xyz_k = fma(P[k][3],c3, fma(P[k][2],c2, fma(P[k][1],c1, P[k][0]*c0)))
+// -- the k-ordered fma chain the reference's CPU bmm produces -- plus the range
+// mask and the 1 -> zhid -> zdim ReLU MLP on z.  zdim lanes cooperate on one pixel.
+__global__ __launch_bounds__(256) void pixel_geometry_kernel(
+    const float* __restrict__ depth, const float* __restrict__ p2p, int B, int Hs, int Ws,
+    const float* __restrict__ bounds, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, int zhid, int zdim,
+    float* __restrict__ xyz, float* __restrict__ mask, float* __restrict__ zfeat, int z_cs, int z_co) {
+  extern __shared__ float smw[];   // w1[zhid] b1[zhid] w2[zdim*zhid] b2[zdim]
+  float* s_w1 = smw; float* s_b1 = s_w1 + zhid; float* s_w2 = s_b1 + zhid; float* s_b2 = s_w2 + zdim * zhid;
+  for (int i = threadIdx.x; i < zhid; i += blockDim.x) { s_w1[i] = w1[i]; s_b1[i] = b1[i]; }
+  for (int i = threadIdx.x; i < zdim * zhid; i += blockDim.x) s_w2[i] = w2[i];
+  for (int i = threadIdx.x; i < zdim; i += blockDim.x) s_b2[i] = b2[i];
+  __syncthreads();
+  const long P = (long)Hs * Ws, total = (long)B * P;
+  const int per = blockDim.x / zdim;                       // pixels per block iteration
+  const int j = threadIdx.x % zdim, slot = threadIdx.x / zdim;
+  for (long base = (long)blockIdx.x * per; base < total; base += (long)gridDim.x * per) {
+    const long g = base + slot;
+    if (g >= total || slot >= per) continue;
+    const int b = (int)(g / P); const long p = g % P;
+    const int v = (int)(p / Ws), u = (int)(p % Ws);
+    const float d = depth[g];
+    const float c0 = (float)u * d, c1 = (float)v * d;
+    const float* M = p2p + (long)b * 16;
+    float q[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      q[k] = __fmaf_rn(M[k * 4 + 3], 1.0f, __fmaf_rn(M[k * 4 + 2], d, __fmaf_rn(M[k * 4 + 1], c1, __fmul_rn(M[k * 4 + 0], c0))));
+    if (j == 0) {
+      xyz[g * 3 + 0] = q[0]; xyz[g * 3 + 1] = q[1]; xyz[g * 3 + 2] = q[2];
+      const bool ok = q[0] >= bounds[0] && q[1] >= bounds[1] && q[2] >= bounds[2] &&
+                      q[0] < bounds[3] && q[1] < bounds[4] && q[2] < bounds[5];
+      mask[g] = ok ? 1.f : 0.f;
+    }
+    float s = s_b2[j];
+    for (int h = 0; h < zhid; ++h) {
+      const float hv = fmaxf(__fmaf_rn(s_w1[h], q[2], s_b1[h]), 0.f);
+      s = __fmaf_rn(s_w2[j * zhid + h], hv, s);
+    }
+    zfeat[g * z_cs + z_co + j] = fmaxf(s, 0.f);
+  }
+}
+
+// ------------------------------------------------------------------------------ channel affine + act
+// y = act(x * scale[c] + shift[c])  (an eval-mode BatchNorm that follows a ReLU and therefore cannot be
+// folded into the preceding conv: MultiScaleFCN trunk, reference conv.py:118-128)
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, int x_cs,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         float* __restrict__ out, int out_cs, long P,
+                                                         int C, int act) {
+  const int cq = C >> 2;
+  const long total = P * cq;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cq) * 4;
+    const long p = i / cq;
+    const f32x4 v = ld4(x + p * x_cs + c), sc = ld4(scale + c), sh = ld4(shift + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = act_apply(__fadd_rn(__fmul_rn(v[j], sc[j]), sh[j]), act);
+    st4(out + p * out_cs + c, o);
+  }
+}
+
+// ------------------------------------------------------------------------------ planar bilinear resize
+// single-channel [N,H,W] -> rows [0,Ho) of a [N,Hd,Wo] plane (F.interpolate(size=...), vin.py:121-125)
+__global__ __launch_bounds__(256) void resize_plane_kernel(const float* __restrict__ in, int H, int W,
+                                                           float* __restrict__ out, int N, int Ho, int Wo,
+                                                           int Hd, float rh, float rw) {
+  const long total = (long)N * Ho * Wo;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % Wo);
+    const int oy = (int)((i / Wo) % Ho);
+    const int n = (int)(i / ((long)Wo * Ho));
+    float sy = rh * ((float)oy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+    float sx = rw * ((float)ox + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* b = in + (long)n * H * W;
+    out[((long)n * Hd + oy) * Wo + ox] = hy * (hx * b[(long)y0 * W + x0] + lx * b[(long)y0 * W + x1]) +
+                                         ly * (hx * b[(long)y1 * W + x0] + lx * b[(long)y1 * W + x1]);
+  }
+}
+
+}  // namespace creste
+
+using namespace creste;
+
+extern "C" int creste_dwconv2d_nhwc_f32(const float* in, const float* w, const float* bias, float* out,
+                                        int N, int H, int W, int C, int Ho, int Wo, int K, int stride,
+                                        int pad_t, int pad_l, int act, void* stream) {
+  CRESTE_REQUIRE(in && w && out, "dwconv: null pointer");
+  CRESTE_REQUIRE(C % 4 == 0 && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "dwconv: bad dims (C%%4)");
+  CRESTE_REQUIRE(K == 3 || K == 5, "dwconv: kernel size %d not built (3 or 5)", K);
+  const long total = (long)N * Ho * Wo * (C / 4);
+  const int grid = grid_for(total, 256, 256 * 32);
+  hipStream_t s = (hipStream_t)stream;
+  if (K == 3) dwconv_kernel<3><<<grid, 256, 0, s>>>(in, w, bias, out, N, H, W, C, Ho, Wo, stride, pad_t, pad_l, act);
+  else dwconv_kernel<5><<<grid, 256, 0, s>>>(in, w, bias, out, N, H, W, C, Ho, Wo, stride, pad_t, pad_l, act);
+  CRESTE_CHECK_LAUNCH("dwconv");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_se_partial_rows(int HW) { return (HW + SE_ROWS_PER_BLOCK - 1) / SE_ROWS_PER_BLOCK; }
+
+extern "C" int creste_se_gate_f32(const float* x, float* partial, const float* w1, const float* b1,
+                                  const float* w2, const float* b2, float* gate, int N, int HW, int C,
+                                  int Cse, void* stream) {
+  CRESTE_REQUIRE(x && partial && w1 && b1 && w2 && b2 && gate, "se_gate: null pointer");
+  CRESTE_REQUIRE(C % 4 == 0 && C > 0 && Cse > 0 && N > 0 && HW > 0, "se_gate: bad dims");
+  const int nchunk = creste_se_partial_rows(HW);
+  const int cq = C / 4;
+  const int slices = 256 / cq > 0 ? 256 / cq : 1;
+  hipStream_t s = (hipStream_t)stream;
+  se_partial_kernel<<<dim3(nchunk, N), 256, (size_t)slices * C * sizeof(float), s>>>(x, partial, HW, C, nchunk);
+  CRESTE_CHECK_LAUNCH("se_partial");
+  se_gate_kernel<<<N, 256, (size_t)(C + Cse) * sizeof(float), s>>>(partial, w1, b1, w2, b2, gate, HW, C, Cse, nchunk);
+  CRESTE_CHECK_LAUNCH("se_gate");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_upsample_concat_nhwc_f32(const float* x1, int N, int H1, int W1, int C1, int x1_cs,
+                                               const float* skip, int C2, int skip_cs, float* out,
+                                               int Ho, int Wo, int out_cs, int out_co, float rh,
+                                               float rw, void* stream) {
+  CRESTE_REQUIRE(x1 && out && (skip || C2 == 0), "upsample_concat: null pointer");
+  CRESTE_REQUIRE(C1 % 4 == 0 && C2 % 4 == 0 && x1_cs % 4 == 0 && out_cs % 4 == 0 && out_co % 4 == 0 &&
+                     (C2 == 0 || skip_cs % 4 == 0),
+                 "upsample_concat: channel counts/strides must be multiples of 4");
+  CRESTE_REQUIRE(out_cs >= out_co + C1 + C2, "upsample_concat: output slice exceeds out_cs");
+  const long total = (long)N * Ho * Wo * ((C1 + C2) / 4);
+  upsample_concat_kernel<<<grid_for(total, 256, 256 * 32), 256, 0, (hipStream_t)stream>>>(
+      x1, H1, W1, C1, x1_cs, skip, C2, skip_cs, out, N, Ho, Wo, out_cs, out_co, rh, rw);
+  CRESTE_CHECK_LAUNCH("upsample_concat");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_maxpool2_nhwc_f32(const float* in, int N, int H, int W, int C, int in_cs, float* out,
+                                        int Ho, int Wo, int out_cs, void* stream) {
+  CRESTE_REQUIRE(in && out && C % 4 == 0 && in_cs % 4 == 0 && out_cs % 4 == 0, "maxpool2: bad args");
+  CRESTE_REQUIRE(2 * Ho <= H && 2 * Wo <= W, "maxpool2: pooled extent exceeds input");
+  const long total = (long)N * Ho * Wo * (C / 4);
+  maxpool2_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(in, H, W, C, in_cs, out, N, Ho, Wo, out_cs);
+  CRESTE_CHECK_LAUNCH("maxpool2");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_nchw_to_nhwc_f32(const float* in, float* out, int out_cs, int N, int C, int H, int W,
+                                       void* stream) {
+  CRESTE_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0 && out_cs >= C, "nchw_to_nhwc: bad args");
+  const long HW = (long)H * W;
+  const dim3 grid((unsigned)((HW + 31) / 32), (C + 31) / 32, N);
+  nchw_to_nhwc_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(in, out, C, HW, out_cs);
+  CRESTE_CHECK_LAUNCH("nchw_to_nhwc");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_nhwc_to_nchw_f32(const float* in, int in_cs, float* out, int N, int C, int H, int W,
+                                       void* stream) {
+  CRESTE_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0 && in_cs >= C, "nhwc_to_nchw: bad args");
+  const long HW = (long)H * W;
+  const dim3 grid((unsigned)((HW + 31) / 32), (C + 31) / 32, N);
+  nhwc_to_nchw_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(in, in_cs, out, C, HW);
+  CRESTE_CHECK_LAUNCH("nhwc_to_nchw");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_depth_expectation_f32(const float* logits, int cs, int64_t P, int nbins,
+                                            const float* bin_values, float* depth_m, int64_t* bins,
+                                            void* stream) {
+  CRESTE_REQUIRE(logits && bin_values && depth_m && bins, "depth_expectation: null pointer");
+  CRESTE_REQUIRE(nbins == 128 && cs % 4 == 0 && cs >= nbins, "depth_expectation: built for 128 bins");
+  depth_expectation_kernel<<<grid_for(P * 32, 256, 256 * 16), 256, 0, (hipStream_t)stream>>>(
+      logits, cs, P, bin_values, depth_m, bins);
+  CRESTE_CHECK_LAUNCH("depth_expectation");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_pixel_geometry_f32(const float* depth, const float* p2p, int B, int Hs, int Ws,
+                                         const float* bounds6, const float* w1, const float* b1,
+                                         const float* w2, const float* b2, int zhid, int zdim,
+                                         float* xyz, float* mask, float* zfeat, int z_cs, int z_co,
+                                         void* stream) {
+  CRESTE_REQUIRE(depth && p2p && bounds6 && w1 && b1 && w2 && b2 && xyz && mask && zfeat,
+                 "pixel_geometry: null pointer");
+  CRESTE_REQUIRE(zdim > 0 && zdim <= 256 && 256 % zdim == 0 && zhid > 0, "pixel_geometry: zdim must divide 256");
+  const long total = (long)B * Hs * Ws;
+  const int per = 256 / zdim;
+  const size_t smem = (size_t)(2 * zhid + zdim * zhid + zdim) * sizeof(float);
+  pixel_geometry_kernel<<<grid_for(total, per, 256 * 16), 256, smem, (hipStream_t)stream>>>(
+      depth, p2p, B, Hs, Ws, bounds6, w1, b1, w2, b2, zhid, zdim, xyz, mask, zfeat, z_cs, z_co);
+  CRESTE_CHECK_LAUNCH("pixel_geometry");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_affine_act_nhwc_f32(const float* x, int x_cs, const float* scale, const float* shift,
+                                          float* out, int out_cs, int64_t P, int C, int act, void* stream) {
+  CRESTE_REQUIRE(x && scale && shift && out, "affine_act: null pointer");
+  CRESTE_REQUIRE(C % 4 == 0 && x_cs % 4 == 0 && out_cs % 4 == 0 && x_cs >= C && out_cs >= C, "affine_act: C%%4");
+  affine_act_kernel<<<grid_for(P * (C / 4)), 256, 0, (hipStream_t)stream>>>(x, x_cs, scale, shift, out, out_cs, P, C, act);
+  CRESTE_CHECK_LAUNCH("affine_act");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_resize_plane_f32(const float* in, int N, int H, int W, float* out, int Ho, int Wo,
+                                       int Hd, float rh, float rw, void* stream) {
+  CRESTE_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && Hd >= Ho, "resize_plane: bad args");
+  resize_plane_kernel<<<grid_for((long)N * Ho * Wo), 256, 0, (hipStream_t)stream>>>(in, H, W, out, N, Ho, Wo, Hd, rh, rw);
+  CRESTE_CHECK_LAUNCH("resize_plane");
+  return CRESTE_OK;
+}

@@ -1,0 +1,310 @@
+"""Tensor-level wrappers over the C ABI (torch is used for device memory and streams only).
+
+Activations travel as `Act`: a view onto an NHWC fp32 buffer `[N,H,W,cs]` that names a channel
+slice `[co, co+C)` of it -- the zero-copy concat the kernels understand (pixel stride `cs`).
+Every wrapper validates device/dtype/contiguity and raises; nothing here computes with torch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_SWISH, PREC_F32, ConvDesc, HipLibraryError  # noqa: F401
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype=torch.float32, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise HipLibraryError(f"{name}: expected a CUDA/HIP tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise HipLibraryError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise HipLibraryError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+@dataclass
+class Act:
+    buf: torch.Tensor      # [N,H,W,cs] contiguous fp32
+    C: int                 # channels in the slice
+    co: int = 0            # channel offset of the slice
+
+    @property
+    def N(self): return self.buf.shape[0]
+    @property
+    def H(self): return self.buf.shape[1]
+    @property
+    def W(self): return self.buf.shape[2]
+    @property
+    def cs(self): return self.buf.shape[3]
+    @property
+    def ptr(self): return self.buf.data_ptr() + 4 * self.co
+
+    @staticmethod
+    def empty(N, H, W, C, device, cs=None):
+        return Act(torch.empty((N, H, W, cs or C), dtype=torch.float32, device=device), C, 0)
+
+    def slice(self, co, C):
+        assert co + C <= self.cs
+        return Act(self.buf, C, co)
+
+    def nchw(self) -> torch.Tensor:
+        """[N,C,H,W]-shaped (channels-last strided) zero-copy view of the slice."""
+        return self.buf[..., self.co:self.co + self.C].permute(0, 3, 1, 2)
+
+
+@dataclass
+class PackedConv:
+    wpk: torch.Tensor          # packed GEMM weights (uint8 storage)
+    bias: torch.Tensor | None  # [Cout] fp32 (conv bias and folded BN shift)
+    Cin: int
+    Cout: int
+    KH: int
+    KW: int
+    stride: int
+    pad_t: int
+    pad_l: int
+    pad_b: int
+    pad_r: int
+    act: int
+    prec: int = PREC_F32
+
+    def out_hw(self, H, W):
+        return ((H + self.pad_t + self.pad_b - self.KH) // self.stride + 1,
+                (W + self.pad_l + self.pad_r - self.KW) // self.stride + 1)
+
+
+def pack_conv(weight: torch.Tensor, bias, bn, stride, pad, act, prec=PREC_F32) -> PackedConv:
+    """weight OIHW (CUDA fp32); bn = None or (gamma, beta, mean, var, eps) -> folded eval-mode BN.
+    pad = int | (pad_t, pad_b, pad_l, pad_r)."""
+    lib = _lib.load()
+    w = _chk(weight.detach().contiguous(), name="conv weight")
+    Cout, Cin, KH, KW = w.shape
+    scale = None
+    b = None if bias is None else bias.detach().float()
+    if bn is not None:
+        gamma, beta, mean, var, eps = bn
+        scale = (gamma.detach() / torch.sqrt(var.detach() + eps)).float().contiguous()
+        shift = beta.detach() - mean.detach() * scale
+        b = shift if b is None else b * scale + shift
+    if b is not None:
+        b = b.contiguous()
+    nbytes = lib.creste_conv_packed_weight_bytes(Cout, Cin, KH, KW, prec)
+    if nbytes <= 0:
+        raise HipLibraryError("conv_packed_weight_bytes: unsupported shape/precision")
+    wpk = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _lib.check(lib.creste_conv_pack_weight(w.data_ptr(), scale.data_ptr() if scale is not None else None,
+                                           wpk.data_ptr(), Cout, Cin, KH, KW, prec, _stream()),
+               "conv_pack_weight")
+    if isinstance(pad, int):
+        pad = (pad, pad, pad, pad)
+    return PackedConv(wpk, b, Cin, Cout, KH, KW, stride, pad[0], pad[2], pad[1], pad[3], act, prec)
+
+
+def conv2d(x: Act, pc: PackedConv, out: Act | None = None, res: Act | None = None,
+           a_scale: torch.Tensor | None = None, row_mask: torch.Tensor | None = None) -> Act:
+    lib = _lib.load()
+    _chk(x.buf, name="conv input")
+    if x.C != pc.Cin:
+        raise HipLibraryError(f"conv2d: input has {x.C} channels, weights expect {pc.Cin}")
+    Ho, Wo = pc.out_hw(x.H, x.W)
+    if out is None:
+        out = Act.empty(x.N, Ho, Wo, pc.Cout, x.buf.device)
+    if (out.N, out.H, out.W, out.C) != (x.N, Ho, Wo, pc.Cout):
+        raise HipLibraryError(f"conv2d: output slice {(out.N, out.H, out.W, out.C)} != "
+                              f"{(x.N, Ho, Wo, pc.Cout)}")
+    d = ConvDesc()
+    d.in_, d.wpk, d.out = x.ptr, pc.wpk.data_ptr(), out.buf.data_ptr()
+    d.bias = pc.bias.data_ptr() if pc.bias is not None else None
+    if res is not None:
+        if (res.N, res.H, res.W, res.C) != (out.N, out.H, out.W, out.C):
+            raise HipLibraryError("conv2d: residual shape mismatch")
+        d.res, d.res_cs = res.ptr, res.cs
+    else:
+        d.res, d.res_cs = None, 0
+    if a_scale is not None:
+        _chk(a_scale, name="a_scale")
+        if tuple(a_scale.shape) != (x.N, pc.Cin):
+            raise HipLibraryError("conv2d: a_scale must be [N,Cin]")
+        d.a_scale = a_scale.data_ptr()
+    if row_mask is not None:
+        _chk(row_mask, name="row_mask")
+        if row_mask.numel() != x.N * Ho * Wo:
+            raise HipLibraryError("conv2d: row_mask must have N*Ho*Wo elements")
+        d.row_mask = row_mask.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.in_cs = x.N, x.H, x.W, pc.Cin, x.cs
+    d.Ho, d.Wo, d.Cout, d.out_cs, d.out_co = Ho, Wo, pc.Cout, out.cs, out.co
+    d.KH, d.KW, d.stride, d.pad_t, d.pad_l = pc.KH, pc.KW, pc.stride, pc.pad_t, pc.pad_l
+    d.act, d.prec = pc.act, pc.prec
+    _lib.check(lib.creste_conv2d_nhwc(C.byref(d), _stream()), "conv2d_nhwc")
+    return out
+
+
+def dwconv2d(x: Act, w_taps: torch.Tensor, bias: torch.Tensor, K, stride, pad, act) -> Act:
+    """w_taps [K*K, C]; pad = (pad_t, pad_b, pad_l, pad_r)."""
+    lib = _lib.load()
+    assert x.co == 0 and x.cs == x.C, "dwconv expects a dense NHWC tensor"
+    Ho = (x.H + pad[0] + pad[1] - K) // stride + 1
+    Wo = (x.W + pad[2] + pad[3] - K) // stride + 1
+    out = Act.empty(x.N, Ho, Wo, x.C, x.buf.device)
+    _lib.check(lib.creste_dwconv2d_nhwc_f32(x.ptr, _chk(w_taps).data_ptr(), _chk(bias).data_ptr(),
+                                            out.ptr, x.N, x.H, x.W, x.C, Ho, Wo, K, stride, pad[0],
+                                            pad[2], act, _stream()), "dwconv2d")
+    return out
+
+
+def se_gate(x: Act, w1, b1, w2, b2) -> torch.Tensor:
+    lib = _lib.load()
+    assert x.co == 0 and x.cs == x.C
+    HW = x.H * x.W
+    Cse = w1.shape[0]
+    partial = torch.empty((x.N, lib.creste_se_partial_rows(HW), x.C), dtype=torch.float32,
+                          device=x.buf.device)
+    gate = torch.empty((x.N, x.C), dtype=torch.float32, device=x.buf.device)
+    _lib.check(lib.creste_se_gate_f32(x.ptr, partial.data_ptr(), _chk(w1).data_ptr(), _chk(b1).data_ptr(),
+                                      _chk(w2).data_ptr(), _chk(b2).data_ptr(), gate.data_ptr(), x.N, HW,
+                                      x.C, Cse, _stream()), "se_gate")
+    return gate
+
+
+def upsample_concat(x1: Act, skip: Act | None, Ho, Wo, rh, rw, out: Act | None = None) -> Act:
+    lib = _lib.load()
+    C2 = skip.C if skip is not None else 0
+    if out is None:
+        out = Act.empty(x1.N, Ho, Wo, x1.C + C2, x1.buf.device)
+    assert out.C == x1.C + C2 and (out.H, out.W) == (Ho, Wo)
+    _lib.check(lib.creste_upsample_concat_nhwc_f32(
+        x1.ptr, x1.N, x1.H, x1.W, x1.C, x1.cs, skip.ptr if skip is not None else None, C2,
+        skip.cs if skip is not None else 0, out.buf.data_ptr(), Ho, Wo, out.cs, out.co, float(rh),
+        float(rw), _stream()), "upsample_concat")
+    return out
+
+
+def maxpool2(x: Act, Ho=None, Wo=None) -> Act:
+    lib = _lib.load()
+    Ho = Ho if Ho is not None else x.H // 2
+    Wo = Wo if Wo is not None else x.W // 2
+    out = Act.empty(x.N, Ho, Wo, x.C, x.buf.device)
+    _lib.check(lib.creste_maxpool2_nhwc_f32(x.ptr, x.N, x.H, x.W, x.C, x.cs, out.ptr, Ho, Wo, out.cs,
+                                            _stream()), "maxpool2")
+    return out
+
+
+def affine_act(x: Act, scale, shift, act) -> Act:
+    lib = _lib.load()
+    out = Act.empty(x.N, x.H, x.W, x.C, x.buf.device)
+    _lib.check(lib.creste_affine_act_nhwc_f32(x.ptr, x.cs, _chk(scale).data_ptr(), _chk(shift).data_ptr(),
+                                              out.ptr, out.cs, x.N * x.H * x.W, x.C, act, _stream()),
+               "affine_act")
+    return out
+
+
+def resize_plane(x: torch.Tensor, Ho, Wo, Hd, rh, rw, out: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    N, H, W = x.shape
+    _lib.check(lib.creste_resize_plane_f32(_chk(x).data_ptr(), N, H, W, _chk(out).data_ptr(), Ho, Wo, Hd,
+                                           float(rh), float(rw), _stream()), "resize_plane")
+    return out
+
+
+def nchw_to_nhwc(x: torch.Tensor, out: Act | None = None) -> Act:
+    lib = _lib.load()
+    N, Cc, H, W = x.shape
+    if out is None:
+        out = Act.empty(N, H, W, Cc, x.device)
+    assert (out.N, out.H, out.W, out.C) == (N, H, W, Cc)
+    _lib.check(lib.creste_nchw_to_nhwc_f32(_chk(x).data_ptr(), out.ptr, out.cs, N, Cc, H, W, _stream()),
+               "nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x: Act) -> torch.Tensor:
+    lib = _lib.load()
+    out = torch.empty((x.N, x.C, x.H, x.W), dtype=torch.float32, device=x.buf.device)
+    _lib.check(lib.creste_nhwc_to_nchw_f32(x.ptr, x.cs, out.data_ptr(), x.N, x.C, x.H, x.W, _stream()),
+               "nhwc_to_nchw")
+    return out
+
+
+def depth_expectation(logits: Act, bin_values: torch.Tensor):
+    lib = _lib.load()
+    P = logits.N * logits.H * logits.W
+    depth = torch.empty((logits.N, logits.H, logits.W), dtype=torch.float32, device=logits.buf.device)
+    bins = torch.empty((logits.N, logits.H, logits.W), dtype=torch.int64, device=logits.buf.device)
+    _lib.check(lib.creste_depth_expectation_f32(logits.ptr, logits.cs, P, logits.C,
+                                                _chk(bin_values).data_ptr(), depth.data_ptr(),
+                                                bins.data_ptr(), _stream()), "depth_expectation")
+    return depth, bins
+
+
+def pixel_geometry(depth, p2p, bounds6, w1, b1, w2, b2, zfeat: Act):
+    """depth [B,Hs,Ws] m, p2p [B,4,4] -> xyz [B,P,3], mask [B,P]; z features into `zfeat` slice."""
+    lib = _lib.load()
+    B, Hs, Ws = depth.shape
+    xyz = torch.empty((B, Hs * Ws, 3), dtype=torch.float32, device=depth.device)
+    mask = torch.empty((B, Hs * Ws), dtype=torch.float32, device=depth.device)
+    zhid, zdim = w1.shape[0], w2.shape[0]
+    assert zfeat.C == zdim
+    _lib.check(lib.creste_pixel_geometry_f32(
+        _chk(depth).data_ptr(), _chk(p2p).data_ptr(), B, Hs, Ws, _chk(bounds6).data_ptr(),
+        _chk(w1).data_ptr(), _chk(b1).data_ptr(), _chk(w2).data_ptr(), _chk(b2).data_ptr(), zhid, zdim,
+        xyz.data_ptr(), mask.data_ptr(), zfeat.buf.data_ptr(), zfeat.cs, zfeat.co, _stream()),
+        "pixel_geometry")
+    return xyz, mask
+
+
+def bev_splat(xyz, feats: Act, off_xy, vox_xy, GH, GW, min_weight=1.0):
+    """xyz [B,P,3], feats Act viewed as [B,P,F] -> (coords [B,P,2], bev Act [B,GH,GW,F], dens [B,GH,GW])."""
+    lib = _lib.load()
+    B, P, _ = xyz.shape
+    F = feats.C
+    dev = xyz.device
+    coords = torch.empty((B, P, 2), dtype=torch.float32, device=dev)
+    bev = Act.empty(B, GH, GW, F, dev)
+    dens = torch.empty((B, GH, GW), dtype=torch.float32, device=dev)
+    work = torch.empty(lib.creste_bev_splat_workspace_bytes(B, P, GH, GW), dtype=torch.uint8, device=dev)
+    _lib.check(lib.creste_bev_splat_f32(_chk(xyz).data_ptr(), feats.ptr, feats.cs, B, P, F,
+                                        float(off_xy[0]), float(off_xy[1]), float(vox_xy[0]),
+                                        float(vox_xy[1]), GH, GW, float(min_weight), coords.data_ptr(),
+                                        bev.ptr, dens.data_ptr(), work.data_ptr(), _stream()), "bev_splat")
+    return coords, bev, dens
+
+
+def value_iteration(r: torch.Tensor, discount: float, threshold: float = 1e-3, max_sweeps: int = 100000):
+    """r [B,H,W] -> v [B,H,W], q [B,8,H,W], policy [B,8,H,W], sweeps (device int32 tensor)."""
+    lib = _lib.load()
+    B, H, W = r.shape
+    dev = r.device
+    v = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    q = torch.empty((B, 8, H, W), dtype=torch.float32, device=dev)
+    pi = torch.empty((B, 8, H, W), dtype=torch.float32, device=dev)
+    sweeps = torch.zeros(1, dtype=torch.int32, device=dev)
+    work = torch.empty(lib.creste_value_iteration_workspace_bytes(B, H, W), dtype=torch.uint8, device=dev)
+    _lib.check(lib.creste_value_iteration_f32(_chk(r).data_ptr(), B, H, W, float(discount),
+                                              float(threshold), int(max_sweeps), v.data_ptr(),
+                                              q.data_ptr(), pi.data_ptr(), sweeps.data_ptr(),
+                                              work.data_ptr(), _stream()), "value_iteration")
+    return v, q, pi, sweeps
+
+
+def expected_svf(policy, expert_xy, fov_u8, T, ds, temperature, sharpen=True, zero_terminal=False):
+    lib = _lib.load()
+    B, A, H, W = policy.shape
+    assert A == 8
+    dev = policy.device
+    sharp = torch.empty_like(policy)
+    svf = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    states = torch.empty((B, T, 2), dtype=torch.int64, device=dev)
+    grid = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    _lib.check(lib.creste_expected_svf_f32(_chk(policy).data_ptr(), _chk(expert_xy).data_ptr(),
+                                           _chk(fov_u8, torch.uint8).data_ptr(), B, H, W, T, float(ds),
+                                           float(temperature), int(sharpen), int(zero_terminal),
+                                           sharp.data_ptr(), svf.data_ptr(), states.data_ptr(),
+                                           grid.data_ptr(), _stream()), "expected_svf")
+    return svf, states, grid

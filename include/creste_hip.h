@@ -1,0 +1,173 @@
+/*
+ * creste_hip.h -- C ABI of libcreste_hip.so: the MI355X (gfx950) kernels behind the CREStE
+ * perception -> costmap -> IRL hot path.
+ *
+ * The reference (ut-amrl/creste_public) has no FFI of its own: every op below replaces a
+ * sequence of stock PyTorch ops inside the reference's nn.Modules; each entry point cites the
+ * reference file:line whose arithmetic it reproduces.  The host-side Python mirror
+ * (creste_public_amd/creste/...) binds these symbols with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers owned by the caller
+ *     (PyTorch allocations, `tensor.data_ptr()`); the library allocates no persistent memory.
+ *   - activations are fp32 NHWC ("channels-last"): element (n,y,x,c) of a tensor with pixel
+ *     stride `cs` lives at ((n*H + y)*W + x)*cs + c.  A pixel stride larger than the channel
+ *     count addresses a channel slice of a wider buffer (zero-copy concat).
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant, and
+ *     keeps no global state besides immutable kernel handles.
+ *   - return value: 0 on success, negative on error (never throws);
+ *     creste_last_error() returns a thread-local description of the last failure.
+ */
+#ifndef CRESTE_HIP_H
+#define CRESTE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRESTE_OK 0
+#define CRESTE_ERR_ARG (-1)
+#define CRESTE_ERR_HIP (-2)
+#define CRESTE_ERR_NOCONV (-3) /* value iteration hit max_sweeps */
+
+#define CRESTE_ACT_NONE 0
+#define CRESTE_ACT_RELU 1
+#define CRESTE_ACT_SWISH 2 /* x * sigmoid(x) (efficientnet_pytorch Swish) */
+
+#define CRESTE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate */
+#define CRESTE_PREC_BF16 1 /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate   */
+
+const char* creste_last_error(void);
+int creste_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense convolution as implicit GEMM on the matrix cores, fused epilogue.
+ * Replaces nn.Conv2d (+ folded eval-mode BatchNorm2d) (+ ReLU / swish) (+ residual add) as used by
+ *   reference creste/models/blocks/effnet.py:16-23,74,87-89 (Up / 1x1), conv.py:21-29,48-55,63-85,
+ *   inpainting.py:52-68,82-103, depth.py:126, distillation.py:179, and the third-party
+ *   EfficientNet-B0 1x1 expand/project convs and ResNet-18 BasicBlocks (call sites effnet.py:83,
+ *   inpainting.py:96-103).
+ *   out[m, co] = act( sum_{ky,kx,ci} in[n, oy*s - pad_t + ky, ox*s - pad_l + kx, ci] * a_scale[n,ci]
+ *                     * w[co, ky, kx, ci]  + bias[co] + res[m, co] ) * row_mask[m]
+ * `wpk` is the packed weight produced by creste_conv_pack_weight_f32 (GEMM B operand,
+ * [cout_pad][KH*KW*cin_pad], zero padded), NOT the torch OIHW tensor. */
+typedef struct creste_conv_desc {
+  const float* in;       /* [N,H,W,in_cs] */
+  const void* wpk;       /* packed weights (f32 or bf16 according to `prec`) */
+  const float* bias;     /* [Cout] or NULL */
+  const float* res;      /* [N,Ho,Wo,res_cs] residual added before the activation, or NULL */
+  const float* a_scale;  /* [N,Cin] per-sample input-channel gate (squeeze-excite), or NULL */
+  const float* row_mask; /* [N*Ho*Wo] multiplied into every output row after the activation, or NULL */
+  float* out;            /* [N,Ho,Wo,out_cs], written at channel offset out_co */
+  int32_t N, H, W, Cin, in_cs;
+  int32_t Ho, Wo, Cout, out_cs, out_co, res_cs;
+  int32_t KH, KW, stride, pad_t, pad_l;
+  int32_t act;  /* CRESTE_ACT_* */
+  int32_t prec; /* CRESTE_PREC_* */
+} creste_conv_desc;
+
+int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream);
+/* Size in BYTES of the packed weight for (Cout,Cin,KH,KW) at precision `prec`. */
+int64_t creste_conv_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int prec);
+/* Pack a torch OIHW fp32 weight (device pointer, contiguous) into the GEMM layout, optionally
+ * scaling output channel co by scale[co] (the folded BatchNorm gamma/sqrt(var+eps)). */
+int creste_conv_pack_weight(const float* w_oihw, const float* scale, void* wpk, int Cout, int Cin,
+                            int KH, int KW, int prec, void* stream);
+
+/* Depthwise KxK conv + bias + activation (EfficientNet MBConv `_depthwise_conv` + `_bn1` + swish,
+ * third-party; static asymmetric "same" padding).  w is [KH*KW][C] (tap-major), BN pre-folded. */
+int creste_dwconv2d_nhwc_f32(const float* in, const float* w, const float* bias, float* out, int N,
+                             int H, int W, int C, int Ho, int Wo, int K, int stride, int pad_t,
+                             int pad_l, int act, void* stream);
+
+/* Squeeze-excite gate of an MBConv block: gate[n,c] = sigmoid(W2 * swish(W1 * mean_hw(x) + b1) + b2).
+ * `partial` is caller workspace of at least N*creste_se_partial_rows(H*W)*C floats. */
+int creste_se_partial_rows(int HW);
+int creste_se_gate_f32(const float* x, float* partial, const float* w1, const float* b1,
+                       const float* w2, const float* b2, float* gate, int N, int HW, int C, int Cse,
+                       void* stream);
+
+/* out[..., 0:C2] = skip ; out[..., C2:C2+C1] = bilinear_upsample(x1) (align_corners=False, PyTorch
+ * source-index rule src = rs*(dst+0.5)-0.5 clamped at 0).  reference effnet.py:25-28
+ * (nn.Upsample + torch.cat) and inpainting.py:57-58.  skip may be NULL (C2 = 0). */
+int creste_upsample_concat_nhwc_f32(const float* x1, int N, int H1, int W1, int C1, int x1_cs,
+                                    const float* skip, int C2, int skip_cs, float* out, int Ho,
+                                    int Wo, int out_cs, int out_co, float rh, float rw, void* stream);
+
+/* 2x2/2 max pool over rows [0, Ho) of the pooled map (F.max_pool2d; vin.py:104-109 crops the
+ * pooled map to its first H//2 rows -> pass Ho = H//4). */
+int creste_maxpool2_nhwc_f32(const float* in, int N, int H, int W, int C, int in_cs, float* out,
+                             int Ho, int Wo, int out_cs, void* stream);
+
+/* y = act(x*scale[c] + shift[c]): an eval-mode BatchNorm that FOLLOWS a ReLU (MultiScaleFCN trunk,
+ * reference conv.py:118-128: conv -> ReLU -> BN -> ReLU) and so cannot be folded into the conv. */
+int creste_affine_act_nhwc_f32(const float* x, int x_cs, const float* scale, const float* shift,
+                               float* out, int out_cs, int64_t P, int C, int act, void* stream);
+
+/* Bilinear resize of single-channel planes [N,H,W] into rows [0,Ho) of [N,Hd,Wo] planes
+ * (F.interpolate(size=...), reference vin.py:121-125 `traversability_preds_full`). */
+int creste_resize_plane_f32(const float* in, int N, int H, int W, float* out, int Ho, int Wo, int Hd,
+                            float rh, float rw, void* stream);
+
+/* layout changes at the module boundary (the reference's tensors are NCHW); out may be a channel
+ * slice of a wider NHWC buffer (pixel stride out_cs). */
+int creste_nchw_to_nhwc_f32(const float* in, float* out, int out_cs, int N, int C, int H, int W,
+                            void* stream);
+int creste_nhwc_to_nchw_f32(const float* in, int in_cs, float* out, int N, int C, int H, int W,
+                            void* stream);
+
+/* Depth-bin logits -> metric depth + argmax bin.  reference depth.py:61-100,129-130 and
+ * depth_utils.py:300-313: depth_m = sum_c softmax(logits)_c * bin_values[c] / 1000. */
+int creste_depth_expectation_f32(const float* logits, int cs, int64_t P, int nbins,
+                                 const float* bin_values, float* depth_m, int64_t* bins,
+                                 void* stream);
+
+/* pixel -> LiDAR point, range mask and z-embedding MLP.  reference splat_projection.py:37-49
+ * (c=[u*d, v*d, d, 1]; xyz = p2p @ c as an fma chain k=0..3), :98-104,:152-157 (z MLP 1->2Z->Z,
+ * ReLU,ReLU), :169 (min_bound <= xyz < max_bound).  zfeat is written at channel offset z_co of a
+ * [B*P, z_cs] buffer. */
+int creste_pixel_geometry_f32(const float* depth, const float* p2p, int B, int Hs, int Ws,
+                              const float* bounds6, const float* w1, const float* b1,
+                              const float* w2, const float* b2, int zhid, int zdim, float* xyz,
+                              float* mask, float* zfeat, int z_cs, int z_co, void* stream);
+
+/* Depth-guided camera->BEV bilinear voxel pooling (mean).  reference splat_projection.py:185-187
+ * (lidar2map, /voxel), :293-352 (floor, 4 taps, scatter-add of weights and weighted features,
+ * / clamp(density, 1)).  Gather formulation: points are binned by base cell, each BEV cell then
+ * sums its (<=4 source cells') points -- no float atomics, every output cell written once.
+ *   xyz     [B,P,3]   LiDAR points (from creste_pixel_geometry_f32)
+ *   feats   [B,P,F]   fused, already range-masked features (pixel stride feats_cs)
+ *   coords  [B,P,2]   OUT un-floored (X,Y) voxel coordinates (bev_coords)
+ *   bev     [B,GH,GW,F] OUT, dens [B,GH,GW] OUT
+ *   work    caller workspace, creste_bev_splat_workspace_bytes(B,P,GH,GW) bytes */
+int64_t creste_bev_splat_workspace_bytes(int B, int P, int GH, int GW);
+int creste_bev_splat_f32(const float* xyz, const float* feats, int feats_cs, int B, int P, int F,
+                         float off_x, float off_y, float vox_x, float vox_y, int GH, int GW,
+                         float min_weight, float* coords, float* bev, float* dens, void* work,
+                         void* stream);
+
+/* Value iteration on the 8-connected grid MDP.  reference vin.py:36-46 (transition kernel),
+ * :48-80 (Jacobi sweeps, hard-max backup, batch-global convergence test, final q + softmax).
+ *   r [B,H,W] -> v [B,H,W], q [B,8,H,W], policy [B,8,H,W]; *sweeps_out (device int) = sweep count.
+ *   work: creste_value_iteration_workspace_bytes(B,H,W) bytes. */
+int64_t creste_value_iteration_workspace_bytes(int B, int H, int W);
+int creste_value_iteration_f32(const float* r, int B, int H, int W, float discount, float threshold,
+                               int max_sweeps, float* v, float* q, float* policy, int32_t* sweeps_out,
+                               void* work, void* stream);
+
+/* Expected state-visitation frequency + greedy rollout.  reference lfd.py:156-277,
+ * train_utils.py:765-803.
+ *   policy [B,8,H,W]; expert_xy [B,T,2] (full-resolution BEV row,col as float); fov [H,W] u8.
+ *   -> exp_svf [B,H,W], state_preds [B,T,2] int64, state_grid [B,H,W].
+ *   sharp_policy: workspace [B,8,H,W] floats (the temperature-sharpened policy). */
+int creste_expected_svf_f32(const float* policy, const float* expert_xy, const uint8_t* fov, int B,
+                            int H, int W, int T, float ds, float temperature, int sharpen,
+                            int zero_terminal, float* sharp_policy, float* exp_svf,
+                            int64_t* state_preds, float* state_grid, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRESTE_HIP_H */

@@ -1,0 +1,59 @@
+"""CPU: the C-ABI library builds/loads and exports every symbol include/creste_hip.h declares
+(no compute calls -- there is no GPU here), and the product path refuses to run without it."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from creste_public_amd import _lib
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "creste_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(creste_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    if not os.path.exists(_lib.LIB_PATH):
+        from creste_public_amd.build import build
+        build(verbose=False)
+    names = declared_symbols()
+    assert len(names) >= 20
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in creste_hip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in _lib.SIGNATURES"
+    assert sorted(_lib.SIGNATURES) == names
+    handle = _lib.load()
+    assert handle.creste_abi_version() == 1
+    # pure-host queries work without a GPU
+    assert handle.creste_conv_packed_weight_bytes(496, 496, 3, 3, 0) == 512 * 9 * 496 * 4
+    assert handle.creste_bev_splat_workspace_bytes(1, 100, 256, 256) > 0
+    assert handle.creste_se_partial_rows(4096) == 2
+
+
+def test_argument_errors_are_reported_not_thrown():
+    handle = _lib.load()
+    rc = handle.creste_conv2d_nhwc(None, None)
+    assert rc == -1 and b"null descriptor" in handle.creste_last_error()
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("CRESTE_HIP_LIB", "/nonexistent/libcreste_hip.so")
+    with pytest.raises(_lib.HipLibraryError):
+        _lib.load()
+    monkeypatch.delenv("CRESTE_HIP_LIB")
+    monkeypatch.setattr(_lib, "_lib", None)
+    _lib.load()
+
+
+def test_cpu_tensors_are_rejected():
+    from creste_public_amd import ops
+    with pytest.raises(_lib.HipLibraryError):
+        ops.nchw_to_nhwc(torch.zeros(1, 4, 8, 8))

@@ -1,0 +1,225 @@
+"""GPU: each HIP kernel, called through the C ABI, against a plain PyTorch-CPU fp32 statement of the
+same op (dense ops) or against the reference-generated golden vectors (splat / VI / SVF)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from creste_public_amd import ops as o
+    o._lib.load()
+    return o
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def to_act(ops, x_nchw):
+    return ops.nchw_to_nhwc(dev(x_nchw))
+
+
+def from_act(a):
+    return a.nchw().contiguous().cpu()
+
+
+CONV_CASES = [
+    # N, Cin, H, W, Cout, K, stride, pad(t,b,l,r), act, bias, bn, res
+    (2, 4, 19, 23, 32, 3, 2, (0, 1, 0, 1), 2, False, True, False),     # stem-like, asymmetric pad, swish
+    (1, 496, 9, 11, 496, 3, 1, (1, 1, 1, 1), 1, False, True, False),   # up3-like channels (not /32)
+    (2, 24, 12, 10, 144, 1, 1, (0, 0, 0, 0), 2, False, True, False),   # expand 1x1
+    (2, 144, 12, 10, 24, 1, 1, (0, 0, 0, 0), 0, False, True, True),    # project 1x1 + residual
+    (1, 96, 20, 20, 64, 7, 2, (3, 3, 3, 3), 1, False, True, False),    # BEV stem 7x7/2
+    (3, 40, 8, 16, 64, 5, 1, (2, 2, 2, 2), 1, False, True, False),     # reward prepool 5x5
+    (1, 128, 16, 16, 6, 1, 1, (0, 0, 0, 0), 0, True, False, False),    # proj with bias, tiny Cout
+    (1, 48, 8, 8, 1, 1, 1, (0, 0, 0, 0), 1, False, True, False),       # postpool Cout=1
+    (2, 64, 17, 13, 128, 3, 2, (1, 1, 1, 1), 1, False, True, False),   # resnet stride-2
+    (1, 256, 130, 3, 128, 3, 1, (1, 1, 1, 1), 1, False, True, False),  # M not a multiple of 128
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_igemm(ops, case):
+    N, Cin, H, W, Cout, K, s, pad, act, use_bias, use_bn, use_res = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g) if use_bias else None
+    bn = None
+    if use_bn:
+        bn = (torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1,
+              torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5, 1e-3)
+    xp = F.pad(x, (pad[2], pad[3], pad[0], pad[1]))
+    ref = F.conv2d(xp.double(), w.double(), None if b is None else b.double(), stride=s)
+    if bn is not None:
+        ref = F.batch_norm(ref, bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(), False, 0.0, bn[4])
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if res is not None:
+        ref = ref + res.double()
+    ref = {0: lambda t: t, 1: F.relu, 2: lambda t: t * torch.sigmoid(t)}[act](ref)
+
+    pc = ops.pack_conv(dev(w), None if b is None else dev(b),
+                       None if bn is None else tuple(dev(t) if isinstance(t, torch.Tensor) else t for t in bn),
+                       s, pad, act)
+    out = ops.conv2d(to_act(ops, x), pc, res=None if res is None else to_act(ops, res))
+    got = from_act(out)
+    assert got.shape == ref.shape
+    torch.testing.assert_close(got.double(), ref, rtol=2e-5, atol=2e-5)
+
+
+def test_conv_slices_gate_and_rowmask(ops):
+    """channel-slice input/output (zero-copy concat), SE gate on the A operand, row mask epilogue."""
+    g = torch.Generator().manual_seed(5)
+    N, H, W = 2, 7, 9
+    x = torch.randn(N, 40, H, W, generator=g)
+    gate = torch.rand(N, 24, generator=g)
+    mask = (torch.rand(N * H * W, generator=g) > 0.3).float()
+    w = torch.randn(16, 24, 1, 1, generator=g) / 5
+    ref = F.conv2d(x[:, 8:32] * gate.view(N, 24, 1, 1), w) * mask.view(N, 1, H, W)
+    xa = to_act(ops, x).slice(8, 24)
+    outbuf = ops.Act.empty(N, H, W, 16, "cuda", cs=48)
+    outbuf.buf.fill_(-7.0)
+    pc = ops.pack_conv(dev(w), None, None, 1, 0, 0)
+    ops.conv2d(xa, pc, out=outbuf.slice(20, 16), a_scale=dev(gate), row_mask=dev(mask))
+    full = outbuf.buf.cpu()
+    torch.testing.assert_close(full[..., 20:36].permute(0, 3, 1, 2), ref, rtol=2e-5, atol=2e-5)
+    assert (full[..., :20] == -7).all() and (full[..., 36:] == -7).all()
+
+
+@pytest.mark.parametrize("K,s,pad", [(3, 1, (1, 1, 1, 1)), (3, 2, (0, 1, 0, 1)), (5, 2, (1, 2, 1, 2)),
+                                     (5, 1, (2, 2, 2, 2))])
+def test_dwconv(ops, K, s, pad):
+    g = torch.Generator().manual_seed(K * 10 + s)
+    N, Cc, H, W = 2, 96, 21, 17
+    x = torch.randn(N, Cc, H, W, generator=g)
+    w = torch.randn(Cc, 1, K, K, generator=g) / K
+    b = torch.randn(Cc, generator=g)
+    ref = F.conv2d(F.pad(x, (pad[2], pad[3], pad[0], pad[1])), w, b, stride=s, groups=Cc)
+    ref = ref * torch.sigmoid(ref)
+    wt = w.view(Cc, K * K).t().contiguous()
+    out = ops.dwconv2d(to_act(ops, x), dev(wt), dev(b), K, s, pad, ops.ACT_SWISH)
+    torch.testing.assert_close(from_act(out), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("Cc,Cse,HW", [(32, 8, (40, 52)), (96, 4, (64, 70)), (1152, 48, (5, 7))])
+def test_se_gate(ops, Cc, Cse, HW):
+    g = torch.Generator().manual_seed(Cc)
+    N = 3
+    x = torch.randn(N, Cc, *HW, generator=g)
+    w1, b1 = torch.randn(Cse, Cc, generator=g) / Cc ** 0.5, torch.randn(Cse, generator=g)
+    w2, b2 = torch.randn(Cc, Cse, generator=g) / Cse ** 0.5, torch.randn(Cc, generator=g)
+    m = x.double().mean(dim=(2, 3))
+    h = m @ w1.double().t() + b1.double()
+    h = h * torch.sigmoid(h)
+    ref = torch.sigmoid(h @ w2.double().t() + b2.double())
+    got = ops.se_gate(to_act(ops, x), dev(w1), dev(b1), dev(w2), dev(b2)).cpu()
+    torch.testing.assert_close(got.double(), ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("sf", [2, 4, (128 / 64, 153 / 76)])
+def test_upsample_concat(ops, sf):
+    g = torch.Generator().manual_seed(3)
+    H1, W1 = (64, 76) if isinstance(sf, tuple) else (9, 11)
+    x1 = torch.randn(2, 8, H1, W1, generator=g)
+    up = torch.nn.Upsample(scale_factor=sf, mode="bilinear", align_corners=False)(x1)
+    Ho, Wo = up.shape[-2:]
+    skip = torch.randn(2, 4, Ho, Wo, generator=g)
+    ref = torch.cat([skip, up], dim=1)
+    sfh, sfw = sf if isinstance(sf, tuple) else (sf, sf)
+    rh, rw = np.float32(1.0 / sfh), np.float32(1.0 / sfw)     # torch: scale = (float)(1.0 / scale_factor)
+    out = ops.upsample_concat(to_act(ops, x1), to_act(ops, skip), Ho, Wo, rh, rw)
+    torch.testing.assert_close(from_act(out), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_maxpool_affine_resize(ops):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 40, 16, 24, generator=g)
+    ref = F.max_pool2d(x, 2, 2)[:, :, :4]
+    out = ops.maxpool2(to_act(ops, x), Ho=4, Wo=12)
+    assert torch.equal(from_act(out), ref)
+    sc, sh = torch.rand(40, generator=g) + 0.5, torch.randn(40, generator=g)
+    ref2 = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    torch.testing.assert_close(from_act(ops.affine_act(to_act(ops, x), dev(sc), dev(sh), ops.ACT_RELU)), ref2,
+                               rtol=1e-6, atol=1e-6)
+    r = torch.rand(3, 1, 8, 16, generator=g)
+    full = torch.zeros(3, 1, 32, 32)
+    full[:, :, :16] = F.interpolate(r, size=(16, 32), mode="bilinear", align_corners=False)
+    o = torch.zeros(3, 32, 32, device="cuda")
+    ops.resize_plane(dev(r[:, 0]), 16, 32, 32, 0.5, 0.5, o)
+    torch.testing.assert_close(o.cpu(), full[:, 0], rtol=1e-6, atol=1e-6)
+
+
+def test_depth_expectation(ops, golden):
+    g = golden("utils.npz")
+    logits = g.t("logits")                                     # [2,128,6,7]
+    bins_v = torch.linspace(300, 25600, 128)
+    d, b = ops.depth_expectation(to_act(ops, logits), dev(bins_v))
+    torch.testing.assert_close(d.cpu() * 1000, g.t("metric_depth_mm"), rtol=1e-5, atol=1e-3)
+    assert torch.equal(b.cpu(), logits.argmax(dim=1))
+
+
+def _splat_inputs(golden, name):
+    g = golden(name)
+    sd = golden("splat_small.npz").sd()
+    return g, sd
+
+
+@pytest.mark.parametrize("name", ["splat_small.npz", "splat_wide.npz"])
+def test_pixel_geometry_and_splat(ops, golden, name):
+    g, sd = _splat_inputs(golden, name)
+    depth, p2p = g.t("depth"), g.t("p2p")
+    B, _, Hs, Ws = depth.shape
+    bounds = torch.cat([sd["min_bound"].view(-1), sd["max_bound"].view(-1)])
+    zbuf = ops.Act.empty(B, Hs, Ws, 32, "cuda", cs=288)
+    xyz, mask = ops.pixel_geometry(dev(depth[:, 0]), dev(p2p[:, 0]), dev(bounds),
+                                   dev(sd["z_proj.0.weight"].view(-1)), dev(sd["z_proj.0.bias"]),
+                                   dev(sd["z_proj.2.weight"]), dev(sd["z_proj.2.bias"]), zbuf.slice(256, 32))
+    ref_xyz = g.t("xyz")[:, 0].permute(0, 2, 3, 1).reshape(B, Hs * Ws, 3)
+    assert torch.equal(xyz.cpu(), ref_xyz)                     # bit-exact fma chain
+    assert torch.equal(mask.cpu().bool(), g.t("mask").view(B, -1))
+    # z features vs the reference MLP
+    z = ref_xyz[..., 2:3]
+    zf = F.relu(F.linear(F.relu(F.linear(z, sd["z_proj.0.weight"], sd["z_proj.0.bias"])),
+                         sd["z_proj.2.weight"], sd["z_proj.2.bias"]))
+    torch.testing.assert_close(zbuf.buf[..., 256:].cpu().view(B, -1, 32), zf, rtol=1e-5, atol=1e-5)
+
+    # splat of the reference's own fused features -> same coords (bit-exact), same sums (sorted order)
+    fused = (g.t("fused") * g.t("mask"))[:, 0]                 # [B,96,Hs,Ws]
+    fa = to_act(ops, fused)
+    coords, bev, dens = ops.bev_splat(xyz, fa, (12.8, 12.8), (np.float32(0.1), np.float32(0.1)), 256, 256)
+    assert torch.equal(coords.cpu(), g.t("bev_coords"))
+    assert torch.equal(coords.cpu().floor().long(), g.t("bev_coords").floor().long())
+    assert torch.equal(dens.cpu().view(B, 1, 256, 256), g.t("bev_densities"))
+    idx = g.t("touched_idx")
+    got = bev.buf.cpu()[idx[:, 0], idx[:, 1], idx[:, 2]]
+    assert torch.equal(got, g.t("touched_feats"))              # reference summation order reproduced
+    torch.testing.assert_close(bev.buf.abs().sum().cpu(), g.t("bev_features_abs_sum"), rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize("name", ["vi_a.npz", "vi_b.npz"])
+def test_value_iteration(ops, golden, name):
+    g = golden(name)
+    r = g.t("r")[:, 0]
+    v, q, pi, sweeps = ops.value_iteration(dev(r), float(g["discount"]), float(g["threshold"]))
+    n = int(sweeps.item())
+    assert abs(n - int(g["sweeps"])) <= 1, (n, int(g["sweeps"]))
+    torch.testing.assert_close(v.cpu(), g.t("v")[:, 0], rtol=2e-5, atol=2e-3)
+    torch.testing.assert_close(q.cpu(), g.t("q"), rtol=2e-5, atol=2e-3)
+    torch.testing.assert_close(pi.cpu(), g.t("policy"), rtol=0, atol=1e-4)
+    torch.testing.assert_close(pi.sum(dim=1).cpu(), torch.ones_like(r), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,zts", [("svf.npz", False), ("svf_zts.npz", True)])
+def test_expected_svf(ops, golden, name, zts):
+    g = golden(name)
+    pol = golden("vi_b.npz").t("policy")
+    expert = g.t("expert")[:, :, :2, 2].contiguous()
+    fov = g.t("fov_mask")[0, 0].to(torch.uint8)
+    svf, states, grid = ops.expected_svf(dev(pol), dev(expert), dev(fov), 50, 2.0, 0.005, True, zts)
+    assert torch.equal(states.cpu(), g.t("state_preds"))
+    assert torch.equal(grid.cpu(), g.t("state_preds_grid"))
+    torch.testing.assert_close(svf.cpu(), g.t("exp_svf"), rtol=1e-5, atol=1e-6)
