@@ -1,0 +1,147 @@
+"""BEV completion heads: 7x7/2 stem + ResNet-18 layer1..3 + N DeconvHeads, on the HIP conv engine.
+
+Mirrors /root/reference/creste/models/blocks/inpainting.py (Inpainting :9-50, DeconvHead :52-68,
+InpaintingResNet18MultiHead :70-109).  The reference takes layer1..3 from torchvision's resnet18
+(un-vendored; call site inpainting.py:80-90); `BasicBlock` below is a parameter container with
+torchvision's key names (conv1/bn1/conv2/bn2/downsample.0/downsample.1).  Residual add + ReLU are fused
+into the second conv's epilogue; the x4-upsample + concat that feeds every head's `up1` is identical
+for all heads and is computed once.
+"""
+import torch
+from torch import nn
+
+from .... import ops
+from ....hipnn import ACT_NONE, ACT_RELU, Act, ConvUnit, require_hip, up_out_size, up_scales
+from .effnet import Up
+
+
+def prefix_dict(prefix, d, seprator="/"):
+    return {prefix + seprator + k: v for k, v in d.items()}
+
+
+class Inpainting(nn.Module):
+    """dict-in / dict-out wrapper with key prefixing (reference inpainting.py:9-50)."""
+
+    def __init__(self, input_key=None, output_prefix=None, learnable_loss_weight=False):
+        super().__init__()
+        self.input_key = input_key or "merged_bev_features"
+        self.output_prefix = output_prefix or "inpainting"
+        self.log_var = nn.Parameter(torch.tensor([0.0])) if learnable_loss_weight else None
+
+    def _wrap(self, out, key_suffix=""):
+        if isinstance(out, list):
+            assert isinstance(self.output_prefix, list) and len(out) == len(self.output_prefix)
+            ret = {}
+            for p, o in zip(self.output_prefix, out):
+                if p == "inpainting_sam":
+                    p = f"{p}{key_suffix}"
+                ret.update(prefix_dict(p, o, seprator="_"))
+            return ret
+        assert isinstance(out, dict)
+        return prefix_dict(f"{self.output_prefix}{key_suffix}", out, seprator="_")
+
+    def forward(self, tensor_dict, key_suffix=""):
+        out = self._forward(tensor_dict[f"{self.input_key}{key_suffix}"])
+        if self.log_var is not None:
+            out["log_variance"] = self.log_var
+        return self._wrap(out, key_suffix)
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        nn.init.constant_(self.bn2.weight, 0)            # zero_init_residual=True (inpainting.py:80)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False),
+                                            nn.BatchNorm2d(cout))
+        self._u = None
+
+    def forward_act(self, x: Act) -> Act:
+        if self._u is None:
+            self._u = (ConvUnit(self.conv1, self.bn1, ACT_RELU), ConvUnit(self.conv2, self.bn2, ACT_RELU),
+                       ConvUnit(self.downsample[0], self.downsample[1], ACT_NONE)
+                       if self.downsample is not None else None)
+        c1, c2, ds = self._u
+        idt = ds(x) if ds is not None else x
+        return c2(c1(x), res=idt)                        # relu(bn2(conv2(.)) + identity)
+
+
+class DeconvHead(nn.Module):
+    def __init__(self, in_ch, out_ch, norm_layer):
+        super().__init__()
+        self.up1 = Up(in_ch, 256, scale_factor=4, norm_layer=norm_layer)
+        self.up2 = nn.Sequential(nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False),
+                                 nn.Conv2d(256, 128, kernel_size=3, padding=1, bias=False),
+                                 norm_layer(128), nn.ReLU(inplace=True))
+        self.proj = nn.Conv2d(128, out_ch, kernel_size=1, padding=0)
+        self._u = None
+
+    def from_concat_act(self, cat: Act, pred_out: Act = None):
+        """cat = [x2 | up4(x1)] (shared by all heads) -> (preds, features)."""
+        if self._u is None:
+            self._u = (ConvUnit(self.up2[1], self.up2[2], ACT_RELU), ConvUnit(self.proj, None, ACT_NONE))
+        c3, proj = self._u
+        h = self.up1.convs_act(cat)
+        sf, (rh, rw) = up_scales(self.up2[0].scale_factor)
+        Ho, Wo = up_out_size(h.H, h.W, sf)
+        feat = c3(ops.upsample_concat(h, None, Ho, Wo, rh, rw))
+        return proj(feat, out=pred_out), feat
+
+    def forward_act(self, x1: Act, x2: Act):
+        return self.from_concat_act(self.up1.concat_act(x1, x2))
+
+    def forward(self, x1, x2):
+        require_hip(x1, "DeconvHead")
+        p, f = self.forward_act(ops.nchw_to_nhwc(x1.contiguous()), ops.nchw_to_nhwc(x2.contiguous()))
+        return p.nchw(), f.nchw()
+
+
+class InpaintingResNet18MultiHead(Inpainting):
+    def __init__(self, num_input_features, num_classes, norm_layer="batch_norm", **kwargs):
+        super().__init__(**kwargs)
+        if norm_layer != "batch_norm":
+            raise Exception("Unsupported norm layer:", norm_layer)
+        nl = nn.BatchNorm2d
+        self.conv1 = nn.Conv2d(num_input_features, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nl(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.layer1 = nn.Sequential(BasicBlock(64, 64, 1), BasicBlock(64, 64, 1))
+        self.layer2 = nn.Sequential(BasicBlock(64, 128, 2), BasicBlock(128, 128, 1))
+        self.layer3 = nn.Sequential(BasicBlock(128, 256, 2), BasicBlock(256, 256, 1))
+        self.out_heads = nn.ModuleList([DeconvHead(64 + 256, n, nl) for n in num_classes])
+        self.num_classes = list(num_classes)
+        self._stem = None
+
+    def forward_act(self, bev: Act, preds_buf: Act = None):
+        """bev [B,G,G,F] -> list of dict(preds=Act, features=Act).  When `preds_buf` (an Act with
+        sum(num_classes) channels) is given, every head's 1x1 projection writes its slice of it, so the
+        reward network's channel-concatenated input exists without a copy."""
+        if self._stem is None:
+            self._stem = ConvUnit(self.conv1, self.bn1, ACT_RELU)
+        x = self._stem(bev)
+        for blk in self.layer1:
+            x = blk.forward_act(x)
+        x1 = x
+        for blk in list(self.layer2) + list(self.layer3):
+            x = blk.forward_act(x)
+        cat = self.out_heads[0].up1.concat_act(x, x1)     # identical for every head: computed once
+        ret, co = [], 0
+        for head, n in zip(self.out_heads, self.num_classes):
+            out = preds_buf.slice(co, n) if preds_buf is not None else None
+            pred, fea = head.from_concat_act(cat, pred_out=out)
+            ret.append(dict(preds=pred, features=fea))
+            co += n
+        return ret
+
+    def _forward(self, x):
+        require_hip(x, "InpaintingResNet18MultiHead")
+        if self.training:
+            raise NotImplementedError("BEV-head training (backward kernels) is not in this round")
+        outs = self.forward_act(ops.nchw_to_nhwc(x.contiguous()))
+        return [dict(preds=o["preds"].nchw(), features=o["features"].nchw()) for o in outs]

@@ -1,0 +1,148 @@
+"""MaxEnt / counterfactual IRL model: frozen TerrainNet + costmap head + MDP solve + expected SVF.
+
+Mirrors /root/reference/creste/models/lfd.py (MaxEntIRL :21-392): constructor config, buffers
+`dynamics` / `transition_probs`, `load_weights`, `expected_state_visitation_frequency`, forward input
+tuple `(image, p2p[, expert])` and output keys.  Value iteration and the 49-step policy propagation +
+greedy rollout are single HIP launches sequences with no per-step host sync (the reference does ~700
+`.item()` syncs per step).  The frozen backbone always runs in eval mode on the HIP path (the reference
+leaves it in train() mode unless `load_weights` ran -- an intentional, documented deviation).
+"""
+import os
+
+import torch
+from torch import nn
+
+from ... import ops
+from ...hipnn import require_hip
+from ..utils import train_utils as tu
+from .blocks.conv import _cfg_get
+from .blocks.vin import VIN
+from .terrainnet import TerrainNet
+
+_DYNAMICS = [[-1, -1], [-1, 0], [-1, 1], [0, -1], [0, 1], [1, -1], [1, 0], [1, 1]]
+
+
+class MaxEntIRL(nn.Module):
+    def __init__(self, model_cfg):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.backbone_cfg = model_cfg["vision_backbone"]
+        self.traversability_head_cfg = model_cfg["traversability_head"]
+        self.policy_cfg = _cfg_get(model_cfg, "policy_kwargs", {})
+        self.ckpt_path = _cfg_get(model_cfg, "ckpt_path", "")
+        self.weights_path = _cfg_get(model_cfg, "weights_path", "")
+        self.map_size = list(_cfg_get(model_cfg, "map_size", [64, 128]))
+        self.policy_method = _cfg_get(model_cfg, "policy_method", "fc")
+        self.goal_cfg = _cfg_get(model_cfg, "goal_kwargs", {})
+        self.action_horizon = _cfg_get(model_cfg, "action_horizon")
+        self.solve_mdp = _cfg_get(model_cfg, "solve_mdp", False)
+        self.zero_terminal_state = _cfg_get(model_cfg, "zero_terminal_state", False)
+        if self.policy_method != "pp":
+            raise NotImplementedError("policy_method 'fc' (iterative_policy_rollout) is not used by the "
+                                      "shipped configs; the HIP path implements 'pp'")
+        self.register_buffer("dynamics", torch.tensor(_DYNAMICS, dtype=torch.long))
+        H, W = self.map_size
+        fov = tu.create_trapezoidal_fov_mask(H * 2, W, 70, 70, 0, 100).view(1, 1, H * 2, W)
+        self.fov_mask = fov[:, :, :H, :W]
+        tp = torch.zeros(8, 1, 3, 3)
+        for a, (dr, dc) in enumerate(_DYNAMICS):          # the previous cell sits opposite the move
+            tp[a, 0, 1 - dr, 1 - dc] = 1.0
+        self.register_buffer("transition_probs", tp)
+
+        if "TerrainNet" not in self.backbone_cfg["project_name"]:
+            raise ValueError(f"Model {self.backbone_cfg['project_name']} not found.")
+        if self.backbone_cfg["load_setting"] not in ("strict_freeze", "strict_unfreezesplat"):
+            self.backbone_cfg["load_setting"] = "strict_freeze"       # lfd.py:80-83
+        self.backbone = TerrainNet(self.backbone_cfg)
+        wp = self.backbone_cfg["weights_path"]
+        if wp and os.path.exists(wp):
+            self.backbone.load_weights(wp)
+        if self.traversability_head_cfg["value_iterator"] != "VIN":
+            raise NotImplementedError(self.traversability_head_cfg["value_iterator"])
+        nk = self.traversability_head_cfg["net_kwargs"]
+        self.traversability_head = VIN(nk["reward_cfg"], nk["qvalue_cfg"])
+        self.freeze_backbone = _cfg_get(model_cfg, "freeze_backbone", True)
+        self.freeze_head = _cfg_get(model_cfg, "freeze_head", False)
+        self.load_strict = _cfg_get(model_cfg, "load_strict", True)
+        for p in self.backbone.parameters():              # the perception backbone is frozen for IRL
+            p.requires_grad = False
+        self.backbone.eval()
+        self._fov_u8 = None
+        if self.weights_path and os.path.isfile(self.weights_path) and not os.path.isfile(self.ckpt_path or ""):
+            self.load_weights(self.weights_path)
+
+    def train(self, mode: bool = True):
+        super().train(mode)
+        self.backbone.eval()          # frozen + folded BN on the HIP path (see module docstring)
+        if self.freeze_head and getattr(self, "_head_frozen", False):
+            self.traversability_head.eval()
+        return self
+
+    def _state_to_coord(self, state, vectorized=False):
+        if vectorized:
+            return torch.stack([state // self.map_size[1], state % self.map_size[1]], dim=1)
+        return torch.tensor([state // self.map_size[1], state % self.map_size[1]], dtype=torch.long)
+
+    def _coord_to_state(self, coord, vectorized=False):
+        return coord[:, 0] * self.map_size[1] + coord[:, 1] if vectorized else coord[0] * self.map_size[1] + coord[1]
+
+    def load_weights(self, weights_path):
+        sd = torch.load(weights_path, weights_only=False)["state_dict"]
+        sd = {k.replace("model.", "", 1): v for k, v in sd.items() if k.startswith("model.")}
+        self.load_state_dict(sd, strict=self.load_strict)
+        if self.freeze_backbone:
+            self.backbone.eval()
+            for p in self.backbone.parameters():
+                p.requires_grad = False
+        if self.freeze_head:
+            self._head_frozen = True
+            self.traversability_head.eval()
+            for p in self.traversability_head.parameters():
+                p.requires_grad = False
+
+    def expected_state_visitation_frequency(self, policy, expert):
+        """policy [B,8,H,W], expert [B,T,3,3] -> exp_svf, state_preds_grid, state_preds (lfd.py:156-277)."""
+        require_hip(policy, "expected_state_visitation_frequency")
+        B, A, H, W = policy.shape
+        ds = self.traversability_head_cfg["net_kwargs"]["reward_cfg"]["ds"]
+        method = self.policy_cfg["method"]
+        if method not in ("sharpen", "none"):
+            raise ValueError(f"Policy method {method} not found.")
+        if self._fov_u8 is None or self._fov_u8.device != policy.device:
+            self._fov_u8 = self.fov_mask[0, 0].to(torch.uint8).to(policy.device).contiguous()
+        assert tuple(self._fov_u8.shape) == (H, W), "policy grid and fov mask disagree"
+        xy = expert[:, :, :2, 2].float().contiguous()
+        svf, states, grid = ops.expected_svf(
+            policy.contiguous().float(), xy, self._fov_u8, self.action_horizon, float(ds),
+            float(_cfg_get(self.policy_cfg, "temperature", 1.0)), method == "sharpen",
+            bool(self.zero_terminal_state))
+        return {"exp_svf": svf, "state_preds_grid": grid, "state_preds": states}
+
+    def forward(self, inputs):
+        image, p2p = inputs[0], inputs[1]
+        require_hip(image, "MaxEntIRL")
+        B = image.shape[0]
+        r = self.backbone.forward_act(image, p2p)
+        outputs = self.backbone.pack_outputs(r, B)
+        head = self.traversability_head
+        Ho, Wo = r["preds_buf"].H, r["preds_buf"].W
+        keys = head.reward_cfg["input_keys"]
+        want = [f"{p}_preds" for p in self.backbone.bevclassifier.output_prefix]
+        if list(keys) != want:
+            raise NotImplementedError(f"reward input_keys {list(keys)} must be the BEV heads' preds {want}")
+        view = head.input_view_act(r["preds_buf"])
+        if not self.solve_mdp:
+            outputs.update(head.forward_from_view(view, Ho, Wo, None, False))
+            return outputs
+        assert len(inputs) > 2, "Goal location required for MDP solver"
+        expert = inputs[2]
+        map_ds = Wo // self.map_size[1]
+        S = expert[:, :, :2, 2].long() // map_ds
+        S[:, :, 0] = S[:, :, 0].clamp(0, self.map_size[0] - 1)
+        S[:, :, 1] = S[:, :, 1].clamp(0, self.map_size[1] - 1)
+        if "method" in self.goal_cfg:
+            raise NotImplementedError("goal maps (goal_kwargs) are not used by the shipped configs")
+        outputs.update(head.forward_from_view(view, Ho, Wo, S, solve_mdp=True))
+        with torch.no_grad():
+            outputs.update(self.expected_state_visitation_frequency(outputs["policy"], expert))
+        return outputs

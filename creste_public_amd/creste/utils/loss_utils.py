@@ -1,0 +1,163 @@
+"""Loss layer of the IRL step -- mirrors /root/reference/creste/utils/loss_utils.py: Loss (:25-60),
+LossManager (:63-91) and MaxEntIRLLoss (:971-1259, with the second `compute_expert_visitation`,
+:1054-1116, the one Python actually binds).  Device-agnostic torch autograd code: the objective is a
+handful of reductions over [B,64,128] maps plus a double backward through the reward network, which
+stays on stock autograd ops.  Inputs `exp_svf`, `traversability_preds`, `input_view` come
+from the HIP path."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import train_utils as tu
+
+
+class Loss(nn.Module):
+    def __init__(self, name, config):
+        super().__init__()
+        self.config = config
+        self._name = name + config.get("tag", "")
+        self.weight = config.get("weight", 1.0)
+        self.task = config.get("task", None)
+
+    @property
+    def name(self):
+        return self._name
+
+    def loss(self, tensor_dict):
+        raise Exception("Not Implemented!")
+
+    def forward(self, tensor_dict):
+        loss_dict, meta = self.loss(tensor_dict)
+        out, w = {}, 1.0
+        logvar_key = self.config.get("logvar_key", None)
+        if logvar_key is not None:                       # learned uncertainty weighting
+            log_var = tensor_dict[logvar_key]
+            w = 1.0 / (2.0 * torch.exp(log_var))
+            out["log_std"] = (1.0, 0.5 * log_var)
+        out.update({k: (self.weight * w, v) for k, v in loss_dict.items()})
+        return out, meta
+
+
+class MaxEntIRLLoss(Loss):
+    def __init__(self, config):
+        super().__init__(config["name"], config)
+        self.pred_key, self.lab_key, self.fov_key = config["pred_key"], config["lab_key"], config["fov_key"]
+        self.map_ds = config.get("map_ds", 2)
+        self.map_sz = config.get("map_sz", [64, 128])
+        self.bandwidth = config.get("bandwidth", 0.2)
+        self.kernel = config.get("kernel", "epanechnikov")
+        self.maxent_weight = config.get("maxent_weight", 1.0)
+        self.reward_weight = config.get("reward_weight", 0.1)
+        self.use_fov_mask = config.get("use_fov_mask", False)
+        self.alpha = config.get("alpha", None)
+        self.cf_key = config.get("cf_key", None)
+
+    @staticmethod
+    def compute_expert_visitation(gt, map_ds, map_sz):
+        """Rasterise expert polylines: every segment is sampled at `max_steps` points (max over the
+        batch of ceil(segment length)), the last pose is appended, points are clamped/truncated to
+        cells and each visited cell counts once.  gt [B,T,3,3] or [B,T,2]."""
+        xy = gt if gt.ndim == 3 else gt[:, :, :2, 2]
+        B = xy.shape[0]
+        H, W = map_sz
+        xy = xy / map_ds
+        seg0, seg1 = xy[:, :-1], xy[:, 1:]
+        max_steps = torch.ceil(torch.norm(seg1 - seg0, dim=-1)).long().max().item()
+        lam = torch.linspace(0, 1, max_steps, device=gt.device).view(1, 1, -1, 1)
+        pts = (seg0.unsqueeze(2) + lam * (seg1 - seg0).unsqueeze(2)).view(B, -1, 2)
+        pts = torch.cat([pts, xy[:, -1:]], dim=1)
+        rows = pts[:, :, 0].clamp(0, H - 1).long()
+        cols = pts[:, :, 1].clamp(0, W - 1).long()
+        lin = rows * W + cols
+        counts = torch.zeros(B, H * W, dtype=torch.float32, device=gt.device)
+        counts.scatter_add_(1, lin, torch.ones_like(lin, dtype=torch.float32))
+        counts = counts.view(B, H, W)
+        counts[counts > 1] = 1
+        return pts, counts
+
+    def loss(self, tensor_dict):
+        exp_svf = tensor_dict[self.pred_key]
+        gt = tensor_dict[self.lab_key]
+        fov_mask = tensor_dict[self.fov_key]
+        reward = tensor_dict["outputs/traversability_preds"].squeeze(1)
+        state_features = tensor_dict["outputs/input_view"]
+        _, Ho, Wo = fov_mask.shape
+        _, H, W = exp_svf.shape
+        fov = tu.resize_and_crop(fov_mask.unsqueeze(1).byte(), (Ho // 2, Wo // 2), (0, H, 0, W))
+        fov = fov.squeeze(1).bool()
+
+        _, svf = self.compute_expert_visitation(gt, self.map_ds, self.map_sz)
+        if self.use_fov_mask:
+            svf = svf * fov.float()
+            exp_svf = exp_svf * fov.float()
+        svf = svf / (svf.sum(dim=(1, 2), keepdim=True) + 1e-5)
+        exp_svf = exp_svf / (exp_svf.sum(dim=(1, 2), keepdim=True) + 1e-5)
+
+        cf_total = torch.zeros_like(svf)
+        policy_svf = exp_svf.clone()
+        if self.cf_key is not None and self.alpha is not None:
+            for i, cf in enumerate(tensor_dict[self.cf_key]):
+                if cf is None:
+                    continue
+                worse = cf["trajectories"][cf["rank"] > 0]          # [n,T,2] sub-optimal alternatives
+                if worse.shape[0] == 0:
+                    continue
+                worse = torch.from_numpy(np.asarray(worse)).to(svf.device)
+                _, cf_svf = self.compute_expert_visitation(worse, self.map_ds, self.map_sz)
+                cf_svf = cf_svf.sum(dim=0)
+                cf_svf = cf_svf / (cf_svf.sum(dim=(0, 1), keepdim=True) + 1e-5)
+                exp_svf[i] = self.alpha * cf_svf + (1 - self.alpha) * exp_svf[i]
+                cf_total[i] = cf_svf
+        assert torch.all(exp_svf >= 0), "Negative expert visitation frequencies"
+        assert torch.all(svf >= 0), "Negative predicted visitation frequencies"
+
+        if self.use_fov_mask:
+            keep = torch.ones_like(reward, dtype=torch.float32)
+            keep[~fov] = 0
+            reward = reward * keep
+        mean_exp = (exp_svf * reward).sum(dim=(1, 2)).mean()
+        mean_svf = (svf * reward).sum(dim=(1, 2)).mean()
+        visitation_loss = mean_exp - mean_svf
+
+        penalty = torch.tensor(0.0, device=svf.device)
+        if reward.requires_grad and self.reward_weight > 0:         # SMODICE-style gradient penalty
+            grad = torch.autograd.grad(outputs=reward.sum(), inputs=state_features, create_graph=True,
+                                       retain_graph=True, only_inputs=True)[0]
+            penalty = ((grad.norm(2, dim=1) - 1) ** 2).mean()
+        total = self.maxent_weight * visitation_loss + self.reward_weight * penalty
+
+        with torch.no_grad():
+            cf_r = (cf_total * reward).sum(dim=(1, 2))
+            opt_r = (policy_svf * reward).sum(dim=(1, 2))
+            has_cf = cf_r != 0
+            cf_r, opt_r = cf_r[has_cf].sum(), opt_r[has_cf].sum()
+        meta = {"reward_penalty": self.reward_weight * penalty, "mean_expected_svf_rewards": mean_exp,
+                "mean_svf_rewards": mean_svf, "sum_cf_rewards": cf_r, "sum_opt_rewards": opt_r}
+        return {"maxentirl_loss": total}, meta
+
+
+_LOSSES = {"MaxEntIRLLoss": MaxEntIRLLoss}
+
+
+class LossManager(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.losses = nn.ModuleList([self.get_loss(lc) for lc in config["loss"]])
+
+    def get_loss(self, config):
+        try:
+            return _LOSSES[config["name"]](config)
+        except KeyError:
+            raise NotImplementedError(
+                f"loss {config['name']}: only the IRL objective is in this round's scope "
+                "(SSC / distillation losses belong to the backbone-training rows, SURVEY.md A12)")
+
+    def forward(self, tensor_dict):
+        loss_dict, meta = {}, {}
+        for l in self.losses:
+            if l.task is None or l.task == tensor_dict["task"]:
+                ld, md = l(tensor_dict)
+                meta.update({f"{l.name}/{k}": v for k, v in md.items()})
+                loss_dict.update({f"{l.name}/{k}": v for k, v in ld.items()})
+        return loss_dict, meta

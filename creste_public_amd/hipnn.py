@@ -1,0 +1,109 @@
+"""Glue between torch parameter containers and the HIP kernels.
+
+The host-side mirror modules (creste_public_amd/creste/...) keep their weights in ordinary
+nn.Conv2d / nn.BatchNorm2d / nn.Linear containers so that the reference's checkpoints load by key
+name.  A `ConvUnit` ties one conv (+ optional eval-mode BatchNorm + activation) to its packed,
+BN-folded GEMM weight on the device; it re-packs when a parameter is replaced or updated in place
+(`tensor._version`), so `load_state_dict` / optimiser steps are picked up automatically.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import ops
+from .ops import ACT_NONE, ACT_RELU, ACT_SWISH, Act, HipLibraryError  # noqa: F401
+
+
+def _sig(tensors):
+    return tuple((t.data_ptr(), t._version, t.device.index) for t in tensors if t is not None)
+
+
+def require_hip(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise HipLibraryError(
+            f"{what}: the CREStE hot path runs on hand-written HIP kernels only; got a "
+            f"{t.device} tensor (there is no CPU fallback -- move model and inputs to the GPU)")
+
+
+def bn_affine(bn: nn.BatchNorm2d):
+    """eval-mode BatchNorm as (scale, shift) fp32 device tensors."""
+    if bn.training:
+        raise NotImplementedError(
+            "BatchNorm in training mode (batch statistics) is not on the HIP path; call .eval() "
+            "on the frozen perception backbone")
+    scale = (bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)).float().contiguous()
+    shift = (bn.bias.detach() - bn.running_mean * scale).float().contiguous()
+    return scale, shift
+
+
+class ConvUnit:
+    """conv (+ folded BN) (+ activation) with a cached packed weight."""
+
+    def __init__(self, conv: nn.Conv2d, bn: nn.BatchNorm2d | None, act: int, pad=None):
+        self.conv, self.bn, self.act = conv, bn, act
+        k = conv.kernel_size
+        assert k[0] == k[1] and conv.stride[0] == conv.stride[1] and conv.groups == 1
+        if pad is None:
+            p = conv.padding
+            pad = (p[0], p[0], p[1], p[1])
+        self.pad = pad                    # (top, bottom, left, right)
+        self._packed = None
+        self._key = None
+
+    def _tensors(self):
+        ts = [self.conv.weight, self.conv.bias]
+        if self.bn is not None:
+            ts += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+        return ts
+
+    def packed(self) -> ops.PackedConv:
+        key = _sig(self._tensors())
+        if self._packed is None or key != self._key:
+            require_hip(self.conv.weight, "conv weight")
+            bn = None
+            if self.bn is not None:
+                if self.bn.training:
+                    raise NotImplementedError(
+                        "BatchNorm in training mode is not on the HIP path (eval-mode folding only)")
+                b = self.bn
+                bn = (b.weight, b.bias, b.running_mean, b.running_var, b.eps)
+            self._packed = ops.pack_conv(self.conv.weight, self.conv.bias, bn, self.conv.stride[0],
+                                         self.pad, self.act)
+            self._key = key
+        return self._packed
+
+    def __call__(self, x: Act, out: Act | None = None, res: Act | None = None, a_scale=None,
+                 row_mask=None) -> Act:
+        return ops.conv2d(x, self.packed(), out=out, res=res, a_scale=a_scale, row_mask=row_mask)
+
+
+class Cached:
+    """Small cache of derived device tensors keyed on the source tensors' identity/version."""
+
+    def __init__(self, sources, build):
+        self.sources, self.build = sources, build
+        self._val, self._key = None, None
+
+    def get(self):
+        src = self.sources()
+        key = _sig(src)
+        if self._val is None or key != self._key:
+            for t in src:
+                if t is not None:
+                    require_hip(t, "parameter")
+            self._val, self._key = self.build(), key
+        return self._val
+
+
+def up_scales(scale_factor):
+    """nn.Upsample(scale_factor=..) -> (sf_h, sf_w) and PyTorch's source-index scales (float32 of the
+    double reciprocal, ATen area_pixel_compute_scale with an explicit scale factor)."""
+    import numpy as np
+    sfh, sfw = scale_factor if isinstance(scale_factor, (tuple, list)) else (scale_factor, scale_factor)
+    return (float(sfh), float(sfw)), (np.float32(1.0 / float(sfh)), np.float32(1.0 / float(sfw)))
+
+
+def up_out_size(h, w, sf):
+    import math
+    return int(math.floor(h * sf[0])), int(math.floor(w * sf[1]))

@@ -1,0 +1,281 @@
+"""GPU: the HIP-backed host modules (creste_public_amd.creste.*) against the CPU oracle on identical
+weights and inputs -- full TerrainNet / MaxEntIRL forward, every output-dict key."""
+import pytest
+import torch
+
+from creste_public_amd import synth
+from creste_public_amd.config import maxent_irl_cfg, terrainnet_cfg
+
+pytestmark = pytest.mark.gpu
+
+H, W, B = 128, 192, 2
+
+
+@torch.no_grad()
+def calibrate_bn(oracle_model, run):
+    """Give a randomly initialised network the BatchNorm statistics of a trained one: one train-mode
+    pass with cumulative-average momentum stores the batch statistics, so eval-mode activations are
+    O(1) at every layer (raw millimetre depth enters the stem un-normalised)."""
+    bns = [m for m in oracle_model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    for m in bns:
+        m.reset_running_stats()
+        m.momentum = None
+    oracle_model.train()
+    run()
+    oracle_model.eval()
+    g = torch.Generator().manual_seed(5)
+    for m in bns:          # non-trivial affine so that folding is exercised, residual BN un-zeroed
+        m.weight.copy_(torch.rand(m.weight.shape, generator=g) * 0.5 + 0.75)
+        m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+
+
+@pytest.fixture(scope="module")
+def irl_pair():
+    from oracle.irl import MaxEntIRL as OracleIRL
+    from creste_public_amd import MaxEntIRL
+    torch.manual_seed(1234)
+    cfg = maxent_irl_cfg((H, W), solve_mdp=True)
+    oracle = OracleIRL(cfg)
+    rgbd, p2p = synth.make_frames(B, H, W, seed=11)
+    expert = synth.make_experts(B, 50, 256, seed=3)
+    calibrate_bn(oracle, lambda: oracle((rgbd, p2p, expert)))
+    with torch.no_grad():      # rewards of O(1) like a trained costmap (sparse BEV input makes BN outputs heavy-tailed)
+        oracle.traversability_head.r.postpool[0].norm.weight.mul_(0.01)
+        oracle.traversability_head.r.postpool[0].norm.bias.mul_(0.01)
+    model = MaxEntIRL(maxent_irl_cfg((H, W), solve_mdp=True))
+    missing = model.load_state_dict(oracle.state_dict(), strict=True)      # identical key names
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model = model.cuda().eval()
+    with torch.no_grad():
+        ref = oracle((rgbd, p2p, expert))
+        got = model((rgbd.cuda(), p2p.cuda(), expert.cuda()))
+    torch.cuda.synchronize()
+    return model, oracle, ref, got, (rgbd, p2p, expert)
+
+
+@pytest.fixture(scope="module")
+def ref64(irl_pair):
+    """The same network evaluated in float64 on the CPU: the yardstick for fp32 round-off.  The fp32
+    reference itself sits ~1e-3 (rms) away from it on the costmap of this randomly initialised network
+    (sparse BEV input -> large BatchNorm gains), so end-to-end agreement is judged against that floor."""
+    import copy
+    _, oracle, _, _, (rgbd, p2p, expert) = irl_pair
+    o64 = copy.deepcopy(oracle).double()
+    o64.fov_mask = oracle.fov_mask
+    with torch.no_grad():
+        return o64((rgbd.double(), p2p.double(), expert.double()))
+
+
+def _rms(t):
+    return float(t.double().pow(2).mean().sqrt())
+
+
+def _stage(got, ref, tol, what):
+    """relative-rms + bounded max error for a stage fed with IDENTICAL inputs"""
+    g, r = got.detach().double().cpu(), ref.detach().double()
+    assert g.shape == r.shape, (what, g.shape, r.shape)
+    scale = max(_rms(r), 1e-12)
+    assert _rms(g - r) <= tol * scale, f"{what}: rel rms {_rms(g - r) / scale:.2e} > {tol:.0e}"
+    assert float((g - r).abs().max()) <= 100 * tol * max(scale, float(r.abs().max()) * 0.01), what
+
+
+
+
+def _cmp(got, ref, key, rtol, atol):
+    g, r = got[key].detach().float().cpu(), ref[key].detach().float()
+    assert g.shape == r.shape, (key, g.shape, r.shape)
+    torch.testing.assert_close(g, r, rtol=rtol, atol=atol, msg=lambda m: f"{key}: {m}")
+
+
+def test_output_contract(irl_pair):
+    _, _, ref, got, _ = irl_pair
+    ref_keys = {k for k in ref if not k.startswith("_")}
+    assert set(got.keys()) == ref_keys
+    for k in ref_keys:
+        assert tuple(got[k].shape) == tuple(ref[k].shape), k
+        assert got[k].dtype == ref[k].dtype, k
+    assert got["depth_preds_bins"].dtype == torch.int64 and got["state_preds"].dtype == torch.int64
+
+
+def test_encoder_and_depth(irl_pair):
+    _, _, ref, got, _ = irl_pair
+    _cmp(got, ref, "depth_preds_feats", 2e-4, 2e-4)
+    _cmp(got, ref, "depth_preds_logits", 5e-4, 5e-4)
+    _cmp(got, ref, "dino_pe_feats", 5e-4, 5e-4)
+    _cmp(got, ref, "depth_preds_metric", 1e-4, 1e-3)
+    same = (got["depth_preds_bins"].cpu() == ref["depth_preds_bins"]).float().mean().item()
+    assert same > 0.999, f"argmax depth bins agree on {same:.5f} of the pixels"
+
+
+def test_end_to_end_within_fp32_noise_floor(irl_pair, ref64):
+    """Every float output: rms distance HIP<->float64 truth is within a small factor of the fp32 CPU
+    reference's own distance to the float64 truth (same network, same inputs)."""
+    _, _, ref, got, _ = irl_pair
+    report = []
+    for k, t in ref64.items():
+        if k.startswith("_") or not torch.is_tensor(t) or not t.is_floating_point():
+            continue
+        g, r, t = got[k].detach().double().cpu(), ref[k].detach().double(), t.detach().double()
+        e_hip, e_cpu = _rms(g - t), _rms(r - t)
+        report.append((k, e_hip, e_cpu))
+        factor = 8.0 if k in ("q_estimate", "value_estimate", "policy", "exp_svf") else 4.0
+        assert e_hip <= factor * e_cpu + 1e-7 * max(_rms(t), 1.0), \
+            f"{k}: |hip-f64| rms {e_hip:.3e} vs reference's own fp32 noise {e_cpu:.3e}"
+    assert len(report) >= 20
+    # voxel indices end to end: the only flips are points whose coordinate noise straddles a cell edge
+    flips = (got["bev_coords"].cpu().floor() != ref["bev_coords"].floor()).any(dim=-1).float().mean().item()
+    assert flips < 2e-2, f"end-to-end voxel-index mismatch rate {flips:.2e} (the splat stage itself is bit-exact)"
+    assert torch.equal(got["state_preds"][:, 0].cpu(), ref["state_preds"][:, 0])
+    assert (got["traversability_preds"] >= 0).all()
+    tot = got["exp_svf"].sum(dim=(1, 2)).cpu()
+    assert (tot <= 50 + 1e-3).all() and (got["exp_svf"] >= 0).all()
+    pol_sum = got["policy"].sum(dim=1).cpu()
+    torch.testing.assert_close(pol_sum, torch.ones_like(pol_sum), rtol=0, atol=1e-5)
+
+
+def test_stages_on_identical_inputs(irl_pair):
+    """Each stage of the HIP pipeline fed with the ORACLE's tensors for the previous stage, so no
+    upstream round-off is amplified: this is where the north-star tolerances apply."""
+    model, _, ref, _, (rgbd, p2p, expert) = irl_pair
+    cu = lambda t: t.detach().cuda().contiguous()
+    with torch.no_grad():
+        # splat stage: bit-exact voxel coordinates / indices, sums to fp32 round-off
+        sp = model.backbone.cam2map([cu(ref["depth_preds_metric"]).view(B, 1, H // 4, W // 4),
+                                     cu(ref["depth_preds_feats"]).view(B, 1, 256, H // 4, W // 4), p2p.cuda()])
+        assert torch.equal(sp["bev_coords"].cpu(), ref["bev_coords"])
+        assert torch.equal(sp["bev_coords"].cpu().floor().long(), ref["bev_coords"].floor().long())
+        _stage(sp["bev_densities"], ref["bev_densities"], 1e-6, "bev_densities")
+        _stage(sp["bev_features"], ref["bev_features"], 1e-5, "bev_features")
+        # BEV heads
+        heads = model.backbone.bevclassifier({"bev_features": cu(ref["bev_features"])})
+        for k in ("inpainting_sam_preds", "inpainting_sam_dynamic_preds", "elevation_preds",
+                  "inpainting_sam_features", "inpainting_sam_dynamic_features", "elevation_features"):
+            _stage(heads[k], ref[k], 2e-5, k)
+        # costmap head: fp32 costmap within 1e-4 (BASELINE.json north_star)
+        vin = model.traversability_head({k: cu(ref[k]) for k in model.traversability_head.reward_cfg["input_keys"]},
+                                        None, False)
+        assert torch.equal(vin["input_view"].cpu(), ref["input_view"].detach())
+        torch.testing.assert_close(vin["traversability_preds"].cpu(), ref["traversability_preds"].detach(),
+                                   rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(vin["traversability_preds_full"].cpu(), ref["traversability_preds_full"],
+                                   rtol=1e-4, atol=1e-4)
+        # MDP solve on the oracle's reward
+        v, pi, q = model.traversability_head.value_iteration_manual(cu(ref["traversability_preds"]), None,
+                                                                    threshold=0.001, discount=0.99)
+        sweeps = int(model.traversability_head.last_sweeps.item())
+        assert abs(sweeps - ref["_vi_sweeps"]) <= 1, (sweeps, ref["_vi_sweeps"])
+        torch.testing.assert_close(v.cpu(), ref["value_estimate"], rtol=2e-5, atol=2e-3)
+        torch.testing.assert_close(q.cpu(), ref["q_estimate"], rtol=2e-5, atol=2e-3)
+        torch.testing.assert_close(pi.cpu(), ref["policy"], rtol=0, atol=2e-4)
+        # SVF on the oracle's policy
+        svf = model.expected_state_visitation_frequency(cu(ref["policy"]), expert.cuda())
+        assert torch.equal(svf["state_preds"].cpu(), ref["state_preds"])
+        assert torch.equal(svf["state_preds_grid"].cpu(), ref["state_preds_grid"])
+        torch.testing.assert_close(svf["exp_svf"].cpu(), ref["exp_svf"], rtol=1e-4, atol=1e-5)
+
+
+def test_inference_mode_matches_and_sub_modules(irl_pair):
+    """solve_mdp=False (the deployment contract of scripts/runtime/compile.py) and stand-alone calls of
+    the mirrored sub-modules give the same tensors as the full pipeline (run-to-run deterministic)."""
+    model, oracle, ref, got, (rgbd, p2p, expert) = irl_pair
+    model.solve_mdp = False
+    try:
+        with torch.no_grad():
+            out = model((rgbd.cuda(), p2p.cuda()))
+    finally:
+        model.solve_mdp = True
+    assert "policy" not in out and "traversability_preds_full" in out
+    assert torch.equal(out["traversability_preds"], got["traversability_preds"])
+    with torch.no_grad():
+        tn = model.backbone((rgbd.cuda(), p2p.cuda()))
+        assert torch.equal(tn["bev_features"], got["bev_features"])
+        db = model.backbone.depthcomp(rgbd.cuda())
+        assert torch.equal(db["depth_preds_metric"], got["depth_preds_metric"])
+        vin = model.traversability_head(got, None, False)
+        assert torch.equal(vin["traversability_preds"], got["traversability_preds"])
+
+
+def _irl_step(m, lm, dev, batch, cf, fov):
+    rgbd, p2p, expert = batch
+    m.train()
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
+    opt.zero_grad()
+    out = m((rgbd.to(dev), p2p.to(dev), expert.to(dev)))
+    td = {f"outputs/{k}": v for k, v in out.items()}
+    td.update({"inputs/traversability_label": expert.to(dev), "inputs/fov_mask": fov.to(dev),
+               "inputs/counterfactuals_label": cf, "task": "irl"})
+    ld, md = lm(td)
+    loss = sum(w * v for w, v in ld.values())
+    loss.backward()
+    grads = {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}
+    before = {n: p.detach().cpu().clone() for n, p in m.named_parameters() if p.requires_grad}
+    opt.step()
+    moved = sum(float((p.detach().cpu() - before[n]).abs().sum()) for n, p in m.named_parameters()
+                if p.requires_grad)
+    return loss.detach().cpu(), grads, md, out, moved
+
+
+def test_irl_training_step(irl_pair):
+    """One manual-optimisation IRL step (reference train_traversability.py:66-105): frozen HIP backbone,
+    autograd reward net, MaxEntIRLLoss with counterfactuals + gradient penalty, Adam step -- against the
+    same step on the CPU oracle."""
+    import copy
+    import numpy as np
+    from oracle import irl as oirl
+    from creste_public_amd import LossManager
+    model, oracle, _, _, batch = irl_pair
+    model, oracle = copy.deepcopy(model).cuda(), _with_eval_backbone(copy.deepcopy(oracle))
+    cfg = maxent_irl_cfg((H, W), solve_mdp=True)
+    fov = torch.ones(B, 256, 256, dtype=torch.bool)
+    rng = np.random.RandomState(0)
+    cf = [dict(trajectories=(np.array([[100.0, 128.0]]) + np.linspace(0, 1, 20)[None, :, None] *
+                             rng.uniform(-80, 80, size=(3, 1, 2))).astype(np.float32),
+               rank=np.array([0, 1, 2])), None]
+    lo, go, _, out_o, _ = _irl_step(oracle, oirl.LossManager(cfg), "cpu", batch, cf, fov)
+    lh, gh, md, out_h, moved = _irl_step(model, LossManager(cfg).cuda(), "cuda", batch, cf, fov)
+    assert moved > 0                                                    # Adam updated the reward net
+    assert set(gh) == set(go) and all(k.startswith("traversability_head.r.") for k in gh)
+    assert all(not p.requires_grad for p in model.backbone.parameters())
+    torch.testing.assert_close(lh, lo, rtol=5e-2, atol=5e-4)           # loss sees the sharpened-policy SVF
+    flat = lambda g: torch.cat([g[k].flatten() for k in sorted(g)]).double()
+    cos = torch.nn.functional.cosine_similarity(flat(gh), flat(go), dim=0).item()
+    assert cos > 0.98, f"gradient direction cosine {cos:.4f}"
+    for k in ("MaxEntIRLLoss/reward_penalty", "MaxEntIRLLoss/mean_svf_rewards"):
+        assert torch.isfinite(md[k]).all()
+
+    # same objective on IDENTICAL inputs (the oracle's input_view / exp_svf): autograd + loss layer only
+    lm_h, lm_o = LossManager(cfg).cuda(), oirl.LossManager(cfg)
+    res = {}
+    for tag, m, lm, dev in (("hip", model, lm_h, "cuda"), ("cpu", oracle, lm_o, "cpu")):
+        rnet = m.traversability_head.r
+        rnet.load_state_dict({k: v.to(dev) for k, v in irl_pair[1].traversability_head.r.state_dict().items()})
+        rnet.train()
+        rnet.zero_grad()
+        iv = out_o["input_view"].detach().to(dev).requires_grad_(True)
+        r = rnet(iv)
+        td = {"outputs/exp_svf": out_o["exp_svf"].to(dev), "outputs/traversability_preds": r,
+              "outputs/input_view": iv, "inputs/traversability_label": batch[2].to(dev),
+              "inputs/fov_mask": fov.to(dev), "inputs/counterfactuals_label": cf, "task": "irl"}
+        ld, _ = lm(td)
+        loss = sum(w * v for w, v in ld.values())
+        loss.backward()
+        res[tag] = (loss.detach().cpu(), {n: p.grad.detach().cpu() for n, p in rnet.named_parameters()})
+    torch.testing.assert_close(res["hip"][0], res["cpu"][0], rtol=1e-4, atol=1e-6)
+    for n in res["cpu"][1]:
+        a, b = res["hip"][1][n], res["cpu"][1][n]
+        assert _rms(a - b) <= 2e-3 * max(_rms(b), 1e-8) + 1e-9, n
+
+
+def _with_eval_backbone(oracle):
+    """The HIP path always runs the frozen backbone in eval mode; mirror that on the oracle."""
+    orig_train = oracle.train
+
+    def train(mode=True):
+        orig_train(mode)
+        oracle.backbone.eval()
+        return oracle
+    oracle.train = train
+    for p in oracle.backbone.parameters():
+        p.requires_grad = False
+    return oracle
