@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Benchmark of the CREStE perception->costmap hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): inference, batch = 16 synthetic frames per GPU of 1216x608 RGB +
+a 128x1024 LiDAR range image projected to the sparse depth channel -> EfficientNet-B0 U-Net encoder ->
+depth-guided BEV splat (256x256) -> ResNet-18 BEV heads -> reward FCN costmap (MaxEntIRL with
+solve_mdp=False, the deployment graph of scripts/runtime/compile.py).  One "step" = one forward pass
+over one batch; inputs are resident in HBM when the timed region starts; frames shard across GPUs as
+independent replicas (no data-path collective): `value` = frames of all ranks / max-over-ranks time.
+
+The JSON line also carries `roofline` for the dominant kernel (the fp32-MFMA implicit-GEMM conv:
+algorithmic FLOPs / HIP-event time per launch, summed over every launch of the timed steps) and
+`cpu_baseline` (the CPU oracle, i.e. the reference's PyTorch op sequence, timed on this host).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+IMG_H, IMG_W, BATCH = 608, 1216, 16
+PEAK = {"f32": 157.3}          # TFLOP/s dense, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
+HBM_PEAK_GBS = 8000.0
+
+
+def build_model(device):
+    from creste_public_amd import MaxEntIRL, maxent_irl_cfg, synth
+    torch.manual_seed(1337)
+    model = MaxEntIRL(maxent_irl_cfg((IMG_H, IMG_W), solve_mdp=False))
+    synth.randomize_bn(model, seed=1337)
+    with torch.no_grad():   # raw millimetre depth enters the stem un-normalised: give BN a matching scale
+        model.backbone.depthcomp.depthcomp.vision_backbone.model.trunk._bn0.running_var.fill_(1.0e7)
+    return model.to(device).eval()
+
+
+class ConvProfiler:
+    """HIP-event pair around every conv launch (recorded on the stream the kernel is launched on)."""
+
+    def __init__(self):
+        self.records = []
+
+    def install(self):
+        from creste_public_amd import ops
+        self._ops, self._orig = ops, ops.conv2d
+        prof = self
+
+        def timed(x, pc, out=None, res=None, a_scale=None, row_mask=None):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = prof._orig(x, pc, out=out, res=res, a_scale=a_scale, row_mask=row_mask)
+            e1.record()
+            flops = 2.0 * y.N * y.H * y.W * pc.Cout * pc.Cin * pc.KH * pc.KW
+            bn = 128 if pc.Cout > 64 else (64 if pc.Cout > 32 else 32)
+            prof.records.append((e0, e1, flops, bn, (pc.Cin, pc.Cout, pc.KH, y.H, y.W)))
+            return y
+        import creste_public_amd.hipnn as hipnn
+        ops.conv2d = timed
+        hipnn.ops.conv2d = timed
+
+    def uninstall(self):
+        self._ops.conv2d = self._orig
+
+    def summary(self):
+        by = {}
+        for e0, e1, fl, bn, shape in self.records:
+            ms = e0.elapsed_time(e1)
+            d = by.setdefault(bn, dict(ms=0.0, flops=0.0, n=0))
+            d["ms"] += ms
+            d["flops"] += fl
+            d["n"] += 1
+        return by
+
+
+def cpu_baseline(sample_frames=1, runs=3):
+    """The oracle (CPU restatement of the reference's PyTorch path) on this host's cores."""
+    from creste_public_amd import maxent_irl_cfg, synth
+    from oracle.irl import MaxEntIRL as OracleIRL
+    cores = os.cpu_count() or 1
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or cores
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    torch.manual_seed(1337)
+    model = OracleIRL(maxent_irl_cfg((IMG_H, IMG_W), solve_mdp=False)).eval()
+    rgbd, p2p = synth.make_frames(sample_frames, IMG_H, IMG_W, seed=1337)
+    times = []
+    with torch.no_grad():
+        model((rgbd, p2p))                       # warm-up
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            model((rgbd, p2p))
+            times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": round(sample_frames / med, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (CPU PyTorch restatement of the reference path), batch={sample_frames} "
+                      f"frame of {IMG_W}x{IMG_H}, median of {runs} runs after 1 warm-up, "
+                      f"{cores} threads, fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world != 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one rank per GPU)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from creste_public_amd import synth
+    model = build_model(device)
+    rgbd, p2p = synth.make_frames(args.batch, IMG_H, IMG_W, seed=1337 + rank)
+    rgbd, p2p = rgbd.to(device), p2p.to(device)
+
+    def step():
+        with torch.no_grad():
+            return model((rgbd, p2p))
+
+    for _ in range(args.warmup):
+        out = step()
+    prof = ConvProfiler()
+    prof.install()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof.uninstall()
+    assert torch.isfinite(out["traversability_preds"]).all()
+    from creste_public_amd import dist_utils
+    elapsed = dist_utils.max_over_ranks(elapsed, device)     # the job is as slow as its slowest rank
+
+    if rank == 0:
+        frames = args.batch * args.gpus * args.steps
+        by = prof.summary()
+        dom = max(by, key=lambda k: by[k]["ms"])
+        d = by[dom]
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        conv_ms = sum(v["ms"] for v in by.values())
+        traffic = None
+        pj = os.path.join(ROOT, "profiles", "roofline_counters.json")
+        if os.path.exists(pj):
+            try:
+                traffic = json.load(open(pj)).get("conv_igemm_f32_bn128", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "frames/sec (RGB+LiDAR->BEV costmap)",
+            "value": round(frames / elapsed, 3),
+            "unit": "frames/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"inference: batch={args.batch}/GPU synthetic {IMG_W}x{IMG_H} RGB + 128x1024 "
+                                   "LiDAR -> 256x256 BEV costmap (MaxEntIRL solve_mdp=False; EfficientNet-B0 U-Net, "
+                                   "BEV splat, ResNet-18 heads, reward FCN), random-init weights",
+                       "batch_per_gpu": args.batch, "image": [IMG_H, IMG_W], "lidar": [128, 1024],
+                       "bev": [256, 256], "parallelism": f"{args.gpus} independent replicas (frame-sharded, no collective)"},
+            "roofline": {"bound": "mfma", "kernel": f"conv_igemm_f32_kernel (BN={dom})",
+                         "achieved": round(achieved, 2), "peak": PEAK["f32"], "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK["f32"], 4), "traffic": traffic,
+                         "launches": d["n"], "avg_launch_ms": round(d["ms"] / d["n"], 4),
+                         "conv_share_of_step": round(conv_ms / args.steps / (elapsed / args.steps * 1e3), 4)},
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -66,6 +66,10 @@ def load(path: str | None = None):
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64; it must be in the process BEFORE this library is opened so that
+    # both share ONE HIP runtime (otherwise the kernels register with a second runtime that owns no
+    # device: "no ROCm-capable device is detected").
+    import torch  # noqa: F401
     p = path or os.environ.get("CRESTE_HIP_LIB", LIB_PATH)
     if not os.path.exists(p):
         raise HipLibraryError(

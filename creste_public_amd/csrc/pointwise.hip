@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256) void pixel_geometry_kernel(
   extern __shared__ float smw[];   // w1[zhid] b1[zhid] w2[zdim*zhid] b2[zdim]
   float* s_w1 = smw; float* s_b1 = s_w1 + zhid; float* s_w2 = s_b1 + zhid; float* s_b2 = s_w2 + zdim * zhid;
   for (int i = threadIdx.x; i < zhid; i += blockDim.x) { s_w1[i] = w1[i]; s_b1[i] = b1[i]; }
-  for (int i = threadIdx.x; i < zdim * zhid; i += blockDim.x) s_w2[i] = w2[i];
+  for (int i = threadIdx.x; i < zdim * zhid; i += blockDim.x)   // transposed: lanes j read consecutive words
+    s_w2[(i % zhid) * zdim + i / zhid] = w2[i];
   for (int i = threadIdx.x; i < zdim; i += blockDim.x) s_b2[i] = b2[i];
   __syncthreads();
   const long P = (long)Hs * Ws, total = (long)B * P;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) void pixel_geometry_kernel(
     float s = s_b2[j];
     for (int h = 0; h < zhid; ++h) {
       const float hv = fmaxf(__fmaf_rn(s_w1[h], q[2], s_b1[h]), 0.f);
-      s = __fmaf_rn(s_w2[j * zhid + h], hv, s);
+      s = __fmaf_rn(s_w2[h * zdim + j], hv, s);
     }
     zfeat[g * z_cs + z_co + j] = fmaxf(s, 0.f);
   }

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): kernel-trace stats + separate PMC passes of the bench command.
+# Outputs land in gpurun_out/prof_<tag>/ ; scripts/summarize_profiles.py turns them into profiles/.
+set -u
+TAG=${1:-r01}
+STEPS=${2:-3}
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+CMD="python bench.py --steps $STEPS --warmup 1 --no-cpu-baseline"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
+grep '^{' $OUT/trace.log > $OUT/bench_under_trace.json
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 1200 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
+done
+find $OUT -type f | head -50
+# keep the merge small: drop the big per-dispatch traces except the stats/counter CSVs
+find $OUT -name "*.db" -delete
+ls -la $OUT/trace $OUT/pmc_FETCH_SIZE 2>/dev/null | head -40

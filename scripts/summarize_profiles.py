@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<tag>/ (rocprofv3 kernel-trace stats + PMC passes of bench.py) into the tracked
+files under profiles/: <tag>_kernel_stats.csv (verbatim rocprofv3 --stats summary),
+<tag>_summary.md and roofline_counters.json (HBM traffic per launch, read by bench.py)."""
+import csv
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+bench = json.loads(open(os.path.join(src, "bench_under_trace.json")).readline())
+
+stats = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
+
+
+def short(name):
+    n = name.replace("void ", "").replace("creste::", "")
+    return n.split("(")[0]
+
+
+pmc = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    per = defaultdict(lambda: [0.0, 0])
+    f = os.path.join(src, f"pmc_{c}", "pmc_counter_collection.csv")
+    if os.path.exists(f):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == c:
+                k = short(row["Kernel_Name"])
+                per[k][0] += float(row["Counter_Value"])
+                per[k][1] += 1
+    pmc[c] = per
+
+# rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB (hbm_bytes = (FETCH+WRITE)*1024); on gfx950 FETCH_SIZE
+# counts 64 B per 128-B request of wide coalesced reads -> x2 (MI355X_MICROARCH.md section HBM).
+counters = {}
+for k in set(pmc["FETCH_SIZE"]) | set(pmc["WRITE_SIZE"]):
+    fk, fn = pmc["FETCH_SIZE"].get(k, [0, 0])
+    wk, wn = pmc["WRITE_SIZE"].get(k, [0, 0])
+    n = max(fn, wn, 1)
+    counters[k] = dict(launches=n, fetch_kib_raw=fk, write_kib_raw=wk,
+                       hbm_bytes_per_launch=(2.0 * fk + wk) * 1024.0 / n,
+                       hbm_bytes_per_launch_uncorrected=(fk + wk) * 1024.0 / n)
+key_map = {"conv_igemm_f32_kernel<2, 2, 2, 2>": "conv_igemm_f32_bn128",
+           "conv_igemm_f32_kernel<2, 2, 2, 1>": "conv_igemm_f32_bn64",
+           "conv_igemm_f32_kernel<4, 1, 1, 1>": "conv_igemm_f32_bn32"}
+out = {key_map.get(k, k): v for k, v in counters.items()}
+out["_note"] = ("per-launch averages over one bench step (batch 16); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, "
+                "the x2 is the gfx950 FETCH_SIZE correction for 16-B/lane coalesced reads")
+json.dump(out, open(os.path.join(dst, "roofline_counters.json"), "w"), indent=1, sort_keys=True)
+
+tot = sum(float(r["TotalDurationNs"]) for r in stats)
+lines = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "",
+         f"command: `python bench.py --steps {bench['steps']} --warmup {bench['warmup']} --no-cpu-baseline` under rocprofv3 "
+         f"(MI355X, 1 GPU); bench line under the profiler: {bench['value']} frames/s, {bench['ms_per_step']} ms/step, "
+         f"dominant kernel {bench['roofline']['kernel']} at {bench['roofline']['achieved']} TFLOP/s "
+         f"(HIP-event avg {bench['roofline']['avg_launch_ms']} ms/launch).", "",
+         "| kernel | calls | total ms | avg us | % of GPU time | HBM MB/launch (PMC, corrected) |", "|---|---|---|---|---|---|"]
+for r in stats[:24]:
+    k = short(r["Name"])
+    c = counters.get(k)
+    hb = f"{c['hbm_bytes_per_launch'] / 1e6:.1f}" if c else ""
+    lines.append(f"| `{k[:70]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | "
+                 f"{float(r['AverageNs']) / 1e3:.1f} | {100 * float(r['TotalDurationNs']) / tot:.1f} | {hb} |")
+open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines[:14]))

@@ -1,0 +1,101 @@
+"""CPU, world_size 2 over gloo: the N>1 paths -- frame sharding + max-over-ranks timing used by
+bench.py, and the flat gradient all-reduce of the IRL step (reward net only, backbone frozen)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from creste_public_amd import dist_utils as du
+
+
+def test_shard_range_partitions_frames():
+    for total in (0, 1, 16, 17, 127):
+        for world in (1, 2, 3, 8):
+            spans = [du.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from creste_public_amd.config import maxent_irl_cfg
+        from creste_public_amd.creste.models.blocks.conv import MultiScaleFCN
+        from creste_public_amd.creste.utils.loss_utils import LossManager
+        cfg = maxent_irl_cfg()
+        torch.manual_seed(0)                                  # identical replicas
+        net = MultiScaleFCN(cfg["traversability_head"]["net_kwargs"]["reward_cfg"]["net_kwargs"]).train()
+        frozen = torch.nn.Linear(4, 4)                        # stands in for the frozen backbone
+        for p in frozen.parameters():
+            p.requires_grad = False
+        lm = LossManager(cfg)
+        B, H, W = 4, 64, 128                                  # global batch 4 -> 2 samples per rank
+        g = torch.Generator().manual_seed(1)
+        feats = torch.randn(B, 40, H, W, generator=g)
+        svf = torch.rand(B, H, W, generator=g)
+        t = torch.linspace(0, 1, 50).view(1, 50, 1)
+        xy = torch.tensor([[120.0, 128.0]]) + t * torch.tensor([[-100.0, 30.0]])
+        expert = torch.eye(3).repeat(B, 50, 1, 1)
+        expert[:, :, :2, 2] = xy
+        fov = torch.ones(B, 256, 256, dtype=torch.bool)
+
+        def grads(lo, hi):
+            net.zero_grad()
+            iv = feats[lo:hi].clone().requires_grad_(True)
+            r = net(iv)
+            td = {"outputs/exp_svf": svf[lo:hi].clone(), "outputs/traversability_preds": r,
+                  "outputs/input_view": iv, "inputs/traversability_label": expert[lo:hi],
+                  "inputs/fov_mask": fov[lo:hi], "inputs/counterfactuals_label": [None] * (hi - lo), "task": "x"}
+            ld, _ = lm(td)
+            sum(w * v for w, v in ld.values()).backward()
+
+        lo, hi = du.shard_range(B, rank, world)
+        grads(lo, hi)
+        n = du.allreduce_mean_grads(list(net.parameters()) + list(frozen.parameters()))
+        mine = torch.cat([p.grad.flatten() for p in net.parameters()])
+        # every rank must hold the same averaged gradient, equal to the mean of the per-shard gradients
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        same = all(torch.equal(gathered[0], x) for x in gathered)
+        shard_grads = []
+        for r_ in range(world):
+            a, b = du.shard_range(B, r_, world)
+            grads(a, b)
+            shard_grads.append(torch.cat([p.grad.flatten() for p in net.parameters()]))
+        expect = torch.stack(shard_grads).mean(0)
+        t_max = du.max_over_ranks(1.0 + rank)
+        frames = du.sum_over_ranks(hi - lo)
+        q.put((rank, n, same, float((mine - expect).abs().max()), float(expect.abs().max()), t_max, frames))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_irl_grad_allreduce_and_timing():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, n, same, err, scale, t_max, frames in res:
+        assert n == 102866                      # the reward net's parameter count
+        assert same
+        assert err <= 1e-6 * max(scale, 1.0)
+        assert t_max == 2.0 and frames == 4.0   # max-over-ranks time, whole-job frame count
