@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", default="", help="write a per-conv-shape timing table to this file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -165,6 +166,16 @@ def main():
     from creste_public_amd import dist_utils
     elapsed = dist_utils.max_over_ranks(elapsed, device)     # the job is as slow as its slowest rank
 
+    if rank == 0 and args.layers:
+        per = {}
+        for e0, e1, fl, bn, shape in prof.records:
+            d = per.setdefault((shape, bn), [0.0, 0.0, 0])
+            d[0] += e0.elapsed_time(e1); d[1] += fl; d[2] += 1
+        with open(args.layers, "w") as f:
+            f.write("Cin,Cout,K,Ho,Wo,BN,calls_per_step,ms_per_step,TFLOPs\n")
+            for (shape, bn), (ms, fl, n) in sorted(per.items(), key=lambda kv: -kv[1][0]):
+                f.write(",".join(map(str, shape)) + f",{bn},{n / args.steps:.1f},{ms / args.steps:.4f},"
+                        f"{fl / (ms * 1e-3) / 1e12:.2f}\n")
     if rank == 0:
         frames = args.batch * args.gpus * args.steps
         by = prof.summary()
