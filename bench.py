@@ -29,7 +29,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 IMG_H, IMG_W, BATCH = 608, 1216, 16
-PEAK = {"f32": 157.3}          # TFLOP/s dense, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
+# TFLOP/s dense (MI355X_MICROARCH.md): fp32 MFMA 157.3; bf16 MFMA 2500.  bf16x3 issues 3 bf16 MFMAs per
+# algorithmic product, so its ceiling in algorithmic FLOPs is 2500/3.
+PEAK = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0 / 3.0, "bf16x6": 2500.0 / 6.0}
+PREC_NAME = {0: "f32", 1: "bf16", 2: "bf16x3", 3: "bf16x6"}
 HBM_PEAK_GBS = 8000.0
 
 
@@ -60,7 +63,7 @@ class ConvProfiler:
             y = prof._orig(x, pc, out=out, res=res, a_scale=a_scale, row_mask=row_mask)
             e1.record()
             flops = 2.0 * y.N * y.H * y.W * pc.Cout * pc.Cin * pc.KH * pc.KW
-            bn = 128 if pc.Cout > 64 else (64 if pc.Cout > 32 else 32)
+            bn = f"{PREC_NAME[pc.prec]}/BN{128 if pc.Cout > 64 else (64 if pc.Cout > 32 or pc.prec else 32)}"
             prof.records.append((e0, e1, flops, bn, (pc.Cin, pc.Cout, pc.KH, y.H, y.W)))
             return y
         import creste_public_amd.hipnn as hipnn
@@ -116,6 +119,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x6", "bf16x3", "bf16"],
+                    help="operand precision of the stride-1 1x1/3x3 convs on the matrix cores")
     ap.add_argument("--layers", default="", help="write a per-conv-shape timing table to this file")
     args = ap.parse_args()
 
@@ -135,7 +140,9 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
+    import creste_public_amd
     from creste_public_amd import synth
+    creste_public_amd.set_precision(args.precision)
     model = build_model(device)
     rgbd, p2p = synth.make_frames(args.batch, IMG_H, IMG_W, seed=1337 + rank)
     rgbd, p2p = rgbd.to(device), p2p.to(device)
@@ -182,12 +189,14 @@ def main():
         dom = max(by, key=lambda k: by[k]["ms"])
         d = by[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        dprec = dom.split("/")[0]
+        kname = ("conv_igemm_f32_kernel" if dprec == "f32" else "conv_patch_kernel") + f" ({dom})"
         conv_ms = sum(v["ms"] for v in by.values())
         traffic = None
         pj = os.path.join(ROOT, "profiles", "roofline_counters.json")
         if os.path.exists(pj):
             try:
-                traffic = json.load(open(pj)).get("conv_igemm_f32_bn128", {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pj)).get(f"conv_{dprec}_bn128", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -197,15 +206,19 @@ def main():
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": {"f32": "f32", "bf16x3": "f32 (bf16x3 split products on the bf16 MFMA, fp32 accumulate)",
+                      "bf16x6": "f32 (fp32 operands as 3 bf16 pieces, 6 exact piece products per multiply on the "
+                                "bf16 MFMA, fp32 accumulate)",
+                      "bf16": "bf16 operands, fp32 accumulate/activations"}[args.precision],
+            "data": "synthetic",
             "config": {"workload": f"inference: batch={args.batch}/GPU synthetic {IMG_W}x{IMG_H} RGB + 128x1024 "
                                    "LiDAR -> 256x256 BEV costmap (MaxEntIRL solve_mdp=False; EfficientNet-B0 U-Net, "
                                    "BEV splat, ResNet-18 heads, reward FCN), random-init weights",
                        "batch_per_gpu": args.batch, "image": [IMG_H, IMG_W], "lidar": [128, 1024],
                        "bev": [256, 256], "parallelism": f"{args.gpus} independent replicas (frame-sharded, no collective)"},
-            "roofline": {"bound": "mfma", "kernel": f"conv_igemm_f32_kernel (BN={dom})",
-                         "achieved": round(achieved, 2), "peak": PEAK["f32"], "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK["f32"], 4), "traffic": traffic,
+            "roofline": {"bound": "mfma", "kernel": kname,
+                         "achieved": round(achieved, 2), "peak": round(PEAK[dprec], 1), "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK[dprec], 4), "traffic": traffic,
                          "launches": d["n"], "avg_launch_ms": round(d["ms"] / d["n"], 4),
                          "conv_share_of_step": round(conv_ms / args.steps / (elapsed / args.steps * 1e3), 4)},
         }

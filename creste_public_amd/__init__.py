@@ -13,6 +13,16 @@ import sys
 from .config import Cfg, as_cfg, maxent_irl_cfg, terrainnet_cfg  # noqa: F401
 from ._lib import HipLibraryError  # noqa: F401
 
+
+def set_precision(name: str):
+    from . import hipnn
+    hipnn.set_precision(name)
+
+
+def get_precision() -> str:
+    from . import hipnn
+    return hipnn.get_precision()
+
 _MIRROR = ["creste", "creste.models", "creste.models.blocks", "creste.models.blocks.conv",
            "creste.models.blocks.effnet", "creste.models.blocks.inpainting",
            "creste.models.blocks.splat_projection", "creste.models.blocks.vin",

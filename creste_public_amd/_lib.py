@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libcreste_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2, 3
 
 
 class HipLibraryError(RuntimeError):
@@ -34,6 +34,7 @@ SIGNATURES = {
     "creste_last_error": (C.c_char_p, []),
     "creste_abi_version": (_i, []),
     "creste_conv2d_nhwc": (_i, [C.POINTER(ConvDesc), _vp]),
+    "creste_conv_supported": (_i, [_i, _i, _i, _i]),
     "creste_conv_packed_weight_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "creste_conv_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "creste_dwconv2d_nhwc_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),

@@ -226,11 +226,25 @@ static inline int pick_bn(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 :
 
 }  // namespace creste
 
+namespace creste {   // conv_patch.hip
+bool conv_patch_supported(int prec, int KH, int KW, int stride);
+int64_t conv_patch_weight_bytes(int Cout, int Cin, int K, int prec);
+int conv_patch_pack(const float* w, const float* scale, void* wpk, int Cout, int Cin, int K, int prec,
+                    hipStream_t s);
+int conv_patch_run(const creste_conv_desc* d, hipStream_t s);
+}  // namespace creste
+
 using namespace creste;
+
+extern "C" int creste_conv_supported(int prec, int KH, int KW, int stride) {
+  if (prec == CRESTE_PREC_F32) return KH > 0 && KW > 0 && stride > 0;
+  return conv_patch_supported(prec, KH, KW, stride) ? 1 : 0;
+}
 
 extern "C" int64_t creste_conv_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int prec) {
   if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return -1;
-  if (prec != CRESTE_PREC_F32) return -1;
+  if (prec != CRESTE_PREC_F32)
+    return conv_patch_supported(prec, KH, KW, 1) ? conv_patch_weight_bytes(Cout, Cin, KH, prec) : -1;
   const int bn = pick_bn(Cout);
   return (int64_t)round_up(Cout, bn) * KH * KW * round_up(Cin, BK) * 4;
 }
@@ -238,7 +252,10 @@ extern "C" int64_t creste_conv_packed_weight_bytes(int Cout, int Cin, int KH, in
 extern "C" int creste_conv_pack_weight(const float* w, const float* scale, void* wpk, int Cout,
                                        int Cin, int KH, int KW, int prec, void* stream) {
   CRESTE_REQUIRE(w && wpk && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, "conv_pack_weight: bad args");
-  CRESTE_REQUIRE(prec == CRESTE_PREC_F32, "conv_pack_weight: precision %d not built", prec);
+  if (prec != CRESTE_PREC_F32) {
+    CRESTE_REQUIRE(conv_patch_supported(prec, KH, KW, 1), "conv_pack_weight: %dx%d not built for precision %d", KH, KW, prec);
+    return conv_patch_pack(w, scale, wpk, Cout, Cin, KH, prec, (hipStream_t)stream);
+  }
   const int cin_pad = round_up(Cin, BK), cout_pad = round_up(Cout, pick_bn(Cout));
   const long total = (long)cout_pad * KH * KW * cin_pad;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
@@ -251,7 +268,8 @@ extern "C" int creste_conv_pack_weight(const float* w, const float* scale, void*
 extern "C" int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream) {
   CRESTE_REQUIRE(d != nullptr, "conv2d: null descriptor");
   CRESTE_REQUIRE(d->in && d->wpk && d->out, "conv2d: null tensor pointer");
-  CRESTE_REQUIRE(d->prec == CRESTE_PREC_F32, "conv2d: precision %d not built", d->prec);
+  CRESTE_REQUIRE(d->prec == CRESTE_PREC_F32 || conv_patch_supported(d->prec, d->KH, d->KW, d->stride),
+                 "conv2d: precision %d not built for %dx%d stride %d", d->prec, d->KH, d->KW, d->stride);
   CRESTE_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 &&
                      d->Wo > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0,
                  "conv2d: non-positive dimension");
@@ -264,6 +282,7 @@ extern "C" int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream) {
   // the output extent must be reachable: last tap of the last pixel may only overhang into padding
   CRESTE_REQUIRE((d->Ho - 1) * d->stride - d->pad_t < d->H && (d->Wo - 1) * d->stride - d->pad_l < d->W,
                  "conv2d: output extent outside the input");
+  if (d->prec != CRESTE_PREC_F32) return conv_patch_run(d, (hipStream_t)stream);
   ConvArgs a;
   a.in = d->in; a.wpk = (const float*)d->wpk; a.bias = d->bias; a.res = d->res;
   a.a_scale = d->a_scale; a.row_mask = d->row_mask; a.out = d->out;

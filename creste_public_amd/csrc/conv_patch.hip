@@ -1,0 +1,515 @@
+// Stride-1 1x1 / 3x3 convolution on the bf16 matrix cores with an LDS-resident halo patch.
+//
+// Why a second conv engine: on gfx950 the bf16 MFMA (v_mfma_f32_32x32x16_bf16) runs at 16x the rate of
+// the fp32 MFMA.  Two operand precisions are built on it:
+//   BF16X3  every fp32 operand is split into bf16 hi + bf16 lo (16 mantissa bits) and a product is
+//           formed as hi*hi + hi*lo + lo*hi with fp32 accumulation -- product error ~2^-16 relative,
+//           i.e. the same order as fp32 accumulation round-off over K~4000 -- at 16/3 = 5.3x the fp32
+//           MFMA rate ("fp32-grade" mode);
+//   BF16    one bf16 product (throughput mode).
+// Activations stay fp32 NHWC in HBM; the split happens while staging into LDS.  Weights are split and
+// laid out once at pack time.
+//
+// Tile: one workgroup (8 waves) computes an 8 x 32 pixel patch x BN (128 or 64) output channels.
+// Per 16-channel chunk the (8+K-1) x (32+K-1) input halo patch is staged ONCE in LDS and reused by all
+// K*K taps (the 3x3 conv's 9 shifted reads hit LDS, not L2/HBM: L2-miss traffic drops to the
+// algorithmic bytes x 1.33 halo overhead); the per-tap weight tile streams from L2 (8 KB per tap).
+// LDS image of both operands: [plane hi|lo][k-octet][row (pixel or channel)][8 bf16 = 16 B].  A lane's
+// MFMA fragment (8 consecutive k of one row) is one ds_read_b128; rows are 16 B apart and the k-octet
+// planes are a multiple of 256 B apart, so the 16-lane service groups of ds_read_b128 (which mix both
+// octets but always cover 16 row indices distinct mod 16) are conflict-free for any tap shift.
+#include "common.h"
+
+namespace creste {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PT_TH = 8, PT_TW = 32;   // output pixel patch per workgroup
+constexpr int PT_CK = 16;              // channels per chunk = K of one MFMA
+#ifndef PATCH_WAVES_PER_SIMD
+#define PATCH_WAVES_PER_SIMD 4        // two 8-wave workgroups per CU: one block's barrier hides behind the other
+#endif
+
+// sum over piece pairs (pa, pb) with pa + pb < SPLIT, smallest magnitude first:
+//   SPLIT 1: a0*b0                       (bf16)
+//   SPLIT 2: a1*b0 + a0*b1 + a0*b0       (bf16x3: 16-bit operands)
+//   SPLIT 3: a2*b0 + a1*b1 + a0*b2 + a1*b0 + a0*b1 + a0*b0   (bf16x6: 24-bit operands = fp32; the dropped
+//            pairs are <= 2^-24 relative, the size of one fp32 product rounding)
+template <int SPLIT>
+__device__ __forceinline__ f32x16 split_mfma(const bf16x8 (&a)[SPLIT], const bf16x8 (&b)[SPLIT], f32x16 c) {
+#pragma unroll
+  for (int order = SPLIT - 1; order >= 0; --order)
+#pragma unroll
+    for (int pa = order; pa >= 0; --pa)
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[order - pa], c, 0, 0, 0);
+  return c;
+}
+
+struct PatchArgs {
+  const float* in;
+  const char* wpk;
+  const float* bias;
+  const float* res;
+  const float* a_scale;
+  const float* row_mask;
+  float* out;
+  int N, H, W, Cin, in_cs;
+  int Ho, Wo, Cout, out_cs, out_co, res_cs;
+  int pad_t, pad_l;
+  int act;
+  int nchunk;
+  int tiles_x, tiles_y, tiles_n;
+};
+
+template <int K, int SPLIT, int TN>
+__global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void conv_patch_kernel(const PatchArgs p) {
+  constexpr int T = K * K;
+  constexpr int PH = PT_TH + K - 1, PW = PT_TW + K - 1, NPIX = PH * PW;
+  constexpr int NPIXP = (NPIX + 15) / 16 * 16;
+  constexpr int BN = 64 * TN;
+  constexpr int A_OCT = NPIXP * 16;             // bytes of one k-octet plane of A
+  constexpr int A_PLANE = 2 * A_OCT;            // hi (or lo) plane
+  constexpr int A_BYTES = SPLIT * A_PLANE;
+  constexpr int B_OCT = BN * 16;
+  constexpr int B_PLANE = 2 * B_OCT;
+  constexpr int B_BYTES = SPLIT * B_PLANE;
+  constexpr int NF4 = NPIX * 4;                 // float4 loads per chunk of the A patch
+  constexpr int ROUNDS = (NF4 + 511) / 512;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const abase = smem;                    // two A buffers, then two B buffers
+  char* const bbase = smem + 2 * A_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;      // 4 (pixel rows) x 2 (channel halves)
+  const int li = lane & 31, lh = lane >> 5;
+
+  // tile decode: channel tile fastest, then x, y, image; contiguous runs per XCD
+  const int nblk = p.tiles_n * p.tiles_x * p.tiles_y * p.N;
+  int id = xcd_remap(blockIdx.x, nblk);
+  const int tn = id % p.tiles_n; id /= p.tiles_n;
+  const int tx = id % p.tiles_x; id /= p.tiles_x;
+  const int ty = id % p.tiles_y;
+  const int img = id / p.tiles_y;
+  const int oy0 = ty * PT_TH, ox0 = tx * PT_TW;
+
+  // ---- per-thread A staging slots (fixed over chunks).  512 % 4 == 0, so a thread always carries the same
+  // channel quad cq of consecutive patch pixels pix = r*128 + tid/4.
+  const int cq = tid & 3;
+  const int a_lofs0 = (cq >> 1) * A_OCT + (tid >> 2) * 16 + (cq & 1) * 8;   // + r*128*16 per round
+  int a_gpix[ROUNDS];      // pixel index (n*H + y)*W + x of the round's patch pixel, -1 if outside / unused
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int pix = r * 128 + (tid >> 2);
+    const int py = pix / PW, px = pix % PW;
+    const int iy = oy0 + py - p.pad_t, ix = ox0 + px - p.pad_l;
+    const bool ok = pix < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    a_gpix[r] = ok ? (img * p.H + iy) * p.W + ix : -1;
+  }
+  // weight tile of step g: B_BYTES contiguous bytes, copied by LDS-DMA in 1 KiB pieces
+  const char* wbase = p.wpk + (size_t)tn * p.nchunk * T * B_BYTES;
+  constexpr int B_INSTR = B_BYTES / 1024;
+  auto dma_b = [&](int g) __attribute__((always_inline)) {
+    const char* src = wbase + (size_t)g * B_BYTES + lane * 16;
+    char* dst = bbase + (g & 1) * B_BYTES;
+#pragma unroll
+    for (int j = 0; j < (B_INSTR + 7) / 8; ++j) {
+      const int i = wave + 8 * j;
+      if (i < B_INSTR)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    }
+  };
+
+  auto load_a = [&](int r, int c) __attribute__((always_inline)) -> f32x4 {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const int ch = c * PT_CK + cq * 4;
+    if (a_gpix[r] >= 0 && ch < p.Cin) {
+      v = *reinterpret_cast<const f32x4*>(p.in + (size_t)a_gpix[r] * p.in_cs + ch);
+      if (p.a_scale) v *= *reinterpret_cast<const f32x4*>(p.a_scale + (size_t)img * p.Cin + ch);
+    }
+    return v;
+  };
+  auto store_a = [&](int r, f32x4 v, char* buf) __attribute__((always_inline)) {
+    if (r * 128 + (tid >> 2) >= NPIX) return;
+    char* dst = buf + a_lofs0 + r * (128 * 16);
+    f32x4 rem = v;
+#pragma unroll
+    for (int pl = 0; pl < SPLIT; ++pl) {           // hi, then the bf16 of what is left, ...
+      const bf16x4 piece = __builtin_convertvector(rem, bf16x4);
+      *reinterpret_cast<bf16x4*>(dst + pl * A_PLANE) = piece;
+      if (pl + 1 < SPLIT) rem -= __builtin_convertvector(piece, f32x4);
+    }
+  };
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- prologue: chunk 0 of A, weight tile (0,0)
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) store_a(r, load_a(r, 0), abase);
+  dma_b(0);
+  __syncthreads();
+
+  const int nsteps = p.nchunk * T;
+  int step = 0;
+  for (int c = 0; c < p.nchunk; ++c) {
+    const char* A = abase + (c & 1) * A_BYTES;
+    char* Anext = abase + ((c + 1) & 1) * A_BYTES;
+    const bool more_a = c + 1 < p.nchunk;
+#pragma unroll
+    for (int t = 0; t < T; ++t, ++step) {
+      const char* B = bbase + (step & 1) * B_BYTES;
+      const bool more_b = step + 1 < nsteps;
+      f32x4 ra[ROUNDS];
+      if (more_b) dma_b(step + 1);
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r)
+        if ((r < T ? r : T - 1) == t && more_a) ra[r] = load_a(r, c + 1);
+
+      // ---- MFMAs of (chunk c, tap t)
+      const int ky = t / K, kx = t % K;
+      bf16x8 af[2][SPLIT], bfr[TN][SPLIT];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int idx = (wm * 2 + mt + ky) * PW + kx + li;
+#pragma unroll
+        for (int pl = 0; pl < SPLIT; ++pl)
+          af[mt][pl] = *reinterpret_cast<const bf16x8*>(A + pl * A_PLANE + lh * A_OCT + idx * 16);
+      }
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) {
+        const int n = (wn * TN + nt) * 32 + li;
+#pragma unroll
+        for (int pl = 0; pl < SPLIT; ++pl)
+          bfr[nt][pl] = *reinterpret_cast<const bf16x8*>(B + pl * B_PLANE + lh * B_OCT + n * 16);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+          acc[mt][nt] = split_mfma<SPLIT>(af[mt], bfr[nt], acc[mt][nt]);
+        }
+
+      // ---- land the prefetched tiles in the other buffers
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r)
+        if ((r < T ? r : T - 1) == t && more_a) store_a(r, ra[r], Anext);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue (C/D layout: col = lane&31 -> channel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> pixel x)
+#pragma unroll
+  for (int nt = 0; nt < TN; ++nt) {
+    const int n = tn * BN + (wn * TN + nt) * 32 + li;
+    const bool n_ok = n < p.Cout;
+    const float bias = (n_ok && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int oy = oy0 + wm * 2 + mt;
+      if (oy >= p.Ho) continue;
+      const long mrow = ((long)img * p.Ho + oy) * p.Wo;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (n_ok && ox < p.Wo) {
+          const long m = mrow + ox;
+          float v = acc[mt][nt][r] + bias;
+          if (p.res) v += p.res[m * p.res_cs + n];
+          v = act_apply(v, p.act);
+          if (p.row_mask) v *= p.row_mask[m];
+          p.out[m * p.out_cs + p.out_co + n] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 variant, second generation: one kernel ROW (3 taps) per barrier interval.
+//   * the weight tiles of the 3 taps arrive by LDS-DMA (global_load_lds_dwordx4: the packed weight image
+//     in HBM is byte-identical to the LDS image, 1 KiB per wave-instruction, no VGPR round trip, no
+//     ds_write), double-buffered;
+//   * the A halo patch is single-buffered: chunk c+1 is prefetched into 12 VGPRs during the three row
+//     steps of chunk c and written (with the bf16 split) between two barriers at the chunk boundary;
+//   => 4 barriers per 16-channel chunk instead of 9, 36 (bf16x3) MFMAs per wave per interval, 70 KB of
+//      LDS so two 8-wave workgroups share a CU and cover each other's barriers.
+template <int SPLIT, int TN>
+__global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void conv_patch3_kernel(const PatchArgs p) {
+  constexpr int K = 3;
+  constexpr int PH = PT_TH + K - 1, PW = PT_TW + K - 1, NPIX = PH * PW;
+  constexpr int NPIXP = (NPIX + 15) / 16 * 16;
+  constexpr int BN = 64 * TN;
+  constexpr int A_OCT = NPIXP * 16, A_PLANE = 2 * A_OCT, A_BYTES = SPLIT * A_PLANE;
+  constexpr int B_OCT = BN * 16, B_PLANE = 2 * B_OCT, B_BYTES = SPLIT * B_PLANE;
+  constexpr int ROW_BYTES = 3 * B_BYTES;               // weight tiles of one kernel row
+  constexpr int ROW_INSTR = ROW_BYTES / 1024;          // 1 KiB LDS-DMA pieces
+  constexpr int ROUNDS = 3;                            // 340 px * 4 float4 over 512 threads
+  static_assert(NPIX * 4 <= ROUNDS * 512, "A patch does not fit the staging rounds");
+  static_assert(ROW_BYTES % 1024 == 0, "weight row must be a whole number of 1 KiB pieces");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const abuf = smem;
+  char* const bbase = smem + A_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int nblk = p.tiles_n * p.tiles_x * p.tiles_y * p.N;
+  int id = xcd_remap(blockIdx.x, nblk);
+  const int tn = id % p.tiles_n; id /= p.tiles_n;
+  const int tx = id % p.tiles_x; id /= p.tiles_x;
+  const int ty = id % p.tiles_y;
+  const int img = id / p.tiles_y;
+  const int oy0 = ty * PT_TH, ox0 = tx * PT_TW;
+
+  const int cq = tid & 3;
+  const int a_lofs0 = (cq >> 1) * A_OCT + (tid >> 2) * 16 + (cq & 1) * 8;
+  int a_gpix[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int pix = r * 128 + (tid >> 2);
+    const int py = pix / PW, px = pix % PW;
+    const int iy = oy0 + py - p.pad_t, ix = ox0 + px - p.pad_l;
+    const bool ok = pix < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    a_gpix[r] = ok ? (img * p.H + iy) * p.W + ix : -1;
+  }
+  auto load_a = [&](int r, int c) __attribute__((always_inline)) -> f32x4 {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const int ch = c * PT_CK + cq * 4;
+    if (a_gpix[r] >= 0 && ch < p.Cin) {
+      v = *reinterpret_cast<const f32x4*>(p.in + (size_t)a_gpix[r] * p.in_cs + ch);
+      if (p.a_scale) v *= *reinterpret_cast<const f32x4*>(p.a_scale + (size_t)img * p.Cin + ch);
+    }
+    return v;
+  };
+  auto store_a = [&](int r, f32x4 v) __attribute__((always_inline)) {
+    if (r * 128 + (tid >> 2) >= NPIX) return;
+    char* dst = abuf + a_lofs0 + r * (128 * 16);
+    f32x4 rem = v;
+#pragma unroll
+    for (int pl = 0; pl < SPLIT; ++pl) {           // hi, then the bf16 of what is left, ...
+      const bf16x4 piece = __builtin_convertvector(rem, bf16x4);
+      *reinterpret_cast<bf16x4*>(dst + pl * A_PLANE) = piece;
+      if (pl + 1 < SPLIT) rem -= __builtin_convertvector(piece, f32x4);
+    }
+  };
+  // weight rows of this channel tile: [chunk][row(ky)] -> ROW_BYTES each, contiguous
+  const char* wrow0 = p.wpk + (size_t)tn * p.nchunk * 3 * ROW_BYTES;
+  auto dma_row = [&](int g) __attribute__((always_inline)) {
+    const char* src = wrow0 + (size_t)g * ROW_BYTES + lane * 16;
+    char* dst = bbase + (g & 1) * ROW_BYTES;
+#pragma unroll
+    for (int j = 0; j < (ROW_INSTR + 7) / 8; ++j) {
+      const int i = wave + 8 * j;
+      if (i < ROW_INSTR)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  dma_row(0);
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) store_a(r, load_a(r, 0));
+  __syncthreads();
+
+  const int nrows = p.nchunk * 3;
+  int g = 0;
+  for (int c = 0; c < p.nchunk; ++c) {
+    const bool more_a = c + 1 < p.nchunk;
+    f32x4 ra[ROUNDS];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky, ++g) {
+      if (g + 1 < nrows) dma_row(g + 1);
+      if (more_a) ra[ky] = load_a(ky, c + 1);
+      const char* Brow = bbase + (g & 1) * ROW_BYTES;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const char* B = Brow + kx * B_BYTES;
+        bf16x8 af[2][SPLIT], bfr[TN][SPLIT];
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+          const int n = (wn * TN + nt) * 32 + li;
+#pragma unroll
+          for (int pl = 0; pl < SPLIT; ++pl)
+            bfr[nt][pl] = *reinterpret_cast<const bf16x8*>(B + pl * B_PLANE + lh * B_OCT + n * 16);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int idx = (wm * 2 + mt + ky) * PW + kx + li;
+#pragma unroll
+          for (int pl = 0; pl < SPLIT; ++pl)
+            af[mt][pl] = *reinterpret_cast<const bf16x8*>(abuf + pl * A_PLANE + lh * A_OCT + idx * 16);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt) {
+            acc[mt][nt] = split_mfma<SPLIT>(af[mt], bfr[nt], acc[mt][nt]);
+          }
+      }
+      __syncthreads();     // row g consumed by every wave; DMA of row g+1 landed (vmcnt drained)
+    }
+    if (more_a) {
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) store_a(r, ra[r]);
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int nt = 0; nt < TN; ++nt) {
+    const int n = tn * BN + (wn * TN + nt) * 32 + li;
+    const bool n_ok = n < p.Cout;
+    const float bias = (n_ok && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int oy = oy0 + wm * 2 + mt;
+      if (oy >= p.Ho) continue;
+      const long mrow = ((long)img * p.Ho + oy) * p.Wo;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (n_ok && ox < p.Wo) {
+          const long m = mrow + ox;
+          float v = acc[mt][nt][r] + bias;
+          if (p.res) v += p.res[m * p.res_cs + n];
+          v = act_apply(v, p.act);
+          if (p.row_mask) v *= p.row_mask[m];
+          p.out[m * p.out_cs + p.out_co + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int SPLIT, int TN>
+static int launch_patch3(const PatchArgs& a, hipStream_t s) {
+  constexpr int NPIXP = ((PT_TH + 2) * (PT_TW + 2) + 15) / 16 * 16;
+  constexpr int smem = SPLIT * 2 * NPIXP * 16 + 2 * 3 * (SPLIT * 2 * 64 * TN * 16);
+  static bool attr_set = false;
+  if (!attr_set && smem > 64 * 1024) {
+    CRESTE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch3_kernel<SPLIT, TN>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  const int nblk = a.tiles_n * a.tiles_x * a.tiles_y * a.N;
+  conv_patch3_kernel<SPLIT, TN><<<nblk, 512, smem, s>>>(a);
+  CRESTE_CHECK_LAUNCH("conv_patch3");
+  return CRESTE_OK;
+}
+
+// weight packing: OIHW fp32 (x scale[co]) -> [ntile][chunk][tap][plane][k-octet][BN][8] bf16
+__global__ void pack_weight_patch_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                         __bf16* __restrict__ out, int Cout, int Cin, int K, int BN,
+                                         int nchunk, int split, long total) {
+  const int T = K * K;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long t = i;
+    const int e = t % 8; t /= 8;
+    const int n = t % BN; t /= BN;
+    const int oct = t % 2; t /= 2;
+    const int pl = t % split; t /= split;
+    const int tap = t % T; t /= T;
+    const int c = t % nchunk;
+    const int tile = (int)(t / nchunk);
+    const int co = tile * BN + n, ci = c * PT_CK + oct * 8 + e;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) {
+      v = w[(((long)co * Cin + ci) * K + tap / K) * K + tap % K];
+      if (scale) v *= scale[co];
+    }
+    __bf16 piece = (__bf16)v;
+    for (int q = 0; q < pl; ++q) { v -= (float)piece; piece = (__bf16)v; }
+    out[i] = piece;
+  }
+}
+
+static inline int patch_bn(int cout) { return cout > 64 ? 128 : 64; }
+static inline int patch_split(int prec) { return prec == CRESTE_PREC_BF16X6 ? 3 : (prec == CRESTE_PREC_BF16X3 ? 2 : 1); }
+
+template <int K, int SPLIT, int TN>
+static int launch_patch(const PatchArgs& a, hipStream_t s) {
+  constexpr int PH = PT_TH + K - 1, PW = PT_TW + K - 1, NPIXP = (PH * PW + 15) / 16 * 16;
+  constexpr int smem = 2 * (SPLIT * 2 * NPIXP * 16) + 2 * (SPLIT * 2 * 64 * TN * 16);
+  static bool attr_set = false;
+  if (!attr_set && smem > 64 * 1024) {
+    CRESTE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_kernel<K, SPLIT, TN>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  const int nblk = a.tiles_n * a.tiles_x * a.tiles_y * a.N;
+  conv_patch_kernel<K, SPLIT, TN><<<nblk, 512, smem, s>>>(a);
+  CRESTE_CHECK_LAUNCH("conv_patch");
+  return CRESTE_OK;
+}
+
+bool conv_patch_supported(int prec, int KH, int KW, int stride) {
+  return (prec == CRESTE_PREC_BF16 || prec == CRESTE_PREC_BF16X3 || prec == CRESTE_PREC_BF16X6) && KH == KW && (KH == 1 || KH == 3) &&
+         stride == 1;
+}
+
+int64_t conv_patch_weight_bytes(int Cout, int Cin, int K, int prec) {
+  const int bn = patch_bn(Cout);
+  const long tiles = (Cout + bn - 1) / bn, nchunk = (Cin + PT_CK - 1) / PT_CK;
+  return tiles * nchunk * K * K * patch_split(prec) * 2 * bn * 16;
+}
+
+int conv_patch_pack(const float* w, const float* scale, void* wpk, int Cout, int Cin, int K, int prec,
+                    hipStream_t s) {
+  const int bn = patch_bn(Cout), split = patch_split(prec), nchunk = (Cin + PT_CK - 1) / PT_CK;
+  const long total = conv_patch_weight_bytes(Cout, Cin, K, prec) / 2;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  pack_weight_patch_kernel<<<blocks, 256, 0, s>>>(w, scale, (__bf16*)wpk, Cout, Cin, K, bn, nchunk, split, total);
+  CRESTE_CHECK_LAUNCH("pack_weight_patch");
+  return CRESTE_OK;
+}
+
+int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
+  PatchArgs a;
+  a.in = d->in; a.wpk = (const char*)d->wpk; a.bias = d->bias; a.res = d->res; a.a_scale = d->a_scale;
+  a.row_mask = d->row_mask; a.out = d->out;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_cs = d->in_cs;
+  a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.out_cs = d->out_cs; a.out_co = d->out_co;
+  a.res_cs = d->res_cs; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.act = d->act;
+  a.nchunk = (d->Cin + PT_CK - 1) / PT_CK;
+  const int bn = patch_bn(d->Cout);
+  a.tiles_n = (d->Cout + bn - 1) / bn;
+  a.tiles_x = (d->Wo + PT_TW - 1) / PT_TW;
+  a.tiles_y = (d->Ho + PT_TH - 1) / PT_TH;
+  const int split = patch_split(d->prec);
+  const int K = d->KH;
+#define CRESTE_PATCH_DISPATCH(FN3, FN1)                                              \
+  if (K == 3) {                                                                      \
+    if (bn == 128) return split == 3 ? FN3<3, 2>(a, s) : split == 2 ? FN3<2, 2>(a, s) : FN3<1, 2>(a, s); \
+    return split == 3 ? FN3<3, 1>(a, s) : split == 2 ? FN3<2, 1>(a, s) : FN3<1, 1>(a, s);              \
+  }                                                                                  \
+  if (bn == 128) return split == 3 ? FN1<1, 3, 2>(a, s) : split == 2 ? FN1<1, 2, 2>(a, s) : FN1<1, 1, 2>(a, s); \
+  return split == 3 ? FN1<1, 3, 1>(a, s) : split == 2 ? FN1<1, 2, 1>(a, s) : FN1<1, 1, 1>(a, s);
+  CRESTE_PATCH_DISPATCH(launch_patch3, launch_patch)
+#undef CRESTE_PATCH_DISPATCH
+}
+
+}  // namespace creste

@@ -15,6 +15,26 @@ from . import ops
 from .ops import ACT_NONE, ACT_RELU, ACT_SWISH, Act, HipLibraryError  # noqa: F401
 
 
+PRECISIONS = {"f32": ops.PREC_F32, "bf16": ops.PREC_BF16, "bf16x3": ops.PREC_BF16X3, "bf16x6": ops.PREC_BF16X6}
+_precision = ops.PREC_F32
+
+
+def set_precision(name: str):
+    """Operand precision of the dense convs on the matrix cores:
+    'f32'    v_mfma_f32_32x32x2_f32, exact fp32 products (parity mode, every conv shape);
+    'bf16x3' fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate
+             (fp32-grade: ~2^-16 product error) -- stride-1 1x1/3x3 convs, the rest stays 'f32';
+    'bf16x6' fp32 operands split into three bf16 pieces, 6 MFMAs per product: fp32-equivalent products
+             (dropped terms <= 2^-24) at 2.7x the fp32 MFMA rate -- same coverage as bf16x3;
+    'bf16'   one bf16 MFMA per product (throughput mode), same coverage."""
+    global _precision
+    _precision = PRECISIONS[name]
+
+
+def get_precision() -> str:
+    return {v: k for k, v in PRECISIONS.items()}[_precision]
+
+
 def _sig(tensors):
     return tuple((t.data_ptr(), t._version, t.device.index) for t in tensors if t is not None)
 
@@ -58,7 +78,9 @@ class ConvUnit:
         return ts
 
     def packed(self) -> ops.PackedConv:
-        key = _sig(self._tensors())
+        k = self.conv.kernel_size[0]
+        prec = _precision if ops.conv_supported(_precision, k, self.conv.stride[0]) else ops.PREC_F32
+        key = (_sig(self._tensors()), prec)
         if self._packed is None or key != self._key:
             require_hip(self.conv.weight, "conv weight")
             bn = None
@@ -69,7 +91,7 @@ class ConvUnit:
                 b = self.bn
                 bn = (b.weight, b.bias, b.running_mean, b.running_var, b.eps)
             self._packed = ops.pack_conv(self.conv.weight, self.conv.bias, bn, self.conv.stride[0],
-                                         self.pad, self.act)
+                                         self.pad, self.act, prec)
             self._key = key
         return self._packed
 

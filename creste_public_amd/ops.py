@@ -12,7 +12,8 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, ACT_SWISH, PREC_F32, ConvDesc, HipLibraryError  # noqa: F401
+from ._lib import (ACT_NONE, ACT_RELU, ACT_SWISH, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F32, ConvDesc,  # noqa: F401
+                   HipLibraryError)
 
 
 def _stream() -> int:
@@ -78,6 +79,10 @@ class PackedConv:
     def out_hw(self, H, W):
         return ((H + self.pad_t + self.pad_b - self.KH) // self.stride + 1,
                 (W + self.pad_l + self.pad_r - self.KW) // self.stride + 1)
+
+
+def conv_supported(prec: int, k: int, stride: int) -> bool:
+    return bool(_lib.load().creste_conv_supported(prec, k, k, stride))
 
 
 def pack_conv(weight: torch.Tensor, bias, bn, stride, pad, act, prec=PREC_F32) -> PackedConv:

@@ -38,6 +38,11 @@ extern "C" {
 
 #define CRESTE_PREC_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate */
 #define CRESTE_PREC_BF16 1 /* v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulate   */
+#define CRESTE_PREC_BF16X3 2 /* fp32 operands split into bf16 hi+lo, hi*hi+hi*lo+lo*hi on the bf16
+                                MFMA, fp32 accumulate: ~2^-16 product error at 5.3x the fp32 MFMA rate */
+#define CRESTE_PREC_BF16X6 3 /* fp32 operands split into THREE bf16 pieces (24 bits = the whole fp32
+                                significand), the 6 piece products >= 2^-16 summed on the bf16 MFMA:
+                                fp32-equivalent products (dropped terms <= 2^-24) at 2.7x the fp32 MFMA rate */
 
 const char* creste_last_error(void);
 int creste_abi_version(void);
@@ -69,6 +74,8 @@ typedef struct creste_conv_desc {
 } creste_conv_desc;
 
 int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream);
+/* 1 when (precision, kernel, stride) is built: F32 covers everything, BF16/BF16X3 cover stride-1 1x1/3x3. */
+int creste_conv_supported(int prec, int KH, int KW, int stride);
 /* Size in BYTES of the packed weight for (Cout,Cin,KH,KW) at precision `prec`. */
 int64_t creste_conv_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int prec);
 /* Pack a torch OIHW fp32 weight (device pointer, contiguous) into the GEMM layout, optionally

@@ -71,6 +71,44 @@ def test_conv_igemm(ops, case):
     torch.testing.assert_close(got.double(), ref, rtol=2e-5, atol=2e-5)
 
 
+PATCH_CASES = [c for c in CONV_CASES if c[5] in (1, 3) and c[6] == 1] + [
+    (2, 64, 37, 70, 96, 3, 1, (1, 1, 1, 1), 1, False, True, True),     # partial tiles in x and y, residual
+    (1, 20, 9, 33, 200, 1, 1, (0, 0, 0, 0), 2, True, True, False),     # Cin not /16, two channel tiles
+    (1, 36, 12, 40, 40, 3, 1, (1, 1, 1, 1), 0, False, False, False),   # ragged chunk, BN=64 variant
+]
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16x6", 2e-6), ("bf16x3", 6e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("case", PATCH_CASES)
+def test_conv_patch_bf16(ops, case, prec, tol):
+    """bf16-MFMA patch engine: relative rms error vs a float64 conv.  bf16x3 must stay fp32-grade."""
+    N, Cin, H, W, Cout, K, s, pad, act, use_bias, use_bn, use_res = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g) if use_bias else None
+    bn = (torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1,
+          torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5, 1e-3) if use_bn else None
+    ref = F.conv2d(F.pad(x, (pad[2], pad[3], pad[0], pad[1])).double(), w.double(),
+                   None if b is None else b.double(), stride=s)
+    if bn is not None:
+        ref = F.batch_norm(ref, bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(), False, 0.0, bn[4])
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if res is not None:
+        ref = ref + res.double()
+    ref = {0: lambda t: t, 1: F.relu, 2: lambda t: t * torch.sigmoid(t)}[act](ref)
+    code = {"bf16x6": ops.PREC_BF16X6, "bf16x3": ops.PREC_BF16X3, "bf16": ops.PREC_BF16}[prec]
+    assert ops.conv_supported(code, K, s)
+    pc = ops.pack_conv(dev(w), None if b is None else dev(b),
+                       None if bn is None else tuple(dev(t) if isinstance(t, torch.Tensor) else t for t in bn),
+                       s, pad, act, code)
+    got = from_act(ops.conv2d(to_act(ops, x), pc, res=None if res is None else to_act(ops, res))).double()
+    assert got.shape == ref.shape
+    rel = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-12))
+    assert rel < tol, f"{prec}: relative rms error {rel:.2e}"
+    assert float((got - ref).abs().max()) < 60 * tol * float(ref.abs().max().clamp_min(1.0))
+
+
 def test_conv_slices_gate_and_rowmask(ops):
     """channel-slice input/output (zero-copy concat), SE gate on the A operand, row mask epilogue."""
     g = torch.Generator().manual_seed(5)

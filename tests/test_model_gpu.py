@@ -6,9 +6,14 @@ import torch
 from creste_public_amd import synth
 from creste_public_amd.config import maxent_irl_cfg, terrainnet_cfg
 
+import os
+
 pytestmark = pytest.mark.gpu
 
 H, W, B = 128, 192, 2
+# conv operand modes that must meet the parity bar: exact fp32 MFMA and the fp32-equivalent bf16x6
+# split (the mode bench.py times).  CRESTE_TEST_PRECISION narrows the run to one mode.
+PRECISIONS = [os.environ["CRESTE_TEST_PRECISION"]] if "CRESTE_TEST_PRECISION" in os.environ else ["f32", "bf16x6"]
 
 
 @torch.no_grad()
@@ -30,9 +35,9 @@ def calibrate_bn(oracle_model, run):
 
 
 @pytest.fixture(scope="module")
-def irl_pair():
+def oracle_case():
+    """oracle model (calibrated), inputs and its fp32 outputs -- shared by every precision."""
     from oracle.irl import MaxEntIRL as OracleIRL
-    from creste_public_amd import MaxEntIRL
     torch.manual_seed(1234)
     cfg = maxent_irl_cfg((H, W), solve_mdp=True)
     oracle = OracleIRL(cfg)
@@ -42,24 +47,34 @@ def irl_pair():
     with torch.no_grad():      # rewards of O(1) like a trained costmap (sparse BEV input makes BN outputs heavy-tailed)
         oracle.traversability_head.r.postpool[0].norm.weight.mul_(0.01)
         oracle.traversability_head.r.postpool[0].norm.bias.mul_(0.01)
+        ref = oracle((rgbd, p2p, expert))
+    return oracle, ref, (rgbd, p2p, expert)
+
+
+@pytest.fixture(scope="module", params=PRECISIONS)
+def irl_pair(request, oracle_case):
+    import creste_public_amd
+    from creste_public_amd import MaxEntIRL
+    creste_public_amd.set_precision(request.param)
+    oracle, ref, (rgbd, p2p, expert) = oracle_case
     model = MaxEntIRL(maxent_irl_cfg((H, W), solve_mdp=True))
     missing = model.load_state_dict(oracle.state_dict(), strict=True)      # identical key names
     assert not missing.missing_keys and not missing.unexpected_keys
     model = model.cuda().eval()
     with torch.no_grad():
-        ref = oracle((rgbd, p2p, expert))
         got = model((rgbd.cuda(), p2p.cuda(), expert.cuda()))
     torch.cuda.synchronize()
-    return model, oracle, ref, got, (rgbd, p2p, expert)
+    yield model, oracle, ref, got, (rgbd, p2p, expert)
+    creste_public_amd.set_precision("f32")
 
 
 @pytest.fixture(scope="module")
-def ref64(irl_pair):
+def ref64(oracle_case):
     """The same network evaluated in float64 on the CPU: the yardstick for fp32 round-off.  The fp32
     reference itself sits ~1e-3 (rms) away from it on the costmap of this randomly initialised network
     (sparse BEV input -> large BatchNorm gains), so end-to-end agreement is judged against that floor."""
     import copy
-    _, oracle, _, _, (rgbd, p2p, expert) = irl_pair
+    oracle, _, (rgbd, p2p, expert) = oracle_case
     o64 = copy.deepcopy(oracle).double()
     o64.fov_mask = oracle.fov_mask
     with torch.no_grad():
