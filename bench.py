@@ -119,8 +119,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x6", "bf16x3", "bf16"],
+    ap.add_argument("--precision", default="bf16x6", choices=["f32", "bf16x6", "bf16x3", "bf16"],
                     help="operand precision of the stride-1 1x1/3x3 convs on the matrix cores")
+    ap.add_argument("--no-modes", action="store_true", help="skip the short extra runs of the other precisions")
     ap.add_argument("--layers", default="", help="write a per-conv-shape timing table to this file")
     args = ap.parse_args()
 
@@ -173,6 +174,21 @@ def main():
     from creste_public_amd import dist_utils
     elapsed = dist_utils.max_over_ranks(elapsed, device)     # the job is as slow as its slowest rank
 
+    modes = {}
+    if args.gpus == 1 and not args.no_modes:
+        # the other conv operand modes, 3 steps each after 1 warm-up (same model, same inputs)
+        for name in ("f32", "bf16x6", "bf16x3", "bf16"):
+            if name == args.precision:
+                continue
+            creste_public_amd.set_precision(name)
+            step(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            modes[name] = round(3 * args.batch / (time.perf_counter() - t1), 2)
+        creste_public_amd.set_precision(args.precision)
+
     if rank == 0 and args.layers:
         per = {}
         for e0, e1, fl, bn, shape in prof.records:
@@ -222,6 +238,11 @@ def main():
                          "launches": d["n"], "avg_launch_ms": round(d["ms"] / d["n"], 4),
                          "conv_share_of_step": round(conv_ms / args.steps / (elapsed / args.steps * 1e3), 4)},
         }
+        if modes:
+            line["modes_frames_per_s"] = dict(modes, **{args.precision: line["value"]})
+            line["modes_note"] = ("conv operand modes: f32 = exact fp32 MFMA; bf16x6 = fp32 operands as 3 bf16 pieces, "
+                                  "6 exact piece products (fp32-equivalent, parity suite green); bf16x3 = 2 pieces "
+                                  "(~6e-5 rel per conv); bf16 = plain bf16 operands (~4e-3 rel per conv)")
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -64,6 +64,51 @@ struct PatchArgs {
   int tiles_x, tiles_y, tiles_n;
 };
 
+// Epilogue.  The MFMAs are issued with the WEIGHT fragment as the first operand, so D = W * X^T: in the
+// 32x32 C/D layout the lane indexes the pixel (col = lane&31) and the registers index channels
+// (row = (r&3) + 8*(r>>2) + 4*(lane>>5)): registers 4g..4g+3 are 4 CONSECUTIVE output channels of one
+// pixel -> one 16-byte store (and one 16-byte residual / bias load) instead of four dword stores; the
+// store tail of a conv is issue-bound, not bandwidth-bound (cdna_hip_programming.md T21).
+template <int TN>
+__device__ __forceinline__ void patch_epilogue(const f32x16 (&acc)[2][TN], const PatchArgs& p, int img,
+                                               int oy0, int ox0, int nbase, int wm, int wn, int li, int lh) {
+  const bool vec_ok = (p.Cout & 3) == 0 && (p.out_cs & 3) == 0 && (p.out_co & 3) == 0 &&
+                      (!p.res || (p.res_cs & 3) == 0);
+  const int ox = ox0 + li;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int oy = oy0 + wm * 2 + mt;
+    if (oy >= p.Ho || ox >= p.Wo) continue;
+    const long m = ((long)img * p.Ho + oy) * p.Wo + ox;
+    const float rmask = p.row_mask ? p.row_mask[m] : 1.f;
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = nbase + (wn * TN + nt) * 32 + 8 * g + 4 * lh;
+        if (n >= p.Cout) continue;
+        f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+        if (vec_ok) {
+          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+          if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * p.res_cs + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], p.act) * rmask;
+          *reinterpret_cast<f32x4*>(p.out + m * p.out_cs + p.out_co + n) = v;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (n + j < p.Cout) {
+              float x = v[j] + (p.bias ? p.bias[n + j] : 0.f);
+              if (p.res) x += p.res[m * p.res_cs + n + j];
+              p.out[m * p.out_cs + p.out_co + n + j] = act_apply(x, p.act) * rmask;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int K, int SPLIT, int TN>
 __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void conv_patch_kernel(const PatchArgs p) {
   constexpr int T = K * K;
@@ -198,7 +243,7 @@ __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void co
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt) {
-          acc[mt][nt] = split_mfma<SPLIT>(af[mt], bfr[nt], acc[mt][nt]);
+          acc[mt][nt] = split_mfma<SPLIT>(bfr[nt], af[mt], acc[mt][nt]);
         }
 
       // ---- land the prefetched tiles in the other buffers
@@ -209,31 +254,7 @@ __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void co
     }
   }
 
-  // ---- epilogue (C/D layout: col = lane&31 -> channel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> pixel x)
-#pragma unroll
-  for (int nt = 0; nt < TN; ++nt) {
-    const int n = tn * BN + (wn * TN + nt) * 32 + li;
-    const bool n_ok = n < p.Cout;
-    const float bias = (n_ok && p.bias) ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int oy = oy0 + wm * 2 + mt;
-      if (oy >= p.Ho) continue;
-      const long mrow = ((long)img * p.Ho + oy) * p.Wo;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n_ok && ox < p.Wo) {
-          const long m = mrow + ox;
-          float v = acc[mt][nt][r] + bias;
-          if (p.res) v += p.res[m * p.res_cs + n];
-          v = act_apply(v, p.act);
-          if (p.row_mask) v *= p.row_mask[m];
-          p.out[m * p.out_cs + p.out_co + n] = v;
-        }
-      }
-    }
-  }
+  patch_epilogue<TN>(acc, p, img, oy0, ox0, tn * BN, wm, wn, li, lh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -367,7 +388,7 @@ __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void co
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
           for (int nt = 0; nt < TN; ++nt) {
-            acc[mt][nt] = split_mfma<SPLIT>(af[mt], bfr[nt], acc[mt][nt]);
+            acc[mt][nt] = split_mfma<SPLIT>(bfr[nt], af[mt], acc[mt][nt]);
           }
       }
       __syncthreads();     // row g consumed by every wave; DMA of row g+1 landed (vmcnt drained)
@@ -379,30 +400,7 @@ __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void co
     }
   }
 
-#pragma unroll
-  for (int nt = 0; nt < TN; ++nt) {
-    const int n = tn * BN + (wn * TN + nt) * 32 + li;
-    const bool n_ok = n < p.Cout;
-    const float bias = (n_ok && p.bias) ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int oy = oy0 + wm * 2 + mt;
-      if (oy >= p.Ho) continue;
-      const long mrow = ((long)img * p.Ho + oy) * p.Wo;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n_ok && ox < p.Wo) {
-          const long m = mrow + ox;
-          float v = acc[mt][nt][r] + bias;
-          if (p.res) v += p.res[m * p.res_cs + n];
-          v = act_apply(v, p.act);
-          if (p.row_mask) v *= p.row_mask[m];
-          p.out[m * p.out_cs + p.out_co + n] = v;
-        }
-      }
-    }
-  }
+  patch_epilogue<TN>(acc, p, img, oy0, ox0, tn * BN, wm, wn, li, lh);
 }
 
 template <int SPLIT, int TN>
