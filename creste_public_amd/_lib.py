@@ -38,7 +38,8 @@ SIGNATURES = {
     "creste_conv_packed_weight_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "creste_conv_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "creste_dwconv2d_nhwc_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
-    "creste_se_partial_rows": (_i, [_i]),
+    "creste_se_partial_count": (_i, [_i, _i]),
+    "creste_dwconv_se_nhwc_f32": (_i, [_vp] * 5 + [_i] * 11 + [_vp]),
     "creste_se_gate_f32": (_i, [_vp] * 7 + [_i] * 4 + [_vp]),
     "creste_upsample_concat_nhwc_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i,
                                               _f, _f, _vp]),

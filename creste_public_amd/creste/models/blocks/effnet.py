@@ -87,8 +87,8 @@ class MBConvBlock(nn.Module):
         p = self._plan
         h = p["expand"](x) if p["expand"] is not None else x
         w, b = p["dw"].get()
-        h = ops.dwconv2d(h, w, b, self.k, self.s, self._depthwise_conv.static_pad, ACT_SWISH)
-        gate = ops.se_gate(h, *p["se"].get())
+        h, gate = ops.dwconv2d_se(h, w, b, self.k, self.s, self._depthwise_conv.static_pad, ACT_SWISH,
+                                  *p["se"].get())
         res = x if (self.s == 1 and self.cin == self.cout) else None   # id_skip (drop-connect is train-only)
         return p["project"](h, res=res, a_scale=gate)
 

@@ -57,7 +57,15 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ i
 }
 
 // ------------------------------------------------------------------------------ squeeze-excite
-constexpr int SE_ROWS_PER_BLOCK = 2048;   // pixels reduced by one block of the partial pass
+// pixels reduced by one block: >= 16 per pixel-slice (so a thread's serial loop stays short when the
+// channel count is large) and large enough that an image needs <= 256 blocks.
+__host__ __device__ inline int se_rows_per_block(int HW, int C) {
+  const int cq = C >> 2;
+  const int slices = 256 / cq > 0 ? 256 / cq : 1;
+  const int a = slices * 16, b = (HW + 255) / 256;
+  return a > b ? a : b;
+}
+   // pixels reduced by one block of the partial pass
 
 // partial[n][chunk][c] = sum over the chunk's pixels of x[n][p][c]   (deterministic order)
 __global__ __launch_bounds__(256) void se_partial_kernel(const float* __restrict__ x,
@@ -67,8 +75,9 @@ __global__ __launch_bounds__(256) void se_partial_kernel(const float* __restrict
   const int n = blockIdx.y, chunk = blockIdx.x;
   const int cq = C >> 2;
   const int slices = 256 / cq > 0 ? 256 / cq : 1;     // pixel slices processed in parallel
-  const int p0 = chunk * SE_ROWS_PER_BLOCK;
-  const int p1 = min(HW, p0 + SE_ROWS_PER_BLOCK);
+  const int rows = se_rows_per_block(HW, C);
+  const int p0 = chunk * rows;
+  const int p1 = min(HW, p0 + rows);
   // thread -> (slice, channel quad); when C/4 > 256 a thread loops over several quads
   for (int q0 = 0; q0 < cq; q0 += 256) {
     const int tq = (cq >= 256) ? q0 + threadIdx.x : threadIdx.x % cq;
@@ -78,6 +87,65 @@ __global__ __launch_bounds__(256) void se_partial_kernel(const float* __restrict
     if (active)
       for (int p = p0 + sl; p < p1; p += slices) s += ld4(x + ((long)n * HW + p) * C + tq * 4);
     if (active) st4(sm + (long)sl * C + tq * 4, s);
+    __syncthreads();
+    if (active && sl == 0) {
+      f32x4 tot = s;
+      for (int k = 1; k < slices; ++k) tot += ld4(sm + (long)k * C + tq * 4);
+      st4(partial + ((long)n * nchunk + chunk) * C + tq * 4, tot);
+    }
+    __syncthreads();
+  }
+}
+
+// depthwise conv + bias + activation AND the squeeze-excite partial channel sums of its OUTPUT in one pass:
+// the SE mean no longer re-reads the (up to 1.1 GB) activated tensor.  Same (slice, channel-quad) thread
+// layout and the same deterministic reduction order as se_partial_kernel.
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict__ in,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias,
+                                                        float* __restrict__ out, float* __restrict__ partial,
+                                                        int H, int W, int C, int Ho, int Wo, int stride,
+                                                        int pad_t, int pad_l, int act, int nchunk) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [slices][C]
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int cq = C >> 2;
+  const int slices = 256 / cq > 0 ? 256 / cq : 1;
+  const int HWo = Ho * Wo;
+  const int rows = se_rows_per_block(HWo, C);
+  const int p0 = chunk * rows;
+  const int p1 = min(HWo, p0 + rows);
+  for (int q0 = 0; q0 < cq; q0 += 256) {
+    const int tq = (cq >= 256) ? q0 + threadIdx.x : threadIdx.x % cq;
+    const int sl = (cq >= 256) ? 0 : threadIdx.x / cq;
+    const bool active = tq < cq && sl < slices;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+      const int c = tq * 4;
+      const f32x4 b4 = bias ? ld4(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int p = p0 + sl; p < p1; p += slices) {
+        const int oy = p / Wo, ox = p % Wo;
+        const int iy0 = oy * stride - pad_t, ix0 = ox * stride - pad_l;
+        f32x4 acc = b4;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          const int iy = iy0 + ky;
+          if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) {
+            const int ix = ix0 + kx;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            acc += ld4(in + (((long)n * H + iy) * W + ix) * C + c) * ld4(w + (ky * K + kx) * C + c);
+          }
+        }
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = act_apply(acc[j], act);
+        st4(out + ((long)n * HWo + p) * C + c, o);
+        s += o;
+      }
+      st4(sm + (long)sl * C + tq * 4, s);
+    }
     __syncthreads();
     if (active && sl == 0) {
       f32x4 tot = s;
@@ -101,9 +169,22 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
   float* hid = sm + C;
   const int n = blockIdx.x;
   const float inv = 1.f / (float)HW;
+  // G thread groups split the chunk list (fixed assignment -> deterministic), then a serial G-way add
+  const int G = C < 256 ? 256 / C : 1;
+  float* gsum = hid + Cse;                               // [G][C] scratch
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int c = c0 + (G > 1 ? threadIdx.x % C : threadIdx.x);
+    const int g = G > 1 ? threadIdx.x / C : 0;
+    if (c < C && g < G) {
+      float s = 0.f;
+      for (int k = g; k < nchunk; k += G) s += partial[((long)n * nchunk + k) * C + c];
+      gsum[g * C + c] = s;
+    }
+  }
+  __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     float s = 0.f;
-    for (int k = 0; k < nchunk; ++k) s += partial[((long)n * nchunk + k) * C + c];
+    for (int g = 0; g < G; ++g) s += gsum[g * C + c];
     mean[c] = s * inv;
   }
   __syncthreads();
@@ -359,20 +440,26 @@ extern "C" int creste_dwconv2d_nhwc_f32(const float* in, const float* w, const f
   return CRESTE_OK;
 }
 
-extern "C" int creste_se_partial_rows(int HW) { return (HW + SE_ROWS_PER_BLOCK - 1) / SE_ROWS_PER_BLOCK; }
+extern "C" int creste_se_partial_count(int HW, int C) {
+  if (HW <= 0 || C <= 0 || (C & 3)) return -1;
+  const int rows = se_rows_per_block(HW, C);
+  return (HW + rows - 1) / rows;
+}
 
 extern "C" int creste_se_gate_f32(const float* x, float* partial, const float* w1, const float* b1,
                                   const float* w2, const float* b2, float* gate, int N, int HW, int C,
                                   int Cse, void* stream) {
-  CRESTE_REQUIRE(x && partial && w1 && b1 && w2 && b2 && gate, "se_gate: null pointer");
+  CRESTE_REQUIRE(partial && w1 && b1 && w2 && b2 && gate, "se_gate: null pointer");
   CRESTE_REQUIRE(C % 4 == 0 && C > 0 && Cse > 0 && N > 0 && HW > 0, "se_gate: bad dims");
-  const int nchunk = creste_se_partial_rows(HW);
+  const int nchunk = creste_se_partial_count(HW, C);
   const int cq = C / 4;
   const int slices = 256 / cq > 0 ? 256 / cq : 1;
   hipStream_t s = (hipStream_t)stream;
-  se_partial_kernel<<<dim3(nchunk, N), 256, (size_t)slices * C * sizeof(float), s>>>(x, partial, HW, C, nchunk);
-  CRESTE_CHECK_LAUNCH("se_partial");
-  se_gate_kernel<<<N, 256, (size_t)(C + Cse) * sizeof(float), s>>>(partial, w1, b1, w2, b2, gate, HW, C, Cse, nchunk);
+  if (x) {   // x == NULL: `partial` was already filled by creste_dwconv_se_nhwc_f32
+    se_partial_kernel<<<dim3(nchunk, N), 256, (size_t)slices * C * sizeof(float), s>>>(x, partial, HW, C, nchunk);
+    CRESTE_CHECK_LAUNCH("se_partial");
+  }
+  se_gate_kernel<<<N, 256, (size_t)(C + Cse + (C < 256 ? (256 / C) * C : C)) * sizeof(float), s>>>(partial, w1, b1, w2, b2, gate, HW, C, Cse, nchunk);
   CRESTE_CHECK_LAUNCH("se_gate");
   return CRESTE_OK;
 }
@@ -465,5 +552,22 @@ extern "C" int creste_resize_plane_f32(const float* in, int N, int H, int W, flo
   CRESTE_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && Hd >= Ho, "resize_plane: bad args");
   resize_plane_kernel<<<grid_for((long)N * Ho * Wo), 256, 0, (hipStream_t)stream>>>(in, H, W, out, N, Ho, Wo, Hd, rh, rw);
   CRESTE_CHECK_LAUNCH("resize_plane");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_dwconv_se_nhwc_f32(const float* in, const float* w, const float* bias, float* out,
+                                         float* partial, int N, int H, int W, int C, int Ho, int Wo, int K,
+                                         int stride, int pad_t, int pad_l, int act, void* stream) {
+  CRESTE_REQUIRE(in && w && out && partial, "dwconv_se: null pointer");
+  CRESTE_REQUIRE(C % 4 == 0 && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "dwconv_se: bad dims (C%%4)");
+  CRESTE_REQUIRE(K == 3 || K == 5, "dwconv_se: kernel size %d not built (3 or 5)", K);
+  const int nchunk = creste_se_partial_count(Ho * Wo, C);
+  const int cq = C / 4;
+  const int slices = 256 / cq > 0 ? 256 / cq : 1;
+  const size_t smem = (size_t)slices * C * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (K == 3) dwconv_se_kernel<3><<<dim3(nchunk, N), 256, smem, s>>>(in, w, bias, out, partial, H, W, C, Ho, Wo, stride, pad_t, pad_l, act, nchunk);
+  else dwconv_se_kernel<5><<<dim3(nchunk, N), 256, smem, s>>>(in, w, bias, out, partial, H, W, C, Ho, Wo, stride, pad_t, pad_l, act, nchunk);
+  CRESTE_CHECK_LAUNCH("dwconv_se");
   return CRESTE_OK;
 }

@@ -164,12 +164,31 @@ def dwconv2d(x: Act, w_taps: torch.Tensor, bias: torch.Tensor, K, stride, pad, a
     return out
 
 
+def dwconv2d_se(x: Act, w_taps, bias, K, stride, pad, act, se_w1, se_b1, se_w2, se_b2):
+    """depthwise conv + activation and the squeeze-excite gate of its output (one read of the tensor)."""
+    lib = _lib.load()
+    assert x.co == 0 and x.cs == x.C, "dwconv expects a dense NHWC tensor"
+    Ho = (x.H + pad[0] + pad[1] - K) // stride + 1
+    Wo = (x.W + pad[2] + pad[3] - K) // stride + 1
+    dev = x.buf.device
+    out = Act.empty(x.N, Ho, Wo, x.C, dev)
+    partial = torch.empty((x.N, lib.creste_se_partial_count(Ho * Wo, x.C), x.C), dtype=torch.float32, device=dev)
+    gate = torch.empty((x.N, x.C), dtype=torch.float32, device=dev)
+    _lib.check(lib.creste_dwconv_se_nhwc_f32(x.ptr, _chk(w_taps).data_ptr(), _chk(bias).data_ptr(), out.ptr,
+                                             partial.data_ptr(), x.N, x.H, x.W, x.C, Ho, Wo, K, stride,
+                                             pad[0], pad[2], act, _stream()), "dwconv_se")
+    _lib.check(lib.creste_se_gate_f32(None, partial.data_ptr(), _chk(se_w1).data_ptr(), _chk(se_b1).data_ptr(),
+                                      _chk(se_w2).data_ptr(), _chk(se_b2).data_ptr(), gate.data_ptr(), x.N,
+                                      Ho * Wo, x.C, se_w1.shape[0], _stream()), "se_gate")
+    return out, gate
+
+
 def se_gate(x: Act, w1, b1, w2, b2) -> torch.Tensor:
     lib = _lib.load()
     assert x.co == 0 and x.cs == x.C
     HW = x.H * x.W
     Cse = w1.shape[0]
-    partial = torch.empty((x.N, lib.creste_se_partial_rows(HW), x.C), dtype=torch.float32,
+    partial = torch.empty((x.N, lib.creste_se_partial_count(HW, x.C), x.C), dtype=torch.float32,
                           device=x.buf.device)
     gate = torch.empty((x.N, x.C), dtype=torch.float32, device=x.buf.device)
     _lib.check(lib.creste_se_gate_f32(x.ptr, partial.data_ptr(), _chk(w1).data_ptr(), _chk(b1).data_ptr(),

@@ -90,8 +90,14 @@ int creste_dwconv2d_nhwc_f32(const float* in, const float* w, const float* bias,
                              int pad_l, int act, void* stream);
 
 /* Squeeze-excite gate of an MBConv block: gate[n,c] = sigmoid(W2 * swish(W1 * mean_hw(x) + b1) + b2).
- * `partial` is caller workspace of at least N*creste_se_partial_rows(H*W)*C floats. */
-int creste_se_partial_rows(int HW);
+ * `partial` is caller workspace of at least N*creste_se_partial_count(H*W, C)*C floats; x may be NULL when
+ * `partial` already holds the sums (creste_dwconv_se_nhwc_f32). */
+int creste_se_partial_count(int HW, int C);   /* partial-sum rows per image for an HW x C tensor */
+/* Depthwise conv + bias + activation that also leaves the squeeze-excite partial channel sums of its
+ * output in `partial` ([N][creste_se_partial_count(Ho*Wo, C)][C]); follow with creste_se_gate_f32(x = NULL). */
+int creste_dwconv_se_nhwc_f32(const float* in, const float* w, const float* bias, float* out,
+                              float* partial, int N, int H, int W, int C, int Ho, int Wo, int K, int stride,
+                              int pad_t, int pad_l, int act, void* stream);
 int creste_se_gate_f32(const float* x, float* partial, const float* w1, const float* b1,
                        const float* w2, const float* b2, float* gate, int N, int HW, int C, int Cse,
                        void* stream);

@@ -34,7 +34,7 @@ def test_header_symbols_are_exported_and_bound():
     # pure-host queries work without a GPU
     assert handle.creste_conv_packed_weight_bytes(496, 496, 3, 3, 0) == 512 * 9 * 496 * 4
     assert handle.creste_bev_splat_workspace_bytes(1, 100, 256, 256) > 0
-    assert handle.creste_se_partial_rows(4096) == 2
+    assert handle.creste_se_partial_count(4096, 96) == 26      # 10 pixel slices x 16 rows
 
 
 def test_argument_errors_are_reported_not_thrown():

@@ -143,6 +143,27 @@ def test_dwconv(ops, K, s, pad):
     torch.testing.assert_close(from_act(out), ref, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("Cc,K,s,pad", [(96, 3, 2, (0, 1, 0, 1)), (240, 5, 1, (2, 2, 2, 2)), (1152, 3, 1, (1, 1, 1, 1))])
+def test_dwconv_se_fused(ops, Cc, K, s, pad):
+    g = torch.Generator().manual_seed(Cc + K)
+    N, H, W, Cse = 2, 45, 31, 12
+    x = torch.randn(N, Cc, H, W, generator=g)
+    w = torch.randn(Cc, 1, K, K, generator=g) / K
+    b = torch.randn(Cc, generator=g)
+    w1, b1 = torch.randn(Cse, Cc, generator=g) / Cc ** 0.5, torch.randn(Cse, generator=g)
+    w2, b2 = torch.randn(Cc, Cse, generator=g) / Cse ** 0.5, torch.randn(Cc, generator=g)
+    y = F.conv2d(F.pad(x, (pad[2], pad[3], pad[0], pad[1])), w, b, stride=s, groups=Cc)
+    y = y * torch.sigmoid(y)
+    m = y.double().mean(dim=(2, 3))
+    h = m @ w1.double().t() + b1.double()
+    h = h * torch.sigmoid(h)
+    gate_ref = torch.sigmoid(h @ w2.double().t() + b2.double())
+    out, gate = ops.dwconv2d_se(to_act(ops, x), dev(w.view(Cc, K * K).t().contiguous()), dev(b), K, s, pad,
+                                ops.ACT_SWISH, dev(w1), dev(b1), dev(w2), dev(b2))
+    torch.testing.assert_close(from_act(out), y, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gate.cpu().double(), gate_ref, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("Cc,Cse,HW", [(32, 8, (40, 52)), (96, 4, (64, 70)), (1152, 48, (5, 7))])
 def test_se_gate(ops, Cc, Cse, HW):
     g = torch.Generator().manual_seed(Cc)
