@@ -112,6 +112,67 @@ def cpu_baseline(sample_frames=1, runs=3):
                       f"{cores} threads, fp32"}
 
 
+def irl_extras(model_infer, device, steps=3):
+    """The second half of BASELINE.json's metric: IRL train-step time (configs[2]).  Reference-config
+    step: batch 8 frames, 64x128 IRL grid (map_ds 2 + front-half crop), frozen HIP backbone, autograd
+    reward net, value iteration + expected SVF kernels, MaxEntIRLLoss with counterfactual mixing and
+    gradient penalty, Adam step (reference train_traversability.py:66-105).  Plus the MDP kernels alone
+    on the 8x256x256 grid BASELINE names."""
+    import numpy as np
+    from creste_public_amd import LossManager, MaxEntIRL, maxent_irl_cfg, ops, synth
+    B = 8
+    cfg = maxent_irl_cfg((IMG_H, IMG_W), solve_mdp=True)
+    model = MaxEntIRL(cfg)
+    model.load_state_dict(model_infer.state_dict(), strict=True)
+    with torch.no_grad():   # costmaps of O(1) as after training (random-init BN gains give rewards ~1e2)
+        model.traversability_head.r.postpool[0].norm.weight.mul_(0.01)
+        model.traversability_head.r.postpool[0].norm.bias.mul_(0.01)
+    model = model.to(device).train()
+    lm = LossManager(cfg).to(device)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-4, betas=(0.9, 0.999))
+    rgbd, p2p = synth.make_frames(B, IMG_H, IMG_W, seed=4242)
+    rgbd, p2p = rgbd.to(device), p2p.to(device)
+    expert = synth.make_experts(B, 50, 256, seed=5).to(device)
+    fov = torch.ones(B, 256, 256, dtype=torch.bool, device=device)
+    rng = np.random.RandomState(0)
+    cf = [dict(trajectories=(np.array([[100.0, 128.0]]) + np.linspace(0, 1, 20)[None, :, None] *
+                             rng.uniform(-80, 80, size=(2, 1, 2))).astype(np.float32), rank=np.array([0, 1]))
+          for _ in range(B)]
+
+    def step():
+        opt.zero_grad()
+        out = model((rgbd, p2p, expert))
+        td = {f"outputs/{k}": v for k, v in out.items()}
+        td.update({"inputs/traversability_label": expert, "inputs/fov_mask": fov,
+                   "inputs/counterfactuals_label": cf, "task": "irl"})
+        ld, _ = lm(td)
+        loss = sum(w * v for w, v in ld.values())
+        loss.backward()
+        opt.step()
+        return loss
+
+    step(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    sweeps = int(model.traversability_head.last_sweeps.item())
+    # MDP kernels alone, 8 x 256 x 256, r ~ U[0,1)
+    r = torch.rand(8, 256, 256, device=device)
+    ops.value_iteration(r, 0.99, 1e-3); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        v, q, pi, sw = ops.value_iteration(r, 0.99, 1e-3)
+    torch.cuda.synchronize()
+    vi_ms = (time.perf_counter() - t0) / 3 * 1e3
+    n = int(sw.item())
+    return {"irl_train_step_ms": round(ms, 2), "irl_config": f"batch {B}, {IMG_W}x{IMG_H} frames, 64x128 IRL grid, "
+            f"{sweeps} VI sweeps, T=50 SVF, CF-IRL loss + gradient penalty + Adam; loss {float(loss):.4f}",
+            "vi_8x256x256_ms": round(vi_ms, 3), "vi_8x256x256_sweeps": n,
+            "vi_8x256x256_algorithmic_GBps": round(8 * 256 * 256 * (12 * n + 72) / vi_ms / 1e6, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +182,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16x6", choices=["f32", "bf16x6", "bf16x3", "bf16"],
                     help="operand precision of the stride-1 1x1/3x3 convs on the matrix cores")
+    ap.add_argument("--no-irl", action="store_true", help="skip the IRL train-step timing")
     ap.add_argument("--no-modes", action="store_true", help="skip the short extra runs of the other precisions")
     ap.add_argument("--layers", default="", help="write a per-conv-shape timing table to this file")
     args = ap.parse_args()
@@ -243,6 +305,8 @@ def main():
             line["modes_note"] = ("conv operand modes: f32 = exact fp32 MFMA; bf16x6 = fp32 operands as 3 bf16 pieces, "
                                   "6 exact piece products (fp32-equivalent, parity suite green); bf16x3 = 2 pieces "
                                   "(~6e-5 rel per conv); bf16 = plain bf16 operands (~4e-3 rel per conv)")
+        if args.gpus == 1 and not args.no_irl:
+            line["irl"] = irl_extras(model, device)
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
