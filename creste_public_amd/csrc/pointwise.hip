@@ -156,40 +156,46 @@ __global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict_
   }
 }
 
-// one block per sample: mean -> FC1 + swish -> FC2 -> sigmoid
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ partial,
-                                                      const float* __restrict__ w1,
-                                                      const float* __restrict__ b1,
-                                                      const float* __restrict__ w2,
-                                                      const float* __restrict__ b2,
-                                                      float* __restrict__ gate, int HW, int C, int Cse,
-                                                      int nchunk) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // mean[C] + hid[Cse]
+// one 1024-thread block per sample: mean -> FC1 + swish -> FC2 -> sigmoid
+constexpr int SEG_T = 1024;
+__global__ __launch_bounds__(SEG_T) void se_gate_kernel(const float* __restrict__ partial,
+                                                        const float* __restrict__ w1,
+                                                        const float* __restrict__ b1,
+                                                        const float* __restrict__ w2,
+                                                        const float* __restrict__ b2,
+                                                        float* __restrict__ gate, int HW, int C, int Cse,
+                                                        int nchunk) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // mean[C] + hid[Cse] + gsum[G][C]
   float* mean = sm;
   float* hid = sm + C;
   const int n = blockIdx.x;
   const float inv = 1.f / (float)HW;
   // G thread groups split the chunk list (fixed assignment -> deterministic), then a serial G-way add
-  const int G = C < 256 ? 256 / C : 1;
+  const int G = C < SEG_T ? SEG_T / C : 1;
   float* gsum = hid + Cse;                               // [G][C] scratch
-  for (int c0 = 0; c0 < C; c0 += 256) {
+  for (int c0 = 0; c0 < C; c0 += SEG_T) {
     const int c = c0 + (G > 1 ? threadIdx.x % C : threadIdx.x);
     const int g = G > 1 ? threadIdx.x / C : 0;
     if (c < C && g < G) {
-      float s = 0.f;
-      for (int k = g; k < nchunk; k += G) s += partial[((long)n * nchunk + k) * C + c];
-      gsum[g * C + c] = s;
+      float s0 = 0.f, s1 = 0.f;
+      int k = g;
+      for (; k + G < nchunk; k += 2 * G) {                // two independent loads in flight
+        s0 += partial[((long)n * nchunk + k) * C + c];
+        s1 += partial[((long)n * nchunk + k + G) * C + c];
+      }
+      if (k < nchunk) s0 += partial[((long)n * nchunk + k) * C + c];
+      gsum[g * C + c] = s0 + s1;
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += SEG_T) {
     float s = 0.f;
     for (int g = 0; g < G; ++g) s += gsum[g * C + c];
     mean[c] = s * inv;
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int j = wave; j < Cse; j += 4) {               // one wave per squeezed channel
+  for (int j = wave; j < Cse; j += SEG_T / 64) {         // one wave per squeezed channel
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += w1[(long)j * C + c] * mean[c];
 #pragma unroll
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
     if (lane == 0) hid[j] = act_apply(s + b1[j], CRESTE_ACT_SWISH);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += SEG_T) {
     float s = b2[c];
     for (int j = 0; j < Cse; ++j) s += w2[(long)c * Cse + j] * hid[j];
     gate[(long)n * C + c] = 1.f / (1.f + expf(-s));
@@ -459,7 +465,7 @@ extern "C" int creste_se_gate_f32(const float* x, float* partial, const float* w
     se_partial_kernel<<<dim3(nchunk, N), 256, (size_t)slices * C * sizeof(float), s>>>(x, partial, HW, C, nchunk);
     CRESTE_CHECK_LAUNCH("se_partial");
   }
-  se_gate_kernel<<<N, 256, (size_t)(C + Cse + (C < 256 ? (256 / C) * C : C)) * sizeof(float), s>>>(partial, w1, b1, w2, b2, gate, HW, C, Cse, nchunk);
+  se_gate_kernel<<<N, SEG_T, (size_t)(C + Cse + (C < SEG_T ? (SEG_T / C) * C : C)) * sizeof(float), s>>>(partial, w1, b1, w2, b2, gate, HW, C, Cse, nchunk);
   CRESTE_CHECK_LAUNCH("se_gate");
   return CRESTE_OK;
 }
