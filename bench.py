@@ -57,10 +57,10 @@ class ConvProfiler:
         self._ops, self._orig = ops, ops.conv2d
         prof = self
 
-        def timed(x, pc, out=None, res=None, a_scale=None, row_mask=None):
+        def timed(x, pc, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            y = prof._orig(x, pc, out=out, res=res, a_scale=a_scale, row_mask=row_mask)
+            y = prof._orig(x, pc, **kw)
             e1.record()
             flops = 2.0 * y.N * y.H * y.W * pc.Cout * pc.Cin * pc.KH * pc.KW
             bn = f"{PREC_NAME[pc.prec]}/BN{128 if pc.Cout > 64 else (64 if pc.Cout > 32 or pc.prec else 32)}"

@@ -21,10 +21,12 @@ class HipLibraryError(RuntimeError):
 
 class ConvDesc(C.Structure):
     _fields_ = [("in_", C.c_void_p), ("wpk", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
-                ("a_scale", C.c_void_p), ("row_mask", C.c_void_p), ("out", C.c_void_p)] + \
+                ("a_scale", C.c_void_p), ("row_mask", C.c_void_p), ("out", C.c_void_p),
+                ("up_src", C.c_void_p)] + \
                [(n, C.c_int32) for n in ("N", "H", "W", "Cin", "in_cs", "Ho", "Wo", "Cout", "out_cs",
                                          "out_co", "res_cs", "KH", "KW", "stride", "pad_t", "pad_l",
-                                         "act", "prec")]
+                                         "act", "prec", "up_H", "up_W", "up_C", "up_cs")] + \
+               [("up_rh", C.c_float), ("up_rw", C.c_float)]
 
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
@@ -35,6 +37,7 @@ SIGNATURES = {
     "creste_abi_version": (_i, []),
     "creste_conv2d_nhwc": (_i, [C.POINTER(ConvDesc), _vp]),
     "creste_conv_supported": (_i, [_i, _i, _i, _i]),
+    "creste_conv_supported_upsample": (_i, [_i, _i, _i, _i]),
     "creste_conv_packed_weight_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "creste_conv_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "creste_dwconv2d_nhwc_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),

@@ -142,20 +142,32 @@ class Up(nn.Module):
             nn.ReLU(inplace=True))
         self._units = None
 
-    def concat_act(self, x1: Act, x2: Act) -> Act:
-        sf, (rh, rw) = up_scales(self.up.scale_factor)
-        Ho, Wo = up_out_size(x1.H, x1.W, sf)
-        assert (Ho, Wo) == (x2.H, x2.W), f"Up: skip is {x2.H}x{x2.W}, upsampled map is {Ho}x{Wo}"
-        return ops.upsample_concat(x1, x2, Ho, Wo, rh, rw)
-
-    def convs_act(self, cat: Act, out: Act = None) -> Act:
+    def _u(self):
         if self._units is None:
             self._units = [ConvUnit(self.conv[0], self.conv[1], ACT_RELU),
                            ConvUnit(self.conv[3], self.conv[4], ACT_RELU)]
-        return self._units[1](self._units[0](cat), out=out)
+        return self._units
 
-    def forward_act(self, x1: Act, x2: Act) -> Act:
-        return self.convs_act(self.concat_act(x1, x2))
+    def _geom(self, x1: Act, x2: Act):
+        sf, (rh, rw) = up_scales(self.up.scale_factor)
+        Ho, Wo = up_out_size(x1.H, x1.W, sf)
+        assert (Ho, Wo) == (x2.H, x2.W), f"Up: skip is {x2.H}x{x2.W}, upsampled map is {Ho}x{Wo}"
+        return Ho, Wo, rh, rw
+
+    def concat_act(self, x1: Act, x2: Act) -> Act:
+        Ho, Wo, rh, rw = self._geom(x1, x2)
+        return ops.upsample_concat(x1, x2, Ho, Wo, rh, rw)
+
+    def convs_act(self, cat: Act, out: Act = None) -> Act:
+        u = self._u()
+        return u[1](u[0](cat), out=out)
+
+    def forward_act(self, x1: Act, x2: Act, out: Act = None) -> Act:
+        u = self._u()
+        if u[0].fuses_upsample():       # upsample + concat happen inside the first conv's loader
+            Ho, Wo, rh, rw = self._geom(x1, x2)
+            return u[1](u[0](x2, up=(x1, Ho, Wo, rh, rw)), out=out)
+        return self.convs_act(self.concat_act(x1, x2), out=out)
 
     def forward(self, x1, x2):
         require_hip(x1, "Up")

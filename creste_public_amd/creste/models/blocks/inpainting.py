@@ -82,19 +82,27 @@ class DeconvHead(nn.Module):
         self.proj = nn.Conv2d(128, out_ch, kernel_size=1, padding=0)
         self._u = None
 
-    def from_concat_act(self, cat: Act, pred_out: Act = None):
-        """cat = [x2 | up4(x1)] (shared by all heads) -> (preds, features)."""
+    def _units(self):
         if self._u is None:
             self._u = (ConvUnit(self.up2[1], self.up2[2], ACT_RELU), ConvUnit(self.proj, None, ACT_NONE))
-        c3, proj = self._u
-        h = self.up1.convs_act(cat)
+        return self._u
+
+    def _tail(self, h: Act, pred_out: Act = None):
+        c3, proj = self._units()
         sf, (rh, rw) = up_scales(self.up2[0].scale_factor)
         Ho, Wo = up_out_size(h.H, h.W, sf)
-        feat = c3(ops.upsample_concat(h, None, Ho, Wo, rh, rw))
+        if c3.fuses_upsample():
+            feat = c3(None, up=(h, Ho, Wo, rh, rw))
+        else:
+            feat = c3(ops.upsample_concat(h, None, Ho, Wo, rh, rw))
         return proj(feat, out=pred_out), feat
 
-    def forward_act(self, x1: Act, x2: Act):
-        return self.from_concat_act(self.up1.concat_act(x1, x2))
+    def from_concat_act(self, cat: Act, pred_out: Act = None):
+        """cat = [x2 | up4(x1)] (shared by all heads) -> (preds, features)."""
+        return self._tail(self.up1.convs_act(cat), pred_out)
+
+    def forward_act(self, x1: Act, x2: Act, pred_out: Act = None):
+        return self._tail(self.up1.forward_act(x1, x2), pred_out)
 
     def forward(self, x1, x2):
         require_hip(x1, "DeconvHead")
@@ -130,11 +138,13 @@ class InpaintingResNet18MultiHead(Inpainting):
         x1 = x
         for blk in list(self.layer2) + list(self.layer3):
             x = blk.forward_act(x)
-        cat = self.out_heads[0].up1.concat_act(x, x1)     # identical for every head: computed once
+        fused = self.out_heads[0].up1._u()[0].fuses_upsample()
+        # un-fused engines: the x4-upsampled concat is identical for every head and is computed once
+        cat = None if fused else self.out_heads[0].up1.concat_act(x, x1)
         ret, co = [], 0
         for head, n in zip(self.out_heads, self.num_classes):
             out = preds_buf.slice(co, n) if preds_buf is not None else None
-            pred, fea = head.from_concat_act(cat, pred_out=out)
+            pred, fea = head.forward_act(x, x1, pred_out=out) if fused else head.from_concat_act(cat, pred_out=out)
             ret.append(dict(preds=pred, features=fea))
             co += n
         return ret

@@ -241,6 +241,10 @@ extern "C" int creste_conv_supported(int prec, int KH, int KW, int stride) {
   return conv_patch_supported(prec, KH, KW, stride) ? 1 : 0;
 }
 
+extern "C" int creste_conv_supported_upsample(int prec, int KH, int KW, int stride) {
+  return prec != CRESTE_PREC_F32 && KH == 3 && KW == 3 && stride == 1 && conv_patch_supported(prec, KH, KW, stride);
+}
+
 extern "C" int64_t creste_conv_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int prec) {
   if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return -1;
   if (prec != CRESTE_PREC_F32)
@@ -267,13 +271,20 @@ extern "C" int creste_conv_pack_weight(const float* w, const float* scale, void*
 
 extern "C" int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream) {
   CRESTE_REQUIRE(d != nullptr, "conv2d: null descriptor");
-  CRESTE_REQUIRE(d->in && d->wpk && d->out, "conv2d: null tensor pointer");
+  CRESTE_REQUIRE(d->wpk && d->out && (d->in || (d->up_src && d->up_C == d->Cin)), "conv2d: null tensor pointer");
+  if (d->up_src) {
+    CRESTE_REQUIRE(creste_conv_supported_upsample(d->prec, d->KH, d->KW, d->stride),
+                   "conv2d: fused upsample input is built for stride-1 3x3 convs on the bf16 MFMA engine only");
+    CRESTE_REQUIRE(d->up_C > 0 && d->up_C <= d->Cin && d->up_C % 4 == 0 && d->up_cs % 4 == 0 && d->up_cs >= d->up_C &&
+                       d->up_H > 0 && d->up_W > 0 && d->H < 65536 && d->W < 65536 && !d->a_scale,
+                   "conv2d: bad fused-upsample descriptor");
+  }
   CRESTE_REQUIRE(d->prec == CRESTE_PREC_F32 || conv_patch_supported(d->prec, d->KH, d->KW, d->stride),
                  "conv2d: precision %d not built for %dx%d stride %d", d->prec, d->KH, d->KW, d->stride);
   CRESTE_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 &&
                      d->Wo > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0,
                  "conv2d: non-positive dimension");
-  CRESTE_REQUIRE(d->Cin % 4 == 0 && d->in_cs % 4 == 0 && d->in_cs >= d->Cin,
+  CRESTE_REQUIRE(d->Cin % 4 == 0 && (!d->in || (d->in_cs % 4 == 0 && d->in_cs >= d->Cin - (d->up_src ? d->up_C : 0))),
                  "conv2d: Cin (%d) and in_cs (%d) must be multiples of 4, in_cs >= Cin", d->Cin, d->in_cs);
   CRESTE_REQUIRE((reinterpret_cast<uintptr_t>(d->in) & 15) == 0, "conv2d: input not 16-byte aligned");
   CRESTE_REQUIRE(d->out_cs >= d->out_co + d->Cout, "conv2d: output slice exceeds out_cs");

@@ -56,6 +56,9 @@ struct PatchArgs {
   const float* a_scale;
   const float* row_mask;
   float* out;
+  const float* up_src;       // fused bilinear upsample + concat source (3x3 kernel only), or nullptr
+  int up_H, up_W, up_C, up_cs;
+  float up_rh, up_rw;
   int N, H, W, Cin, in_cs;
   int Ho, Wo, Cout, out_cs, out_co, res_cs;
   int pad_t, pad_l;
@@ -300,21 +303,38 @@ __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void co
 
   const int cq = tid & 3;
   const int a_lofs0 = (cq >> 1) * A_OCT + (tid >> 2) * 16 + (cq & 1) * 8;
-  int a_gpix[ROUNDS];
+  int a_yx[ROUNDS];        // (iy << 16) | ix of the round's patch pixel, -1 if outside the image / unused
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     const int pix = r * 128 + (tid >> 2);
     const int py = pix / PW, px = pix % PW;
     const int iy = oy0 + py - p.pad_t, ix = ox0 + px - p.pad_l;
     const bool ok = pix < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    a_gpix[r] = ok ? (img * p.H + iy) * p.W + ix : -1;
+    a_yx[r] = ok ? (iy << 16) | ix : -1;
   }
+  const int c_skip = p.up_src ? p.Cin - p.up_C : p.Cin;     // channels below this come from `in`
   auto load_a = [&](int r, int c) __attribute__((always_inline)) -> f32x4 {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const int ch = c * PT_CK + cq * 4;
-    if (a_gpix[r] >= 0 && ch < p.Cin) {
-      v = *reinterpret_cast<const f32x4*>(p.in + (size_t)a_gpix[r] * p.in_cs + ch);
-      if (p.a_scale) v *= *reinterpret_cast<const f32x4*>(p.a_scale + (size_t)img * p.Cin + ch);
+    if (a_yx[r] >= 0 && ch < p.Cin) {
+      const int iy = a_yx[r] >> 16, ix = a_yx[r] & 0xffff;
+      if (ch < c_skip) {
+        v = *reinterpret_cast<const f32x4*>(p.in + ((size_t)(img * p.H + iy) * p.W + ix) * p.in_cs + ch);
+        if (p.a_scale) v *= *reinterpret_cast<const f32x4*>(p.a_scale + (size_t)img * p.Cin + ch);
+      } else {
+        // fused nn.Upsample(bilinear, align_corners=False): PyTorch's source index rule
+        float sy = p.up_rh * ((float)iy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+        float sx = p.up_rw * ((float)ix + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < p.up_H - 1 ? 1 : 0), x1 = x0 + (x0 < p.up_W - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        const float* b = p.up_src + (size_t)img * p.up_H * p.up_W * p.up_cs + (ch - c_skip);
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * p.up_W + x0) * p.up_cs);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * p.up_W + x1) * p.up_cs);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * p.up_W + x0) * p.up_cs);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * p.up_W + x1) * p.up_cs);
+        v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+      }
     }
     return v;
   };
@@ -489,6 +509,8 @@ int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
   PatchArgs a;
   a.in = d->in; a.wpk = (const char*)d->wpk; a.bias = d->bias; a.res = d->res; a.a_scale = d->a_scale;
   a.row_mask = d->row_mask; a.out = d->out;
+  a.up_src = d->up_src; a.up_H = d->up_H; a.up_W = d->up_W; a.up_C = d->up_C; a.up_cs = d->up_cs;
+  a.up_rh = d->up_rh; a.up_rw = d->up_rw;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_cs = d->in_cs;
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.out_cs = d->out_cs; a.out_co = d->out_co;
   a.res_cs = d->res_cs; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.act = d->act;

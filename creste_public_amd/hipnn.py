@@ -15,6 +15,12 @@ from . import ops
 from .ops import ACT_NONE, ACT_RELU, ACT_SWISH, Act, HipLibraryError  # noqa: F401
 
 
+# The 3x3 patch kernel can form cat([skip, bilinear_up(x1)]) inside its loader (tested in
+# tests/test_kernels_gpu.py).  Measured on MI355X it LOSES to the separate upsample_concat pass
+# (bf16x6 222.6 -> 218.5 frames/s, bf16 484 -> 388): the 4-tap gather sits on the loader's critical path
+# and the three BEV heads no longer share one concat.  Kept off.
+FUSE_UPSAMPLE = False
+
 PRECISIONS = {"f32": ops.PREC_F32, "bf16": ops.PREC_BF16, "bf16x3": ops.PREC_BF16X3, "bf16x6": ops.PREC_BF16X6}
 _precision = ops.PREC_F32
 
@@ -96,8 +102,11 @@ class ConvUnit:
         return self._packed
 
     def __call__(self, x: Act, out: Act | None = None, res: Act | None = None, a_scale=None,
-                 row_mask=None) -> Act:
-        return ops.conv2d(x, self.packed(), out=out, res=res, a_scale=a_scale, row_mask=row_mask)
+                 row_mask=None, up=None) -> Act:
+        return ops.conv2d(x, self.packed(), out=out, res=res, a_scale=a_scale, row_mask=row_mask, up=up)
+
+    def fuses_upsample(self) -> bool:
+        return FUSE_UPSAMPLE and ops.conv_supports_upsample(self.packed())
 
 
 class Cached:

@@ -85,6 +85,11 @@ def conv_supported(prec: int, k: int, stride: int) -> bool:
     return bool(_lib.load().creste_conv_supported(prec, k, k, stride))
 
 
+def conv_supports_upsample(pc: "PackedConv") -> bool:
+    """True when `pc` can take its input as cat([skip, bilinear_upsample(x1)]) without materialising it."""
+    return bool(_lib.load().creste_conv_supported_upsample(pc.prec, pc.KH, pc.KW, pc.stride))
+
+
 def pack_conv(weight: torch.Tensor, bias, bn, stride, pad, act, prec=PREC_F32) -> PackedConv:
     """weight OIHW (CUDA fp32); bn = None or (gamma, beta, mean, var, eps) -> folded eval-mode BN.
     pad = int | (pad_t, pad_b, pad_l, pad_r)."""
@@ -112,20 +117,35 @@ def pack_conv(weight: torch.Tensor, bias, bn, stride, pad, act, prec=PREC_F32) -
     return PackedConv(wpk, b, Cin, Cout, KH, KW, stride, pad[0], pad[2], pad[1], pad[3], act, prec)
 
 
-def conv2d(x: Act, pc: PackedConv, out: Act | None = None, res: Act | None = None,
-           a_scale: torch.Tensor | None = None, row_mask: torch.Tensor | None = None) -> Act:
+def conv2d(x: Act | None, pc: PackedConv, out: Act | None = None, res: Act | None = None,
+           a_scale: torch.Tensor | None = None, row_mask: torch.Tensor | None = None, up=None) -> Act:
+    """up = (x1: Act, H, W, rh, rw): the conv input is cat([x, bilinear_upsample(x1 -> HxW)]) formed inside
+    the kernel's loader (x may be None: upsample only)."""
     lib = _lib.load()
-    _chk(x.buf, name="conv input")
-    if x.C != pc.Cin:
-        raise HipLibraryError(f"conv2d: input has {x.C} channels, weights expect {pc.Cin}")
-    Ho, Wo = pc.out_hw(x.H, x.W)
+    if up is not None:
+        x1, H, W, rh, rw = up
+        _chk(x1.buf, name="conv upsample source")
+        N, cin, dev = x1.N, x1.C + (x.C if x is not None else 0), x1.buf.device
+        if x is not None and (x.N, x.H, x.W) != (N, H, W):
+            raise HipLibraryError("conv2d: skip tensor and upsampled size disagree")
+    else:
+        N, H, W, cin, dev = x.N, x.H, x.W, x.C, x.buf.device
+    if x is not None:
+        _chk(x.buf, name="conv input")
+    if cin != pc.Cin:
+        raise HipLibraryError(f"conv2d: input has {cin} channels, weights expect {pc.Cin}")
+    Ho, Wo = pc.out_hw(H, W)
     if out is None:
-        out = Act.empty(x.N, Ho, Wo, pc.Cout, x.buf.device)
-    if (out.N, out.H, out.W, out.C) != (x.N, Ho, Wo, pc.Cout):
+        out = Act.empty(N, Ho, Wo, pc.Cout, dev)
+    if (out.N, out.H, out.W, out.C) != (N, Ho, Wo, pc.Cout):
         raise HipLibraryError(f"conv2d: output slice {(out.N, out.H, out.W, out.C)} != "
-                              f"{(x.N, Ho, Wo, pc.Cout)}")
+                              f"{(N, Ho, Wo, pc.Cout)}")
     d = ConvDesc()
-    d.in_, d.wpk, d.out = x.ptr, pc.wpk.data_ptr(), out.buf.data_ptr()
+    d.in_ = x.ptr if x is not None else None
+    d.wpk, d.out = pc.wpk.data_ptr(), out.buf.data_ptr()
+    if up is not None:
+        d.up_src, d.up_H, d.up_W, d.up_C, d.up_cs = x1.ptr, x1.H, x1.W, x1.C, x1.cs
+        d.up_rh, d.up_rw = float(rh), float(rw)
     d.bias = pc.bias.data_ptr() if pc.bias is not None else None
     if res is not None:
         if (res.N, res.H, res.W, res.C) != (out.N, out.H, out.W, out.C):
@@ -135,15 +155,15 @@ def conv2d(x: Act, pc: PackedConv, out: Act | None = None, res: Act | None = Non
         d.res, d.res_cs = None, 0
     if a_scale is not None:
         _chk(a_scale, name="a_scale")
-        if tuple(a_scale.shape) != (x.N, pc.Cin):
+        if tuple(a_scale.shape) != (N, pc.Cin):
             raise HipLibraryError("conv2d: a_scale must be [N,Cin]")
         d.a_scale = a_scale.data_ptr()
     if row_mask is not None:
         _chk(row_mask, name="row_mask")
-        if row_mask.numel() != x.N * Ho * Wo:
+        if row_mask.numel() != N * Ho * Wo:
             raise HipLibraryError("conv2d: row_mask must have N*Ho*Wo elements")
         d.row_mask = row_mask.data_ptr()
-    d.N, d.H, d.W, d.Cin, d.in_cs = x.N, x.H, x.W, pc.Cin, x.cs
+    d.N, d.H, d.W, d.Cin, d.in_cs = N, H, W, pc.Cin, (x.cs if x is not None else 0)
     d.Ho, d.Wo, d.Cout, d.out_cs, d.out_co = Ho, Wo, pc.Cout, out.cs, out.co
     d.KH, d.KW, d.stride, d.pad_t, d.pad_l = pc.KH, pc.KW, pc.stride, pc.pad_t, pc.pad_l
     d.act, d.prec = pc.act, pc.prec

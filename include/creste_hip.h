@@ -66,16 +66,25 @@ typedef struct creste_conv_desc {
   const float* a_scale;  /* [N,Cin] per-sample input-channel gate (squeeze-excite), or NULL */
   const float* row_mask; /* [N*Ho*Wo] multiplied into every output row after the activation, or NULL */
   float* out;            /* [N,Ho,Wo,out_cs], written at channel offset out_co */
+  const float* up_src;   /* optional fused nn.Upsample(bilinear)+torch.cat (reference effnet.py:25-28): when
+                            non-NULL the conv input is cat([in[..., 0:Cin-up_C], upsample(up_src)], channel)
+                            with up_src [N,up_H,up_W,up_cs] resized to HxW by the PyTorch align_corners=False
+                            rule (source index = up_r*(dst+0.5)-0.5 clamped at 0); `in` may be NULL when
+                            up_C == Cin.  Only where creste_conv_supported_upsample() says so. */
   int32_t N, H, W, Cin, in_cs;
   int32_t Ho, Wo, Cout, out_cs, out_co, res_cs;
   int32_t KH, KW, stride, pad_t, pad_l;
   int32_t act;  /* CRESTE_ACT_* */
   int32_t prec; /* CRESTE_PREC_* */
+  int32_t up_H, up_W, up_C, up_cs;
+  float up_rh, up_rw;
 } creste_conv_desc;
 
 int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream);
 /* 1 when (precision, kernel, stride) is built: F32 covers everything, BF16/BF16X3 cover stride-1 1x1/3x3. */
 int creste_conv_supported(int prec, int KH, int KW, int stride);
+/* 1 when the fused bilinear-upsample+concat input (up_src) is built for this configuration. */
+int creste_conv_supported_upsample(int prec, int KH, int KW, int stride);
 /* Size in BYTES of the packed weight for (Cout,Cin,KH,KW) at precision `prec`. */
 int64_t creste_conv_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int prec);
 /* Pack a torch OIHW fp32 weight (device pointer, contiguous) into the GEMM layout, optionally

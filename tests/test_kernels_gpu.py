@@ -109,6 +109,31 @@ def test_conv_patch_bf16(ops, case, prec, tol):
     assert float((got - ref).abs().max()) < 60 * tol * float(ref.abs().max().clamp_min(1.0))
 
 
+@pytest.mark.parametrize("prec,tol", [("bf16x6", 3e-6), ("bf16x3", 8e-5)])
+@pytest.mark.parametrize("sf,c2", [(2, 24), (4, 64), ((128 / 64, 153 / 76), 8), (2, 0)])
+def test_conv_fused_upsample_concat(ops, sf, c2, prec, tol):
+    """3x3 conv whose input cat([skip, bilinear_up(x1)]) is formed inside the kernel's loader."""
+    g = torch.Generator().manual_seed(17)
+    H1, W1 = (64, 76) if isinstance(sf, tuple) else (13, 21)
+    N, C1, Cout = 2, 40, 72
+    x1 = torch.randn(N, C1, H1, W1, generator=g)
+    up = torch.nn.Upsample(scale_factor=sf, mode="bilinear", align_corners=False)(x1)
+    Ho, Wo = up.shape[-2:]
+    skip = torch.randn(N, c2, Ho, Wo, generator=g) if c2 else None
+    w = torch.randn(Cout, C1 + c2, 3, 3, generator=g) / ((C1 + c2) * 9) ** 0.5
+    cat = up if skip is None else torch.cat([skip, up], dim=1)
+    ref = F.relu(F.conv2d(cat.double(), w.double(), padding=1))
+    code = {"bf16x6": ops.PREC_BF16X6, "bf16x3": ops.PREC_BF16X3}[prec]
+    pc = ops.pack_conv(dev(w), None, None, 1, 1, ops.ACT_RELU, code)
+    assert ops.conv_supports_upsample(pc)
+    sfh, sfw = sf if isinstance(sf, tuple) else (sf, sf)
+    rh, rw = np.float32(1.0 / sfh), np.float32(1.0 / sfw)
+    got = from_act(ops.conv2d(None if skip is None else to_act(ops, skip), pc,
+                              up=(to_act(ops, x1), Ho, Wo, rh, rw))).double()
+    rel = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    assert rel < tol, f"{prec}: relative rms error {rel:.2e}"
+
+
 def test_conv_slices_gate_and_rowmask(ops):
     """channel-slice input/output (zero-copy concat), SE gate on the A operand, row mask epilogue."""
     g = torch.Generator().manual_seed(5)
