@@ -31,6 +31,7 @@ struct SplatWork {
   int* count;    // [B*E]
   int* offset;   // [B*(E+1)]
   int* list;     // [B*P]
+  int* strip;    // [B*ceil(E/1024)] scan strip sums
 };
 
 static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -42,7 +43,8 @@ static SplatWork carve(void* work, int B, int P, int E) {
   w.rank = (int*)p;   p += align256((size_t)B * P * 4);
   w.count = (int*)p;  p += align256((size_t)B * E * 4);
   w.offset = (int*)p; p += align256((size_t)B * (E + 1) * 4);
-  w.list = (int*)p;
+  w.list = (int*)p;   p += align256((size_t)B * P * 4);
+  w.strip = (int*)p;
   return w;
 }
 
@@ -71,28 +73,57 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const float* __restrict_
   }
 }
 
-// one workgroup per frame: offset[b][0..E] = exclusive scan of count[b][0..E)
-__global__ __launch_bounds__(1024) void splat_scan_kernel(const int* __restrict__ count,
-                                                          int* __restrict__ offset, int E) {
-  __shared__ int part[1024];
-  const int b = blockIdx.x, t = threadIdx.x;
-  const int per = (E + 1023) / 1024;
-  const int lo = t * per, hi = min(E, lo + per);
-  const int* c = count + (long)b * E;
+// offset[b][0..E] = exclusive scan of count[b][0..E), two launches over 1024-element strips:
+//   reduce: strip_sum[b][j] = sum of strip j            (grid = strips x frames, coalesced)
+//   apply : every strip adds the (<= 65) preceding strip sums to its local shuffle/LDS scan
+constexpr int SCAN_STRIP = 1024;
+__global__ __launch_bounds__(256) void splat_scan_reduce_kernel(const int* __restrict__ count,
+                                                                int* __restrict__ strip_sum, int E,
+                                                                int nstrip) {
+  __shared__ int ws[4];
+  const int b = blockIdx.y, j = blockIdx.x, t = threadIdx.x;
+  const int* c = count + (long)b * E + (long)j * SCAN_STRIP;
   int s = 0;
-  for (int i = lo; i < hi; ++i) s += c[i];
-  part[t] = s;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {           // Hillis-Steele inclusive scan of the partials
-    const int v = t >= d ? part[t - d] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SCAN_STRIP / 256; ++k) {
+    const int i = k * 256 + t;
+    if (j * SCAN_STRIP + i < E) s += c[i];
   }
-  int run = part[t] - s;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((t & 63) == 0) ws[t >> 6] = s;
+  __syncthreads();
+  if (t == 0) strip_sum[(long)b * nstrip + j] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ __launch_bounds__(1024) void splat_scan_apply_kernel(const int* __restrict__ count,
+                                                                const int* __restrict__ strip_sum,
+                                                                int* __restrict__ offset, int E, int nstrip) {
+  __shared__ int wsum[16];
+  __shared__ int base_s;
+  const int b = blockIdx.y, j = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (wave == 0) {                                   // prefix of the preceding strips (nstrip <= 128)
+    int v = 0;
+    for (int k = lane; k < j; k += 64) v += strip_sum[(long)b * nstrip + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) base_s = v;
+  }
+  const int i = j * SCAN_STRIP + t;
+  const int v = i < E ? count[(long)b * E + i] : 0;
+  int inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(inc, d);
+    if (lane >= d) inc += up;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int wave_off = 0;
+  for (int w = 0; w < wave; ++w) wave_off += wsum[w];
   int* o = offset + (long)b * (E + 1);
-  for (int i = lo; i < hi; ++i) { o[i] = run; run += c[i]; }
-  if (t == 1023) o[E] = part[1023];
+  if (i < E) o[i] = base_s + wave_off + inc - v;
+  if (i == E - 1) o[E] = base_s + wave_off + inc;
 }
 
 __global__ __launch_bounds__(256) void splat_fill_kernel(const int* __restrict__ key,
@@ -191,7 +222,7 @@ extern "C" int64_t creste_bev_splat_workspace_bytes(int B, int P, int GH, int GW
   if (B <= 0 || P <= 0 || GH <= 0 || GW <= 0) return -1;
   const int E = (GH + 1) * (GW + 1);
   return (int64_t)(3 * align256((size_t)B * P * 4) + align256((size_t)B * E * 4) +
-                   align256((size_t)B * (E + 1) * 4));
+                   align256((size_t)B * (E + 1) * 4) + align256((size_t)B * ((E + 1023) / 1024) * 4));
 }
 
 extern "C" int creste_bev_splat_f32(const float* xyz, const float* feats, int feats_cs, int B, int P,
@@ -211,7 +242,9 @@ extern "C" int creste_bev_splat_f32(const float* xyz, const float* feats, int fe
   splat_bin_kernel<<<g1, 256, 0, s>>>(xyz, BP, P, off_x, off_y, vox_x, vox_y, GH, GW, coords, w.key,
                                       w.rank, w.count);
   CRESTE_CHECK_LAUNCH("splat_bin");
-  splat_scan_kernel<<<B, 1024, 0, s>>>(w.count, w.offset, E);
+  const int nstrip = (E + SCAN_STRIP - 1) / SCAN_STRIP;
+  splat_scan_reduce_kernel<<<dim3(nstrip, B), 256, 0, s>>>(w.count, w.strip, E, nstrip);
+  splat_scan_apply_kernel<<<dim3(nstrip, B), 1024, 0, s>>>(w.count, w.strip, w.offset, E, nstrip);
   CRESTE_CHECK_LAUNCH("splat_scan");
   splat_fill_kernel<<<g1, 256, 0, s>>>(w.key, w.rank, w.offset, w.list, BP, P, E);
   CRESTE_CHECK_LAUNCH("splat_fill");

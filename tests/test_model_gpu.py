@@ -294,3 +294,41 @@ def _with_eval_backbone(oracle):
     for p in oracle.backbone.parameters():
         p.requires_grad = False
     return oracle
+
+
+def test_reference_resolution_512x612():
+    """BASELINE configs[0]: one 512x612 frame (the reference's own config: 612 -> 306 -> 153 -> 76 -> 38 -> 19
+    with floor-mode static padding, the odd 64x76 -> 128x153 decoder step, partial conv tiles), batch 1,
+    inference graph (solve_mdp=False)."""
+    import creste_public_amd
+    from creste_public_amd import MaxEntIRL
+    from oracle.irl import MaxEntIRL as OracleIRL
+    Hh, Ww = 512, 612
+    torch.manual_seed(99)
+    cfg = maxent_irl_cfg((Hh, Ww), solve_mdp=False)
+    oracle = OracleIRL(cfg)
+    rgbd, p2p = synth.make_frames(1, Hh, Ww, seed=21)
+    calibrate_bn(oracle, lambda: oracle((rgbd, p2p)))
+    with torch.no_grad():
+        ref = oracle((rgbd, p2p))
+    assert ref["depth_preds_feats"].shape[-2:] == (128, 153)
+    for prec in PRECISIONS:
+        creste_public_amd.set_precision(prec)
+        try:
+            model = MaxEntIRL(maxent_irl_cfg((Hh, Ww), solve_mdp=False))
+            model.load_state_dict(oracle.state_dict(), strict=True)
+            model = model.cuda().eval()
+            with torch.no_grad():
+                got = model((rgbd.cuda(), p2p.cuda()))
+        finally:
+            creste_public_amd.set_precision("f32")
+        assert set(got) == {k for k in ref if not k.startswith("_")}
+        for k in ("depth_preds_feats", "depth_preds_logits", "dino_pe_feats"):
+            _stage(got[k], ref[k], 5e-5, f"{prec}:{k}")
+        _cmp(got, ref, "depth_preds_metric", 1e-4, 2e-3)
+        assert (got["depth_preds_bins"].cpu() == ref["depth_preds_bins"]).float().mean() > 0.999
+        flips = (got["bev_coords"].cpu().floor() != ref["bev_coords"].floor()).any(dim=-1).float().mean().item()
+        assert flips < 2e-2
+        for k in ("bev_features", "inpainting_sam_preds", "elevation_preds", "traversability_preds"):
+            g, r = got[k].detach().double().cpu(), ref[k].detach().double()
+            assert _rms(g - r) <= 2e-2 * max(_rms(r), 1e-9), f"{prec}:{k}: rel rms {_rms(g - r) / _rms(r):.2e}"
