@@ -46,6 +46,18 @@ def build_model(device):
     return model.to(device).eval()
 
 
+def kernel_symbol(pc):
+    """The kernel a packed conv dispatches to (mirrors csrc/conv_igemm.hip / conv_patch.hip), named as
+    rocprofv3 prints it, so bench numbers and profiles/ line up kernel by kernel."""
+    if pc.prec == 0:
+        return ("f32", "conv_igemm_f32_kernel<2, 2, 2, 2>" if pc.Cout > 64 else
+                "conv_igemm_f32_kernel<2, 2, 2, 1>" if pc.Cout > 32 else "conv_igemm_f32_kernel<4, 1, 1, 1>")
+    split = {1: 1, 2: 2, 3: 3}[pc.prec]
+    tn = 2 if pc.Cout > 64 else 1
+    name = f"conv_patch3_kernel<{split}, {tn}>" if pc.KH == 3 else f"conv_patch_kernel<1, {split}, {tn}>"
+    return (PREC_NAME[pc.prec], name)
+
+
 class ConvProfiler:
     """HIP-event pair around every conv launch (recorded on the stream the kernel is launched on)."""
 
@@ -63,8 +75,7 @@ class ConvProfiler:
             y = prof._orig(x, pc, **kw)
             e1.record()
             flops = 2.0 * y.N * y.H * y.W * pc.Cout * pc.Cin * pc.KH * pc.KW
-            bn = f"{PREC_NAME[pc.prec]}/BN{128 if pc.Cout > 64 else (64 if pc.Cout > 32 or pc.prec else 32)}"
-            prof.records.append((e0, e1, flops, bn, (pc.Cin, pc.Cout, pc.KH, y.H, y.W)))
+            prof.records.append((e0, e1, flops, kernel_symbol(pc), (pc.Cin, pc.Cout, pc.KH, y.H, y.W)))
             return y
         import creste_public_amd.hipnn as hipnn
         ops.conv2d = timed
@@ -257,9 +268,9 @@ def main():
             d = per.setdefault((shape, bn), [0.0, 0.0, 0])
             d[0] += e0.elapsed_time(e1); d[1] += fl; d[2] += 1
         with open(args.layers, "w") as f:
-            f.write("Cin,Cout,K,Ho,Wo,BN,calls_per_step,ms_per_step,TFLOPs\n")
+            f.write("Cin,Cout,K,Ho,Wo,kernel,calls_per_step,ms_per_step,TFLOPs\n")
             for (shape, bn), (ms, fl, n) in sorted(per.items(), key=lambda kv: -kv[1][0]):
-                f.write(",".join(map(str, shape)) + f",{bn},{n / args.steps:.1f},{ms / args.steps:.4f},"
+                f.write(",".join(map(str, shape)) + f",{bn[1].replace(',', ';')},{n / args.steps:.1f},{ms / args.steps:.4f},"
                         f"{fl / (ms * 1e-3) / 1e12:.2f}\n")
     if rank == 0:
         frames = args.batch * args.gpus * args.steps
@@ -267,14 +278,13 @@ def main():
         dom = max(by, key=lambda k: by[k]["ms"])
         d = by[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        dprec = dom.split("/")[0]
-        kname = ("conv_igemm_f32_kernel" if dprec == "f32" else "conv_patch_kernel") + f" ({dom})"
+        dprec, kname = dom
         conv_ms = sum(v["ms"] for v in by.values())
         traffic = None
         pj = os.path.join(ROOT, "profiles", "roofline_counters.json")
         if os.path.exists(pj):
             try:
-                traffic = json.load(open(pj)).get(f"conv_{dprec}_bn128", {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pj)).get(kname, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {

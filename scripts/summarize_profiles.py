@@ -48,11 +48,7 @@ for k in set(pmc["FETCH_SIZE"]) | set(pmc["WRITE_SIZE"]):
     counters[k] = dict(launches=n, fetch_kib_raw=fk, write_kib_raw=wk,
                        hbm_bytes_per_launch=(2.0 * fk + wk) * 1024.0 / n,
                        hbm_bytes_per_launch_uncorrected=(fk + wk) * 1024.0 / n)
-key_map = {"conv_igemm_f32_kernel<2, 2, 2, 2>": "conv_f32_bn128",
-           "conv_igemm_f32_kernel<2, 2, 2, 1>": "conv_f32_bn64",
-           "conv_igemm_f32_kernel<4, 1, 1, 1>": "conv_f32_bn32",
-           "conv_patch_kernel<3, 2, 2>": "conv_bf16x3_bn128", "conv_patch_kernel<3, 1, 2>": "conv_bf16_bn128"}
-out = {key_map.get(k, k): v for k, v in counters.items()}
+out = dict(counters)
 out["_note"] = ("per-launch averages over one bench step (batch 16); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, "
                 "the x2 is the gfx950 FETCH_SIZE correction for 16-B/lane coalesced reads")
 json.dump(out, open(os.path.join(dst, "roofline_counters.json"), "w"), indent=1, sort_keys=True)
