@@ -108,13 +108,25 @@ def cpu_baseline(sample_frames=1, runs=3):
     torch.set_num_threads(cores)
     torch.manual_seed(1337)
     model = OracleIRL(maxent_irl_cfg((IMG_H, IMG_W), solve_mdp=False)).eval()
-    rgbd, p2p = synth.make_frames(sample_frames, IMG_H, IMG_W, seed=1337)
+    from oracle import lidar as olidar
+    gen = torch.Generator().manual_seed(1337)
+    rgbd = torch.zeros(sample_frames, 1, 4, IMG_H, IMG_W)
+    rgbd[:, 0, :3] = torch.rand(sample_frames, 3, IMG_H, IMG_W, generator=gen)
+    scan = synth.lidar_scan(sample_frames, gen).numpy()
+    l2c = synth.lidar2camrect(sample_frames, IMG_H, IMG_W).numpy()
+    p2p = synth.make_p2p(sample_frames, IMG_H, IMG_W)
+
+    def cpu_step():
+        for b in range(sample_frames):     # LiDAR scan -> sparse mm depth channel, then the forward
+            rgbd[b, 0, 3] = torch.from_numpy(olidar.depth_image(scan[b], l2c[b], IMG_H, IMG_W) * 1000.0).float()
+        return model((rgbd, p2p))
+
     times = []
     with torch.no_grad():
-        model((rgbd, p2p))                       # warm-up
+        cpu_step()                               # warm-up
         for _ in range(runs):
             t0 = time.perf_counter()
-            model((rgbd, p2p))
+            cpu_step()
             times.append(time.perf_counter() - t0)
     med = statistics.median(times)
     return {"value": round(sample_frames / med, 4), "unit": "frames/s", "cores": cores, "kind": "port",
@@ -218,11 +230,19 @@ def main():
     from creste_public_amd import synth
     creste_public_amd.set_precision(args.precision)
     model = build_model(device)
-    rgbd, p2p = synth.make_frames(args.batch, IMG_H, IMG_W, seed=1337 + rank)
-    rgbd, p2p = rgbd.to(device), p2p.to(device)
+    from creste_public_amd.creste.utils.projection import lidar_depth_images
+    gen = torch.Generator().manual_seed(1337 + rank)
+    rgbd = torch.zeros(args.batch, 1, 4, IMG_H, IMG_W, device=device)
+    rgbd[:, 0, :3] = torch.rand(args.batch, 3, IMG_H, IMG_W, generator=gen).to(device)   # RGB in [0,1)
+    scan = synth.lidar_scan(args.batch, gen).to(device)               # [B, 128*1024, 3] LiDAR points
+    l2c = synth.lidar2camrect(args.batch, IMG_H, IMG_W).to(device)    # float64 projection
+    p2p = synth.make_p2p(args.batch, IMG_H, IMG_W).to(device)
 
     def step():
+        """RGB + LiDAR scan -> costmap: project the scan into the sparse millimetre depth channel of the
+        RGB-D tensor (HIP scatter-max), then the perception -> BEV -> costmap forward."""
         with torch.no_grad():
+            lidar_depth_images(scan, l2c, IMG_H, IMG_W, out=rgbd[:, 0, 3], scale=1000.0, depth_priority="max")
             return model((rgbd, p2p))
 
     for _ in range(args.warmup):
@@ -300,8 +320,9 @@ def main():
                       "bf16": "bf16 operands, fp32 accumulate/activations"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"inference: batch={args.batch}/GPU synthetic {IMG_W}x{IMG_H} RGB + 128x1024 "
-                                   "LiDAR -> 256x256 BEV costmap (MaxEntIRL solve_mdp=False; EfficientNet-B0 U-Net, "
-                                   "BEV splat, ResNet-18 heads, reward FCN), random-init weights",
+                                   "LiDAR scan (projected to the sparse depth channel inside the step) -> 256x256 BEV costmap "
+                                   "(MaxEntIRL solve_mdp=False; EfficientNet-B0 U-Net, BEV splat, ResNet-18 heads, "
+                                   "reward FCN), random-init weights",
                        "batch_per_gpu": args.batch, "image": [IMG_H, IMG_W], "lidar": [128, 1024],
                        "bev": [256, 256], "parallelism": f"{args.gpus} independent replicas (frame-sharded, no collective)"},
             "roofline": {"bound": "mfma", "kernel": kname,

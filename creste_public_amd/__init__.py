@@ -28,7 +28,7 @@ _MIRROR = ["creste", "creste.models", "creste.models.blocks", "creste.models.blo
            "creste.models.blocks.splat_projection", "creste.models.blocks.vin",
            "creste.models.vision_encoder", "creste.models.depth", "creste.models.distillation",
            "creste.models.terrainnet", "creste.models.lfd", "creste.utils", "creste.utils.train_utils",
-           "creste.utils.depth_utils", "creste.utils.loss_utils"]
+           "creste.utils.depth_utils", "creste.utils.loss_utils", "creste.utils.projection"]
 
 
 def install_as_creste():

@@ -51,6 +51,7 @@ SIGNATURES = {
     "creste_resize_plane_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _f, _f, _vp]),
     "creste_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "creste_nhwc_to_nchw_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "creste_lidar_depth_image_f32": (_i, [_vp, _i, _vp, _i, _i, _i64, _i, _i, _i, C.c_double, _vp, _i64, _vp]),
     "creste_depth_expectation_f32": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp]),
     "creste_pixel_geometry_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp,
                                         _vp, _i, _i, _vp]),

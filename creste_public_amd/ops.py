@@ -276,6 +276,24 @@ def nhwc_to_nchw(x: Act) -> torch.Tensor:
     return out
 
 
+def lidar_depth_image(points: torch.Tensor, lidar2cam: torch.Tensor, H: int, W: int, out: torch.Tensor,
+                      scale: float = 1.0, reduce: str = "max") -> torch.Tensor:
+    """points [B,NP,>=3] fp32, lidar2cam [B,3|4,4] float64 -> `out` [B,H,W] (may be a strided batch of
+    contiguous HxW planes, e.g. rgbd[:, 0, 3]) filled with the per-pixel max/min camera depth * scale."""
+    lib = _lib.load()
+    _chk(points, name="points")
+    _chk(lidar2cam, torch.float64, name="lidar2cam")
+    B, NP, ps = points.shape
+    if not out.is_cuda or out.dtype != torch.float32 or tuple(out.shape) != (B, H, W) or \
+            out.stride(2) != 1 or out.stride(1) != W:
+        raise HipLibraryError("lidar_depth_image: out must be CUDA fp32 [B,H,W] with contiguous HxW planes")
+    _lib.check(lib.creste_lidar_depth_image_f32(points.data_ptr(), ps, lidar2cam.data_ptr(),
+                                                lidar2cam.shape[1] * 4, B, NP, H, W, int(reduce == "min"),
+                                                float(scale), out.data_ptr(), out.stride(0) if B > 1 else H * W,
+                                                _stream()), "lidar_depth_image")
+    return out
+
+
 def depth_expectation(logits: Act, bin_values: torch.Tensor):
     lib = _lib.load()
     P = logits.N * logits.H * logits.W

@@ -56,6 +56,25 @@ def lidar_depth_channel(B: int, H: int, W: int, gen: torch.Generator) -> torch.T
     return out
 
 
+def lidar_scan(B: int, gen: torch.Generator) -> torch.Tensor:
+    """[B, 128*1024, 3] fp32 LiDAR points: 128 beams in +-22.5 deg x 1024 azimuth steps, range ~ U[1,40] m."""
+    az = torch.linspace(-math.pi, math.pi, 1025, dtype=torch.float64)[:-1]
+    el = torch.linspace(-22.5, 22.5, 128, dtype=torch.float64) * math.pi / 180
+    el, az = torch.meshgrid(el, az, indexing="ij")
+    rng = torch.rand(B, 128, 1024, generator=gen, dtype=torch.float64) * 39.0 + 1.0
+    pts = torch.stack([rng * torch.cos(el) * torch.cos(az), rng * torch.cos(el) * torch.sin(az),
+                       rng * torch.sin(el)], dim=-1)
+    return pts.view(B, -1, 3).float().contiguous()
+
+
+def lidar2camrect(B: int, H: int, W: int) -> torch.Tensor:
+    """[B,4,4] float64: pixel-homogeneous projection K @ T_cam<-lidar (rows 0..2), last row (0,0,0,1)."""
+    K, T = camera_matrices(H, W)
+    K4 = torch.eye(4, dtype=torch.float64)
+    K4[:3, :3] = K
+    return (K4 @ torch.linalg.inv(T)).unsqueeze(0).repeat(B, 1, 1).contiguous()
+
+
 def make_frames(B: int, H: int, W: int, seed: int = 1337):
     """-> rgbd [B,1,4,H,W] (RGB in [0,1), channel 3 = sparse LiDAR depth in mm), p2p [B,1,4,4]."""
     g = torch.Generator().manual_seed(seed)

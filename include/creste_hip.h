@@ -140,6 +140,16 @@ int creste_nchw_to_nhwc_f32(const float* in, float* out, int out_cs, int N, int 
 int creste_nhwc_to_nchw_f32(const float* in, int in_cs, float* out, int N, int C, int H, int W,
                             void* stream);
 
+/* LiDAR scan -> sparse depth image (input preparation).  reference
+ * creste/utils/projection.py:64-155 (pixels_to_depth): p_cam = lidar2cam[:3,:] @ [x,y,z,1] in float64,
+ * pixel = trunc(clip(p_cam[:2]/p_cam[2])), keep z_cam > 0 and in-image, depth[v,u] = max (or min) over
+ * the points of z_cam*scale, 0 where empty.  points [B,NP,point_stride>=3] fp32, lidar2cam [B][mat_stride>=12]
+ * float64 row-major 3x4 (a 4x4 works with mat_stride 16), depth [B] planes of HxW at depth_batch_stride
+ * elements (e.g. channel 3 of an NCHW rgbd tensor: stride 4*H*W). */
+int creste_lidar_depth_image_f32(const float* points, int point_stride, const double* lidar2cam,
+                                 int mat_stride, int B, int64_t NP, int H, int W, int reduce_min,
+                                 double scale, float* depth, int64_t depth_batch_stride, void* stream);
+
 /* Depth-bin logits -> metric depth + argmax bin.  reference depth.py:61-100,129-130 and
  * depth_utils.py:300-313: depth_m = sum_c softmax(logits)_c * bin_values[c] / 1000. */
 int creste_depth_expectation_f32(const float* logits, int cs, int64_t P, int nbins,
