@@ -1,0 +1,95 @@
+"""Training-step semantics of the IRL stage without Lightning -- the counterpart of the reference's
+`MaxEntIRLModel` (/root/reference/creste/train_traversability.py:34-330):
+
+* manual optimisation, per task: `zero_grad -> forward((image, p2p, expert)) -> LossManager(merged dict)
+  -> sum(weight * value) -> backward -> step` (:66-96);
+* Adam(lr, betas) over the parameters that require grad, ExponentialLR(gamma) stepped once per epoch
+  (:313-330); seed 1337 (`pl.seed_everything`, :401-413);
+* data parallel = one process per GPU; the only exchange is the reward network's gradient (102,866 fp32,
+  0.41 MB): ONE flat RCCL all-reduce per step (`dist_utils.allreduce_mean_grads`) instead of DDP buckets;
+  BatchNorm statistics stay per GPU, as in the reference (no SyncBN);
+* checkpoints use Lightning's layout `{'state_dict': {'model.<name>': tensor}, 'epoch': ..}` so they
+  load through the mirrored `load_weights` of MaxEntIRL / TerrainNet and through the reference itself.
+"""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+import torch
+
+from . import dist_utils
+from .creste.utils import train_utils as tu
+
+
+def seed_everything(seed: int = 1337):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+class IRLTrainer:
+    def __init__(self, model: torch.nn.Module, loss_manager: torch.nn.Module, model_cfg):
+        self.model, self.loss, self.cfg = model, loss_manager, model_cfg
+        oc = model_cfg["optimizer"]
+        if oc["name"] != "Adam":
+            raise NotImplementedError(oc["name"])
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.optimizer = torch.optim.Adam(self.params, betas=(oc["beta1"], oc["beta2"]), lr=oc["lr"])
+        sc = model_cfg["lr_scheduler"]
+        if sc["name"] != "ExponentialLR":
+            raise NotImplementedError(sc["name"])
+        self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=sc["gamma"])
+        self.epoch, self.global_step = 0, 0
+
+    def training_step(self, batch: dict) -> dict:
+        """batch: {task: {'image','p2p','traversability_label', 'fov_mask', 'counterfactuals_label', ...}}"""
+        self.model.train()
+        logs, total = {}, 0.0
+        for task, data in batch.items():
+            self.optimizer.zero_grad()
+            outputs = self.model((data["image"], data["p2p"], data["traversability_label"]))
+            with torch.no_grad():
+                merged = tu.merge_dict(("inputs", data), ("outputs", outputs))
+                merged["task"] = task
+            # tensors that carry the autograd graph must not be detached by the merge above
+            merged["outputs/traversability_preds"] = outputs["traversability_preds"]
+            merged["outputs/input_view"] = outputs["input_view"]
+            loss_dict, meta = self.loss(merged)
+            loss = sum(w * v for w, v in loss_dict.values())
+            loss.backward()
+            dist_utils.allreduce_mean_grads(self.params)          # one flat all-reduce (no-op on 1 GPU)
+            self.optimizer.step()
+            total = total + loss.detach()
+            logs.update({f"train/{k}": (w * v.detach()) for k, (w, v) in loss_dict.items()})
+            logs.update({f"train/{k}": v.detach() for k, v in meta.items()})
+        logs["train/loss"] = total
+        self.global_step += 1
+        return logs
+
+    def on_train_epoch_end(self):
+        self.scheduler.step()
+        self.epoch += 1
+
+    # ---- Lightning-layout checkpoints
+    def checkpoint(self) -> dict:
+        return {"state_dict": {f"model.{k}": v.detach().cpu() for k, v in self.model.state_dict().items()},
+                "epoch": self.epoch, "global_step": self.global_step,
+                "optimizer_states": [self.optimizer.state_dict()],
+                "lr_schedulers": [self.scheduler.state_dict()]}
+
+    def save_checkpoint(self, path: str):
+        if not dist_utils.is_dist() or torch.distributed.get_rank() == 0:
+            torch.save(self.checkpoint(), path)
+
+    def load_checkpoint(self, path: str, strict: bool = True):
+        ck = torch.load(path, weights_only=False, map_location="cpu")
+        sd = {k.replace("model.", "", 1): v for k, v in ck["state_dict"].items() if k.startswith("model.")}
+        self.model.load_state_dict(sd, strict=strict)
+        if "optimizer_states" in ck:
+            self.optimizer.load_state_dict(ck["optimizer_states"][0])
+        if "lr_schedulers" in ck:
+            self.scheduler.load_state_dict(ck["lr_schedulers"][0])
+        self.epoch, self.global_step = ck.get("epoch", 0), ck.get("global_step", 0)
