@@ -8,7 +8,7 @@ Cin, Cout, K, H, W = map(int, sys.argv[2:7])
 N = int(sys.argv[7]) if len(sys.argv) > 7 else 16
 iters = int(sys.argv[8]) if len(sys.argv) > 8 else 10
 torch.manual_seed(0)
-x = ops.Act(torch.randn(N, H, W, Cin, device="cuda"), Cin)
+x = ops.Act((torch.zeros if os.environ.get("ZERO") else torch.randn)(N, H, W, Cin, device="cuda"), Cin)
 w = torch.randn(Cout, Cin, K, K, device="cuda") / (Cin * K * K) ** 0.5
 pc = ops.pack_conv(w, None, None, 1, K // 2, ops.ACT_RELU, prec)
 out = ops.Act.empty(N, H, W, Cout, "cuda")
