@@ -1,0 +1,126 @@
+"""GPU: edge cases of the irregular kernels against the oracle -- empty / out-of-range / piled-up point
+sets for the splat, odd grid sizes, zero reward and large grids for value iteration, window clipping
+and terminal-state handling for the SVF kernel."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from creste_public_amd.config import maxent_irl_cfg, terrainnet_cfg
+from oracle import irl as oi
+from oracle import perception as op
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from creste_public_amd import ops as o
+    o._lib.load()
+    return o
+
+
+def _oracle_splat(xyz, feats):
+    """xyz [B,P,3], feats [B,P,F] -> oracle (coords, bev [B,G,G,F], dens [B,G,G])"""
+    m = op.Camera2MapMulti(terrainnet_cfg()["camera_projector"])
+    xy = m.to_voxel_coords(xyz)
+    vol, dens, _ = m.splat_mean(xy, feats.permute(0, 2, 1).contiguous(), m.grid_size[:2])
+    B, Fd, G = vol.shape
+    return xy, vol.view(B, Fd, 256, 256).permute(0, 2, 3, 1), dens.view(B, 256, 256)
+
+
+@pytest.mark.parametrize("case", ["all_outside", "single_cell_pileup", "borders", "one_point", "odd_channels"])
+def test_splat_edge_cases(ops, case):
+    g = torch.Generator().manual_seed(0)
+    B, P, Fd = 2, 3000, 96
+    xyz = torch.zeros(B, P, 3)
+    if case == "all_outside":
+        xyz[..., 0] = 50.0 + torch.rand(B, P, generator=g)          # far ahead: no tap in the grid
+        xyz[..., 1] = -40.0
+    elif case == "single_cell_pileup":                              # > 2048 points per base cell (unsorted path)
+        xyz[..., 0] = 3.03 + torch.rand(B, P, generator=g) * 0.05
+        xyz[..., 1] = -1.01 + torch.rand(B, P, generator=g) * 0.05
+    elif case == "borders":                                         # straddle every grid edge (taps at -1 / 256)
+        side = torch.randint(0, 4, (B, P), generator=g)
+        t = torch.rand(B, P, generator=g) * 25.6 - 12.8
+        e = torch.rand(B, P, generator=g) * 0.3 - 0.15
+        xyz[..., 0] = torch.where(side == 0, 12.8 + e, torch.where(side == 1, -12.8 + e, t))
+        xyz[..., 1] = torch.where(side == 2, 12.8 + e, torch.where(side == 3, -12.8 + e, t))
+    elif case == "one_point":
+        P = 1
+        xyz = torch.tensor([[[1.234, -5.678, 0.0]], [[-12.8, 12.8 - 1e-4, 0.0]]])
+    elif case == "odd_channels":
+        Fd = 20
+        xyz[..., :2] = torch.rand(B, P, 2, generator=g) * 20 - 10
+    feats = torch.randn(B, xyz.shape[1], Fd, generator=g)
+    ref_xy, ref_bev, ref_dens = _oracle_splat(xyz, feats)
+    fa = ops.Act(feats.view(B, 1, -1, Fd).cuda().contiguous(), Fd)
+    coords, bev, dens = ops.bev_splat(xyz.cuda(), fa, (12.8, 12.8), (np.float32(0.1), np.float32(0.1)), 256, 256)
+    assert torch.equal(coords.cpu(), ref_xy)
+    if case == "single_cell_pileup":
+        torch.testing.assert_close(dens.cpu(), ref_dens, rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(bev.buf.cpu(), ref_bev, rtol=1e-3, atol=1e-3)
+        assert dens.max() > 1000
+    else:
+        assert torch.equal(dens.cpu(), ref_dens)
+        assert torch.equal(bev.buf.cpu(), ref_bev)
+    if case == "all_outside":
+        assert float(bev.buf.abs().sum()) == 0.0 and float(dens.sum()) == 0.0
+
+
+@pytest.mark.parametrize("shape,kind", [((2, 37, 53), "rand"), ((1, 5, 7), "rand"), ((2, 64, 128), "zero"),
+                                        ((1, 256, 256), "rand"), ((3, 64, 128), "mixed"), ((1, 130, 200), "rand")])
+def test_value_iteration_shapes(ops, shape, kind):
+    g = torch.Generator().manual_seed(sum(shape))
+    r = torch.rand(shape, generator=g)
+    if kind == "zero":
+        r.zero_()
+    if kind == "mixed":
+        r[0] = 0.0
+        r[1] *= 5.0
+        r[2, :32] = 0.0
+    nk = maxent_irl_cfg()["traversability_head"]["net_kwargs"]
+    vin = oi.VIN(nk["reward_cfg"], nk["qvalue_cfg"])
+    v0, pi0, q0, n0 = vin.value_iteration(r.unsqueeze(1), 0.001, 0.99)
+    v, q, pi, sweeps = ops.value_iteration(r.cuda(), 0.99, 1e-3)
+    n = int(sweeps.item())
+    assert abs(n - n0) <= 1, (n, n0)
+    if kind == "zero":
+        assert n == 1 and float(v.abs().max()) == 0.0
+    torch.testing.assert_close(v.cpu(), v0[:, 0], rtol=3e-5, atol=3e-3)
+    torch.testing.assert_close(pi.cpu(), pi0, rtol=0, atol=3e-4)
+
+
+def _svf_oracle(policy, expert, T, H, W, zts):
+    m = oi.MaxEntIRL.__new__(oi.MaxEntIRL)
+    torch.nn.Module.__init__(m)
+    cfg = maxent_irl_cfg()
+    m.head_cfg, m.policy_cfg = cfg["traversability_head"], cfg["policy_kwargs"]
+    m.action_horizon, m.map_size, m.zero_terminal_state = T, [H, W], zts
+    m.register_buffer("dynamics", torch.tensor(oi.DYNAMICS, dtype=torch.long))
+    tp = torch.zeros(8, 1, 3, 3)
+    for a, (dr, dc) in enumerate(oi.DYNAMICS):
+        tp[a, 0, 1 - dr, 1 - dc] = 1.0
+    m.register_buffer("transition_probs", tp)
+    m.fov_mask = torch.ones(1, 1, H, W, dtype=torch.bool)
+    return m.expected_svf(policy, expert)
+
+
+@pytest.mark.parametrize("start,zts", [((0.0, 0.0), False), ((127.9, 255.9), False), ((60.0, 2.0), True),
+                                       ((2.0, 250.0), True)])
+def test_svf_window_clipping_and_terminal(ops, start, zts):
+    """start cells in the grid corners/edges: the LDS window is clipped, mass walks off the grid."""
+    H, W, T, B = 64, 128, 50, 2
+    g = torch.Generator().manual_seed(int(start[0] * 7 + start[1]))
+    pol = torch.softmax(torch.randn(B, 8, H, W, generator=g) * 2, dim=1)
+    t = torch.linspace(0, 1, T).view(1, T, 1)
+    xy = torch.tensor([start]).repeat(B, 1).unsqueeze(1) + t * torch.tensor([[[40.0, -60.0]], [[-30.0, 50.0]]])
+    expert = torch.eye(3).repeat(B, T, 1, 1)
+    expert[:, :, :2, 2] = xy
+    ref = _svf_oracle(pol.clone(), expert.clone(), T, H, W, zts)
+    fov = torch.ones(H, W, dtype=torch.uint8)
+    svf, states, grid = ops.expected_svf(pol.cuda(), xy.contiguous().cuda(), fov.cuda(), T, 2.0, 0.005, True, zts)
+    assert torch.equal(states.cpu(), ref["state_preds"])
+    assert torch.equal(grid.cpu(), ref["state_preds_grid"])
+    torch.testing.assert_close(svf.cpu(), ref["exp_svf"], rtol=1e-4, atol=1e-6)
+    assert float(svf.sum(dim=(1, 2)).max()) <= T + 1e-3

@@ -1,0 +1,171 @@
+"""CPU: host-side logic of the mirrored reference API -- checkpoint loading modes and key renaming
+(reference terrainnet.py:111-261, distillation.py:95-127, depth.py:35-58, lfd.py:126-154), package
+aliasing, config protocol, error conventions.  No GPU compute."""
+import sys
+
+import pytest
+import torch
+
+import creste_public_amd
+from creste_public_amd import Cfg, HipLibraryError, maxent_irl_cfg, terrainnet_cfg
+from creste_public_amd.creste.models.distillation import DistillationBackbone
+from creste_public_amd.creste.models.lfd import MaxEntIRL
+from creste_public_amd.creste.models.terrainnet import TerrainNet
+from creste_public_amd.creste.utils.loss_utils import LossManager
+
+IMG = (64, 96)
+
+
+def _ckpt(tmp_path, sd, name="w.ckpt"):
+    p = str(tmp_path / name)
+    torch.save({"state_dict": sd, "epoch": 3}, p)
+    return p
+
+
+@pytest.fixture(scope="module")
+def donor():
+    torch.manual_seed(0)
+    return TerrainNet(terrainnet_cfg(IMG))
+
+
+def test_state_dict_names_match_the_reference_contract(donor):
+    keys = set(donor.state_dict().keys())
+    for k in ["depthcomp.depthcomp.vision_backbone.model.trunk._conv_stem.weight",
+              "depthcomp.depthcomp.vision_backbone.model.trunk._blocks.0._depthwise_conv.weight",
+              "depthcomp.depthcomp.vision_backbone.model.trunk._blocks.1._expand_conv.weight",
+              "depthcomp.depthcomp.vision_backbone.model.trunk._blocks.15._se_reduce.bias",
+              "depthcomp.depthcomp.vision_backbone.model.trunk._blocks.15._bn2.running_var",
+              "depthcomp.depthcomp.vision_backbone.model.trunk._conv_head.weight",
+              "depthcomp.depthcomp.vision_backbone.model.trunk._fc.bias",
+              "depthcomp.depthcomp.vision_backbone.model.up3.conv.4.num_batches_tracked",
+              "depthcomp.depthcomp.vision_backbone.model.conv.bias",
+              "depthcomp.depthcomp.depth_head.model.1.running_mean",
+              "depthcomp.dino_head.model.6.weight", "depthcomp.dino_head.model.7.bias",
+              "cam2map.lidar2map", "cam2map.grid_size", "cam2map.z_proj.2.weight",
+              "cam2map.vision_fusion.convs.1.running_var",
+              "bevclassifier.conv1.weight", "bevclassifier.layer2.0.downsample.0.weight",
+              "bevclassifier.layer3.1.bn2.weight", "bevclassifier.out_heads.2.up1.conv.3.weight",
+              "bevclassifier.out_heads.0.up2.2.running_mean", "bevclassifier.out_heads.1.proj.bias"]:
+        assert k in keys, k
+    assert "depthcomp.depthcomp.vision_backbone.model.trunk._blocks.0._expand_conv.weight" not in keys
+    assert sum(p.numel() for p in donor.parameters()) == 25560908            # SURVEY.md 2.4 (25.6 M)
+    assert list(donor.cam2map.grid_size) == [256, 256, 1]
+    irl = MaxEntIRL(maxent_irl_cfg(IMG))
+    ik = set(irl.state_dict().keys())
+    assert {"dynamics", "transition_probs", "traversability_head.w",
+            "traversability_head.r.prepool.0.conv.weight", "traversability_head.r.trunk.2.running_mean",
+            "traversability_head.r.trunk.4.conv.weight", "traversability_head.r.postpool.0.norm.bias"} <= ik
+    assert all(("backbone." + k) in ik for k in keys)
+    assert sum(p.numel() for p in irl.traversability_head.parameters()) == 102866
+    assert all(not p.requires_grad for p in irl.backbone.parameters()) and not irl.backbone.training
+    irl.train()
+    assert not irl.backbone.training and irl.traversability_head.training    # frozen backbone stays in eval
+
+
+def test_load_weights_key_renaming_and_settings(tmp_path, donor):
+    sd = donor.state_dict()
+    # a stage-1 style checkpoint: Lightning 'model.' prefix, single 'depthcomp.' level, top-level dino_head
+    old = {}
+    for k, v in sd.items():
+        if k.startswith("depthcomp.depthcomp."):
+            k2 = k.replace("depthcomp.depthcomp.", "depthcomp.", 1)
+        elif k.startswith("depthcomp.dino_head."):
+            k2 = k.replace("depthcomp.dino_head.", "dino_head.", 1)
+        else:
+            k2 = k
+        old["model." + k2] = v.clone() + (0.25 if v.is_floating_point() else 0)
+    old["model.loss.some_buffer"] = torch.zeros(1)
+    path = _ckpt(tmp_path, old)
+    for mode, trainable in [("strict", None), ("strict_freeze", lambda n: False),
+                            ("strict_unfreezesplat", lambda n: "cam2map." in n),
+                            ("ft_decoders_all", lambda n: "bevclassifier.out_heads" in n),
+                            ("ft_decoders_partial",
+                             lambda n: "bevclassifier.out_heads" in n and ("up2" in n or "proj" in n))]:
+        cfg = terrainnet_cfg(IMG)
+        cfg["load_setting"] = mode
+        m = TerrainNet(cfg)
+        m.load_weights(path)
+        got = m.state_dict()
+        for k, v in sd.items():
+            dropped = (mode == "ft_decoders_all" and "bevclassifier.out_heads" in k) or \
+                      (mode == "ft_decoders_partial" and "bevclassifier.out_heads" in k and ("up2" in k or "proj" in k))
+            if v.is_floating_point() and not dropped:
+                assert torch.equal(got[k], v + 0.25), (mode, k)
+        if trainable is not None:
+            for n, p in m.named_parameters():
+                assert p.requires_grad == bool(trainable(n)), (mode, n)
+    cfg = terrainnet_cfg(IMG)
+    cfg["load_setting"] = "bogus"
+    with pytest.raises(ValueError):
+        TerrainNet(cfg).load_weights(path)
+    # DistillationBackbone / DepthCompletion loaders (drop bevclassifier + cam2map, undo the renaming)
+    new_style = {"model." + k: v for k, v in sd.items()}
+    p2 = _ckpt(tmp_path, new_style, "new.ckpt")
+    db = DistillationBackbone(terrainnet_cfg(IMG))
+    db.load_weights(p2)
+    assert torch.equal(db.state_dict()["depthcomp.depth_head.model.0.weight"],
+                       sd["depthcomp.depthcomp.depth_head.model.0.weight"])
+    db.depthcomp.load_weights(path)       # stage-1 layout: one 'depthcomp.' level (reference depth.py:41-58)
+    assert torch.equal(db.depthcomp.state_dict()["depth_head.model.0.weight"],
+                       sd["depthcomp.depthcomp.depth_head.model.0.weight"] + 0.25)
+    db.unfreeze_backbone()
+    assert all(p.requires_grad for p in db.depthcomp.parameters())
+    # MaxEntIRL.load_weights: strict load + freezing
+    irl = MaxEntIRL(maxent_irl_cfg(IMG))
+    p3 = _ckpt(tmp_path, {"model." + k: v for k, v in irl.state_dict().items()}, "irl.ckpt")
+    irl2 = MaxEntIRL(maxent_irl_cfg(IMG))
+    irl2.freeze_head = True
+    irl2.load_weights(p3)
+    assert all(not p.requires_grad for p in irl2.parameters())
+    irl2.train()
+    assert not irl2.traversability_head.training
+
+
+def test_install_as_creste_aliases_reference_import_paths():
+    saved = {k: v for k, v in sys.modules.items() if k == "creste" or k.startswith("creste.")}
+    try:
+        creste_public_amd.install_as_creste()
+        from creste.models.lfd import MaxEntIRL as A                     # noqa: the reference's own import lines
+        from creste.models.terrainnet import TerrainNet as B
+        from creste.models.blocks.splat_projection import Camera2MapMulti  # noqa: F401
+        from creste.models.blocks.vin import VIN                         # noqa: F401
+        from creste.utils.loss_utils import LossManager as L
+        import creste.utils.train_utils as tu
+        assert A is MaxEntIRL and B is TerrainNet and L is LossManager
+        assert tu.create_trapezoidal_fov_mask(128, 128, 70, 70, 0, 100).dtype == torch.bool
+    finally:
+        for k in [k for k in sys.modules if k == "creste" or k.startswith("creste.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def test_error_conventions_and_cfg_protocol():
+    cfg = terrainnet_cfg(IMG)
+    assert cfg.vision_backbone.effnet_cfgs.image_size == list(IMG) and cfg.get("nope", 7) == 7
+    assert isinstance(cfg["camera_projector"]["vision_fusion"], Cfg) and cfg.to_dict()["views"] == 1
+    bad = terrainnet_cfg(IMG)
+    bad["vision_backbone"]["class_name"] = "FoundationBackbone"
+    with pytest.raises(NotImplementedError):
+        TerrainNet(bad)
+    bad = terrainnet_cfg(IMG)
+    bad["bev_classifier"]["name"] = "Nope"
+    with pytest.raises(NotImplementedError):
+        TerrainNet(bad)
+    bad = terrainnet_cfg(IMG)
+    bad["use_temporal"] = True
+    with pytest.raises(NotImplementedError):
+        TerrainNet(bad)
+    c = maxent_irl_cfg(IMG)
+    c["loss"][0]["name"] = "VicregLoss"
+    with pytest.raises(NotImplementedError):
+        LossManager(c)
+    c = maxent_irl_cfg(IMG)
+    c["vision_backbone"]["project_name"] = "Other"
+    with pytest.raises(ValueError):
+        MaxEntIRL(c)
+    m = TerrainNet(terrainnet_cfg(IMG)).eval()
+    with pytest.raises(HipLibraryError):                                   # no CPU fallback
+        m((torch.zeros(1, 1, 4, *IMG), torch.eye(4).view(1, 1, 4, 4)))
+    if torch.cuda.is_available():
+        with pytest.raises(NotImplementedError):                           # backbone training: later round
+            m.cuda().train()((torch.zeros(1, 1, 4, *IMG).cuda(), torch.eye(4).view(1, 1, 4, 4).cuda()))
