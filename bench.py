@@ -31,8 +31,8 @@ sys.path.insert(0, ROOT)
 IMG_H, IMG_W, BATCH = 608, 1216, 16
 # TFLOP/s dense (MI355X_MICROARCH.md): fp32 MFMA 157.3; bf16 MFMA 2500.  bf16x3 issues 3 bf16 MFMAs per
 # algorithmic product, so its ceiling in algorithmic FLOPs is 2500/3.
-PEAK = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0 / 3.0, "bf16x6": 2500.0 / 6.0}
-PREC_NAME = {0: "f32", 1: "bf16", 2: "bf16x3", 3: "bf16x6"}
+PEAK = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0 / 3.0, "bf16x6": 2500.0 / 6.0, "f16x3": 2500.0 / 3.0}
+PREC_NAME = {0: "f32", 1: "bf16", 2: "bf16x3", 3: "bf16x6", 4: "f16x3"}
 HBM_PEAK_GBS = 8000.0
 
 
@@ -52,9 +52,11 @@ def kernel_symbol(pc):
     if pc.prec == 0:
         return ("f32", "conv_igemm_f32_kernel<2, 2, 2, 2>" if pc.Cout > 64 else
                 "conv_igemm_f32_kernel<2, 2, 2, 1>" if pc.Cout > 32 else "conv_igemm_f32_kernel<4, 1, 1, 1>")
-    split = {1: 1, 2: 2, 3: 3}[pc.prec]
+    split = {1: 1, 2: 2, 3: 3, 4: 2}[pc.prec]
     tn = 2 if pc.Cout > 64 else 1
-    name = f"conv_patch3_kernel<{split}, {tn}>" if pc.KH == 3 else f"conv_patch_kernel<1, {split}, {tn}>"
+    f16 = "true" if pc.prec == 4 else "false"
+    name = (f"conv_patch3_kernel<{split}, {tn}, {f16}, false>" if pc.KH == 3
+            else f"conv_patch_kernel<1, {split}, {tn}, {f16}>")
     return (PREC_NAME[pc.prec], name)
 
 
@@ -203,7 +205,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="bf16x6", choices=["f32", "bf16x6", "bf16x3", "bf16"],
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16x6", "f16x3", "bf16x3", "bf16"],
                     help="operand precision of the stride-1 1x1/3x3 convs on the matrix cores")
     ap.add_argument("--no-irl", action="store_true", help="skip the IRL train-step timing")
     ap.add_argument("--no-modes", action="store_true", help="skip the short extra runs of the other precisions")
@@ -270,7 +272,7 @@ def main():
     modes = {}
     if args.gpus == 1 and not args.no_modes:
         # the other conv operand modes, 3 steps each after 1 warm-up (same model, same inputs)
-        for name in ("f32", "bf16x6", "bf16x3", "bf16"):
+        for name in ("f32", "bf16x6", "f16x3", "bf16x3", "bf16"):
             if name == args.precision:
                 continue
             creste_public_amd.set_precision(name)
@@ -317,6 +319,8 @@ def main():
             "dtype": {"f32": "f32", "bf16x3": "f32 (bf16x3 split products on the bf16 MFMA, fp32 accumulate)",
                       "bf16x6": "f32 (fp32 operands as 3 bf16 pieces, 6 exact piece products per multiply on the "
                                 "bf16 MFMA, fp32 accumulate)",
+                      "f16x3": "f32 (fp32 operands, power-of-two rescaled, as fp16 hi+lo = 22 significand bits, 3 piece "
+                               "products per multiply on the f16 MFMA, fp32 accumulate)",
                       "bf16": "bf16 operands, fp32 accumulate/activations"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"inference: batch={args.batch}/GPU synthetic {IMG_W}x{IMG_H} RGB + 128x1024 "
@@ -334,7 +338,9 @@ def main():
         if modes:
             line["modes_frames_per_s"] = dict(modes, **{args.precision: line["value"]})
             line["modes_note"] = ("conv operand modes: f32 = exact fp32 MFMA; bf16x6 = fp32 operands as 3 bf16 pieces, "
-                                  "6 exact piece products (fp32-equivalent, parity suite green); bf16x3 = 2 pieces "
+                                  "6 exact piece products (fp32-equivalent, parity suite green); f16x3 = fp32 operands "
+                                  "rescaled by exact powers of two and split into fp16 hi+lo, 3 piece products "
+                                  "(<=2^-21 per product, parity suite green); bf16x3 = 2 pieces "
                                   "(~6e-5 rel per conv); bf16 = plain bf16 operands (~4e-3 rel per conv)")
         if args.gpus == 1 and not args.no_irl:
             line["irl"] = irl_extras(model, device)

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libcreste_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
-PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2, 3
+PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
 
 
 class HipLibraryError(RuntimeError):
@@ -26,7 +26,8 @@ class ConvDesc(C.Structure):
                [(n, C.c_int32) for n in ("N", "H", "W", "Cin", "in_cs", "Ho", "Wo", "Cout", "out_cs",
                                          "out_co", "res_cs", "KH", "KW", "stride", "pad_t", "pad_l",
                                          "act", "prec", "up_H", "up_W", "up_C", "up_cs")] + \
-               [("up_rh", C.c_float), ("up_rw", C.c_float)]
+               [("up_rh", C.c_float), ("up_rw", C.c_float),
+                ("a_amax", C.c_void_p), ("out_amax", C.c_void_p), ("w_unscale", C.c_void_p)]
 
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
@@ -40,6 +41,8 @@ SIGNATURES = {
     "creste_conv_supported_upsample": (_i, [_i, _i, _i, _i]),
     "creste_conv_packed_weight_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "creste_conv_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "creste_conv_pack_weight_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "creste_absmax_nhwc_f32": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "creste_dwconv2d_nhwc_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
     "creste_se_partial_count": (_i, [_i, _i]),
     "creste_dwconv_se_nhwc_f32": (_i, [_vp] * 5 + [_i] * 11 + [_vp]),

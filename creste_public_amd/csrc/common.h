@@ -54,6 +54,42 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
+// max over the 64 lanes of a wave (result in every lane)
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Raise the device-wide running maximum *amax (non-negative float, zero-initialised) to the block's
+// max of `v`.  `scratch` = LDS floats, one per wave, free to overwrite; every thread of the block
+// must call.  Positive floats order like their bit patterns, so the update is an integer atomicMax; a
+// relaxed agent-scope read first makes the atomic rare (the maximum only rises O(log blocks) times).
+__device__ __forceinline__ void block_amax_update(float v, float* amax, float* scratch) {
+  v = wave_max(v);
+  const int nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < nw; ++i) v = fmaxf(v, scratch[i]);
+    const unsigned bits = __float_as_uint(v);
+    unsigned* slot = reinterpret_cast<unsigned*>(amax);
+    if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+  }
+}
+
+// F16X3 operand scale: the power of two that maps an upper bound `amax` of |x| into [2^14, 2^15)
+// (fp16 max 65504); *inv gets its reciprocal.  amax == 0 / denormal -> 1.
+__device__ __forceinline__ float f16_operand_scale(float amax, float* inv) {
+  const int e = (int)((__float_as_uint(amax) >> 23) & 0xff);      // biased exponent: amax in [2^(e-127), 2^(e-126))
+  if (e == 0) { *inv = 1.f; return 1.f; }
+  int se = 127 + 14 - (e - 127);                                   // biased exponent of the scale
+  se = se > 253 ? 253 : (se < 1 ? 1 : se);
+  *inv = __uint_as_float((unsigned)(254 - se) << 23);
+  return __uint_as_float((unsigned)se << 23);
+}
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace creste

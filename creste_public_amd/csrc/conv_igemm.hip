@@ -33,6 +33,7 @@ struct ConvArgs {
   const float* a_scale;
   const float* row_mask;
   float* out;
+  float* out_amax;
   int N, H, W, Cin, in_cs;
   int Ho, Wo, Cout, out_cs, out_co, res_cs;
   int KH, KW, stride, pad_t, pad_l;
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float vmax = 0.f;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = bn0 + wn * TN * 32 + j * 32 + li;
@@ -192,11 +194,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
           if (p.res) v += p.res[(size_t)m * p.res_cs + n];
           v = act_apply(v, p.act);
           if (p.row_mask) v *= p.row_mask[m];
+          vmax = fmaxf(vmax, fabsf(v));
           p.out[(size_t)m * p.out_cs + p.out_co + n] = v;
         }
       }
     }
   }
+  if (p.out_amax) block_amax_update(vmax, p.out_amax, &lds[0][0]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -229,8 +233,8 @@ static inline int pick_bn(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 :
 namespace creste {   // conv_patch.hip
 bool conv_patch_supported(int prec, int KH, int KW, int stride);
 int64_t conv_patch_weight_bytes(int Cout, int Cin, int K, int prec);
-int conv_patch_pack(const float* w, const float* scale, void* wpk, int Cout, int Cin, int K, int prec,
-                    hipStream_t s);
+int conv_patch_pack(const float* w, const float* scale, void* wpk, float* w_unscale, int Cout, int Cin, int K,
+                    int prec, hipStream_t s);
 int conv_patch_run(const creste_conv_desc* d, hipStream_t s);
 }  // namespace creste
 
@@ -242,7 +246,8 @@ extern "C" int creste_conv_supported(int prec, int KH, int KW, int stride) {
 }
 
 extern "C" int creste_conv_supported_upsample(int prec, int KH, int KW, int stride) {
-  return prec != CRESTE_PREC_F32 && KH == 3 && KW == 3 && stride == 1 && conv_patch_supported(prec, KH, KW, stride);
+  return prec != CRESTE_PREC_F32 && prec != CRESTE_PREC_F16X3 && KH == 3 && KW == 3 && stride == 1 &&
+         conv_patch_supported(prec, KH, KW, stride);
 }
 
 extern "C" int64_t creste_conv_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int prec) {
@@ -258,7 +263,8 @@ extern "C" int creste_conv_pack_weight(const float* w, const float* scale, void*
   CRESTE_REQUIRE(w && wpk && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, "conv_pack_weight: bad args");
   if (prec != CRESTE_PREC_F32) {
     CRESTE_REQUIRE(conv_patch_supported(prec, KH, KW, 1), "conv_pack_weight: %dx%d not built for precision %d", KH, KW, prec);
-    return conv_patch_pack(w, scale, wpk, Cout, Cin, KH, prec, (hipStream_t)stream);
+    CRESTE_REQUIRE(prec != CRESTE_PREC_F16X3, "conv_pack_weight: F16X3 weights are packed by creste_conv_pack_weight_f16");
+    return conv_patch_pack(w, scale, wpk, nullptr, Cout, Cin, KH, prec, (hipStream_t)stream);
   }
   const int cin_pad = round_up(Cin, BK), cout_pad = round_up(Cout, pick_bn(Cout));
   const long total = (long)cout_pad * KH * KW * cin_pad;
@@ -267,6 +273,13 @@ extern "C" int creste_conv_pack_weight(const float* w, const float* scale, void*
                                                                  KH, KW, cin_pad, cout_pad);
   CRESTE_CHECK_LAUNCH("pack_weight_f32");
   return CRESTE_OK;
+}
+
+extern "C" int creste_conv_pack_weight_f16(const float* w, const float* scale, void* wpk, float* w_unscale,
+                                           int Cout, int Cin, int KH, int KW, void* stream) {
+  CRESTE_REQUIRE(w && wpk && w_unscale && Cout > 0 && Cin > 0, "conv_pack_weight_f16: bad args");
+  CRESTE_REQUIRE(conv_patch_supported(CRESTE_PREC_F16X3, KH, KW, 1), "conv_pack_weight_f16: %dx%d not built", KH, KW);
+  return conv_patch_pack(w, scale, wpk, w_unscale, Cout, Cin, KH, CRESTE_PREC_F16X3, (hipStream_t)stream);
 }
 
 extern "C" int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream) {
@@ -293,10 +306,12 @@ extern "C" int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream) {
   // the output extent must be reachable: last tap of the last pixel may only overhang into padding
   CRESTE_REQUIRE((d->Ho - 1) * d->stride - d->pad_t < d->H && (d->Wo - 1) * d->stride - d->pad_l < d->W,
                  "conv2d: output extent outside the input");
+  CRESTE_REQUIRE(d->prec != CRESTE_PREC_F16X3 || (d->a_amax && d->w_unscale),
+                 "conv2d: F16X3 needs a_amax (device bound of |in|) and w_unscale (from creste_conv_pack_weight_f16)");
   if (d->prec != CRESTE_PREC_F32) return conv_patch_run(d, (hipStream_t)stream);
   ConvArgs a;
   a.in = d->in; a.wpk = (const float*)d->wpk; a.bias = d->bias; a.res = d->res;
-  a.a_scale = d->a_scale; a.row_mask = d->row_mask; a.out = d->out;
+  a.a_scale = d->a_scale; a.row_mask = d->row_mask; a.out = d->out; a.out_amax = d->out_amax;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_cs = d->in_cs;
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.out_cs = d->out_cs; a.out_co = d->out_co;
   a.res_cs = d->res_cs; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad_t = d->pad_t;

@@ -24,6 +24,8 @@ namespace creste {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -38,13 +40,28 @@ constexpr int PT_CK = 16;              // channels per chunk = K of one MFMA
 //   SPLIT 2: a1*b0 + a0*b1 + a0*b0       (bf16x3: 16-bit operands)
 //   SPLIT 3: a2*b0 + a1*b1 + a0*b2 + a1*b0 + a0*b1 + a0*b0   (bf16x6: 24-bit operands = fp32; the dropped
 //            pairs are <= 2^-24 relative, the size of one fp32 product rounding)
-template <int SPLIT>
-__device__ __forceinline__ f32x16 split_mfma(const bf16x8 (&a)[SPLIT], const bf16x8 (&b)[SPLIT], f32x16 c) {
+//
+// F16X3 is SPLIT 2 on fp16 pieces (v_mfma_f32_32x32x16_f16, same rate): hi + lo carry 22 significand bits
+// instead of 16, so the three products are fp32-grade (<= 2^-21) at HALF the MFMA count of bf16x6.  fp16 has
+// only 5 exponent bits, hence the exact power-of-two rescaling of both operands (activations: per tensor
+// from a running |max| the producing kernel maintains; weights: per output channel at pack time), undone in
+// the epilogue.
+template <bool F16> struct Piece { typedef __bf16 T; typedef bf16x8 V8; typedef bf16x4 V4; };
+template <> struct Piece<true> { typedef _Float16 T; typedef f16x8 V8; typedef f16x4 V4; };
+
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+template <int SPLIT, typename V8>
+__device__ __forceinline__ f32x16 split_mfma(const V8 (&a)[SPLIT], const V8 (&b)[SPLIT], f32x16 c) {
 #pragma unroll
   for (int order = SPLIT - 1; order >= 0; --order)
 #pragma unroll
-    for (int pa = order; pa >= 0; --pa)
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[order - pa], c, 0, 0, 0);
+    for (int pa = order; pa >= 0; --pa) c = mfma16(a[pa], b[order - pa], c);
   return c;
 }
 
@@ -56,6 +73,9 @@ struct PatchArgs {
   const float* a_scale;
   const float* row_mask;
   float* out;
+  const float* a_amax;       // F16X3: device upper bound of |in|
+  float* out_amax;           // running max |out| (any precision), or nullptr
+  const float* w_unscale;    // F16X3: [Cout] inverse weight scale
   const float* up_src;       // fused bilinear upsample + concat source (3x3 kernel only), or nullptr
   int up_H, up_W, up_C, up_cs;
   float up_rh, up_rw;
@@ -72,9 +92,11 @@ struct PatchArgs {
 // (row = (r&3) + 8*(r>>2) + 4*(lane>>5)): registers 4g..4g+3 are 4 CONSECUTIVE output channels of one
 // pixel -> one 16-byte store (and one 16-byte residual / bias load) instead of four dword stores; the
 // store tail of a conv is issue-bound, not bandwidth-bound (cdna_hip_programming.md T21).
-template <int TN>
+template <int TN, bool F16>
 __device__ __forceinline__ void patch_epilogue(const f32x16 (&acc)[2][TN], const PatchArgs& p, int img,
-                                               int oy0, int ox0, int nbase, int wm, int wn, int li, int lh) {
+                                               int oy0, int ox0, int nbase, int wm, int wn, int li, int lh,
+                                               float o_mul, float* scratch) {
+  float vmax = 0.f;
   const bool vec_ok = (p.Cout & 3) == 0 && (p.out_cs & 3) == 0 && (p.out_co & 3) == 0 &&
                       (!p.res || (p.res_cs & 3) == 0);
   const int ox = ox0 + li;
@@ -92,28 +114,39 @@ __device__ __forceinline__ void patch_epilogue(const f32x16 (&acc)[2][TN], const
         if (n >= p.Cout) continue;
         f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
         if (vec_ok) {
+          if (F16) v *= *reinterpret_cast<const f32x4*>(p.w_unscale + n) * o_mul;   // exact: powers of two
           if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
           if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * p.res_cs + n);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], p.act) * rmask;
+          for (int j = 0; j < 4; ++j) {
+            v[j] = act_apply(v[j], p.act) * rmask;
+            vmax = fmaxf(vmax, fabsf(v[j]));
+          }
           *reinterpret_cast<f32x4*>(p.out + m * p.out_cs + p.out_co + n) = v;
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             if (n + j < p.Cout) {
-              float x = v[j] + (p.bias ? p.bias[n + j] : 0.f);
+              float x = v[j];
+              if (F16) x *= p.w_unscale[n + j] * o_mul;
+              x += (p.bias ? p.bias[n + j] : 0.f);
               if (p.res) x += p.res[m * p.res_cs + n + j];
-              p.out[m * p.out_cs + p.out_co + n + j] = act_apply(x, p.act) * rmask;
+              x = act_apply(x, p.act) * rmask;
+              vmax = fmaxf(vmax, fabsf(x));
+              p.out[m * p.out_cs + p.out_co + n + j] = x;
             }
           }
         }
       }
     }
   }
+  if (p.out_amax) block_amax_update(vmax, p.out_amax, scratch);
 }
 
-template <int K, int SPLIT, int TN>
+template <int K, int SPLIT, int TN, bool F16>
 __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void conv_patch_kernel(const PatchArgs p) {
+  typedef typename Piece<F16>::V8 V8;
+  typedef typename Piece<F16>::V4 V4;
   constexpr int T = K * K;
   constexpr int PH = PT_TH + K - 1, PW = PT_TW + K - 1, NPIX = PH * PW;
   constexpr int NPIXP = (NPIX + 15) / 16 * 16;
@@ -145,6 +178,9 @@ __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void co
   const int ty = id % p.tiles_y;
   const int img = id / p.tiles_y;
   const int oy0 = ty * PT_TH, ox0 = tx * PT_TW;
+
+  float a_mul = 1.f, o_mul = 1.f;
+  if (F16) a_mul = f16_operand_scale(*p.a_amax, &o_mul);
 
   // ---- per-thread A staging slots (fixed over chunks).  512 % 4 == 0, so a thread always carries the same
   // channel quad cq of consecutive patch pixels pix = r*128 + tid/4.
@@ -180,6 +216,7 @@ __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void co
     if (a_gpix[r] >= 0 && ch < p.Cin) {
       v = *reinterpret_cast<const f32x4*>(p.in + (size_t)a_gpix[r] * p.in_cs + ch);
       if (p.a_scale) v *= *reinterpret_cast<const f32x4*>(p.a_scale + (size_t)img * p.Cin + ch);
+      if (F16) v *= a_mul;
     }
     return v;
   };
@@ -189,8 +226,8 @@ __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void co
     f32x4 rem = v;
 #pragma unroll
     for (int pl = 0; pl < SPLIT; ++pl) {           // hi, then the bf16 of what is left, ...
-      const bf16x4 piece = __builtin_convertvector(rem, bf16x4);
-      *reinterpret_cast<bf16x4*>(dst + pl * A_PLANE) = piece;
+      const V4 piece = __builtin_convertvector(rem, V4);
+      *reinterpret_cast<V4*>(dst + pl * A_PLANE) = piece;
       if (pl + 1 < SPLIT) rem -= __builtin_convertvector(piece, f32x4);
     }
   };
@@ -227,26 +264,26 @@ __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void co
 
       // ---- MFMAs of (chunk c, tap t)
       const int ky = t / K, kx = t % K;
-      bf16x8 af[2][SPLIT], bfr[TN][SPLIT];
+      V8 af[2][SPLIT], bfr[TN][SPLIT];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int idx = (wm * 2 + mt + ky) * PW + kx + li;
 #pragma unroll
         for (int pl = 0; pl < SPLIT; ++pl)
-          af[mt][pl] = *reinterpret_cast<const bf16x8*>(A + pl * A_PLANE + lh * A_OCT + idx * 16);
+          af[mt][pl] = *reinterpret_cast<const V8*>(A + pl * A_PLANE + lh * A_OCT + idx * 16);
       }
 #pragma unroll
       for (int nt = 0; nt < TN; ++nt) {
         const int n = (wn * TN + nt) * 32 + li;
 #pragma unroll
         for (int pl = 0; pl < SPLIT; ++pl)
-          bfr[nt][pl] = *reinterpret_cast<const bf16x8*>(B + pl * B_PLANE + lh * B_OCT + n * 16);
+          bfr[nt][pl] = *reinterpret_cast<const V8*>(B + pl * B_PLANE + lh * B_OCT + n * 16);
       }
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt) {
-          acc[mt][nt] = split_mfma<SPLIT>(bfr[nt], af[mt], acc[mt][nt]);
+          acc[mt][nt] = split_mfma<SPLIT, V8>(bfr[nt], af[mt], acc[mt][nt]);
         }
 
       // ---- land the prefetched tiles in the other buffers
@@ -257,7 +294,7 @@ __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void co
     }
   }
 
-  patch_epilogue<TN>(acc, p, img, oy0, ox0, tn * BN, wm, wn, li, lh);
+  patch_epilogue<TN, F16>(acc, p, img, oy0, ox0, tn * BN, wm, wn, li, lh, o_mul, reinterpret_cast<float*>(smem));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -269,8 +306,12 @@ __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void co
 //     steps of chunk c and written (with the bf16 split) between two barriers at the chunk boundary;
 //   => 4 barriers per 16-channel chunk instead of 9, 36 (bf16x3) MFMAs per wave per interval, 70 KB of
 //      LDS so two 8-wave workgroups share a CU and cover each other's barriers.
-template <int SPLIT, int TN>
+// UP = the loader also forms the bilinear-upsample half of a concat input (separate instantiation: its
+// address arithmetic costs ~40 VGPRs, which the plain kernels at 128 VGPRs/lane cannot spare).
+template <int SPLIT, int TN, bool F16, bool UP>
 __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void conv_patch3_kernel(const PatchArgs p) {
+  typedef typename Piece<F16>::V8 V8;
+  typedef typename Piece<F16>::V4 V4;
   constexpr int K = 3;
   constexpr int PH = PT_TH + K - 1, PW = PT_TW + K - 1, NPIX = PH * PW;
   constexpr int NPIXP = (NPIX + 15) / 16 * 16;
@@ -301,6 +342,9 @@ __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void co
   const int img = id / p.tiles_y;
   const int oy0 = ty * PT_TH, ox0 = tx * PT_TW;
 
+  float a_mul = 1.f, o_mul = 1.f;
+  if (F16) a_mul = f16_operand_scale(*p.a_amax, &o_mul);
+
   const int cq = tid & 3;
   const int a_lofs0 = (cq >> 1) * A_OCT + (tid >> 2) * 16 + (cq & 1) * 8;
   int a_yx[ROUNDS];        // (iy << 16) | ix of the round's patch pixel, -1 if outside the image / unused
@@ -312,16 +356,16 @@ __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void co
     const bool ok = pix < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
     a_yx[r] = ok ? (iy << 16) | ix : -1;
   }
-  const int c_skip = p.up_src ? p.Cin - p.up_C : p.Cin;     // channels below this come from `in`
+  const int c_skip = UP ? p.Cin - p.up_C : p.Cin;           // channels below this come from `in`
   auto load_a = [&](int r, int c) __attribute__((always_inline)) -> f32x4 {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const int ch = c * PT_CK + cq * 4;
     if (a_yx[r] >= 0 && ch < p.Cin) {
       const int iy = a_yx[r] >> 16, ix = a_yx[r] & 0xffff;
-      if (ch < c_skip) {
+      if (!UP || ch < c_skip) {
         v = *reinterpret_cast<const f32x4*>(p.in + ((size_t)(img * p.H + iy) * p.W + ix) * p.in_cs + ch);
         if (p.a_scale) v *= *reinterpret_cast<const f32x4*>(p.a_scale + (size_t)img * p.Cin + ch);
-      } else {
+      } else if (UP) {
         // fused nn.Upsample(bilinear, align_corners=False): PyTorch's source index rule
         float sy = p.up_rh * ((float)iy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
         float sx = p.up_rw * ((float)ix + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
@@ -335,6 +379,7 @@ __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void co
         const f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * p.up_W + x1) * p.up_cs);
         v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
       }
+      if (F16) v *= a_mul;
     }
     return v;
   };
@@ -344,8 +389,8 @@ __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void co
     f32x4 rem = v;
 #pragma unroll
     for (int pl = 0; pl < SPLIT; ++pl) {           // hi, then the bf16 of what is left, ...
-      const bf16x4 piece = __builtin_convertvector(rem, bf16x4);
-      *reinterpret_cast<bf16x4*>(dst + pl * A_PLANE) = piece;
+      const V4 piece = __builtin_convertvector(rem, V4);
+      *reinterpret_cast<V4*>(dst + pl * A_PLANE) = piece;
       if (pl + 1 < SPLIT) rem -= __builtin_convertvector(piece, f32x4);
     }
   };
@@ -389,27 +434,24 @@ __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void co
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const char* B = Brow + kx * B_BYTES;
-        bf16x8 af[2][SPLIT], bfr[TN][SPLIT];
-#pragma unroll
-        for (int nt = 0; nt < TN; ++nt) {
-          const int n = (wn * TN + nt) * 32 + li;
-#pragma unroll
-          for (int pl = 0; pl < SPLIT; ++pl)
-            bfr[nt][pl] = *reinterpret_cast<const bf16x8*>(B + pl * B_PLANE + lh * B_OCT + n * 16);
-        }
+        V8 af[2][SPLIT];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           const int idx = (wm * 2 + mt + ky) * PW + kx + li;
 #pragma unroll
           for (int pl = 0; pl < SPLIT; ++pl)
-            af[mt][pl] = *reinterpret_cast<const bf16x8*>(abuf + pl * A_PLANE + lh * A_OCT + idx * 16);
+            af[mt][pl] = *reinterpret_cast<const V8*>(abuf + pl * A_PLANE + lh * A_OCT + idx * 16);
         }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int nt = 0; nt < TN; ++nt) {
+          V8 bfr[SPLIT];
+          const int n = (wn * TN + nt) * 32 + li;
 #pragma unroll
-          for (int nt = 0; nt < TN; ++nt) {
-            acc[mt][nt] = split_mfma<SPLIT>(bfr[nt], af[mt], acc[mt][nt]);
-          }
+          for (int pl = 0; pl < SPLIT; ++pl)
+            bfr[pl] = *reinterpret_cast<const V8*>(B + pl * B_PLANE + lh * B_OCT + n * 16);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = split_mfma<SPLIT, V8>(bfr, af[mt], acc[mt][nt]);
+        }
       }
       __syncthreads();     // row g consumed by every wave; DMA of row g+1 landed (vmcnt drained)
     }
@@ -420,29 +462,58 @@ __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void co
     }
   }
 
-  patch_epilogue<TN>(acc, p, img, oy0, ox0, tn * BN, wm, wn, li, lh);
+  patch_epilogue<TN, F16>(acc, p, img, oy0, ox0, tn * BN, wm, wn, li, lh, o_mul, reinterpret_cast<float*>(smem));
 }
 
-template <int SPLIT, int TN>
-static int launch_patch3(const PatchArgs& a, hipStream_t s) {
+template <int SPLIT, int TN, bool F16, bool UP>
+static int launch_patch3_up(const PatchArgs& a, hipStream_t s) {
   constexpr int NPIXP = ((PT_TH + 2) * (PT_TW + 2) + 15) / 16 * 16;
   constexpr int smem = SPLIT * 2 * NPIXP * 16 + 2 * 3 * (SPLIT * 2 * 64 * TN * 16);
   static bool attr_set = false;
   if (!attr_set && smem > 64 * 1024) {
-    CRESTE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch3_kernel<SPLIT, TN>),
+    CRESTE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch3_kernel<SPLIT, TN, F16, UP>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   const int nblk = a.tiles_n * a.tiles_x * a.tiles_y * a.N;
-  conv_patch3_kernel<SPLIT, TN><<<nblk, 512, smem, s>>>(a);
+  conv_patch3_kernel<SPLIT, TN, F16, UP><<<nblk, 512, smem, s>>>(a);
   CRESTE_CHECK_LAUNCH("conv_patch3");
   return CRESTE_OK;
 }
 
-// weight packing: OIHW fp32 (x scale[co]) -> [ntile][chunk][tap][plane][k-octet][BN][8] bf16
+template <int SPLIT, int TN, bool F16>
+static int launch_patch3(const PatchArgs& a, hipStream_t s) {
+  if constexpr (!F16) {
+    if (a.up_src) return launch_patch3_up<SPLIT, TN, F16, true>(a, s);
+  }
+  return launch_patch3_up<SPLIT, TN, F16, false>(a, s);
+}
+
+// F16X3: per output channel, the inverse of the power of two that brings max|w*scale| into [2^7, 2^8)
+__global__ void weight_unscale_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                      float* __restrict__ unscale, int per_co) {
+  __shared__ float scratch[4];
+  const int co = blockIdx.x;
+  const float sc = scale ? scale[co] : 1.f;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < per_co; i += blockDim.x) m = fmaxf(m, fabsf(w[(long)co * per_co + i] * sc));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, scratch[i]);
+    const int e = (int)((__float_as_uint(m) >> 23) & 0xff);
+    int ue = e - 7;                                     // biased exponent of 2^((e-127)-7)
+    ue = ue < 1 ? 1 : (ue > 253 ? 253 : ue);
+    unscale[co] = e == 0 ? 1.f : __uint_as_float((unsigned)ue << 23);
+  }
+}
+
+// weight packing: OIHW fp32 (x scale[co]) -> [ntile][chunk][tap][plane][k-octet][BN][8] bf16 / fp16
+template <typename ET>
 __global__ void pack_weight_patch_kernel(const float* __restrict__ w, const float* __restrict__ scale,
-                                         __bf16* __restrict__ out, int Cout, int Cin, int K, int BN,
-                                         int nchunk, int split, long total) {
+                                         const float* __restrict__ unscale, ET* __restrict__ out, int Cout,
+                                         int Cin, int K, int BN, int nchunk, int split, long total) {
   const int T = K * K;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     long t = i;
@@ -458,35 +529,38 @@ __global__ void pack_weight_patch_kernel(const float* __restrict__ w, const floa
     if (co < Cout && ci < Cin) {
       v = w[(((long)co * Cin + ci) * K + tap / K) * K + tap % K];
       if (scale) v *= scale[co];
+      if (unscale) v *= 1.f / unscale[co];              // exact: power of two
     }
-    __bf16 piece = (__bf16)v;
-    for (int q = 0; q < pl; ++q) { v -= (float)piece; piece = (__bf16)v; }
+    ET piece = (ET)v;
+    for (int q = 0; q < pl; ++q) { v -= (float)piece; piece = (ET)v; }
     out[i] = piece;
   }
 }
 
 static inline int patch_bn(int cout) { return cout > 64 ? 128 : 64; }
-static inline int patch_split(int prec) { return prec == CRESTE_PREC_BF16X6 ? 3 : (prec == CRESTE_PREC_BF16X3 ? 2 : 1); }
+static inline int patch_split(int prec) {
+  return prec == CRESTE_PREC_BF16X6 ? 3 : (prec == CRESTE_PREC_BF16X3 || prec == CRESTE_PREC_F16X3 ? 2 : 1);
+}
 
-template <int K, int SPLIT, int TN>
+template <int K, int SPLIT, int TN, bool F16>
 static int launch_patch(const PatchArgs& a, hipStream_t s) {
   constexpr int PH = PT_TH + K - 1, PW = PT_TW + K - 1, NPIXP = (PH * PW + 15) / 16 * 16;
   constexpr int smem = 2 * (SPLIT * 2 * NPIXP * 16) + 2 * (SPLIT * 2 * 64 * TN * 16);
   static bool attr_set = false;
   if (!attr_set && smem > 64 * 1024) {
-    CRESTE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_kernel<K, SPLIT, TN>),
+    CRESTE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_kernel<K, SPLIT, TN, F16>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   const int nblk = a.tiles_n * a.tiles_x * a.tiles_y * a.N;
-  conv_patch_kernel<K, SPLIT, TN><<<nblk, 512, smem, s>>>(a);
+  conv_patch_kernel<K, SPLIT, TN, F16><<<nblk, 512, smem, s>>>(a);
   CRESTE_CHECK_LAUNCH("conv_patch");
   return CRESTE_OK;
 }
 
 bool conv_patch_supported(int prec, int KH, int KW, int stride) {
-  return (prec == CRESTE_PREC_BF16 || prec == CRESTE_PREC_BF16X3 || prec == CRESTE_PREC_BF16X6) && KH == KW && (KH == 1 || KH == 3) &&
-         stride == 1;
+  return (prec == CRESTE_PREC_BF16 || prec == CRESTE_PREC_BF16X3 || prec == CRESTE_PREC_BF16X6 ||
+          prec == CRESTE_PREC_F16X3) && KH == KW && (KH == 1 || KH == 3) && stride == 1;
 }
 
 int64_t conv_patch_weight_bytes(int Cout, int Cin, int K, int prec) {
@@ -495,12 +569,20 @@ int64_t conv_patch_weight_bytes(int Cout, int Cin, int K, int prec) {
   return tiles * nchunk * K * K * patch_split(prec) * 2 * bn * 16;
 }
 
-int conv_patch_pack(const float* w, const float* scale, void* wpk, int Cout, int Cin, int K, int prec,
-                    hipStream_t s) {
+int conv_patch_pack(const float* w, const float* scale, void* wpk, float* w_unscale, int Cout, int Cin, int K,
+                    int prec, hipStream_t s) {
   const int bn = patch_bn(Cout), split = patch_split(prec), nchunk = (Cin + PT_CK - 1) / PT_CK;
   const long total = conv_patch_weight_bytes(Cout, Cin, K, prec) / 2;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  pack_weight_patch_kernel<<<blocks, 256, 0, s>>>(w, scale, (__bf16*)wpk, Cout, Cin, K, bn, nchunk, split, total);
+  if (prec == CRESTE_PREC_F16X3) {
+    weight_unscale_kernel<<<Cout, 256, 0, s>>>(w, scale, w_unscale, Cin * K * K);
+    CRESTE_CHECK_LAUNCH("weight_unscale");
+    pack_weight_patch_kernel<_Float16><<<blocks, 256, 0, s>>>(w, scale, w_unscale, (_Float16*)wpk, Cout, Cin, K, bn,
+                                                              nchunk, split, total);
+  } else {
+    pack_weight_patch_kernel<__bf16><<<blocks, 256, 0, s>>>(w, scale, nullptr, (__bf16*)wpk, Cout, Cin, K, bn, nchunk,
+                                                            split, total);
+  }
   CRESTE_CHECK_LAUNCH("pack_weight_patch");
   return CRESTE_OK;
 }
@@ -509,6 +591,7 @@ int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
   PatchArgs a;
   a.in = d->in; a.wpk = (const char*)d->wpk; a.bias = d->bias; a.res = d->res; a.a_scale = d->a_scale;
   a.row_mask = d->row_mask; a.out = d->out;
+  a.a_amax = d->a_amax; a.out_amax = d->out_amax; a.w_unscale = d->w_unscale;
   a.up_src = d->up_src; a.up_H = d->up_H; a.up_W = d->up_W; a.up_C = d->up_C; a.up_cs = d->up_cs;
   a.up_rh = d->up_rh; a.up_rw = d->up_rw;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_cs = d->in_cs;
@@ -521,15 +604,22 @@ int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
   a.tiles_y = (d->Ho + PT_TH - 1) / PT_TH;
   const int split = patch_split(d->prec);
   const int K = d->KH;
-#define CRESTE_PATCH_DISPATCH(FN3, FN1)                                              \
-  if (K == 3) {                                                                      \
-    if (bn == 128) return split == 3 ? FN3<3, 2>(a, s) : split == 2 ? FN3<2, 2>(a, s) : FN3<1, 2>(a, s); \
-    return split == 3 ? FN3<3, 1>(a, s) : split == 2 ? FN3<2, 1>(a, s) : FN3<1, 1>(a, s);              \
-  }                                                                                  \
-  if (bn == 128) return split == 3 ? FN1<1, 3, 2>(a, s) : split == 2 ? FN1<1, 2, 2>(a, s) : FN1<1, 1, 2>(a, s); \
-  return split == 3 ? FN1<1, 3, 1>(a, s) : split == 2 ? FN1<1, 2, 1>(a, s) : FN1<1, 1, 1>(a, s);
-  CRESTE_PATCH_DISPATCH(launch_patch3, launch_patch)
-#undef CRESTE_PATCH_DISPATCH
+  if (d->prec == CRESTE_PREC_F16X3) {
+    if (K == 3) return bn == 128 ? launch_patch3<2, 2, true>(a, s) : launch_patch3<2, 1, true>(a, s);
+    return bn == 128 ? launch_patch<1, 2, 2, true>(a, s) : launch_patch<1, 2, 1, true>(a, s);
+  }
+  if (K == 3) {
+    if (bn == 128)
+      return split == 3 ? launch_patch3<3, 2, false>(a, s)
+                        : split == 2 ? launch_patch3<2, 2, false>(a, s) : launch_patch3<1, 2, false>(a, s);
+    return split == 3 ? launch_patch3<3, 1, false>(a, s)
+                      : split == 2 ? launch_patch3<2, 1, false>(a, s) : launch_patch3<1, 1, false>(a, s);
+  }
+  if (bn == 128)
+    return split == 3 ? launch_patch<1, 3, 2, false>(a, s)
+                      : split == 2 ? launch_patch<1, 2, 2, false>(a, s) : launch_patch<1, 1, 2, false>(a, s);
+  return split == 3 ? launch_patch<1, 3, 1, false>(a, s)
+                    : split == 2 ? launch_patch<1, 2, 1, false>(a, s) : launch_patch<1, 1, 1, false>(a, s);
 }
 
 }  // namespace creste

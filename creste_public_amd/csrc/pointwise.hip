@@ -427,6 +427,22 @@ __global__ __launch_bounds__(256) void resize_plane_kernel(const float* __restri
   }
 }
 
+// max |x| over an NHWC slice (C % 4 == 0, 16-byte rows): one streaming read, block reduce, rare atomic
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long pixels, int C, int cs,
+                                                     float* __restrict__ amax) {
+  __shared__ float scratch[4];
+  const int cq = C >> 2;
+  const long total = pixels * cq;
+  float m = 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long px = i / cq;
+    const int q = (int)(i - px * cq);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + px * cs + 4 * q);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  block_amax_update(m, amax, scratch);
+}
+
 }  // namespace creste
 
 using namespace creste;
@@ -575,5 +591,14 @@ extern "C" int creste_dwconv_se_nhwc_f32(const float* in, const float* w, const 
   if (K == 3) dwconv_se_kernel<3><<<dim3(nchunk, N), 256, smem, s>>>(in, w, bias, out, partial, H, W, C, Ho, Wo, stride, pad_t, pad_l, act, nchunk);
   else dwconv_se_kernel<5><<<dim3(nchunk, N), 256, smem, s>>>(in, w, bias, out, partial, H, W, C, Ho, Wo, stride, pad_t, pad_l, act, nchunk);
   CRESTE_CHECK_LAUNCH("dwconv_se");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_absmax_nhwc_f32(const float* x, int64_t pixels, int C, int cs, float* amax, void* stream) {
+  CRESTE_REQUIRE(x && amax && pixels > 0 && C > 0, "absmax: bad args");
+  CRESTE_REQUIRE(C % 4 == 0 && cs % 4 == 0 && cs >= C && (reinterpret_cast<uintptr_t>(x) & 15) == 0,
+                 "absmax: C and cs must be multiples of 4 and the slice 16-byte aligned");
+  absmax_kernel<<<grid_for(pixels * (C / 4), 256, 256 * 8), 256, 0, (hipStream_t)stream>>>(x, pixels, C, cs, amax);
+  CRESTE_CHECK_LAUNCH("absmax");
   return CRESTE_OK;
 }

@@ -21,7 +21,8 @@ from .ops import ACT_NONE, ACT_RELU, ACT_SWISH, Act, HipLibraryError  # noqa: F4
 # and the three BEV heads no longer share one concat.  Kept off.
 FUSE_UPSAMPLE = False
 
-PRECISIONS = {"f32": ops.PREC_F32, "bf16": ops.PREC_BF16, "bf16x3": ops.PREC_BF16X3, "bf16x6": ops.PREC_BF16X6}
+PRECISIONS = {"f32": ops.PREC_F32, "bf16": ops.PREC_BF16, "bf16x3": ops.PREC_BF16X3, "bf16x6": ops.PREC_BF16X6,
+              "f16x3": ops.PREC_F16X3}
 _precision = ops.PREC_F32
 
 
@@ -32,9 +33,14 @@ def set_precision(name: str):
              (fp32-grade: ~2^-16 product error) -- stride-1 1x1/3x3 convs, the rest stays 'f32';
     'bf16x6' fp32 operands split into three bf16 pieces, 6 MFMAs per product: fp32-equivalent products
              (dropped terms <= 2^-24) at 2.7x the fp32 MFMA rate -- same coverage as bf16x3;
+    'f16x3'  fp32 operands rescaled by exact powers of two (activations: per tensor, from the running |max|
+             the producing conv leaves behind; weights: per output channel) and split into fp16 hi+lo = 22
+             significand bits, 3 MFMAs per product: product error <= 2^-21, below the fp32 accumulation
+             round-off of the dot products it feeds -- fp32-grade at HALF the MFMA count of bf16x6;
     'bf16'   one bf16 MFMA per product (throughput mode), same coverage."""
     global _precision
     _precision = PRECISIONS[name]
+    ops.TRACK_AMAX = name == "f16x3"
 
 
 def get_precision() -> str:

@@ -12,8 +12,13 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import (ACT_NONE, ACT_RELU, ACT_SWISH, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F32, ConvDesc,  # noqa: F401
-                   HipLibraryError)
+from ._lib import (ACT_NONE, ACT_RELU, ACT_SWISH, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3, PREC_F32,  # noqa: F401
+                   ConvDesc, HipLibraryError)
+
+# When set, every conv leaves the running max |out| of a freshly allocated output in `Act.amax` (one
+# device float): the F16X3 engine of the NEXT conv reads it as its operand bound instead of making a
+# pass over the tensor.  hipnn.set_precision('f16x3') turns it on.
+TRACK_AMAX = False
 
 
 def _stream() -> int:
@@ -30,11 +35,28 @@ def _chk(t: torch.Tensor, dtype=torch.float32, name="tensor"):
     return t
 
 
+class _AmaxPool:
+    """Zero-initialised device floats handed out one at a time (a fresh 4 KiB block every 1024 slots; a
+    block lives as long as a slot view of it does)."""
+    _blocks: dict = {}
+
+    @classmethod
+    def slot(cls, device) -> torch.Tensor:
+        key = (device.type, device.index)
+        blk = cls._blocks.get(key)
+        if blk is None or blk[1] >= blk[0].numel():
+            blk = [torch.zeros(1024, dtype=torch.float32, device=device), 0]
+            cls._blocks[key] = blk
+        blk[1] += 1
+        return blk[0][blk[1] - 1:blk[1]]
+
+
 @dataclass
 class Act:
     buf: torch.Tensor      # [N,H,W,cs] contiguous fp32
     C: int                 # channels in the slice
     co: int = 0            # channel offset of the slice
+    amax: torch.Tensor | None = None   # device float >= max|slice| when known (see TRACK_AMAX)
 
     @property
     def N(self): return self.buf.shape[0]
@@ -60,6 +82,17 @@ class Act:
         return self.buf[..., self.co:self.co + self.C].permute(0, 3, 1, 2)
 
 
+def absmax(x: Act) -> torch.Tensor:
+    """Device float max|x| of the slice (one streaming read); cached on the Act."""
+    if x.amax is None:
+        lib = _lib.load()
+        slot = _AmaxPool.slot(x.buf.device)
+        _lib.check(lib.creste_absmax_nhwc_f32(x.ptr, x.N * x.H * x.W, x.C, x.cs, slot.data_ptr(), _stream()),
+                   "absmax")
+        x.amax = slot
+    return x.amax
+
+
 @dataclass
 class PackedConv:
     wpk: torch.Tensor          # packed GEMM weights (uint8 storage)
@@ -75,6 +108,7 @@ class PackedConv:
     pad_r: int
     act: int
     prec: int = PREC_F32
+    w_unscale: torch.Tensor | None = None   # F16X3: [Cout] inverse power-of-two weight scale
 
     def out_hw(self, H, W):
         return ((H + self.pad_t + self.pad_b - self.KH) // self.stride + 1,
@@ -109,12 +143,18 @@ def pack_conv(weight: torch.Tensor, bias, bn, stride, pad, act, prec=PREC_F32) -
     if nbytes <= 0:
         raise HipLibraryError("conv_packed_weight_bytes: unsupported shape/precision")
     wpk = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    _lib.check(lib.creste_conv_pack_weight(w.data_ptr(), scale.data_ptr() if scale is not None else None,
-                                           wpk.data_ptr(), Cout, Cin, KH, KW, prec, _stream()),
-               "conv_pack_weight")
+    sp = scale.data_ptr() if scale is not None else None
+    unscale = None
+    if prec == PREC_F16X3:
+        unscale = torch.empty(Cout, dtype=torch.float32, device=w.device)
+        _lib.check(lib.creste_conv_pack_weight_f16(w.data_ptr(), sp, wpk.data_ptr(), unscale.data_ptr(), Cout,
+                                                   Cin, KH, KW, _stream()), "conv_pack_weight_f16")
+    else:
+        _lib.check(lib.creste_conv_pack_weight(w.data_ptr(), sp, wpk.data_ptr(), Cout, Cin, KH, KW, prec,
+                                               _stream()), "conv_pack_weight")
     if isinstance(pad, int):
         pad = (pad, pad, pad, pad)
-    return PackedConv(wpk, b, Cin, Cout, KH, KW, stride, pad[0], pad[2], pad[1], pad[3], act, prec)
+    return PackedConv(wpk, b, Cin, Cout, KH, KW, stride, pad[0], pad[2], pad[1], pad[3], act, prec, unscale)
 
 
 def conv2d(x: Act | None, pc: PackedConv, out: Act | None = None, res: Act | None = None,
@@ -135,6 +175,7 @@ def conv2d(x: Act | None, pc: PackedConv, out: Act | None = None, res: Act | Non
     if cin != pc.Cin:
         raise HipLibraryError(f"conv2d: input has {cin} channels, weights expect {pc.Cin}")
     Ho, Wo = pc.out_hw(H, W)
+    fresh = out is None
     if out is None:
         out = Act.empty(N, Ho, Wo, pc.Cout, dev)
     if (out.N, out.H, out.W, out.C) != (N, Ho, Wo, pc.Cout):
@@ -167,6 +208,13 @@ def conv2d(x: Act | None, pc: PackedConv, out: Act | None = None, res: Act | Non
     d.Ho, d.Wo, d.Cout, d.out_cs, d.out_co = Ho, Wo, pc.Cout, out.cs, out.co
     d.KH, d.KW, d.stride, d.pad_t, d.pad_l = pc.KH, pc.KW, pc.stride, pc.pad_t, pc.pad_l
     d.act, d.prec = pc.act, pc.prec
+    if pc.prec == PREC_F16X3:
+        if up is not None:
+            raise HipLibraryError("conv2d: the fused upsample loader is not built for f16x3")
+        d.a_amax, d.w_unscale = absmax(x).data_ptr(), pc.w_unscale.data_ptr()
+    if fresh and (TRACK_AMAX or pc.prec == PREC_F16X3):     # a slice written by several producers is not tracked
+        out.amax = _AmaxPool.slot(dev)
+        d.out_amax = out.amax.data_ptr()
     _lib.check(lib.creste_conv2d_nhwc(C.byref(d), _stream()), "conv2d_nhwc")
     return out
 

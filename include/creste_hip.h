@@ -43,6 +43,11 @@ extern "C" {
 #define CRESTE_PREC_BF16X6 3 /* fp32 operands split into THREE bf16 pieces (24 bits = the whole fp32
                                 significand), the 6 piece products >= 2^-16 summed on the bf16 MFMA:
                                 fp32-equivalent products (dropped terms <= 2^-24) at 2.7x the fp32 MFMA rate */
+#define CRESTE_PREC_F16X3 4  /* fp32 operands, rescaled by a per-tensor / per-output-channel power of two, split
+                                into fp16 hi+lo (22 significand bits), hi*hi+hi*lo+lo*hi on
+                                v_mfma_f32_32x32x16_f16, fp32 accumulate: product error <= 2^-21 (below the
+                                fp32 accumulation round-off of a K>=16 dot product) at 5.3x the fp32 MFMA
+                                rate; needs creste_conv_desc.a_amax / w_unscale */
 
 const char* creste_last_error(void);
 int creste_abi_version(void);
@@ -78,6 +83,17 @@ typedef struct creste_conv_desc {
   int32_t prec; /* CRESTE_PREC_* */
   int32_t up_H, up_W, up_C, up_cs;
   float up_rh, up_rw;
+  /* Dynamic-range bookkeeping of the fp16-split engine (CRESTE_PREC_F16X3); all three may be NULL otherwise.
+   * a_amax   device float: an UPPER BOUND of max|in| over the slice read (and of up_src); the kernel scales
+   *          the operand by a power of two so that the bound lands in [2^14, 2^15) -- exact, undone in the
+   *          epilogue.  |a_scale| must be <= 1 (the squeeze-excite gate is a sigmoid).
+   * out_amax device float, zero-initialised by the caller: atomically raised to max|out| by every
+   *          workgroup (any precision) -- the next layer's a_amax without another pass over the tensor.
+   * w_unscale [Cout] inverse of the per-output-channel power-of-two weight scale chosen by
+   *          creste_conv_pack_weight (same call's `w_unscale` output). */
+  const float* a_amax;
+  float* out_amax;
+  const float* w_unscale;
 } creste_conv_desc;
 
 int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream);
@@ -91,6 +107,14 @@ int64_t creste_conv_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int p
  * scaling output channel co by scale[co] (the folded BatchNorm gamma/sqrt(var+eps)). */
 int creste_conv_pack_weight(const float* w_oihw, const float* scale, void* wpk, int Cout, int Cin,
                             int KH, int KW, int prec, void* stream);
+/* CRESTE_PREC_F16X3 packing: as above, but every output channel is first scaled by the power of two that
+ * brings max|w[co]*scale[co]| into [2^7, 2^8) (fp16 has 5 exponent bits: small BN-folded weights would
+ * lose their low piece to subnormals); w_unscale[co] receives the inverse factor for the conv epilogue. */
+int creste_conv_pack_weight_f16(const float* w_oihw, const float* scale, void* wpk, float* w_unscale, int Cout,
+                                int Cin, int KH, int KW, void* stream);
+/* amax[0] = max(amax[0], max |x|) over an NHWC slice ([pixels][cs] rows, C channels read per row): the
+ * stand-alone producer of a_amax for tensors that did not come out of creste_conv2d_nhwc. */
+int creste_absmax_nhwc_f32(const float* x, int64_t pixels, int C, int cs, float* amax, void* stream);
 
 /* Depthwise KxK conv + bias + activation (EfficientNet MBConv `_depthwise_conv` + `_bn1` + swish,
  * third-party; static asymmetric "same" padding).  w is [KH*KW][C] (tap-major), BN pre-folded. */

@@ -3,7 +3,7 @@ usage: conv_micro.py PREC Cin Cout K H W [N] [iters]"""
 import sys, os, torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from creste_public_amd import ops
-prec = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}[sys.argv[1]]
+prec = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}[sys.argv[1]]
 Cin, Cout, K, H, W = map(int, sys.argv[2:7])
 N = int(sys.argv[7]) if len(sys.argv) > 7 else 16
 iters = int(sys.argv[8]) if len(sys.argv) > 8 else 10

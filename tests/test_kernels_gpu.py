@@ -78,7 +78,7 @@ PATCH_CASES = [c for c in CONV_CASES if c[5] in (1, 3) and c[6] == 1] + [
 ]
 
 
-@pytest.mark.parametrize("prec,tol", [("bf16x6", 2e-6), ("bf16x3", 6e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("prec,tol", [("bf16x6", 2e-6), ("f16x3", 2e-6), ("bf16x3", 6e-5), ("bf16", 2e-2)])
 @pytest.mark.parametrize("case", PATCH_CASES)
 def test_conv_patch_bf16(ops, case, prec, tol):
     """bf16-MFMA patch engine: relative rms error vs a float64 conv.  bf16x3 must stay fp32-grade."""
@@ -97,7 +97,8 @@ def test_conv_patch_bf16(ops, case, prec, tol):
     if res is not None:
         ref = ref + res.double()
     ref = {0: lambda t: t, 1: F.relu, 2: lambda t: t * torch.sigmoid(t)}[act](ref)
-    code = {"bf16x6": ops.PREC_BF16X6, "bf16x3": ops.PREC_BF16X3, "bf16": ops.PREC_BF16}[prec]
+    code = {"bf16x6": ops.PREC_BF16X6, "bf16x3": ops.PREC_BF16X3, "bf16": ops.PREC_BF16,
+            "f16x3": ops.PREC_F16X3}[prec]
     assert ops.conv_supported(code, K, s)
     pc = ops.pack_conv(dev(w), None if b is None else dev(b),
                        None if bn is None else tuple(dev(t) if isinstance(t, torch.Tensor) else t for t in bn),
@@ -107,6 +108,41 @@ def test_conv_patch_bf16(ops, case, prec, tol):
     rel = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-12))
     assert rel < tol, f"{prec}: relative rms error {rel:.2e}"
     assert float((got - ref).abs().max()) < 60 * tol * float(ref.abs().max().clamp_min(1.0))
+
+
+@pytest.mark.parametrize("xs,ws", [(1e-20, 1.0), (1e-6, 1e3), (1.0, 1e-12), (3e4, 1.0), (1e15, 1e15), ("outlier", 1.0),
+                                   ("zero", 1.0)])
+@pytest.mark.parametrize("K", [1, 3])
+def test_conv_f16x3_dynamic_range(ops, xs, ws, K):
+    """fp16 has 5 exponent bits: the f16x3 engine must stay fp32-grade for ANY operand magnitude (exact
+    power-of-two rescaling from the tracked |max| and per-channel weight scales), including a tensor whose
+    |max| is an outlier 10^4 above the bulk, and must report max|out| of what it wrote."""
+    g = torch.Generator().manual_seed(7 + K)
+    N, Cin, H, W, Cout = 2, 48, 19, 45, 72
+    x = torch.randn(N, Cin, H, W, generator=g)
+    if xs == "outlier":
+        x[1, 5, 7, 9] = 1e4
+    elif xs == "zero":
+        x.zero_()
+    else:
+        x = x * xs
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5 * ws
+    w = w * torch.logspace(-3, 3, Cout).view(-1, 1, 1, 1)            # per-channel spread of BN-folded weights
+    b = torch.randn(Cout, generator=g) * float(w.abs().mean() * x.abs().mean() + 1e-30)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=K // 2)
+    pc = ops.pack_conv(dev(w), dev(b), None, 1, K // 2, 0, ops.PREC_F16X3)
+    xa = to_act(ops, x)
+    out = ops.conv2d(xa, pc)
+    got = from_act(out).double()
+    assert torch.isfinite(got).all()
+    assert float(xa.amax.item()) == float(x.abs().max())
+    assert float(out.amax.item()) == float(got.abs().max())          # tracked bound = exact max of the output
+    if xs == "zero":
+        assert torch.equal(got, b.double().view(1, -1, 1, 1).expand_as(got).contiguous())
+        return
+    # per output channel (the weight scale differs by 10^6 across channels)
+    err = (got - ref).pow(2).mean(dim=(0, 2, 3)).sqrt() / ref.pow(2).mean(dim=(0, 2, 3)).sqrt()
+    assert float(err.max()) < (2e-5 if xs == "outlier" else 2e-6), f"relative rms error {float(err.max()):.2e}"
 
 
 @pytest.mark.parametrize("prec,tol", [("bf16x6", 3e-6), ("bf16x3", 8e-5)])

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 H, W, B = 128, 192, 2
 # conv operand modes that must meet the parity bar: exact fp32 MFMA and the fp32-equivalent bf16x6
 # split (the mode bench.py times).  CRESTE_TEST_PRECISION narrows the run to one mode.
-PRECISIONS = [os.environ["CRESTE_TEST_PRECISION"]] if "CRESTE_TEST_PRECISION" in os.environ else ["f32", "bf16x6"]
+PRECISIONS = [os.environ["CRESTE_TEST_PRECISION"]] if "CRESTE_TEST_PRECISION" in os.environ else ["f32", "bf16x6", "f16x3"]
 
 
 @torch.no_grad()
