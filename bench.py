@@ -53,7 +53,7 @@ def kernel_symbol(pc):
         return ("f32", "conv_igemm_f32_kernel<2, 2, 2, 2>" if pc.Cout > 64 else
                 "conv_igemm_f32_kernel<2, 2, 2, 1>" if pc.Cout > 32 else "conv_igemm_f32_kernel<4, 1, 1, 1>")
     split = {1: 1, 2: 2, 3: 3, 4: 2}[pc.prec]
-    tn = 2 if pc.Cout > 64 else 1
+    tn = 4 if (pc.prec == 4 and pc.Cout > 128) else 2 if pc.Cout > 64 else 1
     f16 = "true" if pc.prec == 4 else "false"
     name = (f"conv_patch3_kernel<{split}, {tn}, {f16}, false>" if pc.KH == 3
             else f"conv_patch_kernel<1, {split}, {tn}, {f16}>")

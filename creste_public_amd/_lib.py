@@ -45,11 +45,11 @@ SIGNATURES = {
     "creste_absmax_nhwc_f32": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "creste_dwconv2d_nhwc_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
     "creste_se_partial_count": (_i, [_i, _i]),
-    "creste_dwconv_se_nhwc_f32": (_i, [_vp] * 5 + [_i] * 11 + [_vp]),
+    "creste_dwconv_se_nhwc_f32": (_i, [_vp] * 6 + [_i] * 11 + [_vp]),
     "creste_se_gate_f32": (_i, [_vp] * 7 + [_i] * 4 + [_vp]),
     "creste_upsample_concat_nhwc_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i,
-                                              _f, _f, _vp]),
-    "creste_maxpool2_nhwc_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+                                              _f, _f, _vp, _vp]),
+    "creste_maxpool2_nhwc_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "creste_affine_act_nhwc_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
     "creste_resize_plane_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _f, _f, _vp]),
     "creste_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -144,7 +144,7 @@ __device__ __forceinline__ void patch_epilogue(const f32x16 (&acc)[2][TN], const
 }
 
 template <int K, int SPLIT, int TN, bool F16>
-__global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void conv_patch_kernel(const PatchArgs p) {
+__global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) void conv_patch_kernel(const PatchArgs p) {
   typedef typename Piece<F16>::V8 V8;
   typedef typename Piece<F16>::V4 V4;
   constexpr int T = K * K;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void co
 // UP = the loader also forms the bilinear-upsample half of a concat input (separate instantiation: its
 // address arithmetic costs ~40 VGPRs, which the plain kernels at 128 VGPRs/lane cannot spare).
 template <int SPLIT, int TN, bool F16, bool UP>
-__global__ __launch_bounds__(512, SPLIT == 3 ? 2 : PATCH_WAVES_PER_SIMD) void conv_patch3_kernel(const PatchArgs p) {
+__global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) void conv_patch3_kernel(const PatchArgs p) {
   typedef typename Piece<F16>::V8 V8;
   typedef typename Piece<F16>::V4 V4;
   constexpr int K = 3;
@@ -537,7 +537,13 @@ __global__ void pack_weight_patch_kernel(const float* __restrict__ w, const floa
   }
 }
 
-static inline int patch_bn(int cout) { return cout > 64 ? 128 : 64; }
+// output channels per workgroup.  f16x3 takes 256-wide tiles when the layer has them: 72 MFMAs per wave and
+// barrier interval (the bf16x6 kernel's ratio of MFMA to LDS traffic), and the halo patch is staged, split
+// and written to LDS once per 256 channels instead of once per 128.
+static inline int patch_bn(int cout, int prec) {
+  if (prec == CRESTE_PREC_F16X3 && cout > 128) return 256;
+  return cout > 64 ? 128 : 64;
+}
 static inline int patch_split(int prec) {
   return prec == CRESTE_PREC_BF16X6 ? 3 : (prec == CRESTE_PREC_BF16X3 || prec == CRESTE_PREC_F16X3 ? 2 : 1);
 }
@@ -564,14 +570,14 @@ bool conv_patch_supported(int prec, int KH, int KW, int stride) {
 }
 
 int64_t conv_patch_weight_bytes(int Cout, int Cin, int K, int prec) {
-  const int bn = patch_bn(Cout);
+  const int bn = patch_bn(Cout, prec);
   const long tiles = (Cout + bn - 1) / bn, nchunk = (Cin + PT_CK - 1) / PT_CK;
   return tiles * nchunk * K * K * patch_split(prec) * 2 * bn * 16;
 }
 
 int conv_patch_pack(const float* w, const float* scale, void* wpk, float* w_unscale, int Cout, int Cin, int K,
                     int prec, hipStream_t s) {
-  const int bn = patch_bn(Cout), split = patch_split(prec), nchunk = (Cin + PT_CK - 1) / PT_CK;
+  const int bn = patch_bn(Cout, prec), split = patch_split(prec), nchunk = (Cin + PT_CK - 1) / PT_CK;
   const long total = conv_patch_weight_bytes(Cout, Cin, K, prec) / 2;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   if (prec == CRESTE_PREC_F16X3) {
@@ -598,15 +604,18 @@ int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.out_cs = d->out_cs; a.out_co = d->out_co;
   a.res_cs = d->res_cs; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.act = d->act;
   a.nchunk = (d->Cin + PT_CK - 1) / PT_CK;
-  const int bn = patch_bn(d->Cout);
+  const int bn = patch_bn(d->Cout, d->prec);
   a.tiles_n = (d->Cout + bn - 1) / bn;
   a.tiles_x = (d->Wo + PT_TW - 1) / PT_TW;
   a.tiles_y = (d->Ho + PT_TH - 1) / PT_TH;
   const int split = patch_split(d->prec);
   const int K = d->KH;
   if (d->prec == CRESTE_PREC_F16X3) {
-    if (K == 3) return bn == 128 ? launch_patch3<2, 2, true>(a, s) : launch_patch3<2, 1, true>(a, s);
-    return bn == 128 ? launch_patch<1, 2, 2, true>(a, s) : launch_patch<1, 2, 1, true>(a, s);
+    if (K == 3)
+      return bn == 256 ? launch_patch3<2, 4, true>(a, s)
+                       : bn == 128 ? launch_patch3<2, 2, true>(a, s) : launch_patch3<2, 1, true>(a, s);
+    return bn == 256 ? launch_patch<1, 2, 4, true>(a, s)
+                     : bn == 128 ? launch_patch<1, 2, 2, true>(a, s) : launch_patch<1, 2, 1, true>(a, s);
   }
   if (K == 3) {
     if (bn == 128)

@@ -97,24 +97,33 @@ __global__ __launch_bounds__(256) void se_partial_kernel(const float* __restrict
   }
 }
 
-// depthwise conv + bias + activation AND the squeeze-excite partial channel sums of its OUTPUT in one pass:
-// the SE mean no longer re-reads the (up to 1.1 GB) activated tensor.  Same (slice, channel-quad) thread
-// layout and the same deterministic reduction order as se_partial_kernel.
-template <int K>
+// depthwise conv + bias + activation AND the squeeze-excite partial channel sums of its OUTPUT in one pass
+// (the SE mean never re-reads the up-to-1.1 GB activated tensor), plus the running |max| of the output for
+// the f16x3 conv that consumes it.
+// Thread = (pixel slice, channel quad) as in se_partial_kernel; the unit of work is a GROUP of XG = 4
+// horizontally adjacent outputs: per kernel row the (XG-1)*S+K input quads are loaded once and feed all
+// four outputs (K=5, S=1: 8 loads instead of 20), the K*K weight quads stay in registers for the thread's
+// whole run.  L1 traffic per output drops 50 -> 10 loads; accumulation order per output is unchanged
+// (bias, then ky-major / kx-minor taps), so results are bit-identical to the one-output-per-thread form.
+// Chunks are remapped so that one XCD's L2 sees a contiguous band of rows (vertical halo reuse).
+template <int K, int S>
 __global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict__ in,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ bias,
                                                         float* __restrict__ out, float* __restrict__ partial,
-                                                        int H, int W, int C, int Ho, int Wo, int stride,
-                                                        int pad_t, int pad_l, int act, int nchunk) {
+                                                        float* __restrict__ amax, int H, int W, int C, int Ho,
+                                                        int Wo, int pad_t, int pad_l, int act, int nchunk) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [slices][C]
-  const int n = blockIdx.y, chunk = blockIdx.x;
+  constexpr int XG = 4, NI = (XG - 1) * S + K;
+  const int n = blockIdx.y, chunk = xcd_remap(blockIdx.x, nchunk);
   const int cq = C >> 2;
   const int slices = 256 / cq > 0 ? 256 / cq : 1;
-  const int HWo = Ho * Wo;
-  const int rows = se_rows_per_block(HWo, C);
-  const int p0 = chunk * rows;
-  const int p1 = min(HWo, p0 + rows);
+  const int gw = (Wo + XG - 1) / XG;                 // groups per output row
+  const int G = Ho * gw;
+  const int per = (G + nchunk - 1) / nchunk;
+  const int g0 = chunk * per, g1 = min(G, g0 + per);
+  const long HWo = (long)Ho * Wo;
+  float vmax = 0.f;
   for (int q0 = 0; q0 < cq; q0 += 256) {
     const int tq = (cq >= 256) ? q0 + threadIdx.x : threadIdx.x % cq;
     const int sl = (cq >= 256) ? 0 : threadIdx.x / cq;
@@ -123,26 +132,46 @@ __global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict_
     if (active) {
       const int c = tq * 4;
       const f32x4 b4 = bias ? ld4(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int p = p0 + sl; p < p1; p += slices) {
-        const int oy = p / Wo, ox = p % Wo;
-        const int iy0 = oy * stride - pad_t, ix0 = ox * stride - pad_l;
-        f32x4 acc = b4;
+      f32x4 wk[K * K];
+#pragma unroll
+      for (int t = 0; t < K * K; ++t) wk[t] = ld4(w + t * C + c);
+      for (int g = g0 + sl; g < g1; g += slices) {
+        const int oy = g / gw, ox0 = (g - oy * gw) * XG;
+        const int iy0 = oy * S - pad_t, ix0 = ox0 * S - pad_l;
+        f32x4 acc[XG];
+#pragma unroll
+        for (int o = 0; o < XG; ++o) acc[o] = b4;
 #pragma unroll
         for (int ky = 0; ky < K; ++ky) {
           const int iy = iy0 + ky;
           if ((unsigned)iy >= (unsigned)H) continue;
+          const float* row = in + ((long)n * H + iy) * W * C + c;
+          f32x4 xin[NI];
 #pragma unroll
-          for (int kx = 0; kx < K; ++kx) {
-            const int ix = ix0 + kx;
-            if ((unsigned)ix >= (unsigned)W) continue;
-            acc += ld4(in + (((long)n * H + iy) * W + ix) * C + c) * ld4(w + (ky * K + kx) * C + c);
+          for (int j = 0; j < NI; ++j) {
+            const int ix = ix0 + j;
+            xin[j] = (unsigned)ix < (unsigned)W ? ld4(row + (long)ix * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+            for (int o = 0; o < XG; ++o) {
+              acc[o] += xin[o * S + kx] * wk[ky * K + kx];   // a tap outside the image adds 0 * w = +-0
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < XG; ++o) {
+          if (ox0 + o < Wo) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v[j] = act_apply(acc[o][j], act);
+              vmax = fmaxf(vmax, fabsf(v[j]));
+            }
+            st4(out + ((long)n * HWo + (long)oy * Wo + ox0 + o) * C + c, v);
+            s += v;
           }
         }
-        f32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = act_apply(acc[j], act);
-        st4(out + ((long)n * HWo + p) * C + c, o);
-        s += o;
       }
       st4(sm + (long)sl * C + tq * 4, s);
     }
@@ -154,6 +183,7 @@ __global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict_
     }
     __syncthreads();
   }
+  if (amax) block_amax_update(vmax, amax, sm);
 }
 
 // one 1024-thread block per sample: mean -> FC1 + swish -> FC2 -> sigmoid
@@ -211,45 +241,54 @@ __global__ __launch_bounds__(SEG_T) void se_gate_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------ upsample + concat
+// One block row per output row (blockIdx.y = n*Ho + oy): the vertical interpolation taps are block
+// constants and the per-element index math is 32-bit (the flat 64-bit div/mod form was ALU-bound at a
+// third of the HBM rate).  Also raises *amax to max|out| (both halves) for the f16x3 consumer.
 __global__ __launch_bounds__(256) void upsample_concat_kernel(
     const float* __restrict__ x1, int H1, int W1, int C1, int x1_cs, const float* __restrict__ skip,
-    int C2, int skip_cs, float* __restrict__ out, int N, int Ho, int Wo, int out_cs, int out_co,
-    float rh, float rw) {
+    int C2, int skip_cs, float* __restrict__ out, int Ho, int Wo, int out_cs, int out_co,
+    float rh, float rw, float* __restrict__ amax) {
+  __shared__ float scratch[4];
   const int cq = (C1 + C2) >> 2, c2q = C2 >> 2;
-  const long total = (long)N * Ho * Wo * cq;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(i % cq);
-    long t = i / cq;
-    const int ox = (int)(t % Wo); t /= Wo;
-    const int oy = (int)(t % Ho);
-    const int n = (int)(t / Ho);
-    const long opix = ((long)n * Ho + oy) * Wo + ox;
+  const int n = blockIdx.y / Ho, oy = blockIdx.y - n * Ho;
+  // PyTorch area_pixel_compute_source_index (align_corners=False): clamp below at 0
+  float sy = rh * ((float)oy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+  const int y0 = (int)sy;
+  const int y1 = y0 + (y0 < H1 - 1 ? 1 : 0);
+  const float ly = sy - (float)y0, hy = 1.f - ly;
+  const float* r0 = x1 + ((long)n * H1 + y0) * W1 * x1_cs;
+  const float* r1 = x1 + ((long)n * H1 + y1) * W1 * x1_cs;
+  const long orow = ((long)n * Ho + oy) * Wo;
+  const int row_items = Wo * cq;
+  float vmax = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < row_items; i += gridDim.x * 256) {
+    const int ox = i / cq, q = i - ox * cq;
     f32x4 v;
     if (q < c2q) {
-      v = ld4(skip + opix * skip_cs + q * 4);
+      v = ld4(skip + (orow + ox) * skip_cs + q * 4);
     } else {
       const int c = (q - c2q) * 4;
-      // PyTorch area_pixel_compute_source_index (align_corners=False): clamp below at 0
-      float sy = rh * ((float)oy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
       float sx = rw * ((float)ox + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
-      const int y0 = (int)sy, x0 = (int)sx;
-      const int y1 = y0 + (y0 < H1 - 1 ? 1 : 0), x1i = x0 + (x0 < W1 - 1 ? 1 : 0);
-      const float ly = sy - (float)y0, lx = sx - (float)x0;
-      const float hy = 1.f - ly, hx = 1.f - lx;
-      const float* b = x1 + (long)n * H1 * W1 * x1_cs + c;
-      const f32x4 v00 = ld4(b + ((long)y0 * W1 + x0) * x1_cs), v01 = ld4(b + ((long)y0 * W1 + x1i) * x1_cs);
-      const f32x4 v10 = ld4(b + ((long)y1 * W1 + x0) * x1_cs), v11 = ld4(b + ((long)y1 * W1 + x1i) * x1_cs);
+      const int x0 = (int)sx;
+      const int x1i = x0 + (x0 < W1 - 1 ? 1 : 0);
+      const float lx = sx - (float)x0, hx = 1.f - lx;
+      const f32x4 v00 = ld4(r0 + (long)x0 * x1_cs + c), v01 = ld4(r0 + (long)x1i * x1_cs + c);
+      const f32x4 v10 = ld4(r1 + (long)x0 * x1_cs + c), v11 = ld4(r1 + (long)x1i * x1_cs + c);
       v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
     }
-    st4(out + opix * out_cs + out_co + q * 4, v);
+    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    st4(out + (orow + ox) * out_cs + out_co + q * 4, v);
   }
+  if (amax) block_amax_update(vmax, amax, scratch);
 }
 
 // ------------------------------------------------------------------------------ max-pool 2x2/2
 __global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ in, int H, int W,
                                                        int C, int in_cs, float* __restrict__ out,
-                                                       int N, int Ho, int Wo, int out_cs) {
+                                                       int N, int Ho, int Wo, int out_cs,
+                                                       float* __restrict__ amax) {
+  __shared__ float scratch[4];
+  float vmax = 0.f;
   const int cq = C >> 2;
   const long total = (long)N * Ho * Wo * cq;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
@@ -264,9 +303,13 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__
                 d = ld4(b + (long)W * in_cs + in_cs);
     f32x4 m;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(a[j], bb[j]), fmaxf(cc[j], d[j]));
+    for (int j = 0; j < 4; ++j) {
+      m[j] = fmaxf(fmaxf(a[j], bb[j]), fmaxf(cc[j], d[j]));
+      vmax = fmaxf(vmax, fabsf(m[j]));
+    }
     st4(out + (((long)n * Ho + oy) * Wo + ox) * out_cs + c, m);
   }
+  if (amax) block_amax_update(vmax, amax, scratch);
 }
 
 // ------------------------------------------------------------------------------ layout transposes
@@ -489,25 +532,27 @@ extern "C" int creste_se_gate_f32(const float* x, float* partial, const float* w
 extern "C" int creste_upsample_concat_nhwc_f32(const float* x1, int N, int H1, int W1, int C1, int x1_cs,
                                                const float* skip, int C2, int skip_cs, float* out,
                                                int Ho, int Wo, int out_cs, int out_co, float rh,
-                                               float rw, void* stream) {
+                                               float rw, float* out_amax, void* stream) {
   CRESTE_REQUIRE(x1 && out && (skip || C2 == 0), "upsample_concat: null pointer");
   CRESTE_REQUIRE(C1 % 4 == 0 && C2 % 4 == 0 && x1_cs % 4 == 0 && out_cs % 4 == 0 && out_co % 4 == 0 &&
                      (C2 == 0 || skip_cs % 4 == 0),
                  "upsample_concat: channel counts/strides must be multiples of 4");
   CRESTE_REQUIRE(out_cs >= out_co + C1 + C2, "upsample_concat: output slice exceeds out_cs");
-  const long total = (long)N * Ho * Wo * ((C1 + C2) / 4);
-  upsample_concat_kernel<<<grid_for(total, 256, 256 * 32), 256, 0, (hipStream_t)stream>>>(
-      x1, H1, W1, C1, x1_cs, skip, C2, skip_cs, out, N, Ho, Wo, out_cs, out_co, rh, rw);
+  CRESTE_REQUIRE((long)N * Ho < 65536 * 32768L && (long)Wo * ((C1 + C2) / 4) < (1L << 30), "upsample_concat: extent too large");
+  const int row_items = Wo * ((C1 + C2) / 4);
+  const int bx = (row_items + 4 * 256 - 1) / (4 * 256);          // ~4 quads per thread
+  upsample_concat_kernel<<<dim3(bx, N * Ho), 256, 0, (hipStream_t)stream>>>(
+      x1, H1, W1, C1, x1_cs, skip, C2, skip_cs, out, Ho, Wo, out_cs, out_co, rh, rw, out_amax);
   CRESTE_CHECK_LAUNCH("upsample_concat");
   return CRESTE_OK;
 }
 
 extern "C" int creste_maxpool2_nhwc_f32(const float* in, int N, int H, int W, int C, int in_cs, float* out,
-                                        int Ho, int Wo, int out_cs, void* stream) {
+                                        int Ho, int Wo, int out_cs, float* out_amax, void* stream) {
   CRESTE_REQUIRE(in && out && C % 4 == 0 && in_cs % 4 == 0 && out_cs % 4 == 0, "maxpool2: bad args");
   CRESTE_REQUIRE(2 * Ho <= H && 2 * Wo <= W, "maxpool2: pooled extent exceeds input");
   const long total = (long)N * Ho * Wo * (C / 4);
-  maxpool2_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(in, H, W, C, in_cs, out, N, Ho, Wo, out_cs);
+  maxpool2_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(in, H, W, C, in_cs, out, N, Ho, Wo, out_cs, out_amax);
   CRESTE_CHECK_LAUNCH("maxpool2");
   return CRESTE_OK;
 }
@@ -578,18 +623,25 @@ extern "C" int creste_resize_plane_f32(const float* in, int N, int H, int W, flo
 }
 
 extern "C" int creste_dwconv_se_nhwc_f32(const float* in, const float* w, const float* bias, float* out,
-                                         float* partial, int N, int H, int W, int C, int Ho, int Wo, int K,
-                                         int stride, int pad_t, int pad_l, int act, void* stream) {
+                                         float* partial, float* out_amax, int N, int H, int W, int C, int Ho,
+                                         int Wo, int K, int stride, int pad_t, int pad_l, int act, void* stream) {
   CRESTE_REQUIRE(in && w && out && partial, "dwconv_se: null pointer");
   CRESTE_REQUIRE(C % 4 == 0 && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "dwconv_se: bad dims (C%%4)");
-  CRESTE_REQUIRE(K == 3 || K == 5, "dwconv_se: kernel size %d not built (3 or 5)", K);
+  CRESTE_REQUIRE((K == 3 || K == 5) && (stride == 1 || stride == 2),
+                 "dwconv_se: kernel size %d / stride %d not built (3 or 5; 1 or 2)", K, stride);
   const int nchunk = creste_se_partial_count(Ho * Wo, C);
   const int cq = C / 4;
   const int slices = 256 / cq > 0 ? 256 / cq : 1;
   const size_t smem = (size_t)slices * C * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-  if (K == 3) dwconv_se_kernel<3><<<dim3(nchunk, N), 256, smem, s>>>(in, w, bias, out, partial, H, W, C, Ho, Wo, stride, pad_t, pad_l, act, nchunk);
-  else dwconv_se_kernel<5><<<dim3(nchunk, N), 256, smem, s>>>(in, w, bias, out, partial, H, W, C, Ho, Wo, stride, pad_t, pad_l, act, nchunk);
+  const dim3 grid(nchunk, N);
+#define CRESTE_DWSE(KK, SS) \
+  dwconv_se_kernel<KK, SS><<<grid, 256, smem, s>>>(in, w, bias, out, partial, out_amax, H, W, C, Ho, Wo, pad_t, pad_l, act, nchunk)
+  if (K == 3 && stride == 1) CRESTE_DWSE(3, 1);
+  else if (K == 3) CRESTE_DWSE(3, 2);
+  else if (stride == 1) CRESTE_DWSE(5, 1);
+  else CRESTE_DWSE(5, 2);
+#undef CRESTE_DWSE
   CRESTE_CHECK_LAUNCH("dwconv_se");
   return CRESTE_OK;
 }

@@ -242,9 +242,12 @@ def dwconv2d_se(x: Act, w_taps, bias, K, stride, pad, act, se_w1, se_b1, se_w2, 
     out = Act.empty(x.N, Ho, Wo, x.C, dev)
     partial = torch.empty((x.N, lib.creste_se_partial_count(Ho * Wo, x.C), x.C), dtype=torch.float32, device=dev)
     gate = torch.empty((x.N, x.C), dtype=torch.float32, device=dev)
+    if TRACK_AMAX:
+        out.amax = _AmaxPool.slot(dev)
     _lib.check(lib.creste_dwconv_se_nhwc_f32(x.ptr, _chk(w_taps).data_ptr(), _chk(bias).data_ptr(), out.ptr,
-                                             partial.data_ptr(), x.N, x.H, x.W, x.C, Ho, Wo, K, stride,
-                                             pad[0], pad[2], act, _stream()), "dwconv_se")
+                                             partial.data_ptr(), out.amax.data_ptr() if TRACK_AMAX else None,
+                                             x.N, x.H, x.W, x.C, Ho, Wo, K, stride, pad[0], pad[2], act,
+                                             _stream()), "dwconv_se")
     _lib.check(lib.creste_se_gate_f32(None, partial.data_ptr(), _chk(se_w1).data_ptr(), _chk(se_b1).data_ptr(),
                                       _chk(se_w2).data_ptr(), _chk(se_b2).data_ptr(), gate.data_ptr(), x.N,
                                       Ho * Wo, x.C, se_w1.shape[0], _stream()), "se_gate")
@@ -268,13 +271,16 @@ def se_gate(x: Act, w1, b1, w2, b2) -> torch.Tensor:
 def upsample_concat(x1: Act, skip: Act | None, Ho, Wo, rh, rw, out: Act | None = None) -> Act:
     lib = _lib.load()
     C2 = skip.C if skip is not None else 0
+    fresh = out is None
     if out is None:
         out = Act.empty(x1.N, Ho, Wo, x1.C + C2, x1.buf.device)
     assert out.C == x1.C + C2 and (out.H, out.W) == (Ho, Wo)
+    if fresh and TRACK_AMAX:
+        out.amax = _AmaxPool.slot(x1.buf.device)
     _lib.check(lib.creste_upsample_concat_nhwc_f32(
         x1.ptr, x1.N, x1.H, x1.W, x1.C, x1.cs, skip.ptr if skip is not None else None, C2,
         skip.cs if skip is not None else 0, out.buf.data_ptr(), Ho, Wo, out.cs, out.co, float(rh),
-        float(rw), _stream()), "upsample_concat")
+        float(rw), out.amax.data_ptr() if fresh and TRACK_AMAX else None, _stream()), "upsample_concat")
     return out
 
 
@@ -283,8 +289,10 @@ def maxpool2(x: Act, Ho=None, Wo=None) -> Act:
     Ho = Ho if Ho is not None else x.H // 2
     Wo = Wo if Wo is not None else x.W // 2
     out = Act.empty(x.N, Ho, Wo, x.C, x.buf.device)
+    if TRACK_AMAX:
+        out.amax = _AmaxPool.slot(x.buf.device)
     _lib.check(lib.creste_maxpool2_nhwc_f32(x.ptr, x.N, x.H, x.W, x.C, x.cs, out.ptr, Ho, Wo, out.cs,
-                                            _stream()), "maxpool2")
+                                            out.amax.data_ptr() if TRACK_AMAX else None, _stream()), "maxpool2")
     return out
 
 

@@ -127,25 +127,28 @@ int creste_dwconv2d_nhwc_f32(const float* in, const float* w, const float* bias,
  * `partial` already holds the sums (creste_dwconv_se_nhwc_f32). */
 int creste_se_partial_count(int HW, int C);   /* partial-sum rows per image for an HW x C tensor */
 /* Depthwise conv + bias + activation that also leaves the squeeze-excite partial channel sums of its
- * output in `partial` ([N][creste_se_partial_count(Ho*Wo, C)][C]); follow with creste_se_gate_f32(x = NULL). */
+ * output in `partial` ([N][creste_se_partial_count(Ho*Wo, C)][C]); follow with creste_se_gate_f32(x = NULL).
+ * out_amax (optional, zero-initialised device float) is raised to max|out| as in creste_conv_desc. */
 int creste_dwconv_se_nhwc_f32(const float* in, const float* w, const float* bias, float* out,
-                              float* partial, int N, int H, int W, int C, int Ho, int Wo, int K, int stride,
-                              int pad_t, int pad_l, int act, void* stream);
+                              float* partial, float* out_amax, int N, int H, int W, int C, int Ho, int Wo,
+                              int K, int stride, int pad_t, int pad_l, int act, void* stream);
 int creste_se_gate_f32(const float* x, float* partial, const float* w1, const float* b1,
                        const float* w2, const float* b2, float* gate, int N, int HW, int C, int Cse,
                        void* stream);
 
 /* out[..., 0:C2] = skip ; out[..., C2:C2+C1] = bilinear_upsample(x1) (align_corners=False, PyTorch
  * source-index rule src = rs*(dst+0.5)-0.5 clamped at 0).  reference effnet.py:25-28
- * (nn.Upsample + torch.cat) and inpainting.py:57-58.  skip may be NULL (C2 = 0). */
+ * (nn.Upsample + torch.cat) and inpainting.py:57-58.  skip may be NULL (C2 = 0).  out_amax: optional
+ * zero-initialised device float raised to max|written values| (creste_conv_desc.out_amax). */
 int creste_upsample_concat_nhwc_f32(const float* x1, int N, int H1, int W1, int C1, int x1_cs,
                                     const float* skip, int C2, int skip_cs, float* out, int Ho,
-                                    int Wo, int out_cs, int out_co, float rh, float rw, void* stream);
+                                    int Wo, int out_cs, int out_co, float rh, float rw, float* out_amax,
+                                    void* stream);
 
 /* 2x2/2 max pool over rows [0, Ho) of the pooled map (F.max_pool2d; vin.py:104-109 crops the
  * pooled map to its first H//2 rows -> pass Ho = H//4). */
 int creste_maxpool2_nhwc_f32(const float* in, int N, int H, int W, int C, int in_cs, float* out,
-                             int Ho, int Wo, int out_cs, void* stream);
+                             int Ho, int Wo, int out_cs, float* out_amax, void* stream);
 
 /* y = act(x*scale[c] + shift[c]): an eval-mode BatchNorm that FOLLOWS a ReLU (MultiScaleFCN trunk,
  * reference conv.py:118-128: conv -> ReLU -> BN -> ReLU) and so cannot be folded into the conv. */
