@@ -5,7 +5,7 @@ import numpy as np
 import bench
 import creste_public_amd
 from creste_public_amd import LossManager, MaxEntIRL, maxent_irl_cfg, synth
-creste_public_amd.set_precision("bf16x6")
+creste_public_amd.set_precision(os.environ.get("PREC", "f16x3"))
 dev = torch.device("cuda", 0)
 B = 8
 cfg = maxent_irl_cfg((bench.IMG_H, bench.IMG_W), solve_mdp=True)
