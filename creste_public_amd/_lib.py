@@ -63,6 +63,19 @@ SIGNATURES = {
                                    _vp, _vp]),
     "creste_value_iteration_workspace_bytes": (_i64, [_i, _i, _i]),
     "creste_value_iteration_f32": (_i, [_vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "creste_conv_wgrad_workspace_bytes": (_i64, [_i] * 6),
+    "creste_conv_wgrad_f32": (_i, [_vp, _i, _vp, _i, _vp] + [_i] * 8 + [_vp, _vp]),
+    "creste_conv_flip_weight_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "creste_bn_workspace_bytes": (_i64, [_i]),
+    "creste_bn_train_forward_f32": (_i, [_vp, _i, _i64, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
+                                         _vp, _vp]),
+    "creste_bn_train_tangent_f32": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "creste_bn_train_backward_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp,
+                                          _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "creste_pointwise2_f32": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
+    "creste_maxpool2_idx_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "creste_maxpool2_route_f32": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "creste_upsample_bwd_nhwc_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _f, _f, _vp]),
     "creste_expected_svf_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp,
                                       _vp]),
 }

@@ -111,9 +111,11 @@ class ConvLayer(nn.Sequential):
 class MultiScaleFCN(nn.Module):
     """Reward / costmap network (reference conv.py:88-161).
 
-    eval(): HIP conv engine (inference costmap).  train(): stock PyTorch autograd ops on the GPU --
-    the IRL loss needs a double backward through this 0.78-GMAC network (gradient penalty,
-    reference loss_utils.py:1207-1217), see DESIGN.md.
+    eval(): HIP conv engine with folded BatchNorm (inference costmap).  train(): the HIP training engine
+    (creste_public_amd/train_ops.py): batch-statistics BatchNorm, fp32 conv forward / dgrad / wgrad, and the
+    gradient penalty's second-order term (reference loss_utils.py:1207-1217) as a tangent forward plus a
+    joint backward -- behind one autograd Function, so `torch.autograd.grad(create_graph=True)` and
+    `.backward()` in the loss code work unchanged.
     """
 
     def __init__(self, model_cfg):
@@ -192,8 +194,8 @@ class MultiScaleFCN(nn.Module):
 
     def forward(self, x):
         """Expects input of shape [B, C, H, W]."""
-        if self.training:
-            h = self.prepool(x)
-            return self.postpool(torch.cat([self.trunk(h), self.skip(h)], dim=1))
         require_hip(x, "MultiScaleFCN")
+        if self.training:
+            from ....train_ops import reward_forward_train
+            return reward_forward_train(self, x)
         return self.forward_act(ops.nchw_to_nhwc(x.contiguous())).nchw()

@@ -1,0 +1,539 @@
+// Training-mode primitives of the IRL reward network (MultiScaleFCN, reference conv.py:88-161) and the
+// pieces of its backward the forward engines cannot provide:
+//   * weight gradient of a stride-1 conv on the fp32 MFMA (a GEMM whose reduction runs over pixels);
+//   * training-mode BatchNorm as (per-channel moments) + (elementwise apply), in three forms:
+//       forward           y  = g*xh + b                        xh = (x - mean)*invstd
+//       tangent (JVP)     yd = g*invstd*(xd - m(xd) - xh*m(xh*xd))
+//       joint backward    cotangents (gy, gyd) of (y, yd) -> (gx, gxd, g_gamma, g_beta)
+//     The tangent/joint pair is what the IRL gradient penalty needs (reference loss_utils.py:1207-1217):
+//       d/dtheta <u, grad_x R(x; theta)> = d/dtheta JVP_x R(x; theta)[u]
+//     i.e. one tangent forward with xd = u and one backward through the (primal, tangent) graph -- no
+//     generic double-backward machinery;
+//   * ReLU, 2x2 max-pool with argmax, add, and the transpose of the bilinear x2 upsample.
+// Everything is NHWC fp32 with an explicit pixel stride (`cs`) so channel slices of a concat buffer are
+// read and written in place.  All reductions run in a fixed order (block partials, then a serial sum):
+// run-to-run deterministic.
+#include "common.h"
+
+namespace creste {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------ conv wgrad
+// partial[chunk][tap][co][ci] = sum over the chunk's pixels of gy[p][co] * x[p + tap][ci]
+// One wave = one 32(co) x 32(ci) tile of one tap; v_mfma_f32_32x32x2_f32 consumes two pixels per issue with
+// both operands read straight from global memory (lane = channel, so the loads are coalesced rows of the
+// NHWC tensors; each element is used exactly once per tile -> nothing to stage in LDS).
+constexpr int WG_PIX = 8;   // pixels per unrolled step (4 MFMAs)
+
+__global__ __launch_bounds__(256) void wgrad_partial_kernel(const float* __restrict__ x, int x_cs,
+                                                            const float* __restrict__ gy, int gy_cs,
+                                                            float* __restrict__ partial, int N, int H, int W,
+                                                            int Cin, int Cout, int K, int pad, int chunk_px) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int chunk = blockIdx.x, tap = blockIdx.y;
+  const int ky = tap / K - pad, kx = tap % K - pad;
+  const int tco = (Cout + 31) / 32, tci = (Cin + 31) / 32;
+  const long M = (long)N * H * W;
+  const long p0 = (long)chunk * chunk_px, p1 = min(M, p0 + chunk_px);
+  for (int t = wave; t < tco * tci; t += 4) {
+    const int co = (t / tci) * 32 + li, ci = (t % tci) * 32 + li;
+    const bool co_ok = co < Cout, ci_ok = ci < Cin;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (long p = p0; p < p1; p += WG_PIX) {
+      float a[WG_PIX / 2], b[WG_PIX / 2];
+#pragma unroll
+      for (int j = 0; j < WG_PIX / 2; ++j) {
+        const long q = p + 2 * j + lh;
+        a[j] = 0.f; b[j] = 0.f;
+        if (q < p1) {
+          const int xx = (int)(q % W);
+          const long rowi = q / W;
+          const int yy = (int)(rowi % H);
+          const int iy = yy + ky, ix = xx + kx;
+          if (co_ok) a[j] = gy[q * gy_cs + co];
+          if (ci_ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+            b[j] = x[(q + (long)ky * W + kx) * x_cs + ci];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < WG_PIX / 2; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+    }
+    // D layout: col (ci) = lane & 31, row (co) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    float* out = partial + ((size_t)chunk * K * K + tap) * Cout * Cin;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (t / tci) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < Cout && ci_ok) out[(size_t)row * Cin + ci] = acc[r];
+    }
+  }
+}
+
+// gw[co][ci][ky][kx] (torch OIHW) = (accumulate ? gw : 0) + sum_chunk partial[chunk][tap][co][ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw, int nchunk,
+                                    int Cout, int Cin, int KK, int accumulate) {
+  const int total = Cout * Cin * KK;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int tap = i % KK, ci = (i / KK) % Cin, co = i / (KK * Cin);
+    float s = 0.f;
+    for (int c = 0; c < nchunk; ++c) s += partial[(((size_t)c * KK + tap) * Cout + co) * Cin + ci];
+    gw[i] = accumulate ? gw[i] + s : s;
+  }
+}
+
+// OIHW -> dgrad weight: w'[ci][co][K-1-ky][K-1-kx] = w[co][ci][ky][kx] (a stride-1 conv's input gradient is
+// the conv of gy with the flipped, channel-transposed kernel, pad K-1-pad); Cout padded with zero input
+// channels up to cout_pad (the conv engine wants Cin % 4 == 0).
+__global__ void flip_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int K,
+                                   int cout_pad) {
+  const int total = Cin * cout_pad * K * K;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int kx = i % K, ky = (i / K) % K, co = (i / (K * K)) % cout_pad, ci = i / (K * K * cout_pad);
+    wt[i] = co < Cout ? w[(((size_t)co * Cin + ci) * K + (K - 1 - ky)) * K + (K - 1 - kx)] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------ channel moments
+// out[k][c] = (1/P) * sum_p f_k(p, c).  Thread = (pixel row, channel); a block reduces its pixel rows through
+// LDS in row order and writes one partial per (k, c); `finalize` sums the block partials serially.
+//   MODE 0: f0 = x                                   (mean)
+//   MODE 1: f0 = (x - mean)^2                        (biased variance)
+//   MODE 2: f0 = xd, f1 = xh * xd                    (tangent moments)
+//   MODE 3: f0 = gy, f1 = gy * xh [, f2 = G, f3 = G * xh, f4 = G * t]   t = (xd - mdot) - xh * c
+constexpr int MOM_MAXK = 5;
+constexpr int MOM_BLOCKS = 256;
+
+struct MomArgs {
+  const float *x, *xd, *gy, *G;
+  int x_cs, xd_cs, gy_cs, G_cs;
+  const float *mean, *invstd, *mdot, *cc;
+  float* partial;      // [blocks][nk][C]
+  long P;
+  int C, nk;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void moments_kernel(const MomArgs a) {
+  extern __shared__ float sm[];   // [nk][rows][C]
+  const int C = a.C, rows = 256 / C > 0 ? 256 / C : 1;
+  const int c = threadIdx.x % C, row = threadIdx.x / C;
+  const bool active = row < rows && (C <= 256 || false);
+  float s[MOM_MAXK] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const float mu = (MODE >= 1) ? a.mean[c] : 0.f;
+    const float is = (MODE >= 2) ? a.invstd[c] : 0.f;
+    const float md = (MODE == 3 && a.G) ? a.mdot[c] : 0.f;
+    const float cc = (MODE == 3 && a.G) ? a.cc[c] : 0.f;
+    for (long p = (long)blockIdx.x * rows + row; p < a.P; p += (long)gridDim.x * rows) {
+      const float xv = a.x[p * a.x_cs + c];
+      if (MODE == 0) s[0] += xv;
+      if (MODE == 1) { const float d = xv - mu; s[0] += d * d; }
+      if (MODE == 2) {
+        const float xh = (xv - mu) * is, xd = a.xd[p * a.xd_cs + c];
+        s[0] += xd; s[1] += xh * xd;
+      }
+      if (MODE == 3) {
+        const float xh = (xv - mu) * is;
+        if (a.gy) { const float g = a.gy[p * a.gy_cs + c]; s[0] += g; s[1] += g * xh; }
+        if (a.G) {
+          const float g = a.G[p * a.G_cs + c];
+          const float t = (a.xd[p * a.xd_cs + c] - md) - xh * cc;
+          s[2] += g; s[3] += g * xh; s[4] += g * t;
+        }
+      }
+    }
+    for (int k = 0; k < a.nk; ++k) sm[((size_t)k * rows + row) * C + c] = s[k];
+  }
+  __syncthreads();
+  if (active && row == 0) {
+    for (int k = 0; k < a.nk; ++k) {
+      float t = 0.f;
+      for (int r = 0; r < rows; ++r) t += sm[((size_t)k * rows + r) * C + c];
+      a.partial[((size_t)blockIdx.x * a.nk + k) * C + c] = t;
+    }
+  }
+}
+
+// out[k][c] = sum_blocks partial / P ; with `var_to_invstd` the single output becomes 1/sqrt(var + eps) and
+// the BatchNorm running statistics are updated (momentum m, unbiased variance) as nn.BatchNorm2d does.
+__global__ void moments_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblocks,
+                                        int nk, int C, float inv_p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nk * C) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * nk * C + i];
+  out[i] = s * inv_p;
+}
+
+__global__ void bn_finish_stats_kernel(const float* __restrict__ mean, const float* __restrict__ var,
+                                       float* __restrict__ invstd, float* running_mean, float* running_var,
+                                       int C, float eps, float momentum, float unbias) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  invstd[c] = 1.f / sqrtf(var[c] + eps);
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (var[c] * unbias);
+}
+
+// ------------------------------------------------------------------------------------ elementwise
+struct EwArgs {
+  const float *x, *xd, *gy, *G;
+  int x_cs, xd_cs, gy_cs, G_cs;
+  const float *gamma, *beta, *mean, *invstd;
+  const float *mom_t;     // tangent moments [2][C]: m(xd), c = m(xh*xd)
+  const float *mom_b;     // backward moments [5][C]
+  float *o0, *o1;         // outputs
+  int o0_cs, o1_cs;
+  long P;
+  int C, relu;
+};
+
+//   MODE 0  bn forward      o0 = gamma*xh + beta (relu optional)
+//   MODE 1  bn tangent      o0 = gamma*invstd*((xd - m(xd)) - xh*c)
+//   MODE 2  bn backward     o0 = gx, o1 = gxd (joint; G may be null -> plain first-order backward)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_elementwise_kernel(const EwArgs a) {
+  const long total = a.P * a.C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i / a.C;
+    const int c = (int)(i - p * a.C);
+    const float g = a.gamma ? a.gamma[c] : 1.f, is = a.invstd[c];
+    const float xh = (a.x[p * a.x_cs + c] - a.mean[c]) * is;
+    if (MODE == 0) {
+      float y = g * xh + (a.beta ? a.beta[c] : 0.f);
+      if (a.relu) y = fmaxf(y, 0.f);
+      a.o0[p * a.o0_cs + c] = y;
+    } else if (MODE == 1) {
+      const float t = (a.xd[p * a.xd_cs + c] - a.mom_t[c]) - xh * a.mom_t[a.C + c];
+      a.o0[p * a.o0_cs + c] = g * is * t;
+    } else {
+      float gx = 0.f;
+      if (a.gy) gx = g * is * (a.gy[p * a.gy_cs + c] - a.mom_b[c] - xh * a.mom_b[a.C + c]);
+      if (a.G) {
+        const float cc = a.mom_t[a.C + c];
+        const float t = (a.xd[p * a.xd_cs + c] - a.mom_t[c]) - xh * cc;
+        const float pg = a.G[p * a.G_cs + c] - a.mom_b[2 * a.C + c] - xh * a.mom_b[3 * a.C + c];   // P(G)
+        gx -= g * is * is * (a.mom_b[4 * a.C + c] * xh + cc * pg + a.mom_b[3 * a.C + c] * t);
+        a.o1[p * a.o1_cs + c] = g * is * pg;
+      }
+      a.o0[p * a.o0_cs + c] = gx;
+    }
+  }
+}
+
+// g_gamma[c] (+)= P*(m(gy*xh) + invstd*m(G*t)),  g_beta[c] (+)= P*m(gy)
+__global__ void bn_param_grad_kernel(const float* __restrict__ mom_b, const float* __restrict__ invstd,
+                                     float* g_gamma, float* g_beta, int C, float P, int has_gy, int has_G,
+                                     int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float gg = 0.f, gb = 0.f;
+  if (has_gy) { gg += P * mom_b[C + c]; gb += P * mom_b[c]; }
+  if (has_G) gg += P * invstd[c] * mom_b[4 * C + c];
+  g_gamma[c] = accumulate ? g_gamma[c] + gg : gg;
+  g_beta[c] = accumulate ? g_beta[c] + gb : gb;
+}
+
+// MODE 0 relu: o = max(a, 0); MODE 1 relu backward / tangent: o = (y > 0) ? b : 0; MODE 2 add: o = a + b
+template <int MODE>
+__global__ __launch_bounds__(256) void pointwise2_kernel(const float* __restrict__ a, int a_cs,
+                                                         const float* __restrict__ b, int b_cs,
+                                                         float* __restrict__ o, int o_cs, long P, int C) {
+  const long total = P * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i / C;
+    const int c = (int)(i - p * C);
+    const float av = a[p * a_cs + c];
+    float r;
+    if (MODE == 0) r = fmaxf(av, 0.f);
+    else if (MODE == 1) r = av > 0.f ? b[p * b_cs + c] : 0.f;
+    else r = av + b[p * b_cs + c];
+    o[p * o_cs + c] = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------ max-pool 2x2/2
+// forward with argmax (first maximum in (dy, dx) scan order, as ATen), tangent (gather by idx), backward
+__global__ __launch_bounds__(256) void maxpool2_idx_kernel(const float* __restrict__ in, int in_cs, int H, int W,
+                                                           int C, float* __restrict__ out, int out_cs,
+                                                           uint8_t* __restrict__ idx, int N, int Ho, int Wo) {
+  const long total = (long)N * Ho * Wo * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float best = 0.f; int bi = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float v = in[(((long)n * H + 2 * oy + (k >> 1)) * W + 2 * ox + (k & 1)) * in_cs + c];
+      if (k == 0 || v > best || v != v) { best = v; bi = k; }
+    }
+    out[(((long)n * Ho + oy) * Wo + ox) * out_cs + c] = best;
+    idx[i] = (uint8_t)bi;
+  }
+}
+
+// MODE 0: out[pooled] = in[full res at idx]   (tangent)
+// MODE 1: out[full res] = (idx == own position) ? in[pooled] : 0   (backward; rows/cols beyond 2*Ho/2*Wo get 0)
+template <int MODE>
+__global__ __launch_bounds__(256) void maxpool2_route_kernel(const float* __restrict__ in, int in_cs,
+                                                             const uint8_t* __restrict__ idx,
+                                                             float* __restrict__ out, int out_cs, int N, int H,
+                                                             int W, int C, int Ho, int Wo) {
+  if (MODE == 0) {
+    const long total = (long)N * Ho * Wo * C;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+      const int c = (int)(i % C);
+      long t = i / C;
+      const int ox = (int)(t % Wo); t /= Wo;
+      const int oy = (int)(t % Ho);
+      const int n = (int)(t / Ho);
+      const int k = idx[i];
+      out[(((long)n * Ho + oy) * Wo + ox) * out_cs + c] =
+          in[(((long)n * H + 2 * oy + (k >> 1)) * W + 2 * ox + (k & 1)) * in_cs + c];
+    }
+  } else {
+    const long total = (long)N * H * W * C;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+      const int c = (int)(i % C);
+      long t = i / C;
+      const int x = (int)(t % W); t /= W;
+      const int y = (int)(t % H);
+      const int n = (int)(t / H);
+      float v = 0.f;
+      const int oy = y >> 1, ox = x >> 1;
+      if (oy < Ho && ox < Wo) {
+        const long pi = (((long)n * Ho + oy) * Wo + ox);
+        if (idx[pi * C + c] == ((y & 1) << 1 | (x & 1))) v = in[pi * in_cs + c];
+      }
+      out[(((long)n * H + y) * W + x) * out_cs + c] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ upsample transpose
+// gx[n, yi, xi, c] = sum over output pixels (yo, xo) of w(yo->yi) * w(xo->xi) * gy[n, yo, xo, c] with the
+// forward's own source-index rule recomputed per candidate output (gather form: deterministic, borders exact).
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ gy, int gy_cs, int Ho, int Wo,
+                                                           float* __restrict__ gx, int gx_cs, int N, int H1,
+                                                           int W1, int C, float rh, float rw, int span_h,
+                                                           int span_w) {
+  const long total = (long)N * H1 * W1 * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int xi = (int)(t % W1); t /= W1;
+    const int yi = (int)(t % H1);
+    const int n = (int)(t / H1);
+    // outputs that can reference row yi lie within +-span of yi / rh
+    const int yc = (int)((float)yi / rh), xc = (int)((float)xi / rw);
+    float s = 0.f;
+    for (int yo = max(0, yc - span_h); yo <= min(Ho - 1, yc + span_h); ++yo) {
+      float sy = rh * ((float)yo + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+      const int y0 = (int)sy, y1 = y0 + (y0 < H1 - 1 ? 1 : 0);
+      const float ly = sy - (float)y0;
+      float wy = 0.f;
+      if (y0 == yi) wy += 1.f - ly;
+      if (y1 == yi) wy += ly;
+      if (wy == 0.f) continue;
+      for (int xo = max(0, xc - span_w); xo <= min(Wo - 1, xc + span_w); ++xo) {
+        float sx = rw * ((float)xo + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
+        const int x0 = (int)sx, x1 = x0 + (x0 < W1 - 1 ? 1 : 0);
+        const float lx = sx - (float)x0;
+        float wx = 0.f;
+        if (x0 == xi) wx += 1.f - lx;
+        if (x1 == xi) wx += lx;
+        if (wx != 0.f) s += wy * wx * gy[(((long)n * Ho + yo) * Wo + xo) * gy_cs + c];
+      }
+    }
+    gx[(((long)n * H1 + yi) * W1 + xi) * gx_cs + c] = s;
+  }
+}
+
+static inline int grid1d(long work, int cap = 4096) {
+  long b = (work + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace creste
+
+using namespace creste;
+
+extern "C" int64_t creste_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int K) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || K <= 0) return -1;
+  const long M = (long)N * H * W;
+  const long nchunk = (M + 1023) / 1024 < 256 ? (M + 1023) / 1024 : 256;
+  return nchunk * K * K * Cout * Cin * 4;
+}
+
+extern "C" int creste_conv_wgrad_f32(const float* x, int x_cs, const float* gy, int gy_cs, float* gw, int N, int H,
+                                     int W, int Cin, int Cout, int K, int pad, int accumulate, void* work,
+                                     void* stream) {
+  CRESTE_REQUIRE(x && gy && gw && work, "conv_wgrad: null pointer");
+  CRESTE_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && K > 0 && pad >= 0 && 2 * pad == K - 1,
+                 "conv_wgrad: stride-1 'same' convolutions only (K=%d pad=%d)", K, pad);
+  CRESTE_REQUIRE(K * K <= 65535, "conv_wgrad: kernel too large");
+  const long M = (long)N * H * W;
+  int nchunk = (int)((M + 1023) / 1024 < 256 ? (M + 1023) / 1024 : 256);
+  long chunk_px = (M + nchunk - 1) / nchunk;
+  chunk_px = (chunk_px + WG_PIX - 1) / WG_PIX * WG_PIX;
+  nchunk = (int)((M + chunk_px - 1) / chunk_px);
+  hipStream_t s = (hipStream_t)stream;
+  wgrad_partial_kernel<<<dim3(nchunk, K * K), 256, 0, s>>>(x, x_cs, gy, gy_cs, (float*)work, N, H, W, Cin, Cout, K,
+                                                          pad, (int)chunk_px);
+  CRESTE_CHECK_LAUNCH("wgrad_partial");
+  wgrad_reduce_kernel<<<grid1d((long)Cout * Cin * K * K, 256), 256, 0, s>>>((const float*)work, gw, nchunk, Cout, Cin,
+                                                                           K * K, accumulate);
+  CRESTE_CHECK_LAUNCH("wgrad_reduce");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_conv_flip_weight_f32(const float* w, float* wt, int Cout, int Cin, int K, int cout_pad,
+                                           void* stream) {
+  CRESTE_REQUIRE(w && wt && Cout > 0 && Cin > 0 && K > 0 && cout_pad >= Cout, "conv_flip_weight: bad args");
+  flip_weight_kernel<<<grid1d((long)Cin * cout_pad * K * K, 256), 256, 0, (hipStream_t)stream>>>(w, wt, Cout, Cin, K,
+                                                                                                 cout_pad);
+  CRESTE_CHECK_LAUNCH("flip_weight");
+  return CRESTE_OK;
+}
+
+static int run_moments(int mode, MomArgs a, float* out, float* partial, hipStream_t s) {
+  CRESTE_REQUIRE(a.C > 0 && a.C <= 256 && a.P > 0, "bn moments: C must be in 1..256");
+  const int rows = 256 / a.C;
+  const long per = (a.P + rows - 1) / rows;
+  const int blocks = (int)(per < MOM_BLOCKS ? per : MOM_BLOCKS);
+  a.partial = partial;
+  const size_t smem = (size_t)a.nk * rows * a.C * sizeof(float);
+  if (mode == 0) moments_kernel<0><<<blocks, 256, smem, s>>>(a);
+  else if (mode == 1) moments_kernel<1><<<blocks, 256, smem, s>>>(a);
+  else if (mode == 2) moments_kernel<2><<<blocks, 256, smem, s>>>(a);
+  else moments_kernel<3><<<blocks, 256, smem, s>>>(a);
+  CRESTE_CHECK_LAUNCH("bn_moments");
+  moments_finalize_kernel<<<(a.nk * a.C + 255) / 256, 256, 0, s>>>(partial, out, blocks, a.nk, a.C,
+                                                                 1.f / (float)a.P);
+  CRESTE_CHECK_LAUNCH("bn_moments_finalize");
+  return CRESTE_OK;
+}
+
+extern "C" int64_t creste_bn_workspace_bytes(int C) { return C > 0 ? (int64_t)MOM_BLOCKS * MOM_MAXK * C * 4 : -1; }
+
+extern "C" int creste_bn_train_forward_f32(const float* x, int x_cs, int64_t P, int C, const float* gamma,
+                                           const float* beta, float eps, float momentum, float* running_mean,
+                                           float* running_var, float* mean, float* invstd, float* var_scratch,
+                                           float* y, int y_cs, int relu, void* work, void* stream) {
+  CRESTE_REQUIRE(x && mean && invstd && var_scratch && y && work && P > 1, "bn_train_forward: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  MomArgs a = {};
+  a.x = x; a.x_cs = x_cs; a.P = P; a.C = C; a.nk = 1;
+  int rc = run_moments(0, a, mean, (float*)work, s);
+  if (rc) return rc;
+  a.mean = mean;
+  rc = run_moments(1, a, var_scratch, (float*)work, s);
+  if (rc) return rc;
+  bn_finish_stats_kernel<<<(C + 255) / 256, 256, 0, s>>>(mean, var_scratch, invstd, running_mean, running_var, C, eps,
+                                                        momentum, (float)P / (float)(P - 1));
+  CRESTE_CHECK_LAUNCH("bn_finish_stats");
+  EwArgs e = {};
+  e.x = x; e.x_cs = x_cs; e.gamma = gamma; e.beta = beta; e.mean = mean; e.invstd = invstd;
+  e.o0 = y; e.o0_cs = y_cs; e.P = P; e.C = C; e.relu = relu;
+  bn_elementwise_kernel<0><<<grid1d(P * C), 256, 0, s>>>(e);
+  CRESTE_CHECK_LAUNCH("bn_forward");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_bn_train_tangent_f32(const float* x, int x_cs, const float* xd, int xd_cs, int64_t P, int C,
+                                           const float* gamma, const float* mean, const float* invstd,
+                                           float* mom_t, float* yd, int yd_cs, void* work, void* stream) {
+  CRESTE_REQUIRE(x && xd && mean && invstd && mom_t && yd && work, "bn_train_tangent: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  MomArgs a = {};
+  a.x = x; a.x_cs = x_cs; a.xd = xd; a.xd_cs = xd_cs; a.P = P; a.C = C; a.nk = 2; a.mean = mean; a.invstd = invstd;
+  const int rc = run_moments(2, a, mom_t, (float*)work, s);
+  if (rc) return rc;
+  EwArgs e = {};
+  e.x = x; e.x_cs = x_cs; e.xd = xd; e.xd_cs = xd_cs; e.gamma = gamma; e.mean = mean; e.invstd = invstd;
+  e.mom_t = mom_t; e.o0 = yd; e.o0_cs = yd_cs; e.P = P; e.C = C;
+  bn_elementwise_kernel<1><<<grid1d(P * C), 256, 0, s>>>(e);
+  CRESTE_CHECK_LAUNCH("bn_tangent");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_bn_train_backward_f32(const float* x, int x_cs, const float* xd, int xd_cs, const float* gy,
+                                            int gy_cs, const float* gyd, int gyd_cs, int64_t P, int C,
+                                            const float* gamma, const float* mean, const float* invstd,
+                                            const float* mom_t, float* mom_b, float* gx, int gx_cs, float* gxd,
+                                            int gxd_cs, float* g_gamma, float* g_beta, int accumulate, void* work,
+                                            void* stream) {
+  CRESTE_REQUIRE(x && mean && invstd && mom_b && gx && work && (gy || gyd), "bn_train_backward: null pointer");
+  CRESTE_REQUIRE(!gyd || (xd && mom_t && gxd), "bn_train_backward: the tangent cotangent needs xd, mom_t and gxd");
+  hipStream_t s = (hipStream_t)stream;
+  MomArgs a = {};
+  a.x = x; a.x_cs = x_cs; a.xd = xd; a.xd_cs = xd_cs; a.gy = gy; a.gy_cs = gy_cs; a.G = gyd; a.G_cs = gyd_cs;
+  a.P = P; a.C = C; a.nk = 5; a.mean = mean; a.invstd = invstd;
+  if (gyd) { a.mdot = mom_t; a.cc = mom_t + C; }
+  const int rc = run_moments(3, a, mom_b, (float*)work, s);
+  if (rc) return rc;
+  EwArgs e = {};
+  e.x = x; e.x_cs = x_cs; e.xd = xd; e.xd_cs = xd_cs; e.gy = gy; e.gy_cs = gy_cs; e.G = gyd; e.G_cs = gyd_cs;
+  e.gamma = gamma; e.mean = mean; e.invstd = invstd; e.mom_t = mom_t; e.mom_b = mom_b;
+  e.o0 = gx; e.o0_cs = gx_cs; e.o1 = gxd; e.o1_cs = gxd_cs; e.P = P; e.C = C;
+  bn_elementwise_kernel<2><<<grid1d(P * C), 256, 0, s>>>(e);
+  CRESTE_CHECK_LAUNCH("bn_backward");
+  if (g_gamma && g_beta) {
+    bn_param_grad_kernel<<<(C + 255) / 256, 256, 0, s>>>(mom_b, invstd, g_gamma, g_beta, C, (float)P, gy != nullptr,
+                                                        gyd != nullptr, accumulate);
+    CRESTE_CHECK_LAUNCH("bn_param_grad");
+  }
+  return CRESTE_OK;
+}
+
+extern "C" int creste_pointwise2_f32(int op, const float* a, int a_cs, const float* b, int b_cs, float* o, int o_cs,
+                                     int64_t P, int C, void* stream) {
+  CRESTE_REQUIRE(a && o && (op == 0 || b) && op >= 0 && op <= 2 && P > 0 && C > 0, "pointwise2: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  const int g = grid1d(P * C);
+  if (op == 0) pointwise2_kernel<0><<<g, 256, 0, s>>>(a, a_cs, b, b_cs, o, o_cs, P, C);
+  else if (op == 1) pointwise2_kernel<1><<<g, 256, 0, s>>>(a, a_cs, b, b_cs, o, o_cs, P, C);
+  else pointwise2_kernel<2><<<g, 256, 0, s>>>(a, a_cs, b, b_cs, o, o_cs, P, C);
+  CRESTE_CHECK_LAUNCH("pointwise2");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_maxpool2_idx_f32(const float* in, int in_cs, int N, int H, int W, int C, float* out,
+                                       int out_cs, uint8_t* idx, void* stream) {
+  CRESTE_REQUIRE(in && out && idx && N > 0 && H > 1 && W > 1 && C > 0, "maxpool2_idx: bad args");
+  maxpool2_idx_kernel<<<grid1d((long)N * (H / 2) * (W / 2) * C), 256, 0, (hipStream_t)stream>>>(
+      in, in_cs, H, W, C, out, out_cs, idx, N, H / 2, W / 2);
+  CRESTE_CHECK_LAUNCH("maxpool2_idx");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_maxpool2_route_f32(int backward, const float* in, int in_cs, const uint8_t* idx, float* out,
+                                         int out_cs, int N, int H, int W, int C, void* stream) {
+  CRESTE_REQUIRE(in && out && idx && N > 0 && H > 1 && W > 1 && C > 0, "maxpool2_route: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  if (!backward)
+    maxpool2_route_kernel<0><<<grid1d((long)N * (H / 2) * (W / 2) * C), 256, 0, s>>>(in, in_cs, idx, out, out_cs, N, H,
+                                                                                    W, C, H / 2, W / 2);
+  else
+    maxpool2_route_kernel<1><<<grid1d((long)N * H * W * C), 256, 0, s>>>(in, in_cs, idx, out, out_cs, N, H, W, C,
+                                                                        H / 2, W / 2);
+  CRESTE_CHECK_LAUNCH("maxpool2_route");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_upsample_bwd_nhwc_f32(const float* gy, int gy_cs, int Ho, int Wo, float* gx, int gx_cs, int N,
+                                            int H1, int W1, int C, float rh, float rw, void* stream) {
+  CRESTE_REQUIRE(gy && gx && N > 0 && H1 > 0 && W1 > 0 && Ho > 0 && Wo > 0 && C > 0 && rh > 0.f && rw > 0.f,
+                 "upsample_bwd: bad args");
+  const int span_h = (int)(1.f / rh) + 2, span_w = (int)(1.f / rw) + 2;
+  upsample_bwd_kernel<<<grid1d((long)N * H1 * W1 * C), 256, 0, (hipStream_t)stream>>>(gy, gy_cs, Ho, Wo, gx, gx_cs, N, H1,
+                                                                                      W1, C, rh, rw, span_h, span_w);
+  CRESTE_CHECK_LAUNCH("upsample_bwd");
+  return CRESTE_OK;
+}

@@ -1,0 +1,442 @@
+"""Training-mode execution of the IRL reward network on the HIP kernels (csrc/train.hip + the fp32 conv engine).
+
+The reference trains `MultiScaleFCN` (creste/models/blocks/conv.py:88-161) through the MaxEnt / counterfactual
+IRL objective (creste/utils/loss_utils.py:1118-1259), which differentiates the reward TWICE: the gradient
+penalty is a function of g = d(sum r)/d(input_view) (`torch.autograd.grad(..., create_graph=True)`, :1207-1217).
+Here the network is one `torch.autograd.Function` pair, so the loss code stays the reference's torch code:
+
+  RewardFn        forward  = primal pass (training-mode BatchNorm: batch statistics, running stats updated)
+                  backward = cotangent gr on r  ->  parameter gradients (wgrad / BN reductions) and the input
+                             gradient g, the latter through InputGradFn so that it stays differentiable
+  InputGradFn     forward  = g = J_x^T gr      (dgrad convs, BN backward, pool/upsample transposes)
+                  backward = cotangent u on g  ->  d<u, J_x^T gr>/d theta = d<gr, J_x u>/d theta:
+                             one TANGENT forward with xd = u, then one backward through the (primal, tangent)
+                             pair with cotangent gr on the tangent output.  No generic double backward.
+
+Every op below implements fwd / tan / bwd on NHWC `Act`s; `bwd(gy, gyd)` takes the cotangents of the primal
+and tangent outputs (either may be None) and accumulates parameter gradients into `grads[param]`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+from .ops import Act, HipLibraryError, _stream
+
+
+def _lib_():
+    return _lib.load()
+
+
+def _new(like: Act, Cn=None, H=None, W=None) -> Act:
+    return Act.empty(like.N, H or like.H, W or like.W, Cn or like.C, like.buf.device)
+
+
+def _px(a: Act) -> int:
+    return a.N * a.H * a.W
+
+
+def as_act(t: torch.Tensor, pad_to4=False) -> Act:
+    """[B,C,H,W] tensor (any strides) -> NHWC Act, zero-copy when it already is a view of an NHWC buffer."""
+    if not t.is_cuda:
+        raise HipLibraryError("reward-network training runs on the HIP kernels only (got a CPU tensor)")
+    t = t.detach().float()
+    B, Cc, H, W = t.shape
+    if pad_to4 and Cc % 4:
+        buf = torch.zeros((B, H, W, (Cc + 3) // 4 * 4), dtype=torch.float32, device=t.device)
+        ops.nchw_to_nhwc(t.contiguous(), out=Act(buf, Cc, 0))
+        return Act(buf, buf.shape[3], 0)
+    p = t.permute(0, 2, 3, 1)
+    if p.is_contiguous():
+        return Act(p, Cc, 0)
+    return ops.nchw_to_nhwc(t.contiguous())
+
+
+def pointwise2(op: int, a: Act, b: Act | None, out: Act | None = None) -> Act:
+    out = out or _new(a)
+    _lib.check(_lib_().creste_pointwise2_f32(op, a.ptr, a.cs, b.ptr if b is not None else None,
+                                             b.cs if b is not None else 0, out.ptr, out.cs, _px(a), a.C, _stream()),
+               "pointwise2")
+    return out
+
+
+class ConvT:
+    """stride-1 'same' conv without bias: y = W * x."""
+
+    def __init__(self, conv: nn.Conv2d):
+        k = conv.kernel_size[0]
+        if conv.bias is not None or conv.stride != (1, 1) or conv.kernel_size != (k, k) or \
+                conv.padding != (k // 2, k // 2) or conv.groups != 1 or conv.dilation != (1, 1):
+            raise NotImplementedError("HIP training path: stride-1 'same' bias-free convs (reward network) only")
+        self.conv, self.K = conv, k
+        self._fw = self._bw = None
+        self._key = None
+
+    def params(self):
+        return [self.conv.weight]
+
+    def _packed(self):
+        w = self.conv.weight
+        key = (w.data_ptr(), w._version)
+        if key != self._key:
+            Cout, Cin = w.shape[:2]
+            self._fw = ops.pack_conv(w, None, None, 1, self.K // 2, ops.ACT_NONE, ops.PREC_F32)
+            cpad = (Cout + 3) // 4 * 4
+            wt = torch.empty((Cin, cpad, self.K, self.K), dtype=torch.float32, device=w.device)
+            _lib.check(_lib_().creste_conv_flip_weight_f32(w.detach().contiguous().data_ptr(), wt.data_ptr(), Cout,
+                                                           Cin, self.K, cpad, _stream()), "conv_flip_weight")
+            self._bw = ops.pack_conv(wt, None, None, 1, self.K // 2, ops.ACT_NONE, ops.PREC_F32)
+            self._key = key
+        return self._fw, self._bw
+
+    def fwd(self, x: Act, out=None) -> Act:
+        self.x = x
+        return ops.conv2d(x, self._packed()[0], out=out)
+
+    def tan(self, xd: Act, out=None) -> Act:
+        self.xd = xd
+        return ops.conv2d(xd, self._packed()[0], out=out)
+
+    def _dgrad(self, gy: Act) -> Act:
+        bw = self._packed()[1]
+        if gy.C != bw.Cin:                       # Cout not a multiple of 4: zero-padded channel copy
+            buf = torch.zeros((gy.N, gy.H, gy.W, bw.Cin), dtype=torch.float32, device=gy.buf.device)
+            pointwise2(2, gy, Act(buf, gy.C, 0), out=Act(buf, gy.C, 0))
+            gy = Act(buf, bw.Cin, 0)
+        return ops.conv2d(gy, bw)
+
+    def _wgrad(self, x: Act, gy: Act, grads):
+        w = self.conv.weight
+        Cout, Cin = w.shape[:2]
+        lib = _lib_()
+        acc = id(w) in grads
+        if not acc:
+            grads[id(w)] = torch.empty_like(w, memory_format=torch.contiguous_format)
+        work = torch.empty(lib.creste_conv_wgrad_workspace_bytes(x.N, x.H, x.W, Cin, Cout, self.K),
+                           dtype=torch.uint8, device=w.device)
+        _lib.check(lib.creste_conv_wgrad_f32(x.ptr, x.cs, gy.ptr, gy.cs, grads[id(w)].data_ptr(), x.N, x.H, x.W, Cin,
+                                             Cout, self.K, self.K // 2, int(acc), work.data_ptr(), _stream()),
+                   "conv_wgrad")
+
+    def bwd(self, gy, gyd, grads, need_input=True):
+        if grads is not None:
+            if gy is not None:
+                self._wgrad(self.x, gy, grads)
+            if gyd is not None:
+                self._wgrad(self.xd, gyd, grads)
+        if not need_input:
+            return None, None
+        return (self._dgrad(gy) if gy is not None else None), (self._dgrad(gyd) if gyd is not None else None)
+
+
+class BNT:
+    """training-mode BatchNorm2d (+ fused ReLU on the primal output)."""
+
+    def __init__(self, bn: nn.BatchNorm2d, relu: bool):
+        if not isinstance(bn, nn.BatchNorm2d) or bn.momentum is None or not bn.affine or not bn.track_running_stats:
+            raise NotImplementedError("HIP training path: affine BatchNorm2d with momentum and running stats only")
+        self.bn, self.relu = bn, relu
+
+    def params(self):
+        return [self.bn.weight, self.bn.bias]
+
+    def _work(self, dev):
+        return torch.empty(_lib_().creste_bn_workspace_bytes(self.bn.num_features), dtype=torch.uint8, device=dev)
+
+    def fwd(self, x: Act, out=None) -> Act:
+        bn, dev = self.bn, x.buf.device
+        Cn = bn.num_features
+        self.x = x
+        self.mean = torch.empty(Cn, device=dev)
+        self.invstd = torch.empty(Cn, device=dev)
+        var = torch.empty(Cn, device=dev)
+        y = out or _new(x)
+        _lib.check(_lib_().creste_bn_train_forward_f32(
+            x.ptr, x.cs, _px(x), Cn, bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), float(bn.momentum),
+            bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.mean.data_ptr(), self.invstd.data_ptr(),
+            var.data_ptr(), y.ptr, y.cs, int(self.relu), self._work(dev).data_ptr(), _stream()), "bn_train_forward")
+        bn.num_batches_tracked += 1
+        self.y = y
+        return y
+
+    def tan(self, xd: Act, out=None) -> Act:
+        bn, dev = self.bn, xd.buf.device
+        self.xd = xd
+        self.mom_t = torch.empty((2, bn.num_features), device=dev)
+        yd = _new(xd) if (out is None or self.relu) else out
+        _lib.check(_lib_().creste_bn_train_tangent_f32(
+            self.x.ptr, self.x.cs, xd.ptr, xd.cs, _px(xd), bn.num_features, bn.weight.data_ptr(),
+            self.mean.data_ptr(), self.invstd.data_ptr(), self.mom_t.data_ptr(), yd.ptr, yd.cs,
+            self._work(dev).data_ptr(), _stream()), "bn_train_tangent")
+        if self.relu:
+            yd = pointwise2(1, self.y, yd, out=out)
+        return yd
+
+    def bwd(self, gy, gyd, grads, need_input=True):
+        bn = self.bn
+        dev = self.x.buf.device
+        if self.relu:                                  # through the ReLU mask first
+            gy = pointwise2(1, self.y, gy) if gy is not None else None
+            gyd = pointwise2(1, self.y, gyd) if gyd is not None else None
+        ref = gy if gy is not None else gyd
+        gx = _new(ref)
+        gxd = _new(ref) if gyd is not None else None
+        mom_b = torch.empty((5, bn.num_features), device=dev)
+        gg = gb = None
+        acc = 0
+        if grads is not None:
+            acc = int(id(bn.weight) in grads)
+            if not acc:
+                grads[id(bn.weight)] = torch.empty_like(bn.weight)
+                grads[id(bn.bias)] = torch.empty_like(bn.bias)
+            gg, gb = grads[id(bn.weight)], grads[id(bn.bias)]
+        has_t = gyd is not None
+        _lib.check(_lib_().creste_bn_train_backward_f32(
+            self.x.ptr, self.x.cs, self.xd.ptr if has_t else None, self.xd.cs if has_t else 0,
+            gy.ptr if gy is not None else None, gy.cs if gy is not None else 0,
+            gyd.ptr if has_t else None, gyd.cs if has_t else 0, _px(self.x), bn.num_features,
+            bn.weight.data_ptr(), self.mean.data_ptr(), self.invstd.data_ptr(),
+            self.mom_t.data_ptr() if has_t else None, mom_b.data_ptr(), gx.ptr, gx.cs,
+            gxd.ptr if has_t else None, gxd.cs if has_t else 0,
+            gg.data_ptr() if gg is not None else None, gb.data_ptr() if gb is not None else None, acc,
+            self._work(dev).data_ptr(), _stream()), "bn_train_backward")
+        return gx, gxd
+
+
+class ReLUT:
+    def params(self):
+        return []
+
+    def fwd(self, x, out=None):
+        self.y = pointwise2(0, x, None, out=out)
+        return self.y
+
+    def tan(self, xd, out=None):
+        return pointwise2(1, self.y, xd, out=out)
+
+    def bwd(self, gy, gyd, grads, need_input=True):
+        return (pointwise2(1, self.y, gy) if gy is not None else None,
+                pointwise2(1, self.y, gyd) if gyd is not None else None)
+
+
+class PoolT:
+    """nn.MaxPool2d(2, 2) with the argmax kept for the tangent and the backward."""
+
+    def params(self):
+        return []
+
+    def fwd(self, x, out=None):
+        self.shape = (x.N, x.H, x.W, x.C)
+        y = out or _new(x, H=x.H // 2, W=x.W // 2)
+        self.idx = torch.empty((x.N, x.H // 2, x.W // 2, x.C), dtype=torch.uint8, device=x.buf.device)
+        _lib.check(_lib_().creste_maxpool2_idx_f32(x.ptr, x.cs, x.N, x.H, x.W, x.C, y.ptr, y.cs, self.idx.data_ptr(),
+                                                   _stream()), "maxpool2_idx")
+        return y
+
+    def _route(self, backward, t: Act, out=None):
+        N, H, W, Cn = self.shape
+        o = out or (Act.empty(N, H, W, Cn, t.buf.device) if backward else Act.empty(N, H // 2, W // 2, Cn, t.buf.device))
+        _lib.check(_lib_().creste_maxpool2_route_f32(int(backward), t.ptr, t.cs, self.idx.data_ptr(), o.ptr, o.cs, N,
+                                                     H, W, Cn, _stream()), "maxpool2_route")
+        return o
+
+    def tan(self, xd, out=None):
+        return self._route(False, xd, out)
+
+    def bwd(self, gy, gyd, grads, need_input=True):
+        return (self._route(True, gy) if gy is not None else None,
+                self._route(True, gyd) if gyd is not None else None)
+
+
+class UpT:
+    """nn.Upsample(scale_factor, bilinear, align_corners=False)."""
+
+    def __init__(self, up: nn.Upsample):
+        if up.mode != "bilinear" or up.align_corners:
+            raise NotImplementedError("HIP training path: bilinear align_corners=False upsampling only")
+        from .hipnn import up_out_size, up_scales
+        self.sf, self.r = up_scales(up.scale_factor)
+        self._out_size = up_out_size
+
+    def params(self):
+        return []
+
+    def _run(self, x, out):
+        Ho, Wo = self._out_size(x.H, x.W, self.sf)
+        self.in_hw = (x.H, x.W)
+        return ops.upsample_concat(x, None, Ho, Wo, self.r[0], self.r[1], out=out)
+
+    def fwd(self, x, out=None):
+        return self._run(x, out)
+
+    def tan(self, xd, out=None):
+        return self._run(xd, out)
+
+    def _t(self, gy: Act):
+        H1, W1 = self.in_hw
+        gx = Act.empty(gy.N, H1, W1, gy.C, gy.buf.device)
+        _lib.check(_lib_().creste_upsample_bwd_nhwc_f32(gy.ptr, gy.cs, gy.H, gy.W, gx.ptr, gx.cs, gy.N, H1, W1, gy.C,
+                                                        float(self.r[0]), float(self.r[1]), _stream()), "upsample_bwd")
+        return gx
+
+    def bwd(self, gy, gyd, grads, need_input=True):
+        return (self._t(gy) if gy is not None else None, self._t(gyd) if gyd is not None else None)
+
+
+class Chain:
+    def __init__(self, op_list):
+        self.ops = op_list
+
+    def params(self):
+        return [p for o in self.ops for p in o.params()]
+
+    def fwd(self, x, out=None):
+        for i, o in enumerate(self.ops):
+            x = o.fwd(x, out=out if i == len(self.ops) - 1 else None)
+        return x
+
+    def tan(self, xd, out=None):
+        for i, o in enumerate(self.ops):
+            xd = o.tan(xd, out=out if i == len(self.ops) - 1 else None)
+        return xd
+
+    def bwd(self, gy, gyd, grads, need_input=True):
+        for i in range(len(self.ops) - 1, -1, -1):
+            gy, gyd = self.ops[i].bwd(gy, gyd, grads, need_input=need_input or i > 0)
+        return gy, gyd
+
+
+def _ops_of(mods) -> list:
+    """nn modules of one MultiScaleFCN branch -> training ops (BatchNorm followed by ReLU is one op)."""
+    flat = []
+    for m in mods:
+        flat += list(m) if isinstance(m, nn.Sequential) else [m]
+    out, i = [], 0
+    while i < len(flat):
+        m = flat[i]
+        nxt = flat[i + 1] if i + 1 < len(flat) else None
+        if isinstance(m, nn.Conv2d):
+            out.append(ConvT(m))
+        elif isinstance(m, nn.BatchNorm2d):
+            fuse = isinstance(nxt, nn.ReLU)
+            out.append(BNT(m, fuse))
+            i += int(fuse)
+        elif isinstance(m, nn.ReLU):
+            out.append(ReLUT())
+        elif isinstance(m, nn.MaxPool2d):
+            if m.kernel_size not in (2, (2, 2)) or m.stride not in (2, (2, 2)):
+                raise NotImplementedError("HIP training path: 2x2/2 max-pool only")
+            out.append(PoolT())
+        elif isinstance(m, nn.Upsample):
+            out.append(UpT(m))
+        else:
+            raise NotImplementedError(f"HIP training path: no training op for {type(m).__name__}")
+        i += 1
+    return out
+
+
+class RewardTrainEngine:
+    """prepool -> {trunk, skip} -> concat -> postpool of a MultiScaleFCN, in training mode."""
+
+    def __init__(self, net):
+        self.prepool = Chain(_ops_of(net.prepool))
+        self.trunk = Chain(_ops_of(net.trunk))
+        self.skip = Chain(_ops_of(net.skip))
+        self.postpool = Chain(_ops_of(net.postpool))
+        self.ct = net.trunk_cfg["dims"][-1]
+        self.ccat = net.postpool_cfg["dims"][0]
+        self.gen = 0          # forward counter: a backward must belong to the latest forward (activations live here)
+
+    def params(self):
+        return self.prepool.params() + self.trunk.params() + self.skip.params() + self.postpool.params()
+
+    def check_gen(self, gen):
+        if gen != self.gen:
+            raise RuntimeError("reward network (HIP training path): backward of a stale forward -- the saved "
+                               "activations belong to a later forward of the same module; run forward/backward in pairs")
+
+    def forward(self, x: Act) -> Act:
+        self.gen += 1
+        h = self.prepool.fwd(x)
+        cat = Act.empty(h.N, h.H, h.W, self.ccat, h.buf.device)
+        self.trunk.fwd(h, out=cat.slice(0, self.ct))
+        self.skip.fwd(h, out=cat.slice(self.ct, self.ccat - self.ct))
+        return self.postpool.fwd(cat)
+
+    def tangent(self, xd: Act) -> Act:
+        hd = self.prepool.tan(xd)
+        catd = Act.empty(hd.N, hd.H, hd.W, self.ccat, hd.buf.device)
+        self.trunk.tan(hd, out=catd.slice(0, self.ct))
+        self.skip.tan(hd, out=catd.slice(self.ct, self.ccat - self.ct))
+        return self.postpool.tan(catd)
+
+    def backward(self, gr, grd, grads, need_input=True):
+        """cotangents of (r, rd) -> (gx, gxd); parameter gradients accumulate into `grads` (None: skip them)."""
+        gc, gcd = self.postpool.bwd(gr, grd, grads)
+        sl = lambda a, lo, n: a.slice(lo, n) if a is not None else None     # noqa: E731
+        gt, gtd = self.trunk.bwd(sl(gc, 0, self.ct), sl(gcd, 0, self.ct), grads)
+        gs, gsd = self.skip.bwd(sl(gc, self.ct, self.ccat - self.ct), sl(gcd, self.ct, self.ccat - self.ct), grads)
+        gh = pointwise2(2, gt, gs) if gt is not None else None
+        ghd = pointwise2(2, gtd, gsd) if gtd is not None else None
+        return self.prepool.bwd(gh, ghd, grads, need_input=need_input)
+
+
+def _grad_list(params, grads):
+    return tuple(grads.get(id(p)) for p in params)
+
+
+class InputGradFn(torch.autograd.Function):
+    """g = J_x^T gr, differentiable w.r.t. the parameters (and gr) through the tangent pass."""
+
+    @staticmethod
+    def forward(ctx, eng, gr, *params):
+        ctx.eng, ctx.gr_act, ctx.gen = eng, as_act(gr, pad_to4=True), eng.gen
+        gx, _ = eng.backward(Act(ctx.gr_act.buf, gr.shape[1], 0), None, None)
+        return gx.nchw()
+
+    @staticmethod
+    def backward(ctx, u):
+        eng = ctx.eng
+        eng.check_gen(ctx.gen)
+        rd = eng.tangent(as_act(u))
+        grads = {}
+        eng.backward(None, Act(ctx.gr_act.buf, rd.C, 0), grads, need_input=False)
+        return (None, rd.nchw(), *_grad_list(eng.params(), grads))
+
+
+class RewardFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, x, *params):
+        ctx.eng = eng
+        ctx.params = params
+        r = eng.forward(as_act(x)).nchw()
+        ctx.gen = eng.gen
+        return r
+
+    @staticmethod
+    def backward(ctx, gr):
+        eng = ctx.eng
+        eng.check_gen(ctx.gen)
+        grads = {}
+        gr_act = as_act(gr, pad_to4=True)
+        gra = Act(gr_act.buf, gr.shape[1], 0)
+        if torch.is_grad_enabled():
+            # create_graph=True (the gradient penalty): the input gradient must remain a function of the
+            # parameters; the parameter gradients of THIS call are first order (not differentiated again).
+            gx = InputGradFn.apply(eng, gr, *ctx.params)
+            eng.backward(gra, None, grads, need_input=False)
+        else:
+            gxa, _ = eng.backward(gra, None, grads, need_input=ctx.needs_input_grad[1])
+            gx = gxa.nchw() if gxa is not None else None
+        return (None, gx, *_grad_list(eng.params(), grads))
+
+
+def reward_forward_train(net, x: torch.Tensor) -> torch.Tensor:
+    """MultiScaleFCN.forward in training mode on the HIP path: x [B,C,H,W] -> r [B,1,H,W] (autograd-aware)."""
+    eng = getattr(net, "_train_engine", None)
+    if eng is None:
+        eng = net._train_engine = RewardTrainEngine(net)
+    return RewardFn.apply(eng, x, *eng.params())

@@ -226,6 +226,61 @@ int creste_expected_svf_f32(const float* policy, const float* expert_xy, const u
                             int zero_terminal, float* sharp_policy, float* exp_svf,
                             int64_t* state_preds, float* state_grid, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training-mode primitives (csrc/train.hip): what the IRL reward network (reference conv.py:88-161,
+ * trained by train_traversability.py:66-105 through loss_utils.py:1118-1259) needs beyond the forward
+ * engines.  NHWC fp32, explicit pixel strides; deterministic reductions.
+ *
+ * The gradient penalty's second-order term is evaluated as a TANGENT (JVP) forward followed by a
+ * backward through the (primal, tangent) pair:  d/dtheta <u, grad_x R> = d/dtheta JVP_x R [u].
+ * --------------------------------------------------------------------------------------------- */
+
+/* gw[Cout][Cin][K][K] (torch OIHW) (+)= sum_pixels gy[p][co] * x[p + tap][ci] for a stride-1 conv with
+ * pad = (K-1)/2 (F.conv2d backward w.r.t. weight).  work: creste_conv_wgrad_workspace_bytes(). */
+int64_t creste_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int K);
+int creste_conv_wgrad_f32(const float* x, int x_cs, const float* gy, int gy_cs, float* gw, int N, int H, int W,
+                          int Cin, int Cout, int K, int pad, int accumulate, void* work, void* stream);
+/* wt[Cin][cout_pad][K][K] = flipped, channel-transposed copy of w[Cout][Cin][K][K] (zero rows for
+ * co >= Cout): packing `wt` with creste_conv_pack_weight and running creste_conv2d_nhwc on gy gives the
+ * input gradient of the stride-1 conv (F.conv2d backward w.r.t. input). */
+int creste_conv_flip_weight_f32(const float* w, float* wt, int Cout, int Cin, int K, int cout_pad, void* stream);
+
+/* Training-mode BatchNorm2d over P = N*H*W pixels x C channels (C <= 256).
+ *   forward : batch mean / biased variance -> mean, invstd = 1/sqrt(var+eps); running stats updated as
+ *             nn.BatchNorm2d (momentum, unbiased variance; pass NULL to skip); y = gamma*xh+beta (+ReLU).
+ *   tangent : yd = gamma*invstd*((xd - m(xd)) - xh*m(xh*xd)); mom_t[2][C] keeps the two moments.
+ *   backward: cotangents gy (of y) and/or gyd (of yd) -> gx, gxd, g_gamma, g_beta ((+)= with
+ *             accumulate); mom_b[5][C] scratch.  gyd == NULL is the ordinary first-order backward.
+ *   work: creste_bn_workspace_bytes(C). */
+int64_t creste_bn_workspace_bytes(int C);
+int creste_bn_train_forward_f32(const float* x, int x_cs, int64_t P, int C, const float* gamma, const float* beta,
+                                float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                                float* invstd, float* var_scratch, float* y, int y_cs, int relu, void* work,
+                                void* stream);
+int creste_bn_train_tangent_f32(const float* x, int x_cs, const float* xd, int xd_cs, int64_t P, int C,
+                                const float* gamma, const float* mean, const float* invstd, float* mom_t,
+                                float* yd, int yd_cs, void* work, void* stream);
+int creste_bn_train_backward_f32(const float* x, int x_cs, const float* xd, int xd_cs, const float* gy, int gy_cs,
+                                 const float* gyd, int gyd_cs, int64_t P, int C, const float* gamma,
+                                 const float* mean, const float* invstd, const float* mom_t, float* mom_b,
+                                 float* gx, int gx_cs, float* gxd, int gxd_cs, float* g_gamma, float* g_beta,
+                                 int accumulate, void* work, void* stream);
+
+/* op 0: o = max(a, 0) | op 1: o = a > 0 ? b : 0 (ReLU backward / tangent with a = the ReLU output) |
+ * op 2: o = a + b.  [P][C] with pixel strides. */
+int creste_pointwise2_f32(int op, const float* a, int a_cs, const float* b, int b_cs, float* o, int o_cs,
+                          int64_t P, int C, void* stream);
+/* 2x2/2 max-pool that also records the argmax (0..3 = dy*2+dx, first maximum wins as in ATen);
+ * route: backward == 0 gathers `in` (full res) at idx -> pooled `out` (tangent); backward == 1 scatters
+ * pooled `in` to the full-res `out` (zeros elsewhere).  H, W are the FULL-resolution extents. */
+int creste_maxpool2_idx_f32(const float* in, int in_cs, int N, int H, int W, int C, float* out, int out_cs,
+                            uint8_t* idx, void* stream);
+int creste_maxpool2_route_f32(int backward, const float* in, int in_cs, const uint8_t* idx, float* out,
+                              int out_cs, int N, int H, int W, int C, void* stream);
+/* transpose of creste_upsample_concat's bilinear resize: gy [N,Ho,Wo,C] -> gx [N,H1,W1,C]. */
+int creste_upsample_bwd_nhwc_f32(const float* gy, int gy_cs, int Ho, int Wo, float* gx, int gx_cs, int N, int H1,
+                                 int W1, int C, float rh, float rw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
