@@ -139,8 +139,8 @@ def cpu_baseline(sample_frames=1, runs=3):
 
 def irl_extras(model_infer, device, steps=3):
     """The second half of BASELINE.json's metric: IRL train-step time (configs[2]).  Reference-config
-    step: batch 8 frames, 64x128 IRL grid (map_ds 2 + front-half crop), frozen HIP backbone, autograd
-    reward net, value iteration + expected SVF kernels, MaxEntIRLLoss with counterfactual mixing and
+    step: batch 8 frames, 64x128 IRL grid (map_ds 2 + front-half crop), frozen HIP backbone, reward net
+    trained on the HIP kernels (train_ops.py, hipGraph replay), value iteration + expected SVF kernels, MaxEntIRLLoss with counterfactual mixing and
     gradient penalty, Adam step (reference train_traversability.py:66-105).  Plus the MDP kernels alone
     on the 8x256x256 grid BASELINE names."""
     import numpy as np
@@ -153,6 +153,7 @@ def irl_extras(model_infer, device, steps=3):
         model.traversability_head.r.postpool[0].norm.weight.mul_(0.01)
         model.traversability_head.r.postpool[0].norm.bias.mul_(0.01)
     model = model.to(device).train()
+    model.traversability_head.r.train_graphs = True      # reward-net launch sequences replayed from hipGraphs
     lm = LossManager(cfg).to(device)
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-4, betas=(0.9, 0.999))
     rgbd, p2p = synth.make_frames(B, IMG_H, IMG_W, seed=4242)
@@ -176,7 +177,7 @@ def irl_extras(model_infer, device, steps=3):
         opt.step()
         return loss
 
-    step(); torch.cuda.synchronize()
+    step(); step(); torch.cuda.synchronize()              # eager step, then the capturing step
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()

@@ -24,7 +24,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // One wave = one 32(co) x 32(ci) tile of one tap; v_mfma_f32_32x32x2_f32 consumes two pixels per issue with
 // both operands read straight from global memory (lane = channel, so the loads are coalesced rows of the
 // NHWC tensors; each element is used exactly once per tile -> nothing to stage in LDS).
-constexpr int WG_PIX = 8;   // pixels per unrolled step (4 MFMAs)
+constexpr int WG_PIX = 16;  // pixels per unrolled step (8 MFMAs, 16 independent loads in flight per lane)
 
 __global__ __launch_bounds__(256) void wgrad_partial_kernel(const float* __restrict__ x, int x_cs,
                                                             const float* __restrict__ gy, int gy_cs,
@@ -35,28 +35,28 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(const float* __restr
   const int chunk = blockIdx.x, tap = blockIdx.y;
   const int ky = tap / K - pad, kx = tap % K - pad;
   const int tco = (Cout + 31) / 32, tci = (Cin + 31) / 32;
-  const long M = (long)N * H * W;
-  const long p0 = (long)chunk * chunk_px, p1 = min(M, p0 + chunk_px);
+  const int M = N * H * W;
+  const int p0 = chunk * chunk_px, p1 = min(M, p0 + chunk_px);
   for (int t = wave; t < tco * tci; t += 4) {
     const int co = (t / tci) * 32 + li, ci = (t % tci) * 32 + li;
     const bool co_ok = co < Cout, ci_ok = ci < Cin;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (long p = p0; p < p1; p += WG_PIX) {
+    for (int p = p0; p < p1; p += WG_PIX) {
       float a[WG_PIX / 2], b[WG_PIX / 2];
 #pragma unroll
       for (int j = 0; j < WG_PIX / 2; ++j) {
-        const long q = p + 2 * j + lh;
+        const int q = p + 2 * j + lh;
         a[j] = 0.f; b[j] = 0.f;
         if (q < p1) {
-          const int xx = (int)(q % W);
-          const long rowi = q / W;
-          const int yy = (int)(rowi % H);
+          const int rowi = q / W;
+          const int xx = q - rowi * W;
+          const int yy = rowi % H;
           const int iy = yy + ky, ix = xx + kx;
-          if (co_ok) a[j] = gy[q * gy_cs + co];
+          if (co_ok) a[j] = gy[(long)q * gy_cs + co];
           if (ci_ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-            b[j] = x[(q + (long)ky * W + kx) * x_cs + ci];
+            b[j] = x[(long)(q + ky * W + kx) * x_cs + ci];
         }
       }
 #pragma unroll
@@ -76,10 +76,12 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(const float* __restr
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw, int nchunk,
                                     int Cout, int Cin, int KK, int accumulate) {
   const int total = Cout * Cin * KK;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int tap = i % KK, ci = (i / KK) % Cin, co = i / (KK * Cin);
+  // threads follow the partial layout [tap][co][ci] (coalesced reads of every chunk); one scattered write each
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+    const int ci = j % Cin, co = (j / Cin) % Cout, tap = j / (Cin * Cout);
     float s = 0.f;
-    for (int c = 0; c < nchunk; ++c) s += partial[(((size_t)c * KK + tap) * Cout + co) * Cin + ci];
+    for (int c = 0; c < nchunk; ++c) s += partial[(size_t)c * total + j];
+    const int i = (co * Cin + ci) * KK + tap;
     gw[i] = accumulate ? gw[i] + s : s;
   }
 }
@@ -159,13 +161,16 @@ __global__ __launch_bounds__(256) void moments_kernel(const MomArgs a) {
 
 // out[k][c] = sum_blocks partial / P ; with `var_to_invstd` the single output becomes 1/sqrt(var + eps) and
 // the BatchNorm running statistics are updated (momentum m, unbiased variance) as nn.BatchNorm2d does.
-__global__ void moments_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblocks,
-                                        int nk, int C, float inv_p) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nk * C) return;
+// one wave per output: lane l sums the partials of blocks l, l+64, ... in order, then a fixed xor tree
+__global__ __launch_bounds__(64) void moments_finalize_kernel(const float* __restrict__ partial,
+                                                             float* __restrict__ out, int nblocks, int nk, int C,
+                                                             float inv_p) {
+  const int i = blockIdx.x;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * nk * C + i];
-  out[i] = s * inv_p;
+  for (int b = threadIdx.x; b < nblocks; b += 64) s += partial[(size_t)b * nk * C + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) out[i] = s * inv_p;
 }
 
 __global__ void bn_finish_stats_kernel(const float* __restrict__ mean, const float* __restrict__ var,
@@ -355,6 +360,14 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
   }
 }
 
+// pixel chunks of the wgrad reduction: ~2048 workgroups over (chunk, tap), at least 256 pixels per chunk
+static inline int wgrad_chunks(long M, int K) {
+  long n = 2048 / (K * K);
+  n = n < 32 ? 32 : (n > 512 ? 512 : n);
+  const long cap = (M + 255) / 256;
+  return (int)(n < cap ? n : cap);
+}
+
 static inline int grid1d(long work, int cap = 4096) {
   long b = (work + 255) / 256;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -366,9 +379,7 @@ using namespace creste;
 
 extern "C" int64_t creste_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int K) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || K <= 0) return -1;
-  const long M = (long)N * H * W;
-  const long nchunk = (M + 1023) / 1024 < 256 ? (M + 1023) / 1024 : 256;
-  return nchunk * K * K * Cout * Cin * 4;
+  return (int64_t)wgrad_chunks((long)N * H * W, K) * K * K * Cout * Cin * 4;
 }
 
 extern "C" int creste_conv_wgrad_f32(const float* x, int x_cs, const float* gy, int gy_cs, float* gw, int N, int H,
@@ -379,7 +390,8 @@ extern "C" int creste_conv_wgrad_f32(const float* x, int x_cs, const float* gy, 
                  "conv_wgrad: stride-1 'same' convolutions only (K=%d pad=%d)", K, pad);
   CRESTE_REQUIRE(K * K <= 65535, "conv_wgrad: kernel too large");
   const long M = (long)N * H * W;
-  int nchunk = (int)((M + 1023) / 1024 < 256 ? (M + 1023) / 1024 : 256);
+  CRESTE_REQUIRE(M < (1L << 31), "conv_wgrad: N*H*W overflows int32");
+  int nchunk = wgrad_chunks(M, K);
   long chunk_px = (M + nchunk - 1) / nchunk;
   chunk_px = (chunk_px + WG_PIX - 1) / WG_PIX * WG_PIX;
   nchunk = (int)((M + chunk_px - 1) / chunk_px);
@@ -414,8 +426,7 @@ static int run_moments(int mode, MomArgs a, float* out, float* partial, hipStrea
   else if (mode == 2) moments_kernel<2><<<blocks, 256, smem, s>>>(a);
   else moments_kernel<3><<<blocks, 256, smem, s>>>(a);
   CRESTE_CHECK_LAUNCH("bn_moments");
-  moments_finalize_kernel<<<(a.nk * a.C + 255) / 256, 256, 0, s>>>(partial, out, blocks, a.nk, a.C,
-                                                                 1.f / (float)a.P);
+  moments_finalize_kernel<<<a.nk * a.C, 64, 0, s>>>(partial, out, blocks, a.nk, a.C, 1.f / (float)a.P);
   CRESTE_CHECK_LAUNCH("bn_moments_finalize");
   return CRESTE_OK;
 }

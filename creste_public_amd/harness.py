@@ -31,8 +31,15 @@ def seed_everything(seed: int = 1337):
 
 
 class IRLTrainer:
-    def __init__(self, model: torch.nn.Module, loss_manager: torch.nn.Module, model_cfg):
+    def __init__(self, model: torch.nn.Module, loss_manager: torch.nn.Module, model_cfg, graphs: bool = False):
+        """graphs=True: the reward network's launch sequences are captured into hipGraphs after one eager step
+        and replayed (train_ops._Phases) -- same results, static shapes required."""
         self.model, self.loss, self.cfg = model, loss_manager, model_cfg
+        if graphs:
+            from .creste.models.blocks.conv import MultiScaleFCN
+            for m in model.modules():
+                if isinstance(m, MultiScaleFCN):
+                    m.train_graphs = True
         oc = model_cfg["optimizer"]
         if oc["name"] != "Adam":
             raise NotImplementedError(oc["name"])

@@ -349,6 +349,8 @@ class RewardTrainEngine:
         self.ct = net.trunk_cfg["dims"][-1]
         self.ccat = net.postpool_cfg["dims"][0]
         self.gen = 0          # forward counter: a backward must belong to the latest forward (activations live here)
+        self.use_graphs = False
+        self.phases = _Phases(self)
 
     def params(self):
         return self.prepool.params() + self.trunk.params() + self.skip.params() + self.postpool.params()
@@ -359,7 +361,6 @@ class RewardTrainEngine:
                                "activations belong to a later forward of the same module; run forward/backward in pairs")
 
     def forward(self, x: Act) -> Act:
-        self.gen += 1
         h = self.prepool.fwd(x)
         cat = Act.empty(h.N, h.H, h.W, self.ccat, h.buf.device)
         self.trunk.fwd(h, out=cat.slice(0, self.ct))
@@ -388,23 +389,109 @@ def _grad_list(params, grads):
     return tuple(grads.get(id(p)) for p in params)
 
 
+class _Phases:
+    """The four launch sequences of one training step as tensor -> tensor functions, each optionally captured
+    into a hipGraph (torch.cuda.CUDAGraph) on its second call and replayed afterwards.
+
+    The reward network is ~280 kernels of a few microseconds each per step: eager, the step is bound by the
+    Python launch path (~15 ms); replayed from four graphs it is bound by the GPU (~1 ms).  Capture needs
+    static shapes (one graph set per input shape) and turns the outputs into static buffers that the next
+    replay overwrites -- the usual CUDA-graph contract, hence opt-in (`MultiScaleFCN.train_graphs = True`,
+    `IRLTrainer(graphs=True)`); results are bit-identical to the eager path (same kernels, same order)."""
+
+    def __init__(self, eng):
+        self.eng = eng
+        self.graphs = {}
+
+    # ---- the phases (eager bodies)
+    def forward(self, x):
+        eng = self.eng
+        if eng.use_graphs:                       # the weights changed since the last step: re-pack inside the graph
+            for ch in (eng.prepool, eng.trunk, eng.skip, eng.postpool):
+                for o in ch.ops:
+                    if isinstance(o, ConvT):
+                        o._key = None
+        return (eng.forward(as_act(x)).nchw(),)
+
+    def input_grad(self, gr):
+        gra = as_act(gr, pad_to4=True)
+        gx, _ = self.eng.backward(Act(gra.buf, gr.shape[1], 0), None, None)
+        return (gx.nchw(),)
+
+    def second_order(self, u, gr):
+        eng = self.eng
+        rd = eng.tangent(as_act(u))
+        gra = as_act(gr, pad_to4=True)
+        grads = {}
+        eng.backward(None, Act(gra.buf, gr.shape[1], 0), grads, need_input=False)
+        return (rd.nchw(), *_grad_list(eng.params(), grads))
+
+    def backward(self, gr):
+        gra = as_act(gr, pad_to4=True)
+        grads = {}
+        self.eng.backward(Act(gra.buf, gr.shape[1], 0), None, grads, need_input=False)
+        return _grad_list(self.eng.params(), grads)
+
+    def backward_with_input(self, gr):
+        gra = as_act(gr, pad_to4=True)
+        grads = {}
+        gx, _ = self.eng.backward(Act(gra.buf, gr.shape[1], 0), None, grads, need_input=True)
+        return (gx.nchw(), *_grad_list(self.eng.params(), grads))
+
+    # ---- dispatch
+    def run(self, name, *ins):
+        fn = getattr(self, name)
+        if not self.eng.use_graphs:
+            return fn(*ins)
+        key = (name, tuple((tuple(t.shape), t.dtype) for t in ins))
+        ent = self.graphs.get(key)
+        if ent is None:                          # first call: eager (lazy kernel loads, function attributes)
+            self.graphs[key] = "warm"
+            return fn(*ins)
+        if ent == "warm":
+            static_in = [t.detach().clone() for t in ins]
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs = fn(*static_in)
+            ent = self.graphs[key] = (g, static_in, outs)
+        g, static_in, outs = ent
+        for st, t in zip(static_in, ins):
+            st.copy_(t)
+        g.replay()
+        return outs
+
+
 class InputGradFn(torch.autograd.Function):
     """g = J_x^T gr, differentiable w.r.t. the parameters (and gr) through the tangent pass."""
 
     @staticmethod
     def forward(ctx, eng, gr, *params):
-        ctx.eng, ctx.gr_act, ctx.gen = eng, as_act(gr, pad_to4=True), eng.gen
-        gx, _ = eng.backward(Act(ctx.gr_act.buf, gr.shape[1], 0), None, None)
-        return gx.nchw()
+        ctx.eng, ctx.gr, ctx.gen = eng, gr.detach(), eng.gen
+        return eng.phases.run("input_grad", gr.detach())[0]
 
     @staticmethod
     def backward(ctx, u):
         eng = ctx.eng
         eng.check_gen(ctx.gen)
-        rd = eng.tangent(as_act(u))
-        grads = {}
-        eng.backward(None, Act(ctx.gr_act.buf, rd.C, 0), grads, need_input=False)
-        return (None, rd.nchw(), *_grad_list(eng.params(), grads))
+        rd, *pg = eng.phases.run("second_order", u.detach(), ctx.gr)
+        return (None, rd, *pg)
+
+
+def _params_wanted(params) -> bool:
+    """True unless the running backward pass provably stops short of every parameter's accumulator."""
+    probe = getattr(torch._C, "_will_engine_execute_node", None)
+    if probe is None:
+        return True
+    try:
+        for p in params:
+            if p.requires_grad:
+                node = p.view_as(p).grad_fn.next_functions[0][0]        # the AccumulateGrad node of the leaf
+                if probe(node):
+                    return True
+        return False
+    except Exception:
+        return True
 
 
 class RewardFn(torch.autograd.Function):
@@ -412,26 +499,26 @@ class RewardFn(torch.autograd.Function):
     def forward(ctx, eng, x, *params):
         ctx.eng = eng
         ctx.params = params
-        r = eng.forward(as_act(x)).nchw()
+        eng.gen += 1
         ctx.gen = eng.gen
-        return r
+        return eng.phases.run("forward", x.detach())[0]
 
     @staticmethod
     def backward(ctx, gr):
         eng = ctx.eng
         eng.check_gen(ctx.gen)
-        grads = {}
-        gr_act = as_act(gr, pad_to4=True)
-        gra = Act(gr_act.buf, gr.shape[1], 0)
         if torch.is_grad_enabled():
             # create_graph=True (the gradient penalty): the input gradient must remain a function of the
-            # parameters; the parameter gradients of THIS call are first order (not differentiated again).
+            # parameters; the parameter gradients of THIS call are first order (not differentiated again)
+            # and are only computed when this backward pass will actually deliver them somewhere
+            # (`autograd.grad(inputs=[input_view])` does not).
             gx = InputGradFn.apply(eng, gr, *ctx.params)
-            eng.backward(gra, None, grads, need_input=False)
+            pg = eng.phases.run("backward", gr.detach()) if _params_wanted(ctx.params) else (None,) * len(ctx.params)
+        elif ctx.needs_input_grad[1]:
+            gx, *pg = eng.phases.run("backward_with_input", gr.detach())
         else:
-            gxa, _ = eng.backward(gra, None, grads, need_input=ctx.needs_input_grad[1])
-            gx = gxa.nchw() if gxa is not None else None
-        return (None, gx, *_grad_list(eng.params(), grads))
+            gx, pg = None, eng.phases.run("backward", gr.detach())
+        return (None, gx, *pg)
 
 
 def reward_forward_train(net, x: torch.Tensor) -> torch.Tensor:
@@ -439,4 +526,5 @@ def reward_forward_train(net, x: torch.Tensor) -> torch.Tensor:
     eng = getattr(net, "_train_engine", None)
     if eng is None:
         eng = net._train_engine = RewardTrainEngine(net)
+    eng.use_graphs = bool(getattr(net, "train_graphs", False))
     return RewardFn.apply(eng, x, *eng.params())

@@ -16,6 +16,7 @@ with torch.no_grad():
     model.backbone.depthcomp.depthcomp.vision_backbone.model.trunk._bn0.running_var.fill_(1e7)
     model.traversability_head.r.postpool[0].norm.weight.mul_(0.01); model.traversability_head.r.postpool[0].norm.bias.mul_(0.01)
 model = model.to(dev).train()
+model.traversability_head.r.train_graphs = bool(int(os.environ.get('GRAPHS', '1')))
 lm = LossManager(cfg).to(dev)
 opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-4)
 rgbd, p2p = synth.make_frames(B, bench.IMG_H, bench.IMG_W, seed=1); rgbd, p2p = rgbd.to(dev), p2p.to(dev)
@@ -25,7 +26,7 @@ rng = np.random.RandomState(0)
 cf = [dict(trajectories=(np.array([[100.0, 128.0]]) + np.linspace(0, 1, 20)[None, :, None] * rng.uniform(-80, 80, size=(2, 1, 2))).astype(np.float32), rank=np.array([0, 1])) for _ in range(B)]
 def T():
     torch.cuda.synchronize(); return time.perf_counter()
-for it in range(3):
+for it in range(5):
     t0 = T(); opt.zero_grad()
     r = model.backbone.forward_act(rgbd, p2p); outputs = model.backbone.pack_outputs(r, B); t1 = T()
     head = model.traversability_head

@@ -33,7 +33,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from creste_public_amd.config import maxent_irl_cfg
-        from creste_public_amd.creste.models.blocks.conv import MultiScaleFCN
+        from oracle.blocks import MultiScaleFCN            # CPU stand-in: the product net trains on HIP kernels only
         from creste_public_amd.creste.utils.loss_utils import LossManager
         cfg = maxent_irl_cfg()
         torch.manual_seed(0)                                  # identical replicas

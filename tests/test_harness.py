@@ -6,7 +6,7 @@ import torch
 
 from creste_public_amd import synth
 from creste_public_amd.config import maxent_irl_cfg
-from creste_public_amd.creste.models.blocks.conv import MultiScaleFCN
+from oracle.blocks import MultiScaleFCN            # CPU stand-in: the product net trains on HIP kernels only
 from creste_public_amd.creste.utils.loss_utils import LossManager
 from creste_public_amd.harness import IRLTrainer, seed_everything
 

@@ -169,3 +169,13 @@ def test_error_conventions_and_cfg_protocol():
     if torch.cuda.is_available():
         with pytest.raises(NotImplementedError):                           # backbone training: later round
             m.cuda().train()((torch.zeros(1, 1, 4, *IMG).cuda(), torch.eye(4).view(1, 1, 4, 4).cuda()))
+
+
+def test_reward_net_training_refuses_cpu():
+    """the product reward network trains on the HIP kernels only: a CPU tensor must fail loudly, not fall back"""
+    from creste_public_amd.creste.models.blocks.conv import MultiScaleFCN
+    from creste_public_amd.ops import HipLibraryError
+    cfg = maxent_irl_cfg()["traversability_head"]["net_kwargs"]["reward_cfg"]["net_kwargs"]
+    net = MultiScaleFCN(cfg).train()
+    with pytest.raises(HipLibraryError):
+        net(torch.rand(1, 40, 16, 16, requires_grad=True))

@@ -79,6 +79,32 @@ def test_reward_net_training_step(shape, lam):
             assert int(b) == int(ref_b[name]), name
 
 
+def test_graph_replay_matches_eager():
+    """hipGraph replay of the four launch sequences: bit-identical parameters after 4 Adam steps."""
+    from creste_public_amd.creste.models.blocks.conv import MultiScaleFCN
+    torch.manual_seed(5)
+    base = MultiScaleFCN(_cfg())
+    xs = [torch.rand(4, 40, 32, 64) * 2 for _ in range(4)]
+    Ds = [torch.randn(4, 1, 32, 64) / 2048 for _ in range(4)]
+    results = []
+    for graphs in (False, True):
+        net = copy.deepcopy(base).cuda().train()
+        net.train_graphs = graphs
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        losses = []
+        for x, D in zip(xs, Ds):
+            opt.zero_grad()
+            _, _, loss = _objective(net, x.cuda(), D.cuda(), 0.1)
+            opt.step()
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        results.append((losses, {k: v.clone() for k, v in net.state_dict().items()}))
+    assert results[0][0] == results[1][0], (results[0][0], results[1][0])
+    for k, v in results[0][1].items():
+        assert torch.equal(v, results[1][1][k]), k
+    assert int(results[1][1]["prepool.0.norm.num_batches_tracked"]) == 4
+
+
 def test_stale_backward_is_refused():
     from creste_public_amd.creste.models.blocks.conv import MultiScaleFCN
     net = MultiScaleFCN(_cfg()).cuda().train()
