@@ -76,6 +76,20 @@ SIGNATURES = {
     "creste_maxpool2_idx_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "creste_maxpool2_route_f32": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "creste_upsample_bwd_nhwc_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _f, _f, _vp]),
+    "creste_conv_wgrad_strided_workspace_bytes": (_i64, [_i] * 6),
+    "creste_conv_wgrad_strided_f32": (_i, [_vp, _i, _vp, _i, _vp] + [_i] * 12 + [_vp, _vp]),
+    "creste_dwconv_dgrad_f32": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
+    "creste_dwconv_wgrad_workspace_bytes": (_i64, [_i, _i]),
+    "creste_dwconv_wgrad_f32": (_i, [_vp, _vp, _vp] + [_i] * 11 + [_vp, _vp]),
+    "creste_train_pointwise_f32": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i64, _i64, _i, _vp]),
+    "creste_sample_reduce_workspace_bytes": (_i64, [_i, _i]),
+    "creste_sample_reduce_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _f, _vp, _vp]),
+    "creste_se_fc_forward_f32": (_i, [_vp] * 8 + [_i, _i, _i, _vp]),
+    "creste_se_fc_backward_f32": (_i, [_vp] * 8 + [_i, _i, _i, _vp]),
+    "creste_fc_wgrad_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "creste_loss_workspace_bytes": (_i64, []),
+    "creste_depth_ce_loss_f32": (_i, [_vp, _i, _vp, _i64, _i, _f, _f, _f, _vp, _i, _vp, _vp, _vp]),
+    "creste_mse_loss_f32": (_i, [_vp, _i, _vp, _i, _i64, _i, _f, _vp, _i, _vp, _vp, _vp]),
     "creste_expected_svf_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp,
                                       _vp]),
 }

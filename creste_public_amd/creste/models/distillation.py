@@ -72,8 +72,8 @@ class DistillationBackbone(nn.Module):
         rgbd = x
         require_hip(rgbd, "DistillationBackbone")
         if self.training:
-            raise NotImplementedError("encoder training (backward kernels) is not in this round; "
-                                      "run the perception backbone in eval() mode")
+            from ...train_backbone import backbone_forward_train
+            return backbone_forward_train(self, rgbd)
         B, V, C, H, W = rgbd.shape
         r = self.forward_act(ops.nchw_to_nhwc(rgbd.reshape(B * V, C, H, W).contiguous().float()))
         return self.pack_outputs(r, B)

@@ -136,7 +136,83 @@ class MaxEntIRLLoss(Loss):
         return {"maxentirl_loss": total}, meta
 
 
-_LOSSES = {"MaxEntIRLLoss": MaxEntIRLLoss}
+def _bin_depths_ud(depth, depth_min, depth_max, num_bins):
+    """target bins of reference depth_utils.bin_depths (mode UD, target=True)."""
+    idx = (depth - depth_min) / ((depth_max - depth_min) / num_bins)
+    bad = (idx < 0) | (idx > num_bins) | (~torch.isfinite(idx))
+    idx = idx.masked_fill(bad, num_bins)
+    return idx.to(torch.int64)
+
+
+def _match_depth_label(pred_hw, gt):
+    """[B,S,H,W] label -> [B*S,h,w] at the prediction's resolution (nearest, as the reference's workaround)."""
+    B, S, H, W = gt.shape
+    if tuple(pred_hw) != (H, W):
+        gt = torch.nn.functional.interpolate(gt, tuple(pred_hw), mode="nearest").detach()
+    return gt.reshape(B * S, *gt.shape[-2:])
+
+
+class CrossEntropyDepth(Loss):
+    """depth as classification (reference loss_utils.py:477-527) -- fused HIP kernel (loss_ops.DepthCEFn)."""
+
+    def __init__(self, config):
+        super().__init__(config["name"], config)
+
+    def loss(self, tensor_dict):
+        from ...loss_ops import DepthCEFn
+        pred = tensor_dict[self.config["pred_key"]]
+        gt = tensor_dict[self.config["lab_key"]]
+        if pred.shape[0] != gt.shape[0] * gt.shape[1]:
+            raise NotImplementedError("multi-frame depth prediction is not configured by the shipped models")
+        d = self.config["discretize"]
+        if d["mode"] != "UD":
+            raise NotImplementedError("HIP depth cross-entropy bins uniformly (mode 'UD')")
+        gt = _match_depth_label(pred.shape[-2:], gt)
+        loss, stats = DepthCEFn.apply(pred, gt, d["num_bins"], d["depth_min"], d["depth_max"])
+        return {"depth/cls_loss": loss}, {"depth/acc": stats[1]}
+
+
+class SmoothL1Depth(Loss):
+    """reference loss_utils.py:530-573.  With the shipped config its prediction is `depth_preds_bins` (integer
+    class indices), so it carries no gradient: evaluated as a logged scalar on the masked pixels."""
+
+    def __init__(self, config):
+        super().__init__(config["name"], config)
+        self.pred_key, self.lab_key = config["pred_key"], config["lab_key"]
+        self.smoothl1_loss = torch.nn.SmoothL1Loss(beta=config["beta"], reduction="mean")
+
+    def loss(self, tensor_dict):
+        pred = tensor_dict[self.pred_key]
+        gt = tensor_dict[self.lab_key]
+        if pred.shape[0] != gt.shape[0] * gt.shape[1]:
+            raise NotImplementedError("multi-frame depth prediction is not configured by the shipped models")
+        if pred.requires_grad:
+            raise NotImplementedError("SmoothL1Depth on a differentiable prediction (metric depth) needs the "
+                                      "softmax-expectation backward, which is not built yet")
+        d = self.config["discretize"]
+        gt = _match_depth_label(pred.shape[-2:], gt)
+        valid = _bin_depths_ud(gt, d["depth_min"], d["depth_max"], d["num_bins"]) != d["num_bins"]
+        return {"depth/reg_loss": self.smoothl1_loss(pred[valid].float(), (gt / 1000.0)[valid].float())}, {}
+
+
+class MSELoss(Loss):
+    """single-view DINO feature match (reference loss_utils.py:606-647, overlap_only=False) -- fused HIP kernel."""
+
+    def __init__(self, config):
+        super().__init__(config["name"], config)
+        self.pred_key, self.lab_key = config["pred_key"], config["lab_key"]
+        if config.get("overlap_only", False):
+            raise NotImplementedError("MSELoss(overlap_only=True) is a BEV-stage option, not on the HIP path yet")
+
+    def loss(self, tensor_dict):
+        from ...loss_ops import MSEFn
+        pred, gt = tensor_dict[self.pred_key], tensor_dict[self.lab_key]
+        B, V, Z, H, W = pred.shape
+        return {"loss": MSEFn.apply(pred.reshape(B * V, Z, H, W), gt.reshape(B * V, Z, H, W))}, {}
+
+
+_LOSSES = {"MaxEntIRLLoss": MaxEntIRLLoss, "CrossEntropyDepth": CrossEntropyDepth, "SmoothL1Depth": SmoothL1Depth,
+           "MSELoss": MSELoss}
 
 
 class LossManager(nn.Module):

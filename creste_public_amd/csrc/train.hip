@@ -119,10 +119,12 @@ struct MomArgs {
 
 template <int MODE>
 __global__ __launch_bounds__(256) void moments_kernel(const MomArgs a) {
-  extern __shared__ float sm[];   // [nk][rows][C]
-  const int C = a.C, rows = 256 / C > 0 ? 256 / C : 1;
-  const int c = threadIdx.x % C, row = threadIdx.x / C;
-  const bool active = row < rows && (C <= 256 || false);
+  extern __shared__ float sm[];   // [nk][rows][Ct]
+  // blockIdx.y walks channel tiles of 256; inside a tile thread = (pixel row, channel)
+  const int cbase = blockIdx.y * 256;
+  const int Ct = min(256, a.C - cbase), rows = 256 / Ct;
+  const int c = cbase + threadIdx.x % Ct, row = threadIdx.x / Ct;
+  const bool active = row < rows;
   float s[MOM_MAXK] = {0.f, 0.f, 0.f, 0.f, 0.f};
   if (active) {
     const float mu = (MODE >= 1) ? a.mean[c] : 0.f;
@@ -147,14 +149,14 @@ __global__ __launch_bounds__(256) void moments_kernel(const MomArgs a) {
         }
       }
     }
-    for (int k = 0; k < a.nk; ++k) sm[((size_t)k * rows + row) * C + c] = s[k];
+    for (int k = 0; k < a.nk; ++k) sm[((size_t)k * rows + row) * Ct + (c - cbase)] = s[k];
   }
   __syncthreads();
   if (active && row == 0) {
     for (int k = 0; k < a.nk; ++k) {
       float t = 0.f;
-      for (int r = 0; r < rows; ++r) t += sm[((size_t)k * rows + r) * C + c];
-      a.partial[((size_t)blockIdx.x * a.nk + k) * C + c] = t;
+      for (int r = 0; r < rows; ++r) t += sm[((size_t)k * rows + r) * Ct + (c - cbase)];
+      a.partial[((size_t)blockIdx.x * a.nk + k) * a.C + c] = t;
     }
   }
 }
@@ -415,16 +417,17 @@ extern "C" int creste_conv_flip_weight_f32(const float* w, float* wt, int Cout, 
 }
 
 static int run_moments(int mode, MomArgs a, float* out, float* partial, hipStream_t s) {
-  CRESTE_REQUIRE(a.C > 0 && a.C <= 256 && a.P > 0, "bn moments: C must be in 1..256");
-  const int rows = 256 / a.C;
+  CRESTE_REQUIRE(a.C > 0 && a.P > 0, "bn moments: bad dims");
+  const int rows = a.C >= 256 ? 1 : 256 / a.C;
   const long per = (a.P + rows - 1) / rows;
   const int blocks = (int)(per < MOM_BLOCKS ? per : MOM_BLOCKS);
   a.partial = partial;
-  const size_t smem = (size_t)a.nk * rows * a.C * sizeof(float);
-  if (mode == 0) moments_kernel<0><<<blocks, 256, smem, s>>>(a);
-  else if (mode == 1) moments_kernel<1><<<blocks, 256, smem, s>>>(a);
-  else if (mode == 2) moments_kernel<2><<<blocks, 256, smem, s>>>(a);
-  else moments_kernel<3><<<blocks, 256, smem, s>>>(a);
+  const size_t smem = (size_t)a.nk * 256 * sizeof(float);
+  const dim3 grid(blocks, (a.C + 255) / 256);
+  if (mode == 0) moments_kernel<0><<<grid, 256, smem, s>>>(a);
+  else if (mode == 1) moments_kernel<1><<<grid, 256, smem, s>>>(a);
+  else if (mode == 2) moments_kernel<2><<<grid, 256, smem, s>>>(a);
+  else moments_kernel<3><<<grid, 256, smem, s>>>(a);
   CRESTE_CHECK_LAUNCH("bn_moments");
   moments_finalize_kernel<<<a.nk * a.C, 64, 0, s>>>(partial, out, blocks, a.nk, a.C, 1.f / (float)a.P);
   CRESTE_CHECK_LAUNCH("bn_moments_finalize");

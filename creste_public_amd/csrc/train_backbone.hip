@@ -1,0 +1,639 @@
+// Backward primitives of the RGB-D encoder (stage-1 distillation, reference train_pefree.py:71-99 through
+// creste/models/distillation.py:145-207, blocks/effnet.py, efficientnet_pytorch MBConv blocks) and its
+// training objectives (reference loss_utils.py: CrossEntropyDepth :477-527, MSELoss :606-647).
+//   * general conv weight gradient (stride, asymmetric static padding, any K) on the fp32 MFMA;
+//   * depthwise conv: input gradient and per-tap weight gradient;
+//   * swish, per-sample scaling (squeeze-excite gate, drop-connect), per-sample channel reductions;
+//   * the squeeze-excite bottleneck (two tiny FCs) forward / backward;
+//   * fused depth-classification loss (bin the metric label, softmax cross-entropy over the valid pixels,
+//     accuracy, gradient w.r.t. the logits) and the masked MSE of the distilled features.
+// NHWC fp32 with explicit pixel strides; fixed-order reductions (block partials + ordered finalisation).
+#include "common.h"
+
+namespace creste {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+static inline int grid1d(long work, int cap = 8192) {
+  long b = (work + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// ------------------------------------------------------------------------------------ general conv wgrad
+// partial[chunk][tap][co][ci] = sum over the chunk's OUTPUT pixels q of gy[q][co] * x[q*stride + tap - pad][ci]
+constexpr int WGS_PIX = 16;
+__global__ __launch_bounds__(256) void wgrad_strided_partial_kernel(
+    const float* __restrict__ x, int x_cs, const float* __restrict__ gy, int gy_cs, float* __restrict__ partial,
+    int N, int H, int W, int Ho, int Wo, int Cin, int Cout, int K, int stride, int pad_t, int pad_l, int chunk_px) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int chunk = blockIdx.x, tap = blockIdx.y;
+  const int ky = tap / K - pad_t, kx = tap % K - pad_l;
+  const int tco = (Cout + 31) / 32, tci = (Cin + 31) / 32;
+  const int M = N * Ho * Wo;
+  const int p0 = chunk * chunk_px, p1 = min(M, p0 + chunk_px);
+  for (int t = wave; t < tco * tci; t += 4) {
+    const int co = (t / tci) * 32 + li, ci = (t % tci) * 32 + li;
+    const bool co_ok = co < Cout, ci_ok = ci < Cin;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int p = p0; p < p1; p += WGS_PIX) {
+      float a[WGS_PIX / 2], b[WGS_PIX / 2];
+#pragma unroll
+      for (int j = 0; j < WGS_PIX / 2; ++j) {
+        const int q = p + 2 * j + lh;
+        a[j] = 0.f; b[j] = 0.f;
+        if (q < p1) {
+          const int rowi = q / Wo;
+          const int ox = q - rowi * Wo;
+          const int n = rowi / Ho;
+          const int oy = rowi - n * Ho;
+          const int iy = oy * stride + ky, ix = ox * stride + kx;
+          if (co_ok) a[j] = gy[(long)q * gy_cs + co];
+          if (ci_ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+            b[j] = x[(((long)n * H + iy) * W + ix) * x_cs + ci];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < WGS_PIX / 2; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+    }
+    float* out = partial + ((size_t)chunk * K * K + tap) * Cout * Cin;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (t / tci) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < Cout && ci_ok) out[(size_t)row * Cin + ci] = acc[r];
+    }
+  }
+}
+
+__global__ void wgrad_strided_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw, int nchunk,
+                                            int Cout, int Cin, int KK, int accumulate) {
+  const int total = Cout * Cin * KK;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+    const int ci = j % Cin, co = (j / Cin) % Cout, tap = j / (Cin * Cout);
+    float s = 0.f;
+    for (int c = 0; c < nchunk; ++c) s += partial[(size_t)c * total + j];
+    const int i = (co * Cin + ci) * KK + tap;
+    gw[i] = accumulate ? gw[i] + s : s;
+  }
+}
+
+static inline int wgrad_chunks(long M, int K) {
+  long n = 2048 / (K * K);
+  n = n < 32 ? 32 : (n > 512 ? 512 : n);
+  const long cap = (M + 255) / 256;
+  return (int)(n < cap ? n : cap);
+}
+
+// ------------------------------------------------------------------------------------ depthwise conv backward
+// gx[n,iy,ix,c] = sum_taps w[tap][c] * gy[n,(iy+pad_t-ky)/s,(ix+pad_l-kx)/s,c]  (where divisible and inside)
+__global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                           float* __restrict__ gx, int N, int H, int W, int C, int Ho,
+                                                           int Wo, int K, int stride, int pad_t, int pad_l) {
+  const int cq = C >> 2;
+  const long total = (long)N * H * W * cq;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % cq) * 4;
+    long t = i / cq;
+    const int ix = (int)(t % W); t /= W;
+    const int iy = (int)(t % H);
+    const int n = (int)(t / H);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < K; ++ky) {
+      const int ty = iy + pad_t - ky;
+      if (ty < 0 || ty % stride) continue;
+      const int oy = ty / stride;
+      if (oy >= Ho) continue;
+      for (int kx = 0; kx < K; ++kx) {
+        const int tx = ix + pad_l - kx;
+        if (tx < 0 || tx % stride) continue;
+        const int ox = tx / stride;
+        if (ox >= Wo) continue;
+        acc += ld4(gy + (((long)n * Ho + oy) * Wo + ox) * C + c) * ld4(w + (ky * K + kx) * C + c);
+      }
+    }
+    st4(gx + i * 4, acc);
+  }
+}
+
+// partial[blk][tap][c] = sum over the block's output pixels of gy[q][c] * x[q*s + tap - pad][c]
+constexpr int DW_BLOCKS = 256;
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                           float* __restrict__ partial, int N, int H, int W, int C,
+                                                           int Ho, int Wo, int stride, int pad_t, int pad_l) {
+  extern __shared__ float sm[];   // [rows][C] per tap, reused tap by tap
+  const int rows = 256 / C > 0 ? 256 / C : 1;
+  const long M = (long)N * Ho * Wo;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int c = c0 + (C >= 256 ? threadIdx.x : threadIdx.x % C);
+    const int row = C >= 256 ? 0 : threadIdx.x / C;
+    const bool active = c < C && row < rows;
+    float s[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) s[t] = 0.f;
+    if (active) {
+      for (long q = (long)blockIdx.x * rows + row; q < M; q += (long)gridDim.x * rows) {
+        const int ox = (int)(q % Wo);
+        const long r = q / Wo;
+        const int oy = (int)(r % Ho), n = (int)(r / Ho);
+        const float g = gy[q * C + c];
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          const int iy = oy * stride + ky - pad_t;
+          if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) {
+            const int ix = ox * stride + kx - pad_l;
+            if ((unsigned)ix < (unsigned)W) s[ky * K + kx] += g * x[(((long)n * H + iy) * W + ix) * C + c];
+          }
+        }
+      }
+    }
+    const int cw = C >= 256 ? 256 : C;           // channels handled in this pass
+    for (int t = 0; t < K * K; ++t) {
+      __syncthreads();
+      if (active) sm[row * cw + (c - c0)] = s[t];
+      __syncthreads();
+      if (active && row == 0) {
+        float tot = 0.f;
+        for (int r = 0; r < rows; ++r) tot += sm[r * cw + (c - c0)];
+        partial[((size_t)blockIdx.x * K * K + t) * C + c] = tot;
+      }
+    }
+  }
+}
+
+// out[i] (+)= sum_b partial[b][i] ; one wave per output (ordered lanes + xor tree)
+__global__ __launch_bounds__(64) void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                          int nblocks, int n, float scale, int accumulate) {
+  const int i = blockIdx.x;
+  float s = 0.f;
+  for (int b = threadIdx.x; b < nblocks; b += 64) s += partial[(size_t)b * n + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) out[i] = (accumulate ? out[i] : 0.f) + s * scale;
+}
+
+// ------------------------------------------------------------------------------------ elementwise
+//   op 0 swish             o = a * sigmoid(a)
+//   op 1 swish backward    o = b * (sg + a*sg*(1-sg)),  sg = sigmoid(a)      (a = pre-activation, b = gy)
+//   op 2 gate              o = a * g[n][c]
+//   op 3 gate + residual   o = b + a * g[n][c]        (g may have C == 1 stride: per-sample scalar, drop-connect)
+//   op 4 gate backward     o = b * g[n][c] + r[n][c] / HW    (b = gy, r = gradient of the pooled mean; r may be null)
+__global__ __launch_bounds__(256) void train_pointwise_kernel(int op, const float* __restrict__ a, int a_cs,
+                                                              const float* __restrict__ b, int b_cs,
+                                                              const float* __restrict__ g, int g_c,
+                                                              const float* __restrict__ r, float* __restrict__ o,
+                                                              int o_cs, long HW, long P, int C) {
+  const long total = P * C;
+  const float inv_hw = 1.f / (float)HW;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i / C;
+    const int c = (int)(i - p * C);
+    const long n = p / HW;
+    float v;
+    if (op == 0) { const float x = a[p * a_cs + c]; v = x / (1.f + expf(-x)); }
+    else if (op == 1) {
+      const float x = a[p * a_cs + c], sg = 1.f / (1.f + expf(-x));
+      v = b[p * b_cs + c] * (sg + x * sg * (1.f - sg));
+    } else if (op == 2) v = a[p * a_cs + c] * g[n * g_c + (g_c == 1 ? 0 : c)];
+    else if (op == 3) v = b[p * b_cs + c] + a[p * a_cs + c] * g[n * g_c + (g_c == 1 ? 0 : c)];
+    else v = b[p * b_cs + c] * g[n * g_c + (g_c == 1 ? 0 : c)] + (r ? r[n * C + c] * inv_hw : 0.f);
+    o[p * o_cs + c] = v;
+  }
+}
+
+// per-sample channel sums: out[n][c] = scale * sum_hw a[n,p,c] * (b ? b[n,p,c] : 1); grid (chunks, N)
+constexpr int SR_CHUNKS = 64;
+__global__ __launch_bounds__(256) void sample_reduce_kernel(const float* __restrict__ a, int a_cs,
+                                                            const float* __restrict__ b, int b_cs,
+                                                            float* __restrict__ partial, long HW, int C) {
+  extern __shared__ float sm[];
+  const int n = blockIdx.y;
+  const int rows = 256 / C > 0 ? 256 / C : 1;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int c = c0 + (C >= 256 ? threadIdx.x : threadIdx.x % C);
+    const int row = C >= 256 ? 0 : threadIdx.x / C;
+    const bool active = c < C && row < rows;
+    float s = 0.f;
+    if (active)
+      for (long p = (long)blockIdx.x * rows + row; p < HW; p += (long)gridDim.x * rows) {
+        const long q = (long)n * HW + p;
+        s += a[q * a_cs + c] * (b ? b[q * b_cs + c] : 1.f);
+      }
+    const int cw = C >= 256 ? 256 : C;
+    __syncthreads();
+    if (active) sm[row * cw + (c - c0)] = s;
+    __syncthreads();
+    if (active && row == 0) {
+      float tot = 0.f;
+      for (int r = 0; r < rows; ++r) tot += sm[r * cw + (c - c0)];
+      partial[((size_t)n * gridDim.x + blockIdx.x) * C + c] = tot;
+    }
+  }
+}
+
+__global__ void sample_reduce_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int chunks,
+                                              int NC, int C, float scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NC) return;
+  const int n = i / C, c = i % C;
+  float s = 0.f;
+  for (int k = 0; k < chunks; ++k) s += partial[((size_t)n * chunks + k) * C + c];
+  out[i] = s * scale;
+}
+
+// ------------------------------------------------------------------------------------ squeeze-excite FCs
+// forward (one block per sample): hpre = W1 s + b1 ; h = swish(hpre) ; z = W2 h + b2 ; gate = sigmoid(z)
+__global__ __launch_bounds__(256) void se_fc_forward_kernel(const float* __restrict__ s, const float* __restrict__ w1,
+                                                            const float* __restrict__ b1, const float* __restrict__ w2,
+                                                            const float* __restrict__ b2, float* __restrict__ hpre,
+                                                            float* __restrict__ hact, float* __restrict__ gate, int C,
+                                                            int Cse) {
+  extern __shared__ float sm[];   // s[C] | h[Cse]
+  float* ss = sm; float* hh = sm + C;
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) ss[c] = s[(size_t)n * C + c];
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int j = wave; j < Cse; j += 4) {
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc += w1[(size_t)j * C + c] * ss[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+      const float hp = acc + b1[j];
+      hpre[(size_t)n * Cse + j] = hp;
+      hh[j] = hp / (1.f + expf(-hp));
+      hact[(size_t)n * Cse + j] = hh[j];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float z = b2[c];
+    for (int j = 0; j < Cse; ++j) z += w2[(size_t)c * Cse + j] * hh[j];
+    gate[(size_t)n * C + c] = 1.f / (1.f + expf(-z));
+  }
+}
+
+// backward (one block per sample): gg = d loss / d gate ->
+//   gz = gg*gate*(1-gate) ; gh = W2^T gz ; ghpre = gh * swish'(hpre) ; gs = W1^T ghpre
+// gz and ghpre are kept for the weight gradients (summed over the batch by se_fc_wgrad_kernel).
+__global__ __launch_bounds__(256) void se_fc_backward_kernel(const float* __restrict__ gg, const float* __restrict__ gate,
+                                                             const float* __restrict__ hpre,
+                                                             const float* __restrict__ w1, const float* __restrict__ w2,
+                                                             float* __restrict__ gz, float* __restrict__ ghpre,
+                                                             float* __restrict__ gs, int C, int Cse) {
+  extern __shared__ float sm[];   // gz[C] | ghpre[Cse]
+  float* sz = sm; float* sh = sm + C;
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float g = gate[(size_t)n * C + c];
+    const float v = gg[(size_t)n * C + c] * g * (1.f - g);
+    sz[c] = v; gz[(size_t)n * C + c] = v;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int j = wave; j < Cse; j += 4) {
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc += w2[(size_t)c * Cse + j] * sz[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+      const float x = hpre[(size_t)n * Cse + j], sg = 1.f / (1.f + expf(-x));
+      const float v = acc * (sg + x * sg * (1.f - sg));
+      sh[j] = v; ghpre[(size_t)n * Cse + j] = v;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float acc = 0.f;
+    for (int j = 0; j < Cse; ++j) acc += w1[(size_t)j * C + c] * sh[j];
+    gs[(size_t)n * C + c] = acc;
+  }
+}
+
+// gw[o][i] (+)= sum_n go[n][o] * in[n][i] ; gb[o] (+)= sum_n go[n][o]
+__global__ void fc_wgrad_kernel(const float* __restrict__ go, const float* __restrict__ in, float* __restrict__ gw,
+                                float* __restrict__ gb, int N, int O, int I, int accumulate) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < O * I) {
+    const int o = idx / I, i = idx % I;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += go[(size_t)n * O + o] * in[(size_t)n * I + i];
+    gw[idx] = accumulate ? gw[idx] + s : s;
+  }
+  if (idx < O) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += go[(size_t)n * O + idx];
+    gb[idx] = accumulate ? gb[idx] + s : s;
+  }
+}
+
+// ------------------------------------------------------------------------------------ losses
+// Depth classification (reference CrossEntropyDepth): label bin = trunc((d - dmin) / bin_size) (UD), invalid when
+// outside [0, num_bins) or non-finite (index num_bins); loss = mean over valid pixels of -log softmax[bin].
+// Pass 1 (count_valid) counts the valid pixels; pass 2 evaluates loss / accuracy partial sums and writes
+// g_logits = weight * (softmax - onehot) / n_valid (zero rows for invalid pixels).  32 lanes per pixel, C = 128.
+__device__ __forceinline__ int depth_bin(float d, float dmin, float bin_size, int nb) {
+  const float idx = (d - dmin) / bin_size;
+  if (!(idx >= 0.f) || idx > (float)nb || !isfinite(idx)) return nb;
+  return (int)idx;
+}
+
+__global__ __launch_bounds__(256) void depth_count_valid_kernel(const float* __restrict__ gt, long P, float dmin,
+                                                                float bin_size, int nb, float* __restrict__ partial) {
+  __shared__ float sm[4];
+  float cnt = 0.f;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < P; p += (long)gridDim.x * 256)
+    cnt += depth_bin(gt[p], dmin, bin_size, nb) != nb ? 1.f : 0.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ __launch_bounds__(256) void depth_ce_kernel(const float* __restrict__ logits, int cs, const float* __restrict__ gt,
+                                                       long P, float dmin, float bin_size, int nb,
+                                                       const float* __restrict__ n_valid, float weight,
+                                                       float* __restrict__ g_logits, int g_cs,
+                                                       float* __restrict__ partial /* [blocks][2] */) {
+  __shared__ float sm[8][2];
+  const int sub = threadIdx.x & 31;
+  const long half = (blockIdx.x * 256L + threadIdx.x) >> 5;
+  const long nhalf = ((long)gridDim.x * 256) >> 5;
+  const float inv_n = 1.f / fmaxf(*n_valid, 1.f);
+  float loss = 0.f, hit = 0.f;
+  for (long p = half; p < P; p += nhalf) {
+    const int bin = depth_bin(gt[p], dmin, bin_size, nb);
+    f32x4 gout = {0.f, 0.f, 0.f, 0.f};
+    if (bin != nb) {
+      const f32x4 x = ld4(logits + p * cs + sub * 4);
+      float mx = x[0]; int am = sub * 4;
+#pragma unroll
+      for (int j = 1; j < 4; ++j) if (x[j] > mx) { mx = x[j]; am = sub * 4 + j; }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        const float om = __shfl_xor(mx, o);
+        const int oa = __shfl_xor(am, o);
+        if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
+      }
+      f32x4 e;
+      float se = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { e[j] = expf(x[j] - mx); se += e[j]; }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) se += __shfl_xor(se, o);
+      const float inv = 1.f / se;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = sub * 4 + j;
+        gout[j] = (e[j] * inv - (k == bin ? 1.f : 0.f)) * inv_n * weight;
+        if (k == bin) loss += -(x[j] - mx - logf(se));
+      }
+      if (sub == 0 && am == bin) hit += 1.f;
+    }
+    if (g_logits) st4(g_logits + p * g_cs + sub * 4, gout);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { loss += __shfl_xor(loss, o, 64); hit += __shfl_xor(hit, o, 64); }
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = loss; sm[threadIdx.x >> 6][1] = hit; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = sm[0][0] + sm[1][0] + sm[2][0] + sm[3][0];
+    partial[2 * blockIdx.x + 1] = sm[0][1] + sm[1][1] + sm[2][1] + sm[3][1];
+  }
+}
+
+// masked MSE (reference MSELoss: mean over the elements whose label is not +-inf)
+//   pass 1: partial[blk] = (sum (pred-gt)^2, count) ; pass 2: g = weight * 2 (pred-gt) / count (0 where masked)
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ pred, int p_cs,
+                                                          const float* __restrict__ gt, int g_cs, long P, int C,
+                                                          float* __restrict__ partial) {
+  __shared__ float sm[4][2];
+  float s = 0.f, n = 0.f;
+  const long total = P * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i / C; const int c = (int)(i - p * C);
+    const float g = gt[p * g_cs + c];
+    if (!isinf(g)) { const float d = pred[p * p_cs + c] - g; s += d * d; n += 1.f; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); n += __shfl_xor(n, o, 64); }
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = s; sm[threadIdx.x >> 6][1] = n; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = sm[0][0] + sm[1][0] + sm[2][0] + sm[3][0];
+    partial[2 * blockIdx.x + 1] = sm[0][1] + sm[1][1] + sm[2][1] + sm[3][1];
+  }
+}
+
+__global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ pred, int p_cs,
+                                                       const float* __restrict__ gt, int g_cs, long P, int C,
+                                                       const float* __restrict__ sums /* [2]: sq, count */, float weight,
+                                                       float* __restrict__ g, int o_cs) {
+  const float sc = 2.f * weight / fmaxf(sums[1], 1.f);
+  const long total = P * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i / C; const int c = (int)(i - p * C);
+    const float t = gt[p * g_cs + c];
+    g[p * o_cs + c] = isinf(t) ? 0.f : sc * (pred[p * p_cs + c] - t);
+  }
+}
+
+__global__ void depth_ce_finish_kernel(const float* __restrict__ sums, float* __restrict__ out3) {
+  const float n = fmaxf(out3[2], 1.f);
+  out3[0] = sums[0] / n;
+  out3[1] = sums[1] / n;
+}
+
+__global__ void mse_finish_kernel(const float* __restrict__ sums, float* __restrict__ out2) {
+  out2[0] = sums[0] / fmaxf(sums[1], 1.f);
+  out2[1] = sums[1];
+}
+
+// out[k] = sum_b partial[b][k], k < nk (single block, ordered)
+__global__ void reduce_small_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblocks, int nk) {
+  const int k = threadIdx.x;
+  if (k >= nk) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * nk + k];
+  out[k] = s;
+}
+
+}  // namespace creste
+
+using namespace creste;
+
+extern "C" int64_t creste_conv_wgrad_strided_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int K) {
+  if (N <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || K <= 0) return -1;
+  return (int64_t)wgrad_chunks((long)N * Ho * Wo, K) * K * K * Cout * Cin * 4;
+}
+
+extern "C" int creste_conv_wgrad_strided_f32(const float* x, int x_cs, const float* gy, int gy_cs, float* gw, int N,
+                                             int H, int W, int Ho, int Wo, int Cin, int Cout, int K, int stride,
+                                             int pad_t, int pad_l, int accumulate, void* work, void* stream) {
+  CRESTE_REQUIRE(x && gy && gw && work, "conv_wgrad_strided: null pointer");
+  CRESTE_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cout > 0 && K > 0 && stride > 0 &&
+                     K * K <= 65535, "conv_wgrad_strided: bad dims");
+  const long M = (long)N * Ho * Wo;
+  CRESTE_REQUIRE(M < (1L << 31), "conv_wgrad_strided: N*Ho*Wo overflows int32");
+  int nchunk = wgrad_chunks(M, K);
+  long chunk_px = (M + nchunk - 1) / nchunk;
+  chunk_px = (chunk_px + WGS_PIX - 1) / WGS_PIX * WGS_PIX;
+  nchunk = (int)((M + chunk_px - 1) / chunk_px);
+  hipStream_t s = (hipStream_t)stream;
+  wgrad_strided_partial_kernel<<<dim3(nchunk, K * K), 256, 0, s>>>(x, x_cs, gy, gy_cs, (float*)work, N, H, W, Ho, Wo,
+                                                                  Cin, Cout, K, stride, pad_t, pad_l, (int)chunk_px);
+  CRESTE_CHECK_LAUNCH("wgrad_strided_partial");
+  wgrad_strided_reduce_kernel<<<grid1d((long)Cout * Cin * K * K, 1024), 256, 0, s>>>((const float*)work, gw, nchunk,
+                                                                                    Cout, Cin, K * K, accumulate);
+  CRESTE_CHECK_LAUNCH("wgrad_strided_reduce");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_dwconv_dgrad_f32(const float* gy, const float* w, float* gx, int N, int H, int W, int C, int Ho,
+                                       int Wo, int K, int stride, int pad_t, int pad_l, void* stream) {
+  CRESTE_REQUIRE(gy && w && gx && C % 4 == 0 && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && K > 0 && stride > 0,
+                 "dwconv_dgrad: bad args");
+  dwconv_dgrad_kernel<<<grid1d((long)N * H * W * (C / 4)), 256, 0, (hipStream_t)stream>>>(gy, w, gx, N, H, W, C, Ho, Wo,
+                                                                                         K, stride, pad_t, pad_l);
+  CRESTE_CHECK_LAUNCH("dwconv_dgrad");
+  return CRESTE_OK;
+}
+
+extern "C" int64_t creste_dwconv_wgrad_workspace_bytes(int C, int K) {
+  return C > 0 && K > 0 ? (int64_t)DW_BLOCKS * K * K * C * 4 : -1;
+}
+
+extern "C" int creste_dwconv_wgrad_f32(const float* x, const float* gy, float* gw_taps, int N, int H, int W, int C,
+                                       int Ho, int Wo, int K, int stride, int pad_t, int pad_l, int accumulate,
+                                       void* work, void* stream) {
+  CRESTE_REQUIRE(x && gy && gw_taps && work && C > 0 && N > 0, "dwconv_wgrad: bad args");
+  CRESTE_REQUIRE(K == 3 || K == 5, "dwconv_wgrad: kernel size %d not built (3 or 5)", K);
+  const int rows = 256 / C > 0 ? 256 / C : 1;
+  const long M = (long)N * Ho * Wo;
+  const long per = (M + rows - 1) / rows;
+  const int blocks = (int)(per < DW_BLOCKS ? per : DW_BLOCKS);
+  const size_t smem = (size_t)rows * (C >= 256 ? 256 : C) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (K == 3) dwconv_wgrad_kernel<3><<<blocks, 256, smem, s>>>(x, gy, (float*)work, N, H, W, C, Ho, Wo, stride, pad_t, pad_l);
+  else dwconv_wgrad_kernel<5><<<blocks, 256, smem, s>>>(x, gy, (float*)work, N, H, W, C, Ho, Wo, stride, pad_t, pad_l);
+  CRESTE_CHECK_LAUNCH("dwconv_wgrad");
+  sum_partials_kernel<<<K * K * C, 64, 0, s>>>((const float*)work, gw_taps, blocks, K * K * C, 1.f, accumulate);
+  CRESTE_CHECK_LAUNCH("dwconv_wgrad_sum");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_train_pointwise_f32(int op, const float* a, int a_cs, const float* b, int b_cs, const float* g,
+                                          int g_c, const float* r, float* o, int o_cs, int64_t HW, int64_t P, int C,
+                                          void* stream) {
+  CRESTE_REQUIRE(a && o && op >= 0 && op <= 4 && P > 0 && C > 0 && HW > 0, "train_pointwise: bad args");
+  CRESTE_REQUIRE((op != 1 && op != 3 && op != 4) || b, "train_pointwise: op %d needs b", op);
+  CRESTE_REQUIRE(op < 2 || g, "train_pointwise: op %d needs the gate", op);
+  train_pointwise_kernel<<<grid1d(P * C), 256, 0, (hipStream_t)stream>>>(op, a, a_cs, b, b_cs, g, g_c, r, o, o_cs, HW, P, C);
+  CRESTE_CHECK_LAUNCH("train_pointwise");
+  return CRESTE_OK;
+}
+
+extern "C" int64_t creste_sample_reduce_workspace_bytes(int N, int C) {
+  return N > 0 && C > 0 ? (int64_t)N * SR_CHUNKS * C * 4 : -1;
+}
+
+extern "C" int creste_sample_reduce_f32(const float* a, int a_cs, const float* b, int b_cs, float* out, int N,
+                                        int64_t HW, int C, float scale, void* work, void* stream) {
+  CRESTE_REQUIRE(a && out && work && N > 0 && HW > 0 && C > 0, "sample_reduce: bad args");
+  const int rows = 256 / C > 0 ? 256 / C : 1;
+  const long per = (HW + rows - 1) / rows;
+  const int chunks = (int)(per < SR_CHUNKS ? per : SR_CHUNKS);
+  const size_t smem = (size_t)rows * (C >= 256 ? 256 : C) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  sample_reduce_kernel<<<dim3(chunks, N), 256, smem, s>>>(a, a_cs, b, b_cs, (float*)work, HW, C);
+  CRESTE_CHECK_LAUNCH("sample_reduce");
+  sample_reduce_finalize_kernel<<<(N * C + 255) / 256, 256, 0, s>>>((const float*)work, out, chunks, N * C, C, scale);
+  CRESTE_CHECK_LAUNCH("sample_reduce_finalize");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_se_fc_forward_f32(const float* s, const float* w1, const float* b1, const float* w2,
+                                        const float* b2, float* hpre, float* hact, float* gate, int N, int C, int Cse,
+                                        void* stream) {
+  CRESTE_REQUIRE(s && w1 && b1 && w2 && b2 && hpre && hact && gate && N > 0 && C > 0 && Cse > 0,
+                 "se_fc_forward: bad args");
+  se_fc_forward_kernel<<<N, 256, (size_t)(C + Cse) * 4, (hipStream_t)stream>>>(s, w1, b1, w2, b2, hpre, hact, gate, C,
+                                                                              Cse);
+  CRESTE_CHECK_LAUNCH("se_fc_forward");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_se_fc_backward_f32(const float* gg, const float* gate, const float* hpre, const float* w1,
+                                         const float* w2, float* gz, float* ghpre, float* gs, int N, int C, int Cse,
+                                         void* stream) {
+  CRESTE_REQUIRE(gg && gate && hpre && w1 && w2 && gz && ghpre && gs && N > 0 && C > 0 && Cse > 0,
+                 "se_fc_backward: bad args");
+  se_fc_backward_kernel<<<N, 256, (size_t)(C + Cse) * 4, (hipStream_t)stream>>>(gg, gate, hpre, w1, w2, gz, ghpre, gs,
+                                                                               C, Cse);
+  CRESTE_CHECK_LAUNCH("se_fc_backward");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_fc_wgrad_f32(const float* go, const float* in, float* gw, float* gb, int N, int O, int I,
+                                   int accumulate, void* stream) {
+  CRESTE_REQUIRE(go && in && gw && gb && N > 0 && O > 0 && I > 0, "fc_wgrad: bad args");
+  fc_wgrad_kernel<<<(O * I + 255) / 256, 256, 0, (hipStream_t)stream>>>(go, in, gw, gb, N, O, I, accumulate);
+  CRESTE_CHECK_LAUNCH("fc_wgrad");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_depth_ce_loss_f32(const float* logits, int cs, const float* gt_mm, int64_t P, int num_bins,
+                                        float depth_min, float depth_max, float weight, float* g_logits, int g_cs,
+                                        float* out3 /* loss, accuracy, n_valid */, void* work, void* stream) {
+  CRESTE_REQUIRE(logits && gt_mm && out3 && work && P > 0, "depth_ce_loss: bad args");
+  CRESTE_REQUIRE(num_bins == 128 && cs % 4 == 0 && (!g_logits || g_cs % 4 == 0),
+                 "depth_ce_loss: built for 128 depth bins (32 lanes x 4 logits per pixel)");
+  hipStream_t s = (hipStream_t)stream;
+  float* wk = (float*)work;                       // [1024] count partials | [2048] loss partials | [4] sums
+  const float bin_size = (depth_max - depth_min) / (float)num_bins;
+  const int b1 = grid1d(P, 1024);
+  depth_count_valid_kernel<<<b1, 256, 0, s>>>(gt_mm, P, depth_min, bin_size, num_bins, wk);
+  CRESTE_CHECK_LAUNCH("depth_count_valid");
+  reduce_small_kernel<<<1, 64, 0, s>>>(wk, out3 + 2, b1, 1);
+  CRESTE_CHECK_LAUNCH("depth_count_reduce");
+  const int b2 = grid1d(P * 32, 1024);
+  depth_ce_kernel<<<b2, 256, 0, s>>>(logits, cs, gt_mm, P, depth_min, bin_size, num_bins, out3 + 2, weight, g_logits, g_cs,
+                                     wk + 1024);
+  CRESTE_CHECK_LAUNCH("depth_ce");
+  reduce_small_kernel<<<1, 64, 0, s>>>(wk + 1024, wk + 1024 + 2048, b2, 2);
+  CRESTE_CHECK_LAUNCH("depth_ce_reduce");
+  depth_ce_finish_kernel<<<1, 1, 0, s>>>(wk + 1024 + 2048, out3);   // loss_sum / n_valid, hits / n_valid
+  CRESTE_CHECK_LAUNCH("depth_ce_finish");
+  return CRESTE_OK;
+}
+
+extern "C" int64_t creste_loss_workspace_bytes(void) { return (1024 + 2048 + 8) * 4; }
+
+extern "C" int creste_mse_loss_f32(const float* pred, int p_cs, const float* gt, int g_cs, int64_t P, int C,
+                                   float weight, float* g_pred, int o_cs, float* out2 /* loss, count */, void* work,
+                                   void* stream) {
+  CRESTE_REQUIRE(pred && gt && out2 && work && P > 0 && C > 0, "mse_loss: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  float* wk = (float*)work;
+  const int b = grid1d(P * C, 1024);
+  mse_partial_kernel<<<b, 256, 0, s>>>(pred, p_cs, gt, g_cs, P, C, wk);
+  CRESTE_CHECK_LAUNCH("mse_partial");
+  reduce_small_kernel<<<1, 64, 0, s>>>(wk, wk + 2048, b, 2);
+  CRESTE_CHECK_LAUNCH("mse_reduce");
+  if (g_pred) {
+    mse_grad_kernel<<<grid1d(P * C), 256, 0, s>>>(pred, p_cs, gt, g_cs, P, C, wk + 2048, weight, g_pred, o_cs);
+    CRESTE_CHECK_LAUNCH("mse_grad");
+  }
+  mse_finish_kernel<<<1, 1, 0, s>>>(wk + 2048, out2);
+  CRESTE_CHECK_LAUNCH("mse_finish");
+  return CRESTE_OK;
+}

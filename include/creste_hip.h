@@ -281,6 +281,50 @@ int creste_maxpool2_route_f32(int backward, const float* in, int in_cs, const ui
 int creste_upsample_bwd_nhwc_f32(const float* gy, int gy_cs, int Ho, int Wo, float* gx, int gx_cs, int N, int H1,
                                  int W1, int C, float rh, float rw, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Encoder backward primitives and stage-1 distillation losses (csrc/train_backbone.hip): reference
+ * train_pefree.py:71-99 -> distillation.py:145-207 -> blocks/effnet.py + efficientnet_pytorch MBConv.
+ * --------------------------------------------------------------------------------------------- */
+
+/* conv weight gradient for any stride / static asymmetric padding (stem, ResNet strided convs, heads):
+ * gw[Cout][Cin][K][K] (+)= sum over output pixels q of gy[q][co] * x[q*stride + tap - pad][ci]. */
+int64_t creste_conv_wgrad_strided_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int K);
+int creste_conv_wgrad_strided_f32(const float* x, int x_cs, const float* gy, int gy_cs, float* gw, int N, int H,
+                                  int W, int Ho, int Wo, int Cin, int Cout, int K, int stride, int pad_t, int pad_l,
+                                  int accumulate, void* work, void* stream);
+/* depthwise conv backward (weights tap-major [K*K][C] as in creste_dwconv2d_nhwc_f32): input gradient and
+ * per-tap weight gradient gw_taps[K*K][C] (+)=. */
+int creste_dwconv_dgrad_f32(const float* gy, const float* w, float* gx, int N, int H, int W, int C, int Ho, int Wo,
+                            int K, int stride, int pad_t, int pad_l, void* stream);
+int64_t creste_dwconv_wgrad_workspace_bytes(int C, int K);
+int creste_dwconv_wgrad_f32(const float* x, const float* gy, float* gw_taps, int N, int H, int W, int C, int Ho,
+                            int Wo, int K, int stride, int pad_t, int pad_l, int accumulate, void* work, void* stream);
+/* op 0 swish(a) | 1 swish'(a)*b | 2 a*g[n][c] | 3 b + a*g[n][c] | 4 b*g[n][c] + r[n][c]/HW.
+ * g is [N][g_c] with g_c == C (squeeze-excite gate) or 1 (per-sample scalar: drop-connect). */
+int creste_train_pointwise_f32(int op, const float* a, int a_cs, const float* b, int b_cs, const float* g, int g_c,
+                               const float* r, float* o, int o_cs, int64_t HW, int64_t P, int C, void* stream);
+/* out[n][c] = scale * sum_hw a[n,p,c] * (b ? b[n,p,c] : 1)  (squeeze-excite pool and its gate gradient). */
+int64_t creste_sample_reduce_workspace_bytes(int N, int C);
+int creste_sample_reduce_f32(const float* a, int a_cs, const float* b, int b_cs, float* out, int N, int64_t HW, int C,
+                             float scale, void* work, void* stream);
+/* squeeze-excite bottleneck: hpre = W1 s + b1, hact = swish(hpre), gate = sigmoid(W2 hact + b2); backward gives
+ * gz = d/d(W2 hact + b2), ghpre = d/d hpre, gs = d/d s; weight gradients via creste_fc_wgrad_f32. */
+int creste_se_fc_forward_f32(const float* s, const float* w1, const float* b1, const float* w2, const float* b2,
+                             float* hpre, float* hact, float* gate, int N, int C, int Cse, void* stream);
+int creste_se_fc_backward_f32(const float* gg, const float* gate, const float* hpre, const float* w1, const float* w2,
+                              float* gz, float* ghpre, float* gs, int N, int C, int Cse, void* stream);
+int creste_fc_wgrad_f32(const float* go, const float* in, float* gw, float* gb, int N, int O, int I, int accumulate,
+                        void* stream);
+/* CrossEntropyDepth (loss_utils.py:477-527, UD bins): out3 = {loss, accuracy, n_valid}; g_logits (optional) =
+ * weight * d loss / d logits.  MSELoss (:606-647, +-inf labels masked): out2 = {loss, count}.
+ * work: creste_loss_workspace_bytes(). */
+int64_t creste_loss_workspace_bytes(void);
+int creste_depth_ce_loss_f32(const float* logits, int cs, const float* gt_mm, int64_t P, int num_bins, float depth_min,
+                             float depth_max, float weight, float* g_logits, int g_cs, float* out3, void* work,
+                             void* stream);
+int creste_mse_loss_f32(const float* pred, int p_cs, const float* gt, int g_cs, int64_t P, int C, float weight,
+                        float* g_pred, int o_cs, float* out2, void* work, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
