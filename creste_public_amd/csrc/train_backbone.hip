@@ -70,6 +70,119 @@ __global__ __launch_bounds__(256) void wgrad_strided_partial_kernel(
   }
 }
 
+// LDS-tiled variant for the wide layers: a workgroup (2 x 2 waves) owns a (64*WM) x (64*WN) block of one tap's
+// [Cout x Cin] gradient and walks its pixel chunk in steps of 16; per step the gy rows (A^T, 16 x BM) and the
+// shifted x rows (B, 16 x BN) are staged ONCE in LDS (float4 global loads, zero fill outside the image) and feed
+// 8 * WM * WN fp32 MFMAs per wave -- the direct kernel above re-reads both operands from L2 for every 32x32 tile
+// (24 TFLOP/s on 496->496); register-staged double buffering, one barrier per step.
+constexpr int WT_KS = 16;
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_tiled_kernel(
+    const float* __restrict__ x, int x_cs, const float* __restrict__ gy, int gy_cs, float* __restrict__ partial,
+    int N, int H, int W, int Ho, int Wo, int Cin, int Cout, int K, int stride, int pad_t, int pad_l, int chunk_px,
+    int tiles_co, int tiles_ci) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int A_F4 = WT_KS * BM / 4 / 256, B_F4 = WT_KS * BN / 4 / 256;     // float4 loads per thread per step
+  static_assert(A_F4 >= 1 && B_F4 >= 1, "tile too small for 256 loader threads");
+  __shared__ __attribute__((aligned(16))) float As[2][WT_KS][BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][WT_KS][BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  int id = blockIdx.x;
+  const int tci = id % tiles_ci; id /= tiles_ci;
+  const int tco = id % tiles_co;
+  const int chunk = id / tiles_co;
+  const int tap = blockIdx.y;
+  const int ky = tap / K - pad_t, kx = tap % K - pad_l;
+  const int co0 = tco * BM, ci0 = tci * BN;
+  const int M = N * Ho * Wo;
+  const int p0 = chunk * chunk_px, p1 = min(M, p0 + chunk_px);
+
+  f32x16 c[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[i][j][r] = 0.f;
+
+  f32x4 ra[A_F4], rb[B_F4];
+  auto load = [&](int p) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < A_F4; ++u) {
+      const int e = tid + 256 * u;                   // float4 index inside the 16 x BM tile
+      const int k = e / (BM / 4), cq = e % (BM / 4);
+      const int q = p + k, co = co0 + cq * 4;
+      ra[u] = (q < p1 && co < Cout) ? ld4(gy + (long)q * gy_cs + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < B_F4; ++u) {
+      const int e = tid + 256 * u;
+      const int k = e / (BN / 4), cq = e % (BN / 4);
+      const int q = p + k, ci = ci0 + cq * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (q < p1 && ci < Cin) {
+        const int rowi = q / Wo;
+        const int ox = q - rowi * Wo;
+        const int n = rowi / Ho;
+        const int oy = rowi - n * Ho;
+        const int iy = oy * stride + ky, ix = ox * stride + kx;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = ld4(x + (((long)n * H + iy) * W + ix) * x_cs + ci);
+      }
+      rb[u] = v;
+    }
+  };
+  auto store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < A_F4; ++u) {
+      const int e = tid + 256 * u;
+      st4(&As[buf][e / (BM / 4)][(e % (BM / 4)) * 4], ra[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < B_F4; ++u) {
+      const int e = tid + 256 * u;
+      st4(&Bs[buf][e / (BN / 4)][(e % (BN / 4)) * 4], rb[u]);
+    }
+  };
+
+  load(p0);
+  store(0);
+  __syncthreads();
+  int buf = 0;
+  for (int p = p0; p < p1; p += WT_KS) {
+    const bool more = p + WT_KS < p1;
+    if (more) load(p + WT_KS);
+#pragma unroll
+    for (int kk = 0; kk < WT_KS; kk += 2) {
+      float a[WM], b[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = As[buf][kk + lh][wm * 32 * WM + i * 32 + li];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[j] = Bs[buf][kk + lh][wn * 32 * WN + j * 32 + li];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], c[i][j], 0, 0, 0);
+    }
+    if (more) store(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  float* out = partial + ((size_t)chunk * K * K + tap) * Cout * Cin;
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = ci0 + wn * 32 * WN + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = co0 + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < Cout && col < Cin) out[(size_t)row * Cin + col] = c[i][j][r];
+      }
+    }
+}
+
 __global__ void wgrad_strided_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw, int nchunk,
                                             int Cout, int Cin, int KK, int accumulate) {
   const int total = Cout * Cin * KK;
@@ -484,14 +597,38 @@ extern "C" int creste_conv_wgrad_strided_f32(const float* x, int x_cs, const flo
                      K * K <= 65535, "conv_wgrad_strided: bad dims");
   const long M = (long)N * Ho * Wo;
   CRESTE_REQUIRE(M < (1L << 31), "conv_wgrad_strided: N*Ho*Wo overflows int32");
-  int nchunk = wgrad_chunks(M, K);
-  long chunk_px = (M + nchunk - 1) / nchunk;
-  chunk_px = (chunk_px + WGS_PIX - 1) / WGS_PIX * WGS_PIX;
-  nchunk = (int)((M + chunk_px - 1) / chunk_px);
   hipStream_t s = (hipStream_t)stream;
-  wgrad_strided_partial_kernel<<<dim3(nchunk, K * K), 256, 0, s>>>(x, x_cs, gy, gy_cs, (float*)work, N, H, W, Ho, Wo,
-                                                                  Cin, Cout, K, stride, pad_t, pad_l, (int)chunk_px);
-  CRESTE_CHECK_LAUNCH("wgrad_strided_partial");
+  int nchunk;
+  const bool vec = Cin % 4 == 0 && Cout % 4 == 0 && x_cs % 4 == 0 && gy_cs % 4 == 0 &&
+                   ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0;
+  if (vec && Cin >= 32 && Cout >= 32) {
+    const bool big = Cin > 64 && Cout > 64;
+    const int bm = big ? 128 : 64;
+    const int tiles_co = (Cout + bm - 1) / bm, tiles_ci = (Cin + bm - 1) / bm;
+    const long tiles = (long)tiles_co * tiles_ci * K * K;
+    long want = (2048 + tiles - 1) / tiles;                       // ~2048 workgroups in flight
+    const long cap = wgrad_chunks(M, K);                          // the workspace was sized for at most this many
+    nchunk = (int)(want < 1 ? 1 : (want > cap ? cap : want));
+    long chunk_px = (M + nchunk - 1) / nchunk;
+    chunk_px = (chunk_px + WT_KS - 1) / WT_KS * WT_KS;
+    nchunk = (int)((M + chunk_px - 1) / chunk_px);
+    const dim3 grid(nchunk * tiles_co * tiles_ci, K * K);
+    if (big)
+      wgrad_tiled_kernel<2, 2><<<grid, 256, 0, s>>>(x, x_cs, gy, gy_cs, (float*)work, N, H, W, Ho, Wo, Cin, Cout, K, stride,
+                                                   pad_t, pad_l, (int)chunk_px, tiles_co, tiles_ci);
+    else
+      wgrad_tiled_kernel<1, 1><<<grid, 256, 0, s>>>(x, x_cs, gy, gy_cs, (float*)work, N, H, W, Ho, Wo, Cin, Cout, K, stride,
+                                                   pad_t, pad_l, (int)chunk_px, tiles_co, tiles_ci);
+    CRESTE_CHECK_LAUNCH("wgrad_tiled");
+  } else {
+    nchunk = wgrad_chunks(M, K);
+    long chunk_px = (M + nchunk - 1) / nchunk;
+    chunk_px = (chunk_px + WGS_PIX - 1) / WGS_PIX * WGS_PIX;
+    nchunk = (int)((M + chunk_px - 1) / chunk_px);
+    wgrad_strided_partial_kernel<<<dim3(nchunk, K * K), 256, 0, s>>>(x, x_cs, gy, gy_cs, (float*)work, N, H, W, Ho, Wo,
+                                                                    Cin, Cout, K, stride, pad_t, pad_l, (int)chunk_px);
+    CRESTE_CHECK_LAUNCH("wgrad_strided_partial");
+  }
   wgrad_strided_reduce_kernel<<<grid1d((long)Cout * Cin * K * K, 1024), 256, 0, s>>>((const float*)work, gw, nchunk,
                                                                                     Cout, Cin, K * K, accumulate);
   CRESTE_CHECK_LAUNCH("wgrad_strided_reduce");

@@ -65,3 +65,69 @@ def allreduce_mean_grads(params) -> int:
             p.grad.copy_(g)
         off += n
     return int(flat.numel())
+
+
+class GradArena(dict):
+    """Gradient store of one backward pass: every parameter's gradient is a view into ONE flat fp32 buffer laid
+    out in the order in which the backward finishes them, so data-parallel averaging needs no gather/scatter
+    copies and can start while the backward is still running.
+
+    `order`: parameters in backward-completion order.  The backward calls `done(params)` after the op owning
+    them has run; whenever the completed prefix crosses a bucket boundary the bucket goes out as an async
+    all-reduce (RCCL on its own stream; ring all-reduce over xGMI is per-link bound, so a few 32 MB buckets --
+    not hundreds of per-tensor calls -- keep the links busy while the remaining wgrad kernels run).
+    `finish()` sends the tail, waits, and divides by the world size.  Without an initialised process group it
+    is just the arena.  Keys are id(param) (what the training engines use)."""
+
+    def __init__(self, order, bucket_bytes: int = 32 << 20, device=None):
+        super().__init__()
+        self.order = [p for p in order]
+        dev = device or self.order[0].device
+        self.offsets, n = {}, 0
+        for p in self.order:
+            self.offsets[id(p)] = (n, p.numel(), p.shape)
+            n += p.numel()
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.views = {k: self.flat[o:o + c].view(shape) for k, (o, c, shape) in self.offsets.items()}
+        self.pos = {id(p): i for i, p in enumerate(self.order)}
+        self.finished = [False] * len(self.order)
+        self.prefix = 0                      # number of leading parameters that are final
+        self.sent = 0                        # elements already handed to the collective
+        self.bucket = max(1, bucket_bytes // 4)
+        self.handles = []
+        self.touched = set()
+
+    def view(self, p):
+        """the arena slice of parameter p (registers it as written)."""
+        self.touched.add(id(p))
+        v = self.views[id(p)]
+        self[id(p)] = v
+        return v
+
+    def _send(self, upto):
+        if upto > self.sent and is_dist():
+            self.handles.append(dist.all_reduce(self.flat[self.sent:upto], op=dist.ReduceOp.SUM, async_op=True))
+        self.sent = max(self.sent, upto)
+
+    def done(self, params):
+        for p in params:
+            i = self.pos.get(id(p))
+            if i is not None:
+                if id(p) not in self.touched:            # no gradient reached it on this rank: contributes zeros
+                    self.view(p).zero_()
+                self.finished[i] = True
+        while self.prefix < len(self.order) and self.finished[self.prefix]:
+            self.prefix += 1
+        end = self.offsets[id(self.order[self.prefix - 1])] if self.prefix else (0, 0, None)
+        upto = end[0] + end[1]
+        if upto - self.sent >= self.bucket:
+            self._send(upto)
+
+    def finish(self):
+        self.done([p for p in self.order if not self.finished[self.pos[id(p)]]])
+        self._send(self.flat.numel())
+        for h in self.handles:
+            h.wait()
+        if is_dist():
+            self.flat /= dist.get_world_size()
+        return self

@@ -100,3 +100,61 @@ class IRLTrainer:
         if "lr_schedulers" in ck:
             self.scheduler.load_state_dict(ck["lr_schedulers"][0])
         self.epoch, self.global_step = ck.get("epoch", 0), ck.get("global_step", 0)
+
+
+def distillation_cfg(image_size=(512, 612)):
+    """Stage-1 distillation hyper-parameters (reference configs/model/distillation/effnet_ds2_dinov2_128.yaml:
+    optimiser :63-71, losses :72-88) on top of the backbone config."""
+    from .config import terrainnet_cfg
+    cfg = terrainnet_cfg(image_size)
+    disc = dict(cfg["discretize"])
+    cfg["optimizer"] = dict(name="Adam", beta1=0.9, beta2=0.999, lr=0.0005, eps=1e-7)
+    cfg["lr_scheduler"] = dict(name="ExponentialLR", gamma=0.98)
+    cfg["loss"] = [
+        dict(name="CrossEntropyDepth", weight=0.5, pred_key="outputs/depth_preds_logits",
+             lab_key="inputs/depth_label", discretize=disc),
+        dict(name="SmoothL1Depth", weight=0.1, pred_key="outputs/depth_preds_bins", lab_key="inputs/depth_label",
+             beta=0.5, discretize=disc),
+        dict(name="MSELoss", weight=1.0, pred_key="outputs/dino_pe_feats", lab_key="inputs/fimg_label",
+             overlap_only=False)]
+    return cfg
+
+
+class DistillTrainer(IRLTrainer):
+    """Stage-1 distillation step (reference train_pefree.py:71-99, Lightning automatic optimisation + DDP):
+    zero_grad -> DistillationBackbone(rgbd) in training mode -> LossManager -> backward -> optimizer.step.
+    Data parallel: the backbone's gradients are produced into one flat buffer in backward-completion order and
+    all-reduced bucket by bucket while the backward runs (dist_utils.GradArena) -- the ~102 MB exchange of
+    SURVEY section 8e; BatchNorm statistics stay per rank, as in the reference (no SyncBN)."""
+
+    def __init__(self, model, loss_manager, model_cfg, bucket_mb: int = 32):
+        super().__init__(model, loss_manager, model_cfg)
+        oc = model_cfg["optimizer"]
+        self.optimizer = torch.optim.Adam(self.params, betas=(oc["beta1"], oc["beta2"]), lr=oc["lr"])
+        self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=model_cfg["lr_scheduler"]["gamma"])
+        self.bucket_bytes = bucket_mb << 20
+
+    def training_step(self, batch: dict) -> dict:
+        """batch: {'image' [B,1,4,H,W], 'depth_label' [B,1,Hs,Ws] mm, 'fimg_label' [B,1,Z,Hs,Ws], ...}"""
+        self.model.train()
+        self.optimizer.zero_grad()
+        outputs = self.model(batch["image"])
+        eng = getattr(self.model, "_train_engine", None)
+        if eng is not None:                               # HIP engine: gradients in a flat arena, comm overlapped
+            eng.arena, eng.bucket_bytes = True, self.bucket_bytes
+        with torch.no_grad():
+            merged = tu.merge_dict(("inputs", batch), ("outputs", outputs))
+            merged["task"] = None
+        for k, v in outputs.items():                      # keep the autograd graph of the differentiable outputs
+            merged[f"outputs/{k}"] = v
+        loss_dict, meta = self.loss(merged)
+        loss = sum(w * v for w, v in loss_dict.values())
+        loss.backward()
+        if eng is None:                                   # stand-in models (CPU tests): one flat all-reduce afterwards
+            dist_utils.allreduce_mean_grads(self.params)
+        self.optimizer.step()
+        logs = {f"train/{k}": (w * v.detach()) for k, (w, v) in loss_dict.items()}
+        logs.update({f"train/{k}": v.detach() for k, v in meta.items()})
+        logs["train/loss"] = loss.detach()
+        self.global_step += 1
+        return logs

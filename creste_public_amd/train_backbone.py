@@ -21,20 +21,13 @@ from torch import nn
 from . import _lib, hipnn, ops
 from .ops import Act, HipLibraryError, _stream
 from .train_ops import BNT, UpT, _new, _px, as_act, pointwise2
+from .train_ops import grad_slot as _acc
 
 DROP_CONNECT = 0.2          # efficientnet_pytorch global_params.drop_connect_rate of efficientnet-b0
 
 
 def _lib_():
     return _lib.load()
-
-
-def _acc(grads: dict, p: torch.Tensor):
-    """-> (tensor to write into, accumulate flag) for parameter p."""
-    acc = id(p) in grads
-    if not acc:
-        grads[id(p)] = torch.empty_like(p, memory_format=torch.contiguous_format)
-    return grads[id(p)], int(acc)
 
 
 def tpoint(op: int, a: Act, b: Act | None = None, gate: torch.Tensor | None = None, r: torch.Tensor | None = None,
@@ -199,11 +192,10 @@ class DwConvT:
             _lib.check(lib.creste_dwconv_wgrad_f32(x.ptr, gy.ptr, gt.data_ptr(), x.N, x.H, x.W, Cn, gy.H, gy.W, self.K,
                                                    self.s, self.pad[0], self.pad[2], 0, work.data_ptr(), _stream()),
                        "dwconv_wgrad")
-            g = gt.t().reshape(w.shape)                                          # layout change back to [C,1,K,K]
-            if id(w) in grads:
-                grads[id(w)] = grads[id(w)] + g
-            else:
-                grads[id(w)] = g.contiguous()
+            dst, acc = _acc(grads, w)
+            if acc:
+                raise RuntimeError("depthwise weight gradient written twice in one backward")
+            dst.copy_(gt.t().reshape(w.shape))                                  # layout change back to [C,1,K,K]
         if not need_input:
             return None
         gx = _new(x)
@@ -272,7 +264,12 @@ class Seq:
     def bwd(self, gy, grads, need_input=True):
         for i in range(len(self.ops) - 1, -1, -1):
             gy = self.ops[i].bwd(gy, grads, need_input=need_input or i > 0)
+            if hasattr(grads, "done"):
+                grads.done(self.ops[i].params())
         return gy
+
+    def backward_order(self):
+        return [p for o in reversed(self.ops) for p in o.params()]
 
 
 class MBConvT:
@@ -380,6 +377,8 @@ class BackboneTrainEngine:
         self.dino_head = Seq(_stack_ops(model.dino_head.model))
         self.model = model
         self.gen = 0
+        self.arena = False            # True: gradients live in one flat buffer, all-reduced bucket by bucket during backward
+        self.bucket_bytes = 32 << 20
 
     def params(self):
         ps = self.stem.params()
@@ -388,6 +387,21 @@ class BackboneTrainEngine:
         for u in self.ups:
             ps += u.params()
         return ps + self.final.params() + self.depth_head.params() + self.dino_head.params()
+
+    def backward_order(self):
+        """parameters in the order the backward finishes them (layout of dist_utils.GradArena)."""
+        order = self.depth_head.backward_order() + self.dino_head.backward_order() + list(self.final.params())
+        for u in reversed(self.ups):
+            order += u.convs.backward_order()
+        for b in reversed(self.blocks):
+            order += b.body.backward_order()
+        return order + self.stem.backward_order()
+
+    def new_grad_store(self):
+        if self.arena:
+            from .dist_utils import GradArena
+            return GradArena(self.backward_order(), self.bucket_bytes)
+        return {}
 
     def forward(self, x: Act):
         h = self.stem.fwd(x)
@@ -420,6 +434,8 @@ class BackboneTrainEngine:
         if gf is None:
             return
         g = self.final.bwd(gf, grads, True)
+        if hasattr(grads, "done"):
+            grads.done(self.final.params())
         pending = {}                                      # output index -> cotangent from a decoder skip
         for j in range(len(self.ups) - 1, -1, -1):
             g, g_skip = self.ups[j].bwd(g, grads)
@@ -453,9 +469,11 @@ class BackboneFn(torch.autograd.Function):
         eng = ctx.eng
         if ctx.gen != eng.gen:
             raise RuntimeError("backbone (HIP training path): backward of a stale forward; run forward/backward in pairs")
-        grads = {}
+        grads = eng.new_grad_store()
         a = lambda t: as_act(t) if t is not None else None       # noqa: E731
         eng.backward(a(g_logits), a(g_feats), a(g_dino), grads)
+        if hasattr(grads, "finish"):
+            grads.finish()                                        # tail bucket, wait, average over ranks
         return (None, None, *(grads.get(id(p)) for p in eng.params()))
 
 

@@ -55,6 +55,18 @@ def as_act(t: torch.Tensor, pad_to4=False) -> Act:
     return ops.nchw_to_nhwc(t.contiguous())
 
 
+def grad_slot(grads: dict, p: torch.Tensor):
+    """-> (tensor the gradient of parameter p is written into, accumulate flag).  `grads` is a plain dict keyed
+    by id(param) or a dist_utils.GradArena (then the tensor is a slice of the flat all-reduce buffer)."""
+    acc = id(p) in grads
+    if not acc:
+        if hasattr(grads, "view"):
+            grads.view(p)
+        else:
+            grads[id(p)] = torch.empty_like(p, memory_format=torch.contiguous_format)
+    return grads[id(p)], int(acc)
+
+
 def pointwise2(op: int, a: Act, b: Act | None, out: Act | None = None) -> Act:
     out = out or _new(a)
     _lib.check(_lib_().creste_pointwise2_f32(op, a.ptr, a.cs, b.ptr if b is not None else None,
@@ -112,9 +124,7 @@ class ConvT:
         w = self.conv.weight
         Cout, Cin = w.shape[:2]
         lib = _lib_()
-        acc = id(w) in grads
-        if not acc:
-            grads[id(w)] = torch.empty_like(w, memory_format=torch.contiguous_format)
+        _, acc = grad_slot(grads, w)
         work = torch.empty(lib.creste_conv_wgrad_workspace_bytes(x.N, x.H, x.W, Cin, Cout, self.K),
                            dtype=torch.uint8, device=w.device)
         _lib.check(lib.creste_conv_wgrad_f32(x.ptr, x.cs, gy.ptr, gy.cs, grads[id(w)].data_ptr(), x.N, x.H, x.W, Cin,
@@ -188,11 +198,8 @@ class BNT:
         gg = gb = None
         acc = 0
         if grads is not None:
-            acc = int(id(bn.weight) in grads)
-            if not acc:
-                grads[id(bn.weight)] = torch.empty_like(bn.weight)
-                grads[id(bn.bias)] = torch.empty_like(bn.bias)
-            gg, gb = grads[id(bn.weight)], grads[id(bn.bias)]
+            gg, acc = grad_slot(grads, bn.weight)
+            gb, _ = grad_slot(grads, bn.bias)
         has_t = gyd is not None
         _lib.check(_lib_().creste_bn_train_backward_f32(
             self.x.ptr, self.x.cs, self.xd.ptr if has_t else None, self.xd.cs if has_t else 0,

@@ -99,3 +99,63 @@ def test_two_rank_gloo_irl_grad_allreduce_and_timing():
         assert same
         assert err <= 1e-6 * max(scale, 1.0)
         assert t_max == 2.0 and frames == 4.0   # max-over-ranks time, whole-job frame count
+
+
+def _arena_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.zeros(s)) for s in [(10,), (3, 4), (7,), (2, 2, 2), (5,), (33,)]]
+        order = list(reversed(params))                     # the backward finishes the last layer first
+        arena = du.GradArena(order, bucket_bytes=16 * 4)   # 16-element buckets -> several async all-reduces
+        g = torch.Generator().manual_seed(100 + rank)
+        mine = {}
+        for i, p in enumerate(order):
+            if i == 2 and rank == 1:                       # a parameter that received no gradient on this rank
+                arena.done([p])
+                mine[id(p)] = torch.zeros_like(p)
+                continue
+            v = torch.randn(p.shape, generator=g)
+            arena.view(p).copy_(v)
+            mine[id(p)] = v
+            arena.done([p])
+        n_async = len(arena.handles)
+        arena.finish()
+        # expected: mean over ranks of what every rank wrote
+        flat_mine = torch.cat([mine[id(p)].flatten() for p in order])
+        gathered = [torch.zeros_like(flat_mine) for _ in range(world)]
+        dist.all_gather(gathered, flat_mine)
+        expect = torch.stack(gathered).mean(0)
+        got = torch.cat([arena[id(p)].flatten() for p in order])
+        q.put((rank, float((got - expect).abs().max()), n_async, all(arena[id(p)].shape == p.shape for p in params),
+               arena.flat.data_ptr() == arena[id(order[0])].data_ptr()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_grad_arena_bucketed_overlap():
+    """dist_utils.GradArena: gradients written in backward order into one flat buffer, buckets all-reduced while
+    later gradients are still being produced, averaged result identical on every rank."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_arena_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, n_async, shapes_ok, zero_copy in res:
+        assert err < 1e-6 and shapes_ok and zero_copy
+        assert n_async >= 2                    # buckets left before finish(): the exchange overlaps the backward
+
+
+def test_grad_arena_without_process_group():
+    params = [torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.zeros(2, 3))]
+    a = du.GradArena(params)
+    a.view(params[0]).fill_(2.0)
+    a.done([params[0]])
+    a.finish()                                 # params[1] never written -> zeros
+    assert torch.equal(a[id(params[0])], torch.full((4,), 2.0)) and float(a[id(params[1])].abs().sum()) == 0.0

@@ -27,7 +27,11 @@ def _rel(a, b):
     (2, 4, 33, 47, 32, 3, 2, (0, 1, 0, 1), False),      # stem: stride 2, asymmetric static pad
     (2, 24, 17, 20, 40, 3, 1, (1, 1, 1, 1), False),
     (3, 16, 9, 11, 96, 1, 1, (0, 0, 0, 0), True),
-    (1, 36, 12, 10, 20, 3, 1, (1, 1, 1, 1), True)])
+    (1, 36, 12, 10, 20, 3, 1, (1, 1, 1, 1), True),
+    (2, 96, 19, 23, 136, 3, 1, (1, 1, 1, 1), False),    # LDS-tiled wgrad, 128x128 tiles with ragged edges
+    (1, 200, 9, 31, 72, 1, 1, (0, 0, 0, 0), False),     # 128-tile in Cin only -> 64x64 tiles
+    (2, 48, 21, 18, 40, 5, 1, (2, 2, 2, 2), True),      # 64x64 tiles, 25 taps
+    (2, 64, 20, 24, 64, 3, 2, (0, 1, 0, 1), False)])    # strided, tiled
 def test_conv_general_backward(N, Cin, H, W, Cout, K, s, pad, bias):
     from creste_public_amd import train_backbone as TB, train_ops as T
     g = torch.Generator().manual_seed(Cin + K)
@@ -248,3 +252,64 @@ def test_drop_connect_follows_the_host_rng():
     torch.manual_seed(100)                                   # other masks -> a different activation
     out2 = model(rgbd.cuda())
     assert _rel(out2["depth_preds_feats"], out_r["depth_preds_feats"]) > 1e-2
+
+
+def _distill_batch(B, H, W, seed=0):
+    from creste_public_amd import synth
+    rgbd, _ = synth.make_frames(B, H, W, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    Hs, Ws = H // 4, W // 4
+    return {"image": rgbd.cuda(), "depth_label": (torch.rand(B, 1, Hs, Ws, generator=g) * 26000.0).cuda(),
+            "fimg_label": torch.randn(B, 1, 128, Hs, Ws, generator=g).cuda()}
+
+
+def test_distill_trainer_steps_and_arena_equivalence(tmp_path):
+    """row H (train_pefree.py): Adam steps reduce the loss on a fixed batch; gradients produced into the flat
+    all-reduce arena are bit-identical to the per-tensor ones; Lightning-layout checkpoint round trip."""
+    from creste_public_amd import harness
+    from creste_public_amd.creste.models.distillation import DistillationBackbone
+    from creste_public_amd.creste.utils.loss_utils import LossManager
+    H, W, B = 64, 96, 4
+    harness.seed_everything(3)
+    cfg = harness.distillation_cfg((H, W))
+    model = DistillationBackbone(cfg).cuda()
+    batch = _distill_batch(B, H, W)
+    lm = LossManager(cfg)
+
+    # per-tensor gradients vs the arena (same RNG state for the drop-connect masks)
+    grads = []
+    for arena in (False, True):
+        torch.manual_seed(11)
+        model.train()
+        model.zero_grad(set_to_none=True)
+        out = model(batch["image"])
+        model._train_engine.arena = arena
+        td = {f"outputs/{k}": v for k, v in out.items()}
+        td.update({f"inputs/{k}": v for k, v in batch.items()})
+        td["task"] = None
+        ld, _ = lm(td)
+        sum(w * v for w, v in ld.values()).backward()
+        grads.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 200
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n
+
+    tr = harness.DistillTrainer(model, lm, cfg)
+    losses = [float(tr.training_step(batch)["train/loss"]) for _ in range(6)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    assert tr.global_step == 6 and model._train_engine.arena
+    tr.on_train_epoch_end()
+    assert abs(tr.optimizer.param_groups[0]["lr"] - 0.0005 * 0.98) < 1e-12
+    path = tmp_path / "distill.ckpt"
+    tr.save_checkpoint(str(path))
+    ck = torch.load(path, weights_only=False)
+    assert all(k.startswith("model.") for k in ck["state_dict"])
+    model2 = DistillationBackbone(cfg)
+    tr2 = harness.DistillTrainer(model2, lm, cfg)
+    tr2.load_checkpoint(str(path))
+    for (k, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert torch.equal(a.cpu(), b), k
+    model.eval()                                       # the trained weights run on the inference path unchanged
+    with torch.no_grad():
+        out = model(batch["image"])
+    assert torch.isfinite(out["depth_preds_metric"]).all()
