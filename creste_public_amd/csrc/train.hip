@@ -106,7 +106,8 @@ __global__ void flip_weight_kernel(const float* __restrict__ w, float* __restric
 //   MODE 2: f0 = xd, f1 = xh * xd                    (tangent moments)
 //   MODE 3: f0 = gy, f1 = gy * xh [, f2 = G, f3 = G * xh, f4 = G * t]   t = (xd - mdot) - xh * c
 constexpr int MOM_MAXK = 5;
-constexpr int MOM_BLOCKS = 256;
+constexpr int MOM_BLOCKS = 2048;          // upper bound; see mom_blocks()
+__host__ __device__ inline int mom_blocks(int C) { const int b = 262144 / C; return b < 256 ? 256 : (b > MOM_BLOCKS ? MOM_BLOCKS : b); }
 
 struct MomArgs {
   const float *x, *xd, *gy, *G;
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(256) void moments_kernel(const MomArgs a) {
     const float is = (MODE >= 2) ? a.invstd[c] : 0.f;
     const float md = (MODE == 3 && a.G) ? a.mdot[c] : 0.f;
     const float cc = (MODE == 3 && a.G) ? a.cc[c] : 0.f;
+#pragma unroll 4
     for (long p = (long)blockIdx.x * rows + row; p < a.P; p += (long)gridDim.x * rows) {
       const float xv = a.x[p * a.x_cs + c];
       if (MODE == 0) s[0] += xv;
@@ -420,7 +422,7 @@ static int run_moments(int mode, MomArgs a, float* out, float* partial, hipStrea
   CRESTE_REQUIRE(a.C > 0 && a.P > 0, "bn moments: bad dims");
   const int rows = a.C >= 256 ? 1 : 256 / a.C;
   const long per = (a.P + rows - 1) / rows;
-  const int blocks = (int)(per < MOM_BLOCKS ? per : MOM_BLOCKS);
+  const int blocks = (int)(per < mom_blocks(a.C) ? per : mom_blocks(a.C));
   a.partial = partial;
   const size_t smem = (size_t)a.nk * 256 * sizeof(float);
   const dim3 grid(blocks, (a.C + 255) / 256);
@@ -434,7 +436,7 @@ static int run_moments(int mode, MomArgs a, float* out, float* partial, hipStrea
   return CRESTE_OK;
 }
 
-extern "C" int64_t creste_bn_workspace_bytes(int C) { return C > 0 ? (int64_t)MOM_BLOCKS * MOM_MAXK * C * 4 : -1; }
+extern "C" int64_t creste_bn_workspace_bytes(int C) { return C > 0 ? (int64_t)mom_blocks(C) * MOM_MAXK * C * 4 : -1; }
 
 extern "C" int creste_bn_train_forward_f32(const float* x, int x_cs, int64_t P, int C, const float* gamma,
                                            const float* beta, float eps, float momentum, float* running_mean,

@@ -234,7 +234,8 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const float* __restri
 }
 
 // partial[blk][tap][c] = sum over the block's output pixels of gy[q][c] * x[q*s + tap - pad][c]
-constexpr int DW_BLOCKS = 256;
+constexpr int DW_BLOCKS = 2048;           // upper bound; see dw_blocks()
+static inline int dw_blocks(int C, int K) { const int b = 1048576 / (C * K * K); return b < 128 ? 128 : (b > DW_BLOCKS ? DW_BLOCKS : b); }
 template <int K>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                            float* __restrict__ partial, int N, int H, int W, int C,
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void train_pointwise_kernel(int op, const floa
 }
 
 // per-sample channel sums: out[n][c] = scale * sum_hw a[n,p,c] * (b ? b[n,p,c] : 1); grid (chunks, N)
-constexpr int SR_CHUNKS = 64;
+constexpr int SR_CHUNKS = 256;
 __global__ __launch_bounds__(256) void sample_reduce_kernel(const float* __restrict__ a, int a_cs,
                                                             const float* __restrict__ b, int b_cs,
                                                             float* __restrict__ partial, long HW, int C) {
@@ -335,6 +336,7 @@ __global__ __launch_bounds__(256) void sample_reduce_kernel(const float* __restr
     const bool active = c < C && row < rows;
     float s = 0.f;
     if (active)
+#pragma unroll 4
       for (long p = (long)blockIdx.x * rows + row; p < HW; p += (long)gridDim.x * rows) {
         const long q = (long)n * HW + p;
         s += a[q * a_cs + c] * (b ? b[q * b_cs + c] : 1.f);
@@ -646,7 +648,7 @@ extern "C" int creste_dwconv_dgrad_f32(const float* gy, const float* w, float* g
 }
 
 extern "C" int64_t creste_dwconv_wgrad_workspace_bytes(int C, int K) {
-  return C > 0 && K > 0 ? (int64_t)DW_BLOCKS * K * K * C * 4 : -1;
+  return C > 0 && K > 0 ? (int64_t)dw_blocks(C, K) * K * K * C * 4 : -1;
 }
 
 extern "C" int creste_dwconv_wgrad_f32(const float* x, const float* gy, float* gw_taps, int N, int H, int W, int C,
@@ -657,7 +659,7 @@ extern "C" int creste_dwconv_wgrad_f32(const float* x, const float* gy, float* g
   const int rows = 256 / C > 0 ? 256 / C : 1;
   const long M = (long)N * Ho * Wo;
   const long per = (M + rows - 1) / rows;
-  const int blocks = (int)(per < DW_BLOCKS ? per : DW_BLOCKS);
+  const int blocks = (int)(per < dw_blocks(C, K) ? per : dw_blocks(C, K));
   const size_t smem = (size_t)rows * (C >= 256 ? 256 : C) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   if (K == 3) dwconv_wgrad_kernel<3><<<blocks, 256, smem, s>>>(x, gy, (float*)work, N, H, W, C, Ho, Wo, stride, pad_t, pad_l);
