@@ -137,6 +137,37 @@ def cpu_baseline(sample_frames=1, runs=3):
                       f"{cores} threads, fp32"}
 
 
+def distill_extras(device, steps=3, B=8):
+    """BASELINE configs[3], per-GPU part: one stage-1 distillation training step (train_pefree.py) -- training-mode
+    forward, CrossEntropyDepth + SmoothL1Depth + MSELoss, backward to all 25.5 M encoder parameters into the flat
+    all-reduce arena, Adam -- batch 8 of 1216x608 on the HIP training kernels."""
+    from creste_public_amd import harness, synth
+    from creste_public_amd.creste.models.distillation import DistillationBackbone
+    from creste_public_amd.creste.utils.loss_utils import LossManager
+    cfg = harness.distillation_cfg((IMG_H, IMG_W))
+    torch.manual_seed(0)
+    model = DistillationBackbone(cfg).to(device)
+    synth.randomize_bn(model, seed=1)
+    rgbd, _ = synth.make_frames(B, IMG_H, IMG_W, seed=2)
+    g = torch.Generator().manual_seed(3)
+    batch = {"image": rgbd.to(device),
+             "depth_label": (torch.rand(B, 1, IMG_H // 4, IMG_W // 4, generator=g) * 26000.0).to(device),
+             "fimg_label": torch.randn(B, 1, 128, IMG_H // 4, IMG_W // 4, generator=g).to(device)}
+    tr = harness.DistillTrainer(model, LossManager(cfg), cfg)
+    tr.training_step(batch); tr.training_step(batch); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        logs = tr.training_step(batch)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    n = sum(p.numel() for p in model.parameters() if p.grad is not None)
+    del tr, model, batch
+    torch.cuda.empty_cache()
+    return {"distill_train_step_ms": round(ms, 1), "distill_frames_per_s": round(B / ms * 1e3, 1),
+            "distill_config": f"batch {B}, {IMG_W}x{IMG_H}, EfficientNet-B0 U-Net + depth/DINO heads in training mode, "
+                              f"{n} parameters with gradients, Adam; loss {float(logs['train/loss']):.3f}"}
+
+
 def irl_extras(model_infer, device, steps=3):
     """The second half of BASELINE.json's metric: IRL train-step time (configs[2]).  Reference-config
     step: batch 8 frames, 64x128 IRL grid (map_ds 2 + front-half crop), frozen HIP backbone, reward net
@@ -345,6 +376,7 @@ def main():
                                   "(~6e-5 rel per conv); bf16 = plain bf16 operands (~4e-3 rel per conv)")
         if args.gpus == 1 and not args.no_irl:
             line["irl"] = irl_extras(model, device)
+            line["distill"] = distill_extras(device)
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
