@@ -776,3 +776,148 @@ extern "C" int creste_mse_loss_f32(const float* pred, int p_cs, const float* gt,
   CRESTE_CHECK_LAUNCH("mse_finish");
   return CRESTE_OK;
 }
+
+// ------------------------------------------------------------------------------------ BEV splat backward
+// Forward (csrc/bev_splat.hip, reference splat_projection.py:262-354): for point p with map coords (X, Y),
+//   D[i]     += w_tap            S[c][i] += w_tap * f_c(p)          over its (up to) 4 valid taps i
+//   bev[c,i]  = S[c][i] / max(D[i], min_w)         dens[i] = D[i]
+// Backward, given g_bev [B,GH,GW,F] and (optionally) g_dens [B,GH,GW]:
+//   gD[i]   = g_dens[i] - [D[i] >= min_w] * sum_c g_bev[c,i] * bev[c,i] / D[i]                 (cell pass)
+//   gf_c(p) = sum_taps w_tap * g_bev[c,i] / max(D[i], min_w)
+//   gw_tap  = sum_c g_bev[c,i] * f_c(p) / max(D[i], min_w) + gD[i]
+//   gX = sum_taps gw_tap * (2xd-1) * wy_tap ,  gY = sum_taps gw_tap * wx_tap * (2yd-1)     (floor has no gradient)
+//   X = (-y + off_x)/vox_x, Y = (-x + off_y)/vox_y  ->  g_y = -gX / vox_x ,  g_x = -gY / vox_y ,  g_z = 0
+// One 32-lane half-wave per point, lanes over channels (a gather: no atomics, deterministic).
+namespace creste {
+
+__global__ __launch_bounds__(256) void splat_cell_grad_kernel(const float* __restrict__ g_bev,
+                                                              const float* __restrict__ bev,
+                                                              const float* __restrict__ dens,
+                                                              const float* __restrict__ g_dens,
+                                                              float* __restrict__ gD, long ncell, int F, float min_w) {
+  const int sub = threadIdx.x & 31;
+  const long half = (blockIdx.x * 256L + threadIdx.x) >> 5, nhalf = ((long)gridDim.x * 256) >> 5;
+  for (long i = half; i < ncell; i += nhalf) {
+    const float D = dens[i];
+    float s = 0.f;
+    if (D >= min_w)                               // torch.clamp(min=) passes the gradient at equality
+      for (int c = sub; c < F; c += 32) s += g_bev[i * F + c] * bev[i * F + c];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (sub == 0) gD[i] = (g_dens ? g_dens[i] : 0.f) - (D >= min_w ? s / D : 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void splat_point_grad_kernel(
+    const float* __restrict__ coords, const float* __restrict__ feats, int feats_cs, const float* __restrict__ g_bev,
+    const float* __restrict__ dens, const float* __restrict__ gD, float* __restrict__ g_feats, int gf_cs,
+    float* __restrict__ g_xyz, long BP, int P, int F, int GH, int GW, float vox_x, float vox_y, float min_w) {
+  const int sub = threadIdx.x & 31;
+  const long half = (blockIdx.x * 256L + threadIdx.x) >> 5, nhalf = ((long)gridDim.x * 256) >> 5;
+  for (long p = half; p < BP; p += nhalf) {
+    const long b = p / P;
+    const float X = coords[p * 2], Y = coords[p * 2 + 1];
+    const float fx = floorf(X), fy = floorf(Y);
+    const float rX = X - fx, rY = Y - fy;
+    const int X0 = (int)fx, Y0 = (int)fy;
+    float gX = 0.f, gY = 0.f;
+    float gf[8];                                   // F <= 256: up to 8 channels per lane
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gf[j] = 0.f;
+    const bool near = fx >= -1.f && fx <= (float)(GW - 1) && fy >= -1.f && fy <= (float)(GH - 1);
+    if (near) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int xd = t >> 1, yd = t & 1;           // reference tap order (0,0),(0,1),(1,0),(1,1)
+        const int xi = X0 + xd, yi = Y0 + yd;
+        if ((unsigned)xi >= (unsigned)GW || (unsigned)yi >= (unsigned)GH) continue;
+        const float wx = xd ? rX : 1.f - rX, wy = yd ? rY : 1.f - rY;
+        const long cell = (b * GH + yi) * GW + xi;
+        const float inv = 1.f / fmaxf(dens[cell], min_w);
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = sub + 32 * j;
+          if (c < F) {
+            const float g = g_bev[cell * F + c];
+            gf[j] += wx * wy * g * inv;
+            dot += g * feats[p * feats_cs + c];
+          }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+        const float gw = dot * inv + gD[cell];
+        gX += gw * (xd ? 1.f : -1.f) * wy;
+        gY += gw * wx * (yd ? 1.f : -1.f);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = sub + 32 * j;
+      if (c < F) g_feats[p * gf_cs + c] = gf[j];
+    }
+    if (sub == 0 && g_xyz) {
+      g_xyz[p * 3 + 0] = -gY / vox_y;
+      g_xyz[p * 3 + 1] = -gX / vox_x;
+      g_xyz[p * 3 + 2] = 0.f;
+    }
+  }
+}
+
+// depth = sum_k softmax(logits)_k * bins_k / 1000  ->  g_logits_k (+)= g_depth * p_k * (bins_k/1000 - depth)
+__global__ __launch_bounds__(256) void depth_expectation_bwd_kernel(const float* __restrict__ logits, int cs, long P,
+                                                                    const float* __restrict__ bin_values,
+                                                                    const float* __restrict__ g_depth,
+                                                                    float* __restrict__ g_logits, int g_cs,
+                                                                    int accumulate) {
+  const int sub = threadIdx.x & 31;
+  const long half = (blockIdx.x * 256L + threadIdx.x) >> 5, nhalf = ((long)gridDim.x * 256) >> 5;
+  const f32x4 bv = ld4(bin_values + sub * 4);
+  for (long p = half; p < P; p += nhalf) {
+    const f32x4 x = ld4(logits + p * cs + sub * 4);
+    float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    f32x4 e;
+    float se = 0.f, sw = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { e[j] = expf(x[j] - mx); se += e[j]; sw += e[j] * bv[j]; }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { se += __shfl_xor(se, o); sw += __shfl_xor(sw, o); }
+    const float depth = (sw / se) / 1000.f, gd = g_depth[p];
+    f32x4 g = accumulate ? ld4(g_logits + p * g_cs + sub * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] += gd * (e[j] / se) * (bv[j] / 1000.f - depth);
+    st4(g_logits + p * g_cs + sub * 4, g);
+  }
+}
+
+}  // namespace creste
+
+extern "C" int creste_bev_splat_bwd_f32(const float* coords, const float* feats, int feats_cs, const float* g_bev,
+                                        const float* g_dens, const float* bev, const float* dens, int B, int P, int F,
+                                        int GH, int GW, float vox_x, float vox_y, float min_weight, float* g_feats,
+                                        int gf_cs, float* g_xyz, float* cell_work, void* stream) {
+  CRESTE_REQUIRE(coords && feats && g_bev && bev && dens && g_feats && cell_work, "bev_splat_bwd: null pointer");
+  CRESTE_REQUIRE(B > 0 && P > 0 && F > 0 && F <= 256 && GH > 0 && GW > 0 && vox_x > 0.f && vox_y > 0.f,
+                 "bev_splat_bwd: bad dims (F <= 256)");
+  hipStream_t s = (hipStream_t)stream;
+  const long ncell = (long)B * GH * GW, BP = (long)B * P;
+  splat_cell_grad_kernel<<<grid1d(ncell * 32), 256, 0, s>>>(g_bev, bev, dens, g_dens, cell_work, ncell, F, min_weight);
+  CRESTE_CHECK_LAUNCH("splat_cell_grad");
+  splat_point_grad_kernel<<<grid1d(BP * 32), 256, 0, s>>>(coords, feats, feats_cs, g_bev, dens, cell_work, g_feats, gf_cs,
+                                                         g_xyz, BP, P, F, GH, GW, vox_x, vox_y, min_weight);
+  CRESTE_CHECK_LAUNCH("splat_point_grad");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_depth_expectation_bwd_f32(const float* logits, int cs, int64_t P, int C, const float* bin_values,
+                                                const float* g_depth, float* g_logits, int g_cs, int accumulate,
+                                                void* stream) {
+  CRESTE_REQUIRE(logits && bin_values && g_depth && g_logits && P > 0, "depth_expectation_bwd: null pointer");
+  CRESTE_REQUIRE(C == 128 && cs % 4 == 0 && g_cs % 4 == 0, "depth_expectation_bwd: built for 128 bins");
+  depth_expectation_bwd_kernel<<<grid1d(P * 32), 256, 0, (hipStream_t)stream>>>(logits, cs, P, bin_values, g_depth,
+                                                                                g_logits, g_cs, accumulate);
+  CRESTE_CHECK_LAUNCH("depth_expectation_bwd");
+  return CRESTE_OK;
+}

@@ -394,6 +394,36 @@ def bev_splat(xyz, feats: Act, off_xy, vox_xy, GH, GW, min_weight=1.0):
     return coords, bev, dens
 
 
+def bev_splat_bwd(coords, feats: Act, g_bev: Act, g_dens, bev: Act, dens, vox_xy, min_weight=1.0):
+    """cotangents of (bev, dens) -> (g_feats Act viewed as [B,P,F], g_xyz [B,P,3]); see creste_bev_splat_bwd_f32."""
+    lib = _lib.load()
+    B, P, _ = coords.shape
+    F, GH, GW = feats.C, bev.H, bev.W
+    dev = coords.device
+    assert g_bev.cs == F and g_bev.co == 0 and bev.cs == F and bev.co == 0, "dense [B,GH,GW,F] maps expected"
+    g_feats = Act.empty(feats.N, feats.H, feats.W, F, dev)
+    g_xyz = torch.empty((B, P, 3), dtype=torch.float32, device=dev)
+    work = torch.empty(B * GH * GW, dtype=torch.float32, device=dev)
+    _lib.check(lib.creste_bev_splat_bwd_f32(_chk(coords).data_ptr(), feats.ptr, feats.cs, g_bev.ptr,
+                                            _chk(g_dens).data_ptr() if g_dens is not None else None, bev.ptr,
+                                            _chk(dens).data_ptr(), B, P, F, GH, GW, float(vox_xy[0]), float(vox_xy[1]),
+                                            float(min_weight), g_feats.ptr, g_feats.cs, g_xyz.data_ptr(),
+                                            work.data_ptr(), _stream()), "bev_splat_bwd")
+    return g_feats, g_xyz
+
+
+def depth_expectation_bwd(logits: Act, bin_values, g_depth, g_logits: Act | None = None):
+    """g_logits (+)= d depth / d logits * g_depth (accumulates when g_logits is given)."""
+    lib = _lib.load()
+    acc = g_logits is not None
+    if not acc:
+        g_logits = Act.empty(logits.N, logits.H, logits.W, logits.C, logits.buf.device)
+    _lib.check(lib.creste_depth_expectation_bwd_f32(logits.ptr, logits.cs, logits.N * logits.H * logits.W, logits.C,
+                                                    _chk(bin_values).data_ptr(), _chk(g_depth).data_ptr(), g_logits.ptr,
+                                                    g_logits.cs, int(acc), _stream()), "depth_expectation_bwd")
+    return g_logits
+
+
 def value_iteration(r: torch.Tensor, discount: float, threshold: float = 1e-3, max_sweeps: int = 100000):
     """r [B,H,W] -> v [B,H,W], q [B,8,H,W], policy [B,8,H,W], sweeps (device int32 tensor)."""
     lib = _lib.load()

@@ -325,6 +325,18 @@ int creste_depth_ce_loss_f32(const float* logits, int cs, const float* gt_mm, in
 int creste_mse_loss_f32(const float* pred, int p_cs, const float* gt, int g_cs, int64_t P, int C, float weight,
                         float* g_pred, int o_cs, float* out2, void* work, void* stream);
 
+/* Backward of creste_bev_splat_f32 (reference autograd through splat_projection.py:262-354):
+ * coords / bev / dens are the forward's outputs, feats its (range-masked) input.  g_feats [B*P][gf_cs] and
+ * g_xyz [B*P][3] (LiDAR x, y; z gets 0) are gathers -- no atomics.  cell_work: B*GH*GW floats.  g_dens may be
+ * NULL. */
+int creste_bev_splat_bwd_f32(const float* coords, const float* feats, int feats_cs, const float* g_bev,
+                             const float* g_dens, const float* bev, const float* dens, int B, int P, int F, int GH,
+                             int GW, float vox_x, float vox_y, float min_weight, float* g_feats, int gf_cs,
+                             float* g_xyz, float* cell_work, void* stream);
+/* Backward of creste_depth_expectation_f32: g_logits (+)= g_depth * softmax * (bin/1000 - depth). */
+int creste_depth_expectation_bwd_f32(const float* logits, int cs, int64_t P, int C, const float* bin_values,
+                                     const float* g_depth, float* g_logits, int g_cs, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
