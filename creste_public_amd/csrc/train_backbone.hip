@@ -183,6 +183,136 @@ __global__ __launch_bounds__(256) void wgrad_tiled_kernel(
     }
 }
 
+// f16x3 variant (same operand scheme as the forward patch engine, csrc/conv_patch.hip): both operands are
+// rescaled by exact powers of two from device-side |max| bounds, split into fp16 hi+lo while they are staged,
+// and multiplied as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate) with fp32
+// accumulation over the pixel chunk.  The MFMA's K runs over PIXELS, which are the strided dimension of the
+// NHWC tensors: a loader thread owns one channel and reads its 8 consecutive pixels with 8 coalesced-across-
+// lanes dword loads, so the transpose happens in registers and the LDS image is the conflict-free
+// [piece][k-octet][channel][8 x fp16] layout of the forward engine (one 16-byte write, one ds_read_b128 fragment).
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void wgrad_f16_kernel(
+    const float* __restrict__ x, int x_cs, const float* __restrict__ gy, int gy_cs, float* __restrict__ partial,
+    const float* __restrict__ x_amax, const float* __restrict__ gy_amax, int N, int H, int W, int Ho, int Wo, int Cin,
+    int Cout, int K, int stride, int pad_t, int pad_l, int chunk_px, int tiles_co, int tiles_ci) {
+  constexpr int BM = 128, KS = 32, NOCT = KS / 8;
+  constexpr int OCT = BM * 16, PLANE = NOCT * OCT, TILE = 2 * PLANE;   // bytes: [piece][octet][row][8 fp16]
+  __shared__ __attribute__((aligned(16))) char As[2][TILE];
+  __shared__ __attribute__((aligned(16))) char Bs[2][TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  int id = blockIdx.x;
+  const int tci = id % tiles_ci; id /= tiles_ci;
+  const int tco = id % tiles_co;
+  const int chunk = id / tiles_co;
+  const int tap = blockIdx.y;
+  const int ky = tap / K - pad_t, kx = tap % K - pad_l;
+  const int co0 = tco * BM, ci0 = tci * BM;
+  const int M = N * Ho * Wo;
+  const int p0 = chunk * chunk_px, p1 = min(M, p0 + chunk_px);
+  float a_inv, b_inv;
+  const float a_mul = f16_operand_scale(*gy_amax, &a_inv), b_mul = f16_operand_scale(*x_amax, &b_inv);
+
+  // loader: threads 0..127 stage gy (A), 128..255 stage x (B); a thread owns one channel QUAD and one pixel octet:
+  // 8 float4 loads (consecutive lanes = consecutive quads: coalesced rows), transposed in registers into four
+  // 8-pixel fp16 rows
+  const bool isB = tid >= 128;
+  const int u = tid & 127, quad = u & 31, loct = u >> 5;
+  const int ch = (isB ? ci0 : co0) + quad * 4;
+  const bool ch_ok = ch < (isB ? Cin : Cout);
+  f32x4 rv[8];
+  auto load = [&](int p) __attribute__((always_inline)) {
+    int q = p + loct * 8;
+    int rowi = q / Wo;
+    int ox = q - rowi * Wo;
+    int n = rowi / Ho;
+    int oy = rowi - n * Ho;
+#pragma unroll
+    for (int j = 0; j < 8; ++j, ++q) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (q < p1 && ch_ok) {
+        if (!isB) v = ld4(gy + (long)q * gy_cs + ch);
+        else {
+          const int iy = oy * stride + ky, ix = ox * stride + kx;
+          if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = ld4(x + (((long)n * H + iy) * W + ix) * x_cs + ch);
+        }
+      }
+      rv[j] = v;
+      if (++ox == Wo) { ox = 0; if (++oy == Ho) { oy = 0; ++n; } }
+    }
+  };
+  auto store = [&](int buf) __attribute__((always_inline)) {
+    char* base = (isB ? Bs[buf] : As[buf]) + loct * OCT + quad * 4 * 16;
+    const float mul = isB ? b_mul : a_mul;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      h8 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = rv[j][c] * mul;
+        hi[j] = (_Float16)v;
+        lo[j] = (_Float16)(v - (float)hi[j]);
+      }
+      *reinterpret_cast<h8*>(base + c * 16) = hi;
+      *reinterpret_cast<h8*>(base + PLANE + c * 16) = lo;
+    }
+  };
+
+  f32x16 c[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[i][j][r] = 0.f;
+
+  load(p0);
+  store(0);
+  __syncthreads();
+  int buf = 0;
+  for (int p = p0; p < p1; p += KS) {
+    const bool more = p + KS < p1;
+    if (more) load(p + KS);
+#pragma unroll
+    for (int ks = 0; ks < KS / 16; ++ks) {
+      h8 a[2][2], b[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          const int o = pl * PLANE + (ks * 2 + lh) * OCT;
+          a[i][pl] = *reinterpret_cast<const h8*>(&As[buf][o + (wm * 64 + i * 32 + li) * 16]);
+          b[i][pl] = *reinterpret_cast<const h8*>(&Bs[buf][o + (wn * 64 + i * 32 + li) * 16]);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[j][0], c[i][j], 0, 0, 0);
+          c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][1], c[i][j], 0, 0, 0);
+          c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[j][0], c[i][j], 0, 0, 0);
+        }
+    }
+    if (more) store(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  const float sc = a_inv * b_inv;
+  float* out = partial + ((size_t)chunk * K * K + tap) * Cout * Cin;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = ci0 + wn * 64 + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < Cout && col < Cin) out[(size_t)row * Cin + col] = c[i][j][r] * sc;
+      }
+    }
+}
+
 __global__ void wgrad_strided_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw, int nchunk,
                                             int Cout, int Cin, int KK, int accumulate) {
   const int total = Cout * Cin * KK;
@@ -235,18 +365,18 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const float* __restri
 
 // partial[blk][tap][c] = sum over the block's output pixels of gy[q][c] * x[q*s + tap - pad][c]
 constexpr int DW_BLOCKS = 2048;           // upper bound; see dw_blocks()
-static inline int dw_blocks(int C, int K) { const int b = 1048576 / (C * K * K); return b < 128 ? 128 : (b > DW_BLOCKS ? DW_BLOCKS : b); }
+static inline int dw_blocks(int C, int K) { const int b = 4194304 / (C * K * K); return b < 256 ? 256 : (b > DW_BLOCKS ? DW_BLOCKS : b); }
 template <int K>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                            float* __restrict__ partial, int N, int H, int W, int C,
                                                            int Ho, int Wo, int stride, int pad_t, int pad_l) {
-  extern __shared__ float sm[];   // [rows][C] per tap, reused tap by tap
-  const int rows = 256 / C > 0 ? 256 / C : 1;
+  extern __shared__ float sm[];   // [rows][Ct] per tap, reused tap by tap
   const long M = (long)N * Ho * Wo;
-  for (int c0 = 0; c0 < C; c0 += 256) {
-    const int c = c0 + (C >= 256 ? threadIdx.x : threadIdx.x % C);
-    const int row = C >= 256 ? 0 : threadIdx.x / C;
-    const bool active = c < C && row < rows;
+  {                                // blockIdx.y walks channel tiles of 256
+    const int c0 = blockIdx.y * 256;
+    const int Ct = min(256, C - c0), rows = 256 / Ct;
+    const int c = c0 + threadIdx.x % Ct, row = threadIdx.x / Ct;
+    const bool active = row < rows;
     float s[K * K];
 #pragma unroll
     for (int t = 0; t < K * K; ++t) s[t] = 0.f;
@@ -268,7 +398,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
         }
       }
     }
-    const int cw = C >= 256 ? 256 : C;           // channels handled in this pass
+    const int cw = Ct;                           // channels handled by this block
     for (int t = 0; t < K * K; ++t) {
       __syncthreads();
       if (active) sm[row * cw + (c - c0)] = s[t];
@@ -637,6 +767,37 @@ extern "C" int creste_conv_wgrad_strided_f32(const float* x, int x_cs, const flo
   return CRESTE_OK;
 }
 
+extern "C" int creste_conv_wgrad_f16x3(const float* x, int x_cs, const float* gy, int gy_cs, float* gw,
+                                       const float* x_amax, const float* gy_amax, int N, int H, int W, int Ho, int Wo,
+                                       int Cin, int Cout, int K, int stride, int pad_t, int pad_l, int accumulate,
+                                       void* work, void* stream) {
+  CRESTE_REQUIRE(x && gy && gw && work && x_amax && gy_amax, "conv_wgrad_f16x3: null pointer");
+  CRESTE_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cout > 0 && K > 0 && stride > 0 &&
+                     K * K <= 65535, "conv_wgrad_f16x3: bad dims");
+  const long M = (long)N * Ho * Wo;
+  CRESTE_REQUIRE(M < (1L << 31), "conv_wgrad_f16x3: N*Ho*Wo overflows int32");
+  const int tiles_co = (Cout + 127) / 128, tiles_ci = (Cin + 127) / 128;
+  const long tiles = (long)tiles_co * tiles_ci * K * K;
+  long want = (2048 + tiles - 1) / tiles;
+  const long cap = wgrad_chunks(M, K);
+  int nchunk = (int)(want < 1 ? 1 : (want > cap ? cap : want));
+  long chunk_px = (M + nchunk - 1) / nchunk;
+  chunk_px = (chunk_px + 31) / 32 * 32;
+  nchunk = (int)((M + chunk_px - 1) / chunk_px);
+  hipStream_t s = (hipStream_t)stream;
+  CRESTE_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0 && x_cs % 4 == 0 && gy_cs % 4 == 0 &&
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0,
+                 "conv_wgrad_f16x3: channel counts / strides must be multiples of 4, tensors 16-byte aligned");
+  wgrad_f16_kernel<<<dim3(nchunk * tiles_co * tiles_ci, K * K), 256, 0, s>>>(
+      x, x_cs, gy, gy_cs, (float*)work, x_amax, gy_amax, N, H, W, Ho, Wo, Cin, Cout, K, stride, pad_t, pad_l,
+      (int)chunk_px, tiles_co, tiles_ci);
+  CRESTE_CHECK_LAUNCH("wgrad_f16");
+  wgrad_strided_reduce_kernel<<<grid1d((long)Cout * Cin * K * K, 1024), 256, 0, s>>>((const float*)work, gw, nchunk,
+                                                                                    Cout, Cin, K * K, accumulate);
+  CRESTE_CHECK_LAUNCH("wgrad_strided_reduce");
+  return CRESTE_OK;
+}
+
 extern "C" int creste_dwconv_dgrad_f32(const float* gy, const float* w, float* gx, int N, int H, int W, int C, int Ho,
                                        int Wo, int K, int stride, int pad_t, int pad_l, void* stream) {
   CRESTE_REQUIRE(gy && w && gx && C % 4 == 0 && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && K > 0 && stride > 0,
@@ -656,14 +817,15 @@ extern "C" int creste_dwconv_wgrad_f32(const float* x, const float* gy, float* g
                                        void* work, void* stream) {
   CRESTE_REQUIRE(x && gy && gw_taps && work && C > 0 && N > 0, "dwconv_wgrad: bad args");
   CRESTE_REQUIRE(K == 3 || K == 5, "dwconv_wgrad: kernel size %d not built (3 or 5)", K);
-  const int rows = 256 / C > 0 ? 256 / C : 1;
+  const int rows = C >= 256 ? 1 : 256 / C;
   const long M = (long)N * Ho * Wo;
   const long per = (M + rows - 1) / rows;
   const int blocks = (int)(per < dw_blocks(C, K) ? per : dw_blocks(C, K));
-  const size_t smem = (size_t)rows * (C >= 256 ? 256 : C) * sizeof(float);
+  const size_t smem = 256 * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-  if (K == 3) dwconv_wgrad_kernel<3><<<blocks, 256, smem, s>>>(x, gy, (float*)work, N, H, W, C, Ho, Wo, stride, pad_t, pad_l);
-  else dwconv_wgrad_kernel<5><<<blocks, 256, smem, s>>>(x, gy, (float*)work, N, H, W, C, Ho, Wo, stride, pad_t, pad_l);
+  const dim3 grid(blocks, (C + 255) / 256);
+  if (K == 3) dwconv_wgrad_kernel<3><<<grid, 256, smem, s>>>(x, gy, (float*)work, N, H, W, C, Ho, Wo, stride, pad_t, pad_l);
+  else dwconv_wgrad_kernel<5><<<grid, 256, smem, s>>>(x, gy, (float*)work, N, H, W, C, Ho, Wo, stride, pad_t, pad_l);
   CRESTE_CHECK_LAUNCH("dwconv_wgrad");
   sum_partials_kernel<<<K * K * C, 64, 0, s>>>((const float*)work, gw_taps, blocks, K * K * C, 1.f, accumulate);
   CRESTE_CHECK_LAUNCH("dwconv_wgrad_sum");

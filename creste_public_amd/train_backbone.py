@@ -114,9 +114,17 @@ class ConvG:
             gw, acc = _acc(grads, w)
             work = torch.empty(lib.creste_conv_wgrad_strided_workspace_bytes(gy.N, gy.H, gy.W, Cin, Cout, self.K),
                                dtype=torch.uint8, device=w.device)
-            _lib.check(lib.creste_conv_wgrad_strided_f32(x.ptr, x.cs, gy.ptr, gy.cs, gw.data_ptr(), x.N, x.H, x.W, gy.H,
-                                                         gy.W, Cin, Cout, self.K, self.s, self.pad[0], self.pad[2], acc,
-                                                         work.data_ptr(), _stream()), "conv_wgrad_strided")
+            if hipnn._precision == ops.PREC_F16X3 and Cin >= 32 and Cout >= 32:
+                # f16x3 wgrad: fp16 hi+lo operands from the tensors' |max| bounds, fp32 accumulation
+                _lib.check(lib.creste_conv_wgrad_f16x3(x.ptr, x.cs, gy.ptr, gy.cs, gw.data_ptr(),
+                                                       ops.absmax(x).data_ptr(), ops.absmax(gy).data_ptr(), x.N, x.H,
+                                                       x.W, gy.H, gy.W, Cin, Cout, self.K, self.s, self.pad[0],
+                                                       self.pad[2], acc, work.data_ptr(), _stream()), "conv_wgrad_f16x3")
+            else:
+                _lib.check(lib.creste_conv_wgrad_strided_f32(x.ptr, x.cs, gy.ptr, gy.cs, gw.data_ptr(), x.N, x.H, x.W,
+                                                             gy.H, gy.W, Cin, Cout, self.K, self.s, self.pad[0],
+                                                             self.pad[2], acc, work.data_ptr(), _stream()),
+                           "conv_wgrad_strided")
             if self.conv.bias is not None:
                 gb, accb = _acc(grads, self.conv.bias)
                 s = sample_reduce(gy, None, 1.0, per_sample=False).view(-1)

@@ -292,6 +292,11 @@ int64_t creste_conv_wgrad_strided_workspace_bytes(int N, int Ho, int Wo, int Cin
 int creste_conv_wgrad_strided_f32(const float* x, int x_cs, const float* gy, int gy_cs, float* gw, int N, int H,
                                   int W, int Ho, int Wo, int Cin, int Cout, int K, int stride, int pad_t, int pad_l,
                                   int accumulate, void* work, void* stream);
+/* Same gradient with f16x3 operands (fp32 accumulation): x_amax / gy_amax are device floats bounding |x| and
+ * |gy| (creste_absmax_nhwc_f32 or a tracked out_amax); same workspace. */
+int creste_conv_wgrad_f16x3(const float* x, int x_cs, const float* gy, int gy_cs, float* gw, const float* x_amax,
+                            const float* gy_amax, int N, int H, int W, int Ho, int Wo, int Cin, int Cout, int K,
+                            int stride, int pad_t, int pad_l, int accumulate, void* work, void* stream);
 /* depthwise conv backward (weights tap-major [K*K][C] as in creste_dwconv2d_nhwc_f32): input gradient and
  * per-tap weight gradient gw_taps[K*K][C] (+)=. */
 int creste_dwconv_dgrad_f32(const float* gy, const float* w, float* gx, int N, int H, int W, int C, int Ho, int Wo,

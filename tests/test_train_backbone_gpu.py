@@ -361,3 +361,34 @@ def test_depth_expectation_backward():
     assert _rel(gl.nchw(), lr.grad) < 1e-5
     gl2 = ops.depth_expectation_bwd(la, bins.cuda(), gd.cuda().contiguous(), g_logits=gl)     # accumulate
     assert _rel(gl2.nchw(), 2 * lr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,K,s,pad,gscale", [
+    (2, 96, 19, 23, 136, 3, 1, (1, 1, 1, 1), 1.0), (1, 200, 9, 31, 72, 1, 1, (0, 0, 0, 0), 1e-7),
+    (2, 48, 21, 18, 40, 5, 1, (2, 2, 2, 2), 1e4), (2, 64, 20, 24, 64, 3, 2, (0, 1, 0, 1), 1e-3)])
+def test_conv_backward_f16x3(N, Cin, H, W, Cout, K, s, pad, gscale):
+    """the training convs in the f16x3 operand mode: forward / dgrad on the patch engine, wgrad on the fp16-split
+    MFMA kernel; gradient tensors of any magnitude (1e-7 .. 1e4) keep fp32-grade accuracy through the |max| scaling"""
+    import creste_public_amd
+    from creste_public_amd import train_backbone as TB, train_ops as T
+    g = torch.Generator().manual_seed(Cin + K)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    conv = torch.nn.Conv2d(Cin, Cout, K, stride=s, bias=False)
+    ref = copy.deepcopy(conv).double()
+    xr = x.double().requires_grad_(True)
+    y = ref(F.pad(xr, (pad[2], pad[3], pad[0], pad[1])))
+    gy = torch.randn(y.shape, generator=g) * gscale
+    y.backward(gy.double())
+    creste_public_amd.set_precision("f16x3")
+    try:
+        op = TB.ConvG(conv.cuda(), pad=pad)
+        ya = op.fwd(T.as_act(x.cuda()))
+        grads = {}
+        gx = op.bwd(T.as_act(gy.cuda()), grads, need_input=(s == 1))
+        torch.cuda.synchronize()
+    finally:
+        creste_public_amd.set_precision("f32")
+    assert _rel(ya.nchw(), y.detach()) < 3e-6
+    assert _rel(grads[id(op.conv.weight)], ref.weight.grad) < 3e-6
+    if s == 1:
+        assert _rel(gx.nchw(), xr.grad) < 3e-6
