@@ -202,11 +202,14 @@ __global__ __launch_bounds__(256) void wgrad_f16_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  int id = blockIdx.x;
+  // block order: tap fastest, then the channel tiles, then the pixel chunk, and contiguous ranges per XCD -- the
+  // K*K*tiles workgroups that stream the SAME pixel range run together on ONE L2 (each operand element is needed
+  // by K*K*tiles of them; with the tap in grid.y they were dispatched far apart and every one went to HBM)
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int tap = id % (K * K); id /= K * K;
   const int tci = id % tiles_ci; id /= tiles_ci;
   const int tco = id % tiles_co;
   const int chunk = id / tiles_co;
-  const int tap = blockIdx.y;
   const int ky = tap / K - pad_t, kx = tap % K - pad_l;
   const int co0 = tco * BM, ci0 = tci * BM;
   const int M = N * Ho * Wo;
@@ -788,7 +791,7 @@ extern "C" int creste_conv_wgrad_f16x3(const float* x, int x_cs, const float* gy
   CRESTE_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0 && x_cs % 4 == 0 && gy_cs % 4 == 0 &&
                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0,
                  "conv_wgrad_f16x3: channel counts / strides must be multiples of 4, tensors 16-byte aligned");
-  wgrad_f16_kernel<<<dim3(nchunk * tiles_co * tiles_ci, K * K), 256, 0, s>>>(
+  wgrad_f16_kernel<<<nchunk * tiles_co * tiles_ci * K * K, 256, 0, s>>>(
       x, x_cs, gy, gy_cs, (float*)work, x_amax, gy_amax, N, H, W, Ho, Wo, Cin, Cout, K, stride, pad_t, pad_l,
       (int)chunk_px, tiles_co, tiles_ci);
   CRESTE_CHECK_LAUNCH("wgrad_f16");
