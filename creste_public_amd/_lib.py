@@ -11,6 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libcreste_hip.so")
 
+ABI_VERSION = 2          # creste_abi_version() of the library this binding was written against
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
 
@@ -125,6 +126,9 @@ def load(path: str | None = None):
         except AttributeError as e:
             raise HipLibraryError(f"{p} does not export {name}") from e
         fn.restype, fn.argtypes = res, args
+    if lib.creste_abi_version() != ABI_VERSION:
+        raise HipLibraryError(f"{p} has ABI version {lib.creste_abi_version()}, this package binds version "
+                              f"{ABI_VERSION}: rebuild with `python -m creste_public_amd.build`")
     _lib = lib
     return lib
 

@@ -30,7 +30,7 @@ def test_header_symbols_are_exported_and_bound():
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in _lib.SIGNATURES"
     assert sorted(_lib.SIGNATURES) == names
     handle = _lib.load()
-    assert handle.creste_abi_version() == 2
+    assert handle.creste_abi_version() == _lib.ABI_VERSION
     # pure-host queries work without a GPU
     assert handle.creste_conv_packed_weight_bytes(496, 496, 3, 3, 0) == 512 * 9 * 496 * 4
     assert handle.creste_bev_splat_workspace_bytes(1, 100, 256, 256) > 0
