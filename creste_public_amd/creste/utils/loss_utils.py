@@ -138,7 +138,10 @@ class MaxEntIRLLoss(Loss):
 
 def _bin_depths_ud(depth, depth_min, depth_max, num_bins):
     """target bins of reference depth_utils.bin_depths (mode UD, target=True)."""
-    idx = (depth - depth_min) / ((depth_max - depth_min) / num_bins)
+    # tensor / tensor: a true IEEE division on every device (tensor / python-scalar becomes a multiplication by the
+    # reciprocal on the GPU, which moves labels that sit exactly on a bin edge, e.g. depth == depth_max)
+    bin_size = torch.tensor((depth_max - depth_min) / num_bins, dtype=depth.dtype, device=depth.device)
+    idx = (depth - depth_min) / bin_size
     bad = (idx < 0) | (idx > num_bins) | (~torch.isfinite(idx))
     idx = idx.masked_fill(bad, num_bins)
     return idx.to(torch.int64)

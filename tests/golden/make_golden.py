@@ -323,6 +323,48 @@ def gen_blocks_and_utils():
                                   (0, 2, 0, 4)))
 
 
+def gen_distill_losses():
+    """CrossEntropyDepth / SmoothL1Depth / MSELoss of the stage-1 distillation config, run through the reference's
+    own LossManager (loss_utils.py:63-91, 477-573, 606-647): losses, metrics and the gradients w.r.t. the
+    predictions."""
+    import creste.utils.loss_utils as lu
+    g = torch.Generator().manual_seed(23)
+    B, Hs, Ws, Z = 3, 10, 13, 32
+    disc = dict(mode="UD", num_bins=128, depth_min=300, depth_max=25600)
+    cfg = wrap(dict(loss=[
+        dict(name="CrossEntropyDepth", weight=0.5, pred_key="outputs/depth_preds_logits",
+             lab_key="inputs/depth_label", discretize=disc),
+        dict(name="SmoothL1Depth", weight=0.1, pred_key="outputs/depth_preds_bins", lab_key="inputs/depth_label",
+             beta=0.5, discretize=disc),
+        dict(name="MSELoss", weight=1.0, pred_key="outputs/dino_pe_feats", lab_key="inputs/fimg_label",
+             overlap_only=False)]))
+    lm = lu.LossManager(cfg)
+    logits = (torch.randn(B, 128, Hs, Ws, generator=g) * 3).requires_grad_(True)
+    depth = torch.rand(B, 1, Hs, Ws, generator=g) * 30000.0 - 1500.0
+    depth[0, 0, 0, :4] = float("nan")
+    depth[1, 0, 2, 3] = 25600.0
+    depth[2, 0, 5, 5] = 300.0
+    feats = torch.randn(B, 1, Z, Hs, Ws, generator=g).requires_grad_(True)
+    label = torch.randn(B, 1, Z, Hs, Ws, generator=g)
+    label[0, 0, :, 1, 2] = float("inf")
+    label[2, 0, 3, 4, 4] = float("-inf")
+    bins = logits.detach().argmax(1)
+    td = {"outputs/depth_preds_logits": logits, "outputs/depth_preds_bins": bins, "outputs/dino_pe_feats": feats,
+          "inputs/depth_label": depth.clone(), "inputs/fimg_label": label.clone(), "task": None}
+    with torch.enable_grad():
+        ld, meta = lm(td)
+        total = sum(w * v for w, v in ld.values())
+        total.backward()
+    out = dict(logits=logits.detach(), depth_label=depth, feats=feats.detach(), fimg_label=label, pred_bins=bins,
+               total=total.detach(), g_logits=logits.grad, g_feats=feats.grad)
+    for k, (w, v) in ld.items():
+        out[f"loss/{k}"] = v.detach()
+        out[f"weight/{k}"] = torch.tensor(float(w))
+    for k, v in meta.items():
+        out[f"meta/{k}"] = v.detach()
+    npz("distill_losses.npz", **out)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference tree not mounted: fixtures can only be made in the build container"
     sys.path.insert(0, os.path.abspath(os.path.join(OUT, "..", "..")))
@@ -332,3 +374,4 @@ if __name__ == "__main__":
     gen_splat()
     gen_vin_svf_loss()
     gen_blocks_and_utils()
+    gen_distill_losses()

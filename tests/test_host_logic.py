@@ -179,3 +179,23 @@ def test_reward_net_training_refuses_cpu():
     net = MultiScaleFCN(cfg).train()
     with pytest.raises(HipLibraryError):
         net(torch.rand(1, 40, 16, 16, requires_grad=True))
+
+
+def test_depth_label_binning_and_smoothl1_match_reference_golden():
+    """host-side label logic of the distillation losses against vectors produced by the reference's own code
+    (tests/golden/make_golden.py: depth_utils.bin_depths target bins; SmoothL1Depth through its LossManager)."""
+    import os
+    import numpy as np
+    from creste_public_amd.creste.utils.loss_utils import SmoothL1Depth, _bin_depths_ud
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    u = np.load(os.path.join(gold, "utils.npz"))
+    got = _bin_depths_ud(torch.from_numpy(u["depth_map"]), 300, 25600, 128)
+    assert torch.equal(got, torch.from_numpy(u["bins_target"]))
+    d = np.load(os.path.join(gold, "distill_losses.npz"))
+    disc = dict(mode="UD", num_bins=128, depth_min=300, depth_max=25600)
+    l1 = SmoothL1Depth(dict(name="SmoothL1Depth", weight=0.1, pred_key="outputs/depth_preds_bins",
+                            lab_key="inputs/depth_label", beta=0.5, discretize=disc))
+    out, _ = l1({"outputs/depth_preds_bins": torch.from_numpy(d["pred_bins"]),
+                 "inputs/depth_label": torch.from_numpy(d["depth_label"])})
+    w, v = out["depth/reg_loss"]
+    assert abs(float(v) - float(d["loss/SmoothL1Depth/depth/reg_loss"])) < 1e-5 * float(v) and w == 0.1

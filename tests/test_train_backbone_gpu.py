@@ -392,3 +392,36 @@ def test_conv_backward_f16x3(N, Cin, H, W, Cout, K, s, pad, gscale):
     assert _rel(grads[id(op.conv.weight)], ref.weight.grad) < 3e-6
     if s == 1:
         assert _rel(gx.nchw(), xr.grad) < 3e-6
+
+
+def test_distillation_losses_match_reference_golden():
+    """the fused HIP losses behind the LossManager API against the REFERENCE's own LossManager (golden vectors from
+    tests/golden/make_golden.py::gen_distill_losses): loss values, accuracy, weighted total and the gradients
+    w.r.t. logits and features (nan / out-of-range / == depth_max labels, +-inf feature labels included)."""
+    import os
+    import numpy as np
+    from creste_public_amd.creste.utils.loss_utils import LossManager
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "distill_losses.npz"))
+    t = lambda k: torch.from_numpy(d[k])          # noqa: E731
+    disc = dict(mode="UD", num_bins=128, depth_min=300, depth_max=25600)
+    lm = LossManager({"loss": [
+        dict(name="CrossEntropyDepth", weight=0.5, pred_key="outputs/depth_preds_logits", lab_key="inputs/depth_label",
+             discretize=disc),
+        dict(name="SmoothL1Depth", weight=0.1, pred_key="outputs/depth_preds_bins", lab_key="inputs/depth_label",
+             beta=0.5, discretize=disc),
+        dict(name="MSELoss", weight=1.0, pred_key="outputs/dino_pe_feats", lab_key="inputs/fimg_label",
+             overlap_only=False)]})
+    logits, feats = t("logits").cuda().requires_grad_(True), t("feats").cuda().requires_grad_(True)
+    ld, meta = lm({"outputs/depth_preds_logits": logits, "outputs/depth_preds_bins": t("pred_bins").cuda(),
+                   "outputs/dino_pe_feats": feats, "inputs/depth_label": t("depth_label").cuda(),
+                   "inputs/fimg_label": t("fimg_label").cuda(), "task": None})
+    total = sum(w * v for w, v in ld.values())
+    total.backward()
+    for k in ("CrossEntropyDepth/depth/cls_loss", "SmoothL1Depth/depth/reg_loss", "MSELoss/loss"):
+        w, v = ld[k]
+        assert abs(float(v) - float(d[f"loss/{k}"])) < 2e-6 * abs(float(d[f"loss/{k}"])) + 1e-7, k
+        assert abs(float(w) - float(d[f"weight/{k}"])) < 1e-7
+    assert abs(float(meta["CrossEntropyDepth/depth/acc"]) - float(d["meta/CrossEntropyDepth/depth/acc"])) < 1e-7
+    assert abs(float(total) - float(d["total"])) < 2e-6 * float(d["total"])
+    assert _rel(logits.grad, t("g_logits")) < 2e-6
+    assert _rel(feats.grad, t("g_feats")) < 2e-6
