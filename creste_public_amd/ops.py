@@ -51,6 +51,12 @@ class _AmaxPool:
         return blk[0][blk[1] - 1:blk[1]]
 
 
+def reset_amax_pool():
+    """Drop the current slot blocks: the next slot comes from a freshly zero-filled block.  Call right before a
+    hipGraph capture so that the fill is part of the graph and every replay starts from zeroed |max| slots."""
+    _AmaxPool._blocks.clear()
+
+
 @dataclass
 class Act:
     buf: torch.Tensor      # [N,H,W,cs] contiguous fp32
