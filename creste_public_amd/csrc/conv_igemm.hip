@@ -303,8 +303,9 @@ extern "C" int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream) {
   CRESTE_REQUIRE(d->out_cs >= d->out_co + d->Cout, "conv2d: output slice exceeds out_cs");
   CRESTE_REQUIRE(!d->res || d->res_cs >= d->Cout, "conv2d: res_cs < Cout");
   CRESTE_REQUIRE((long)d->N * d->Ho * d->Wo < (1L << 31), "conv2d: M overflows int32");
-  // the output extent must be reachable: last tap of the last pixel may only overhang into padding
-  CRESTE_REQUIRE((d->Ho - 1) * d->stride - d->pad_t < d->H && (d->Wo - 1) * d->stride - d->pad_l < d->W,
+  // sanity: the last output pixel may lie in trailing padding (the input gradient of a strided conv has rows the
+  // forward never sampled), but not further than one kernel beyond the input
+  CRESTE_REQUIRE((d->Ho - 1) * d->stride - d->pad_t < d->H + d->KH && (d->Wo - 1) * d->stride - d->pad_l < d->W + d->KW,
                  "conv2d: output extent outside the input");
   CRESTE_REQUIRE(d->prec != CRESTE_PREC_F16X3 || (d->a_amax && d->w_unscale),
                  "conv2d: F16X3 needs a_amax (device bound of |in|) and w_unscale (from creste_conv_pack_weight_f16)");

@@ -1086,3 +1086,35 @@ extern "C" int creste_depth_expectation_bwd_f32(const float* logits, int cs, int
   CRESTE_CHECK_LAUNCH("depth_expectation_bwd");
   return CRESTE_OK;
 }
+
+// ------------------------------------------------------------------------------------ strided dgrad helper
+// gz[n, s*oy, s*ox, c] = gy[n, oy, ox, c], zeros elsewhere ([N,Hz,Wz,C], Hz = (Ho-1)*s+1): the input gradient of a
+// stride-s conv is the stride-1 conv of this zero-inserted cotangent with the flipped, channel-transposed kernel.
+namespace creste {
+__global__ __launch_bounds__(256) void zero_insert_kernel(const float* __restrict__ gy, int gy_cs, float* __restrict__ gz,
+                                                          int N, int Ho, int Wo, int C, int s, int Hz, int Wz) {
+  const int cq = C >> 2;
+  const long total = (long)N * Hz * Wz * cq;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % cq) * 4;
+    long t = i / cq;
+    const int x = (int)(t % Wz); t /= Wz;
+    const int y = (int)(t % Hz);
+    const int n = (int)(t / Hz);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (y % s == 0 && x % s == 0) v = ld4(gy + (((long)n * Ho + y / s) * Wo + x / s) * gy_cs + c);
+    st4(gz + i * 4, v);
+  }
+}
+}  // namespace creste
+
+extern "C" int creste_zero_insert_nhwc_f32(const float* gy, int gy_cs, float* gz, int N, int Ho, int Wo, int C,
+                                           int stride, void* stream) {
+  CRESTE_REQUIRE(gy && gz && N > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0 && gy_cs % 4 == 0 && stride > 0,
+                 "zero_insert: bad args (C % 4)");
+  const int Hz = (Ho - 1) * stride + 1, Wz = (Wo - 1) * stride + 1;
+  zero_insert_kernel<<<grid1d((long)N * Hz * Wz * (C / 4)), 256, 0, (hipStream_t)stream>>>(gy, gy_cs, gz, N, Ho, Wo, C,
+                                                                                          stride, Hz, Wz);
+  CRESTE_CHECK_LAUNCH("zero_insert");
+  return CRESTE_OK;
+}

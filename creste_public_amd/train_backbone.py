@@ -88,16 +88,16 @@ class ConvG:
             self._fw = ops.pack_conv(w, b, None, self.s, self.pad, ops.ACT_NONE, self._prec())
             self._bw, self._key = None, key
         if want_bw and self._bw is None:
-            if self.s != 1:
-                raise NotImplementedError("HIP training path: input gradient of strided dense convs is not built "
-                                          "(only the stem conv is strided in the encoder, and its input is the image)")
             Cout, Cin = w.shape[:2]
-            wt = torch.empty((Cin, Cout, self.K, self.K), dtype=torch.float32, device=w.device)
+            cpad = (Cout + 3) // 4 * 4                   # the conv engine wants Cin % 4 == 0: zero input channels
+            wt = torch.empty((Cin, cpad, self.K, self.K), dtype=torch.float32, device=w.device)
             _lib.check(_lib_().creste_conv_flip_weight_f32(w.detach().contiguous().data_ptr(), wt.data_ptr(), Cout, Cin,
-                                                           self.K, Cout, _stream()), "conv_flip_weight")
+                                                           self.K, cpad, _stream()), "conv_flip_weight")
             t, b_, l, r = self.pad
             k1 = self.K - 1
-            prec = self._prec() if ops.conv_supported(self._prec(), self.K, 1) else ops.PREC_F32
+            prec = hipnn._precision if ops.conv_supported(hipnn._precision, self.K, 1) else ops.PREC_F32
+            # stride s: the same stride-1 conv, applied to the zero-inserted cotangent; the far-side pads then depend
+            # on the input extent (how many trailing rows the strided conv never reached) and are set per call
             self._bw = ops.pack_conv(wt, None, None, 1, (k1 - t, k1 - b_, k1 - l, k1 - r), ops.ACT_NONE, prec)
         return self._fw, self._bw
 
@@ -134,7 +134,21 @@ class ConvG:
                     gb.copy_(s)
         if not need_input:
             return None
-        return ops.conv2d(gy, self._packed(True)[1])
+        bw = self._packed(True)[1]
+        if gy.C != bw.Cin:                               # Cout % 4 != 0 (e.g. the 2- and 6-class projections)
+            buf = torch.zeros((gy.N, gy.H, gy.W, bw.Cin), dtype=torch.float32, device=gy.buf.device)
+            pointwise2(2, gy, Act(buf, gy.C, 0), out=Act(buf, gy.C, 0))
+            gy = Act(buf, bw.Cin, 0)
+        if self.s == 1:
+            return ops.conv2d(gy, bw)
+        gz = Act.empty(gy.N, (gy.H - 1) * self.s + 1, (gy.W - 1) * self.s + 1, gy.C, gy.buf.device)
+        _lib.check(lib.creste_zero_insert_nhwc_f32(gy.ptr, gy.cs, gz.ptr, gy.N, gy.H, gy.W, gy.C, self.s, _stream()),
+                   "zero_insert")
+        k1 = self.K - 1
+        import dataclasses
+        pt, pl = k1 - self.pad[0], k1 - self.pad[2]
+        bw = dataclasses.replace(bw, pad_t=pt, pad_l=pl, pad_b=x.H - gz.H - pt + k1, pad_r=x.W - gz.W - pl + k1)
+        return ops.conv2d(gz, bw)
 
 
 class SwishT:

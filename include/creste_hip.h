@@ -342,6 +342,11 @@ int creste_bev_splat_bwd_f32(const float* coords, const float* feats, int feats_
 int creste_depth_expectation_bwd_f32(const float* logits, int cs, int64_t P, int C, const float* bin_values,
                                      const float* g_depth, float* g_logits, int g_cs, int accumulate, void* stream);
 
+/* gz [N,(Ho-1)*s+1,(Wo-1)*s+1,C] = gy with s-1 zeros between neighbours: creste_conv2d_nhwc on gz with the
+ * creste_conv_flip_weight_f32 kernel (stride 1, pad K-1-pad) is the input gradient of a stride-s conv. */
+int creste_zero_insert_nhwc_f32(const float* gy, int gy_cs, float* gz, int N, int Ho, int Wo, int C, int stride,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif
