@@ -96,6 +96,8 @@ SIGNATURES = {
                                       _vp, _vp]),
     "creste_depth_expectation_bwd_f32": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "creste_zero_insert_nhwc_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "creste_pixel_geometry_bwd_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp,
+                                           _vp, _vp, _vp]),
     "creste_expected_svf_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp,
                                       _vp]),
 }

@@ -152,7 +152,6 @@ class TerrainNet(nn.Module):
         rgbd, p2p = x[:2]
         require_hip(rgbd, "TerrainNet")
         if self.training:
-            raise NotImplementedError(
-                "TerrainNet training (conv/BN/splat backward kernels) is not in this round: the HIP "
-                "path covers eval-mode forward (inference and the frozen IRL backbone); call .eval()")
+            from ...train_terrain import terrainnet_forward_train
+            return terrainnet_forward_train(self, rgbd, p2p)
         return self.pack_outputs(self.forward_act(rgbd, p2p), rgbd.shape[0])

@@ -1118,3 +1118,70 @@ extern "C" int creste_zero_insert_nhwc_f32(const float* gy, int gy_cs, float* gz
   CRESTE_CHECK_LAUNCH("zero_insert");
   return CRESTE_OK;
 }
+
+// ------------------------------------------------------------------------------------ pixel geometry backward
+// Forward (csrc/pointwise.hip pixel_geometry_kernel; reference splat_projection.py:19-51,98-104,152-157):
+//   c = [u*d, v*d, d, 1] ; xyz_k = P[k] . c ; z = xyz_2 ; h = relu(w1*z + b1) ; zf = relu(W2 h + b2)
+// Backward per pixel, given g_xyz [3] and g_zf [zdim] (a slice of the fusion conv's input gradient):
+//   gq = g_zf * (zf > 0) ; gh = W2^T gq ; ghp = gh * (h > 0) ; g_z = w1 . ghp + g_xyz_2
+//   g_d = sum_k g_xyz'_k * (P[k][0]*u + P[k][1]*v + P[k][2])          (g_xyz' = g_xyz with g_z in component 2)
+// gq [P][zdim], ghp [P][zhid], h [P][zhid] and z [P] are written out: the four parameter gradients are then plain
+// reductions over pixels (W2: gq^T h, w1: ghp^T z via the 1x1 wgrad kernel; biases: channel sums).
+namespace creste {
+__global__ __launch_bounds__(256) void pixel_geometry_bwd_kernel(
+    const float* __restrict__ depth, const float* __restrict__ p2p, int B, int Hs, int Ws, const float* __restrict__ w1,
+    const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2, int zhid, int zdim,
+    const float* __restrict__ g_xyz, const float* __restrict__ g_zf, int gz_cs, float* __restrict__ g_depth,
+    float* __restrict__ gq, float* __restrict__ ghp, float* __restrict__ hbuf, float* __restrict__ zbuf) {
+  extern __shared__ float smw[];   // w1[zhid] b1[zhid] w2[zdim*zhid] b2[zdim]
+  float* s_w1 = smw; float* s_b1 = s_w1 + zhid; float* s_w2 = s_b1 + zhid; float* s_b2 = s_w2 + zdim * zhid;
+  for (int i = threadIdx.x; i < zhid; i += blockDim.x) { s_w1[i] = w1[i]; s_b1[i] = b1[i]; }
+  for (int i = threadIdx.x; i < zdim * zhid; i += blockDim.x) s_w2[i] = w2[i];      // [zdim][zhid] row-major
+  for (int i = threadIdx.x; i < zdim; i += blockDim.x) s_b2[i] = b2[i];
+  __syncthreads();
+  const long P = (long)Hs * Ws, total = (long)B * P;
+  for (long g = blockIdx.x * 256L + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+    const int b = (int)(g / P); const long p = g % P;
+    const int v = (int)(p / Ws), u = (int)(p % Ws);
+    const float d = depth[g];
+    const float* M = p2p + (long)b * 16;
+    const float z = __fmaf_rn(M[11], 1.0f, __fmaf_rn(M[10], d, __fmaf_rn(M[9], (float)v * d, __fmul_rn(M[8], (float)u * d))));
+    zbuf[g] = z;
+    // hidden layer
+    float gz = 0.f;
+    for (int h = 0; h < zhid; ++h) hbuf[g * zhid + h] = fmaxf(__fmaf_rn(s_w1[h], z, s_b1[h]), 0.f);
+    for (int h = 0; h < zhid; ++h) ghp[g * zhid + h] = 0.f;
+    for (int j = 0; j < zdim; ++j) {
+      float s = s_b2[j];
+      for (int h = 0; h < zhid; ++h) s = __fmaf_rn(s_w2[j * zhid + h], hbuf[g * zhid + h], s);
+      const float q = s > 0.f ? g_zf[g * gz_cs + j] : 0.f;
+      gq[g * zdim + j] = q;
+      if (q != 0.f)
+        for (int h = 0; h < zhid; ++h) ghp[g * zhid + h] += s_w2[j * zhid + h] * q;
+    }
+    for (int h = 0; h < zhid; ++h) {
+      const float t = hbuf[g * zhid + h] > 0.f ? ghp[g * zhid + h] : 0.f;
+      ghp[g * zhid + h] = t;
+      gz += s_w1[h] * t;
+    }
+    const float gx0 = g_xyz[g * 3], gx1 = g_xyz[g * 3 + 1], gx2 = g_xyz[g * 3 + 2] + gz;
+    const float fu = (float)u, fv = (float)v;
+    g_depth[g] = gx0 * (M[0] * fu + M[1] * fv + M[2]) + gx1 * (M[4] * fu + M[5] * fv + M[6]) +
+                 gx2 * (M[8] * fu + M[9] * fv + M[10]);
+  }
+}
+}  // namespace creste
+
+extern "C" int creste_pixel_geometry_bwd_f32(const float* depth, const float* p2p, int B, int Hs, int Ws, const float* w1,
+                                             const float* b1, const float* w2, const float* b2, int zhid, int zdim,
+                                             const float* g_xyz, const float* g_zf, int gz_cs, float* g_depth, float* gq,
+                                             float* ghp, float* hbuf, float* zbuf, void* stream) {
+  CRESTE_REQUIRE(depth && p2p && w1 && b1 && w2 && b2 && g_xyz && g_zf && g_depth && gq && ghp && hbuf && zbuf,
+                 "pixel_geometry_bwd: null pointer");
+  CRESTE_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && zhid > 0 && zdim > 0, "pixel_geometry_bwd: bad dims");
+  const size_t smem = (size_t)(2 * zhid + zdim * zhid + zdim) * sizeof(float);
+  pixel_geometry_bwd_kernel<<<grid1d((long)B * Hs * Ws), 256, smem, (hipStream_t)stream>>>(
+      depth, p2p, B, Hs, Ws, w1, b1, w2, b2, zhid, zdim, g_xyz, g_zf, gz_cs, g_depth, gq, ghp, hbuf, zbuf);
+  CRESTE_CHECK_LAUNCH("pixel_geometry_bwd");
+  return CRESTE_OK;
+}

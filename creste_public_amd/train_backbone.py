@@ -31,10 +31,11 @@ def _lib_():
 
 
 def tpoint(op: int, a: Act, b: Act | None = None, gate: torch.Tensor | None = None, r: torch.Tensor | None = None,
-           out: Act | None = None) -> Act:
-    """creste_train_pointwise_f32 (swish / swish' / per-sample gate ops)."""
+           out: Act | None = None, hw: int | None = None) -> Act:
+    """creste_train_pointwise_f32 (swish / swish' / per-sample gate ops); hw=1 turns the per-sample gate into a
+    per-pixel one (the splat's range mask)."""
     out = out or _new(a)
-    HW = a.H * a.W
+    HW = hw or a.H * a.W
     _lib.check(_lib_().creste_train_pointwise_f32(
         op, a.ptr, a.cs, b.ptr if b is not None else None, b.cs if b is not None else 0,
         gate.data_ptr() if gate is not None else None, gate.shape[1] if gate is not None else 0,
@@ -483,17 +484,26 @@ class BackboneFn(torch.autograd.Function):
         ctx.eng, ctx.gen = eng, eng.gen
         logits, feats, dino = eng.forward(x)
         depth, bins = ops.depth_expectation(logits, eng.model.depthcomp._bin_values(x.buf.device))
-        ctx.mark_non_differentiable(depth, bins)
+        ctx.mark_non_differentiable(bins)
+        ctx.logits = logits
         return logits.nchw(), feats.nchw(), dino.nchw(), depth, bins
 
     @staticmethod
-    def backward(ctx, g_logits, g_feats, g_dino, _gd, _gb):
+    def backward(ctx, g_logits, g_feats, g_dino, _gd, _gb):   # _gd: cotangent of depth_preds_metric
         eng = ctx.eng
         if ctx.gen != eng.gen:
             raise RuntimeError("backbone (HIP training path): backward of a stale forward; run forward/backward in pairs")
         grads = eng.new_grad_store()
         a = lambda t: as_act(t) if t is not None else None       # noqa: E731
-        eng.backward(a(g_logits), a(g_feats), a(g_dino), grads)
+        gl = a(g_logits)
+        if _gd is not None:                                       # metric depth = softmax expectation of the logits
+            if gl is not None and (gl.cs != gl.C or not gl.buf.is_contiguous()):
+                gl = Act(gl.nchw().permute(0, 2, 3, 1).contiguous(), gl.C, 0)
+            elif gl is not None:
+                gl = Act(gl.buf.clone(), gl.C, 0)                 # accumulated in place below: do not alias autograd's
+            gl = ops.depth_expectation_bwd(ctx.logits, eng.model.depthcomp._bin_values(ctx.logits.buf.device),
+                                           _gd.detach().float().contiguous(), g_logits=gl)
+        eng.backward(gl, a(g_feats), a(g_dino), grads)
         if hasattr(grads, "finish"):
             grads.finish()                                        # tail bucket, wait, average over ranks
         return (None, None, *(grads.get(id(p)) for p in eng.params()))

@@ -347,6 +347,14 @@ int creste_depth_expectation_bwd_f32(const float* logits, int cs, int64_t P, int
 int creste_zero_insert_nhwc_f32(const float* gy, int gy_cs, float* gz, int N, int Ho, int Wo, int C, int stride,
                                 void* stream);
 
+/* Backward of creste_pixel_geometry_f32: cotangents of xyz [B*P][3] and of the z features (a slice of a wider
+ * buffer, pixel stride gz_cs) -> g_depth [B*P]; gq [B*P][zdim], ghp [B*P][zhid], hbuf [B*P][zhid], zbuf [B*P] are the
+ * per-pixel factors of the z-MLP's parameter gradients (W2: gq^T hbuf, w1: ghp^T zbuf, b2: sum gq, b1: sum ghp). */
+int creste_pixel_geometry_bwd_f32(const float* depth, const float* p2p, int B, int Hs, int Ws, const float* w1,
+                                  const float* b1, const float* w2, const float* b2, int zhid, int zdim,
+                                  const float* g_xyz, const float* g_zf, int gz_cs, float* g_depth, float* gq,
+                                  float* ghp, float* hbuf, float* zbuf, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
