@@ -176,8 +176,9 @@ class CrossEntropyDepth(Loss):
 
 
 class SmoothL1Depth(Loss):
-    """reference loss_utils.py:530-573.  With the shipped config its prediction is `depth_preds_bins` (integer
-    class indices), so it carries no gradient: evaluated as a logged scalar on the masked pixels."""
+    """reference loss_utils.py:530-573: smooth-L1 between the predicted depth and the label in metres over the
+    pixels whose label falls into a bin.  The distillation config feeds it `depth_preds_bins` (integer class
+    indices: no gradient, a logged scalar); the SSC config feeds it `depth_preds_metric`."""
 
     def __init__(self, config):
         super().__init__(config["name"], config)
@@ -189,13 +190,202 @@ class SmoothL1Depth(Loss):
         gt = tensor_dict[self.lab_key]
         if pred.shape[0] != gt.shape[0] * gt.shape[1]:
             raise NotImplementedError("multi-frame depth prediction is not configured by the shipped models")
-        if pred.requires_grad:
-            raise NotImplementedError("SmoothL1Depth on a differentiable prediction (metric depth) needs the "
-                                      "softmax-expectation backward, which is not built yet")
+        # `depth_preds_metric` (the SSC config) is differentiable: its cotangent re-enters the HIP path through the
+        # softmax-expectation backward (BackboneFn); `depth_preds_bins` (the distillation config) is an integer map
         d = self.config["discretize"]
         gt = _match_depth_label(pred.shape[-2:], gt)
         valid = _bin_depths_ud(gt, d["depth_min"], d["depth_max"], d["num_bins"]) != d["num_bins"]
         return {"depth/reg_loss": self.smoothl1_loss(pred[valid].float(), (gt / 1000.0)[valid].float())}, {}
+
+
+def remap_labels_in_batch(gt, ignore_idx=0):
+    """labels of different samples -> disjoint ascending classes, `ignore_idx` kept (reference utils/utils.py:59-77)."""
+    B = gt.shape[0]
+    out = torch.ones_like(gt) * ignore_idx
+    offset = 0
+    for b in range(B):
+        # the running index counts the ignore label too (it is enumerated, then skipped), so the first real label
+        # of a sample never collides with ignore_idx = 0
+        remap = {l: i + offset for i, l in enumerate(torch.unique(gt[b])) if l != ignore_idx}
+        for l, new in remap.items():
+            out[b, gt[b] == l] = new
+        offset += len(remap)
+    return out
+
+
+def extract_max_per_class(tensor, max_per_class=100):
+    """indices of at most `max_per_class` random elements of every class, classes ascending
+    (reference train_utils.py:324-352; the permutation comes from the host generator, as there)."""
+    picked = torch.LongTensor().to(tensor.device)
+    for cls in torch.unique(tensor):
+        idx = (tensor == cls).nonzero(as_tuple=False).reshape(-1)
+        if idx.size(0) > max_per_class:
+            idx = idx[torch.randperm(idx.size(0))[:max_per_class]]
+        picked = torch.cat((picked, idx))
+    return picked
+
+
+class MultiPosConLoss(nn.Module):
+    """multi-positive contrastive loss over [N,D] features (reference models/losses/supcon_loss.py:56-115): features
+    L2-normalised, all-gathered across ranks (with gradient) when a process group exists, positives = same label
+    (self excluded), cross-entropy between the positive distribution and the softmax of the similarities / T.
+    The reference rebuilds its label mask only when the local batch size changes (:87-99); that is reproduced
+    (`_last_n`) because it changes the loss on consecutive batches of equal size."""
+
+    def __init__(self, temperature=0.1, class_weights=None):
+        super().__init__()
+        self.temperature, self.class_weights = temperature, class_weights
+        self.logits_mask = self.mask = self._last_n = None
+
+    def forward(self, outputs):
+        import torch.distributed as dist
+        feats, labels = outputs["feats"], outputs["labels"]
+        if self.class_weights is not None:
+            self.class_weights = self.class_weights.to(feats.device)
+        feats = torch.nn.functional.normalize(feats, dim=-1, p=2)
+        n = feats.size(0)
+        rank = 0
+        if dist.is_available() and dist.is_initialized():
+            from torch.distributed.nn import all_gather as all_gather_with_grad
+            all_feats = torch.cat(all_gather_with_grad(feats), dim=0)
+            gathered = [torch.ones_like(labels) for _ in range(dist.get_world_size())]
+            dist.all_gather(gathered, labels)
+            all_labels = torch.cat(gathered, dim=0)
+            rank = dist.get_rank()
+        else:
+            all_feats, all_labels = feats, labels
+        if n != self._last_n:
+            mask = torch.eq(labels.view(-1, 1), all_labels.contiguous().view(1, -1)).float()
+            self.logits_mask = torch.scatter(torch.ones_like(mask), 1,
+                                             torch.arange(n, device=feats.device).view(-1, 1) + n * rank, 0)
+            self._last_n = n
+            self.mask = mask * self.logits_mask
+        mask = self.mask
+        logits = torch.matmul(feats, all_feats.T) / self.temperature
+        logits = logits - (1 - self.logits_mask) * 1e9
+        logits = logits - logits.max(dim=-1, keepdim=True)[0].detach()
+        p = mask / mask.sum(1, keepdim=True).clamp(min=1.0)
+        loss = torch.sum(p * torch.log_softmax(logits, dim=-1), dim=-1)
+        if self.class_weights is not None:
+            loss = loss * self.class_weights[labels]
+        loss = -loss.mean()
+        return {"loss": loss, "image_loss": loss}
+
+
+def _class_weights(config, eps=1e-5):
+    """1 / log(frequency + eps) from the text file the config names (reference loss_utils.py:383-391)."""
+    if "class_weights" not in config:
+        return None
+    freq = np.loadtxt(config["class_weights"]) if isinstance(config["class_weights"], str) else np.asarray(config["class_weights"])
+    return torch.from_numpy(1 / np.log(freq + eps)).float()
+
+
+class SupPixelConLoss(Loss):
+    """supervised pixel-contrastive loss on BEV embeddings (reference loss_utils.py:203-286)."""
+
+    def __init__(self, config):
+        super().__init__(config["name"], config)
+        self.views = config.get("views", 1)
+        self.temperature = config.get("temperature", 0.1)
+        cw = _class_weights(config)
+        if cw is not None:
+            self.register_buffer("class_weights", cw)
+            assert config["num_class"] == len(cw)
+        else:
+            self.class_weights = None
+        self.supcon_loss = MultiPosConLoss(temperature=self.temperature, class_weights=self.class_weights)
+        self.ignore_index = config.get("ignore_index", -1)
+        self.mask_key = config.get("mask_key", "inputs/fov_mask")
+        self.pred_key = config.get("pred_key", "outputs/inpainting_preds")
+        self.lab_key = config.get("lab_key", "inputs/sem_label")
+        self.lab_suffix_key = self.lab_key.split("/")[-1]
+        self.task = config.get("task", "3d_ssc")
+
+    def loss(self, tensor_dict):
+        preds, gt_prob, fov_mask = tensor_dict[self.pred_key], tensor_dict[self.lab_key], tensor_dict[self.mask_key]
+        C = gt_prob.shape[1]
+        BV, Z, H, W = preds.shape
+        B = BV // self.views
+        gt_label = torch.argmax(gt_prob, dim=1) if C > 1 else gt_prob.squeeze(1)
+        if self.lab_key == "inputs/3d_sam_label":
+            gt_label = remap_labels_in_batch(gt_label, ignore_idx=0)
+        valid = (gt_label != self.ignore_index) & fov_mask
+        valid = valid.view(B, self.views, H, W).permute(0, 2, 3, 1)[:, :, :, 0]
+        preds = preds.permute(0, 2, 3, 1).view(B, self.views, H, W, Z).permute(0, 2, 3, 1, 4)
+        preds = preds[valid][:, 0]
+        gt_label = gt_label.view(B, self.views, H, W).permute(0, 2, 3, 1)[valid][:, 0]
+        counts = torch.bincount(gt_label)
+        nz = counts[counts.nonzero(as_tuple=True)].float()
+        median = min(nz.median().int(), 1000)
+        sel = extract_max_per_class(gt_label, median)
+        out = self.supcon_loss({"feats": preds[sel, :], "labels": gt_label[sel]})
+        k = f"{self.task}/{self.lab_suffix_key}/supcon"
+        return {f"{k}/sem_loss": out["loss"], f"{k}/img_loss": out["image_loss"]}, {}
+
+
+class CrossEntropy(Loss):
+    """BEV classification with optional class weights / ignore index (reference loss_utils.py:379-474)."""
+
+    def __init__(self, config):
+        super().__init__(config["name"], config)
+        self.num_class = config["num_class"]
+        self.epsilon_w = 1e-5
+        cw = _class_weights(config, self.epsilon_w)
+        if cw is not None:
+            self.register_buffer("class_weights", cw)
+            assert self.num_class == len(cw)
+        else:
+            self.class_weights = None
+        self.mask_key = config.get("mask_key", "inputs/fov_mask")
+        self.pred_key = config.get("pred_key", "outputs/inpainting_preds")
+        self.lab_key = config.get("lab_key", "inputs/sem_label")
+        self.ignore_index = config.get("ignore_index", None)
+        self.task = config.get("task", "3d_ssc")
+        self.class_dim = config.get("class_dim", -1)
+        kw = dict(reduction="mean", weight=self.class_weights)
+        if self.ignore_index is not None:
+            kw["ignore_index"] = self.ignore_index
+        self.cs_loss = torch.nn.CrossEntropyLoss(**kw)
+
+    def loss(self, tensor_dict):
+        pred, gt, fov = tensor_dict[self.pred_key], tensor_dict[self.lab_key], tensor_dict[self.mask_key]
+        if self.class_dim < 0:
+            gt_mode = torch.argmax(gt / (torch.sum(gt, dim=1, keepdim=True) + self.epsilon_w), dim=1)
+        else:
+            gt_mode = gt[:, self.class_dim, :, :].long()
+        pred = pred.permute(0, 2, 3, 1)[fov, :]
+        gt_mode = gt_mode[fov]
+        loss = self.cs_loss(pred, gt_mode)
+        with torch.no_grad():
+            mode = torch.argmax(torch.softmax(pred, dim=1), dim=1)
+            lab = gt_mode != 0                          # class 0 is taken to be the ignore label in the metric
+            acc = torch.sum(mode[lab] == gt_mode[lab]) / (torch.numel(gt_mode[lab]) + self.epsilon_w)
+        return {f"{self.task}/cls_loss": loss}, {f"{self.task}/mIoU": acc}
+
+
+class SmoothL1(Loss):
+    """elevation regression (reference loss_utils.py:576-603): channel 1 relative to channel 0 unless `absolute`,
+    optional spatial-gradient form, nan / inf labels masked.  (The reference rewrites the label tensor in place;
+    the same values are used here without mutating the caller's tensor.)"""
+
+    def __init__(self, config):
+        super().__init__(config["name"], config)
+        self.pred_key, self.lab_key = config["pred_key"], config["lab_key"]
+        self.absolute = config.get("absolute", False)
+        self.take_grad = config.get("take_grad", False)
+        self.smoothl1_loss = torch.nn.SmoothL1Loss(beta=config["beta"])
+
+    def loss(self, tensor_dict):
+        pred, gt = tensor_dict[self.pred_key], tensor_dict[self.lab_key]
+        if not self.absolute:
+            gt = gt.clone()
+            gt[:, 1, :, :] = gt[:, 1, :, :] - gt[:, 0, :, :]
+        if self.take_grad:
+            assert pred.dim() == 4
+            pred = torch.cat(torch.gradient(pred, dim=[2, 3]), dim=1)
+            gt = torch.cat(torch.gradient(gt, dim=[2, 3]), dim=1)
+        valid = ~torch.isnan(gt) & ~torch.isinf(gt)
+        return {"val": self.smoothl1_loss(pred[valid], gt[valid])}, {}
 
 
 class MSELoss(Loss):
@@ -215,7 +405,7 @@ class MSELoss(Loss):
 
 
 _LOSSES = {"MaxEntIRLLoss": MaxEntIRLLoss, "CrossEntropyDepth": CrossEntropyDepth, "SmoothL1Depth": SmoothL1Depth,
-           "MSELoss": MSELoss}
+           "MSELoss": MSELoss, "SupPixelConLoss": SupPixelConLoss, "CrossEntropy": CrossEntropy, "SmoothL1": SmoothL1}
 
 
 class LossManager(nn.Module):

@@ -158,3 +158,90 @@ class DistillTrainer(IRLTrainer):
         logs["train/loss"] = loss.detach()
         self.global_step += 1
         return logs
+
+
+def ssc_cfg(image_size=(512, 612), class_weights=None, freeze_backbone_epochs=0):
+    """BEV-SSC hyper-parameters (reference configs/model/ssc_sam/terrainnet_supcon_sam2dynelev_jointdinopretrain.yaml:
+    optimiser / scheduler :80-89, losses :93-135).  `class_weights`: path of the 6-class frequency file the reference
+    reads (data/creste/class_weights_3d_sam_dynamic_6.txt) or a list of frequencies; None = unweighted."""
+    from .config import terrainnet_cfg
+    cfg = terrainnet_cfg(image_size)
+    disc = dict(cfg["discretize"])
+    cfg["optimizer"] = dict(name="Adam", beta1=0.9, beta2=0.999, lr=0.0005, eps=1e-7)
+    cfg["lr_scheduler"] = dict(name="ExponentialLR", gamma=0.98)
+    cfg["freeze_backbone_epochs"] = freeze_backbone_epochs
+    ce = dict(name="CrossEntropy", weight=2.0, pred_key="outputs/inpainting_sam_dynamic_preds",
+              lab_key="inputs/3d_sam_dynamic_label", num_class=6, class_dim=1, task="joint")
+    if class_weights is not None:
+        ce["class_weights"] = class_weights
+    cfg["loss"] = [
+        dict(name="SupPixelConLoss", views=1, weight=1.0, pred_key="outputs/inpainting_sam_preds",
+             lab_key="inputs/3d_sam_label", ignore_index=0, temperature=0.1, task="joint", contrast_mode="batch_all"),
+        ce,
+        dict(name="MSELoss", weight=2.0, pred_key="outputs/dino_pe_feats", lab_key="inputs/fimg_label", overlap_only=False),
+        dict(name="CrossEntropyDepth", weight=0.5, pred_key="outputs/depth_preds_logits", lab_key="inputs/depth_label",
+             discretize=disc),
+        dict(name="SmoothL1Depth", weight=0.1, pred_key="outputs/depth_preds_metric", lab_key="inputs/depth_label",
+             beta=0.5, discretize=disc),
+        dict(name="SmoothL1", weight=3.0, beta=0.2, pred_key="outputs/elevation_preds", lab_key="inputs/elevation_label",
+             absolute=False, task="joint")]
+    return cfg
+
+
+class SSCTrainer(DistillTrainer):
+    """BEV-SSC step (reference train_ssc.py:62-129, Lightning automatic optimisation + DDP): for every task of the batch
+    TerrainNet((image, p2p)) in training mode and the task's losses; the summed loss is backpropagated once, gradients are
+    averaged over ranks, Adam steps.  `on_train_epoch_start` freezes / unfreezes `model.depthcomp` by epoch (:71-80)."""
+
+    def __init__(self, model, loss_manager, model_cfg, bucket_mb: int = 32):
+        super().__init__(model, loss_manager, model_cfg, bucket_mb)
+        self.freeze_backbone_epochs = model_cfg.get("freeze_backbone_epochs", 0)
+        self.backbone_frozen = False
+        self.on_train_epoch_start()
+
+    def _rebuild_optimizer(self):
+        oc = self.cfg["optimizer"]
+        lr = self.optimizer.param_groups[0]["lr"]
+        self.params = [p for p in self.model.parameters() if p.requires_grad]
+        self.optimizer = torch.optim.Adam(self.params, betas=(oc["beta1"], oc["beta2"]), lr=lr)
+        self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=self.cfg["lr_scheduler"]["gamma"])
+
+    def on_train_epoch_start(self):
+        if self.epoch >= self.freeze_backbone_epochs and self.backbone_frozen:
+            self.model.depthcomp.unfreeze_backbone()
+            self.backbone_frozen = False
+            self._rebuild_optimizer()
+        elif self.epoch < self.freeze_backbone_epochs and not self.backbone_frozen:
+            for p in self.model.depthcomp.parameters():
+                p.requires_grad = False
+            self.backbone_frozen = True
+            self._rebuild_optimizer()
+
+    def load_checkpoint(self, path: str, strict: bool = True):
+        # the optimiser's parameter group depends on the freeze schedule: restore the epoch first
+        self.epoch = torch.load(path, weights_only=False, map_location="cpu").get("epoch", 0)
+        self.on_train_epoch_start()
+        super().load_checkpoint(path, strict)
+
+    def training_step(self, batch: dict) -> dict:
+        """batch: {task: {'image', 'p2p', labels ...}}"""
+        self.model.train()
+        self.optimizer.zero_grad()
+        total, logs = 0.0, {}
+        for task, data in batch.items():
+            outputs = self.model((data["image"], data["p2p"]))
+            with torch.no_grad():
+                merged = tu.merge_dict(("inputs", data), ("outputs", outputs))
+                merged["task"] = task
+            for k, v in outputs.items():
+                merged[f"outputs/{k}"] = v
+            loss_dict, meta = self.loss(merged)
+            total = total + sum(w * v for w, v in loss_dict.values())
+            logs.update({f"train/{k}": (w * v.detach()) for k, (w, v) in loss_dict.items()})
+            logs.update({f"train/{k}": v.detach() for k, v in meta.items()})
+        total.backward()
+        dist_utils.allreduce_mean_grads(self.params)          # one flat all-reduce over the trainable parameters
+        self.optimizer.step()
+        logs["train/loss"] = total.detach()
+        self.global_step += 1
+        return logs

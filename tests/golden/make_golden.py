@@ -365,6 +365,64 @@ def gen_distill_losses():
     npz("distill_losses.npz", **out)
 
 
+def gen_ssc_losses():
+    """SupPixelConLoss (+MultiPosConLoss), CrossEntropy (class_dim=1, class weights), SmoothL1 (relative elevation),
+    SmoothL1Depth on metric depth -- through the reference's own LossManager (loss_utils.py:203-286, 379-474,
+    530-603; models/losses/supcon_loss.py:56-115), in a 1-rank gloo group because MultiPosConLoss all-gathers."""
+    import tempfile
+    import torch.distributed as dist
+    import creste.utils.loss_utils as lu
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method=f"file://{tempfile.mkdtemp()}/pg", rank=0, world_size=1)
+    g = torch.Generator().manual_seed(41)
+    B, G, Z = 2, 24, 8
+    freq = np.array([0.5, 0.2, 0.1, 0.1, 0.05, 0.05])
+    wfile = os.path.join(tempfile.mkdtemp(), "w6.txt")
+    np.savetxt(wfile, freq)
+    disc = dict(mode="UD", num_bins=128, depth_min=300, depth_max=25600)
+    cfg = wrap(dict(loss=[
+        dict(name="SupPixelConLoss", views=1, weight=1.0, pred_key="outputs/inpainting_sam_preds",
+             lab_key="inputs/3d_sam_label", ignore_index=0, temperature=0.1, task="joint", contrast_mode="batch_all"),
+        dict(name="CrossEntropy", weight=2.0, pred_key="outputs/inpainting_sam_dynamic_preds",
+             lab_key="inputs/3d_sam_dynamic_label", num_class=6, class_weights=wfile, class_dim=1, task="joint"),
+        dict(name="SmoothL1Depth", weight=0.1, pred_key="outputs/depth_preds_metric", lab_key="inputs/depth_label",
+             beta=0.5, discretize=disc),
+        dict(name="SmoothL1", weight=3.0, beta=0.2, pred_key="outputs/elevation_preds", lab_key="inputs/elevation_label",
+             absolute=False, task="joint")]))
+    lm = lu.LossManager(cfg)
+    sam_pred = torch.randn(B, Z, G, G, generator=g).requires_grad_(True)
+    sam_label = torch.randint(0, 5, (B, 1, G, G), generator=g)              # 0 = ignore; remapped per sample
+    dyn_pred = torch.randn(B, 6, G, G, generator=g).requires_grad_(True)
+    dyn_label = torch.stack([torch.zeros(B, G, G), torch.randint(0, 6, (B, G, G), generator=g).float()], dim=1)
+    fov = torch.rand(B, G, G, generator=g) > 0.3
+    Hs, Ws = 7, 9
+    depth_pred = (torch.rand(B, Hs, Ws, generator=g) * 20.0).requires_grad_(True)
+    depth_label = torch.rand(B, 1, Hs, Ws, generator=g) * 30000.0 - 1500.0
+    elev_pred = torch.randn(B, 2, G, G, generator=g).requires_grad_(True)
+    elev_label = torch.randn(B, 2, G, G, generator=g)
+    elev_label[0, :, 2, 3] = float("nan")
+    elev_label[1, 1, 4, 4] = float("inf")
+    td = {"outputs/inpainting_sam_preds": sam_pred, "inputs/3d_sam_label": sam_label.clone(),
+          "outputs/inpainting_sam_dynamic_preds": dyn_pred, "inputs/3d_sam_dynamic_label": dyn_label.clone(),
+          "inputs/fov_mask": fov, "outputs/depth_preds_metric": depth_pred, "inputs/depth_label": depth_label.clone(),
+          "outputs/elevation_preds": elev_pred, "inputs/elevation_label": elev_label.clone(), "task": "joint"}
+    torch.manual_seed(77)                                                     # extract_max_per_class draws randperm
+    with torch.enable_grad():
+        ld, meta = lm(td)
+        total = sum(w * v for w, v in ld.values())
+        total.backward()
+    out = dict(sam_pred=sam_pred.detach(), sam_label=sam_label, dyn_pred=dyn_pred.detach(), dyn_label=dyn_label,
+               fov=fov, depth_pred=depth_pred.detach(), depth_label=depth_label, elev_pred=elev_pred.detach(),
+               elev_label=elev_label, class_freq=torch.from_numpy(freq), total=total.detach(),
+               g_sam=sam_pred.grad, g_dyn=dyn_pred.grad, g_depth=depth_pred.grad, g_elev=elev_pred.grad)
+    for k, (w, v) in ld.items():
+        out[f"loss/{k}"] = v.detach()
+        out[f"weight/{k}"] = torch.tensor(float(w))
+    for k, v in meta.items():
+        out[f"meta/{k}"] = v.detach()
+    npz("ssc_losses.npz", **out)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference tree not mounted: fixtures can only be made in the build container"
     sys.path.insert(0, os.path.abspath(os.path.join(OUT, "..", "..")))
@@ -375,3 +433,4 @@ if __name__ == "__main__":
     gen_vin_svf_loss()
     gen_blocks_and_utils()
     gen_distill_losses()
+    gen_ssc_losses()

@@ -199,3 +199,47 @@ def test_depth_label_binning_and_smoothl1_match_reference_golden():
                  "inputs/depth_label": torch.from_numpy(d["depth_label"])})
     w, v = out["depth/reg_loss"]
     assert abs(float(v) - float(d["loss/SmoothL1Depth/depth/reg_loss"])) < 1e-5 * float(v) and w == 0.1
+
+
+def test_ssc_losses_match_reference_golden(tmp_path):
+    """SupPixelConLoss / MultiPosConLoss, CrossEntropy (class weights, class_dim), SmoothL1 (relative elevation, nan/inf
+    masked) and SmoothL1Depth on metric depth: the host-side mirrors against the reference's own LossManager
+    (tests/golden/make_golden.py::gen_ssc_losses) -- losses, metric, weighted total and all four prediction gradients."""
+    import os
+    import numpy as np
+    from creste_public_amd.creste.utils.loss_utils import LossManager
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "ssc_losses.npz"))
+    t = lambda k: torch.from_numpy(d[k])          # noqa: E731
+    wfile = tmp_path / "w6.txt"
+    np.savetxt(wfile, d["class_freq"])
+    disc = dict(mode="UD", num_bins=128, depth_min=300, depth_max=25600)
+    lm = LossManager({"loss": [
+        dict(name="SupPixelConLoss", views=1, weight=1.0, pred_key="outputs/inpainting_sam_preds",
+             lab_key="inputs/3d_sam_label", ignore_index=0, temperature=0.1, task="joint", contrast_mode="batch_all"),
+        dict(name="CrossEntropy", weight=2.0, pred_key="outputs/inpainting_sam_dynamic_preds",
+             lab_key="inputs/3d_sam_dynamic_label", num_class=6, class_weights=str(wfile), class_dim=1, task="joint"),
+        dict(name="SmoothL1Depth", weight=0.1, pred_key="outputs/depth_preds_metric", lab_key="inputs/depth_label",
+             beta=0.5, discretize=disc),
+        dict(name="SmoothL1", weight=3.0, beta=0.2, pred_key="outputs/elevation_preds", lab_key="inputs/elevation_label",
+             absolute=False, task="joint")]})
+    preds = {k: t(k).clone().requires_grad_(True) for k in ("sam_pred", "dyn_pred", "depth_pred", "elev_pred")}
+    elev_label = t("elev_label").clone()
+    td = {"outputs/inpainting_sam_preds": preds["sam_pred"], "inputs/3d_sam_label": t("sam_label"),
+          "outputs/inpainting_sam_dynamic_preds": preds["dyn_pred"], "inputs/3d_sam_dynamic_label": t("dyn_label"),
+          "inputs/fov_mask": t("fov"), "outputs/depth_preds_metric": preds["depth_pred"],
+          "inputs/depth_label": t("depth_label"), "outputs/elevation_preds": preds["elev_pred"],
+          "inputs/elevation_label": elev_label, "task": "joint"}
+    torch.manual_seed(77)
+    ld, meta = lm(td)
+    total = sum(w * v for w, v in ld.values())
+    total.backward()
+    assert set(ld) == {k[5:] for k in d.files if k.startswith("loss/")}
+    for k, (w, v) in ld.items():
+        assert abs(float(v) - float(d[f"loss/{k}"])) < 1e-5 * abs(float(d[f"loss/{k}"])), k
+        assert abs(float(w) - float(d[f"weight/{k}"])) < 1e-7, k
+    assert abs(float(meta["CrossEntropy/joint/mIoU"]) - float(d["meta/CrossEntropy/joint/mIoU"])) < 1e-6
+    assert abs(float(total) - float(d["total"])) < 1e-5 * float(d["total"])
+    for k, gk in (("sam_pred", "g_sam"), ("dyn_pred", "g_dyn"), ("depth_pred", "g_depth"), ("elev_pred", "g_elev")):
+        torch.testing.assert_close(preds[k].grad, t(gk), rtol=1e-4, atol=1e-7)
+    nan_ok = torch.isnan(elev_label) == torch.isnan(t("elev_label"))       # the caller's label tensor is not rewritten
+    assert nan_ok.all() and torch.equal(torch.nan_to_num(elev_label), torch.nan_to_num(t("elev_label")))

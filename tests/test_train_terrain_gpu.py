@@ -132,3 +132,59 @@ def test_terrainnet_training_step():
         if e > 2e-2:
             bad.append((name, f"{e:.1e}"))
     assert not bad, (len(bad), bad[:30])
+
+
+def _ssc_batch(B, H, W, seed=0, G=256):
+    rgbd, p2p = synth.make_frames(B, H, W, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    Hs, Ws = H // 4, W // 4
+    blocks = torch.randint(0, 5, (B, 1, G // 16, G // 16), generator=g)        # piecewise-constant SAM segments
+    data = {"image": rgbd, "p2p": p2p,
+            "depth_label": torch.rand(B, 1, Hs, Ws, generator=g) * 26000.0,
+            "fimg_label": torch.randn(B, 1, 128, Hs, Ws, generator=g),
+            "3d_sam_label": blocks.repeat_interleave(16, 2).repeat_interleave(16, 3),
+            "3d_sam_dynamic_label": torch.stack([torch.zeros(B, G, G),
+                                                 torch.randint(0, 6, (B, G // 8, G // 8), generator=g).float()
+                                                 .repeat_interleave(8, 1).repeat_interleave(8, 2)], dim=1),
+            "fov_mask": torch.rand(B, G, G, generator=g) > 0.5,
+            "elevation_label": torch.randn(B, 2, G, G, generator=g)}
+    return {"joint": {k: v.cuda() for k, v in data.items()}}
+
+
+def test_ssc_trainer_steps_freeze_schedule_and_checkpoint(tmp_path):
+    """row H (train_ssc.py): the full six-loss SSC objective drives Adam steps of TerrainNet on the HIP training path;
+    the backbone is frozen for the first epoch and unfrozen afterwards; Lightning-layout checkpoint round trip."""
+    from creste_public_amd import harness
+    from creste_public_amd.creste.models.terrainnet import TerrainNet
+    from creste_public_amd.creste.utils.loss_utils import LossManager
+    H, W, B = 64, 96, 2
+    harness.seed_everything(5)
+    cfg = harness.ssc_cfg((H, W), class_weights=[0.5, 0.2, 0.1, 0.1, 0.05, 0.05], freeze_backbone_epochs=1)
+    model = TerrainNet(cfg).cuda()
+    synth.randomize_bn(model, seed=2)
+    tr = harness.SSCTrainer(model, LossManager(cfg).cuda(), cfg)
+    batch = _ssc_batch(B, H, W)
+    assert tr.backbone_frozen and not any(p.requires_grad for p in model.depthcomp.parameters())
+    w0 = model.depthcomp.depthcomp.vision_backbone.model.up3.conv[0].weight.detach().clone()
+    h0 = model.bevclassifier.conv1.weight.detach().clone()
+    logs = [tr.training_step(batch) for _ in range(3)]
+    assert all(torch.isfinite(l["train/loss"]) for l in logs)
+    assert torch.equal(w0, model.depthcomp.depthcomp.vision_backbone.model.up3.conv[0].weight)     # frozen
+    assert not torch.equal(h0, model.bevclassifier.conv1.weight)
+    expect = {"train/SupPixelConLoss/joint/3d_sam_label/supcon/sem_loss", "train/CrossEntropy/joint/cls_loss",
+              "train/MSELoss/loss", "train/CrossEntropyDepth/depth/cls_loss", "train/SmoothL1Depth/depth/reg_loss",
+              "train/SmoothL1/val", "train/CrossEntropy/joint/mIoU", "train/loss"}
+    assert expect <= set(logs[0])
+    tr.on_train_epoch_end()
+    tr.on_train_epoch_start()                                   # epoch 1 >= freeze_backbone_epochs -> unfreeze
+    assert not tr.backbone_frozen
+    losses = [float(tr.training_step(batch)["train/loss"]) for _ in range(4)]
+    assert not torch.equal(w0, model.depthcomp.depthcomp.vision_backbone.model.up3.conv[0].weight)
+    assert losses[-1] < float(logs[0]["train/loss"]), (losses, float(logs[0]["train/loss"]))
+    path = tmp_path / "ssc.ckpt"
+    tr.save_checkpoint(str(path))
+    model2 = TerrainNet(cfg)
+    tr2 = harness.SSCTrainer(model2, LossManager(cfg), cfg)
+    tr2.load_checkpoint(str(path))
+    for (k, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert torch.equal(a.cpu(), b), k
