@@ -168,6 +168,44 @@ def distill_extras(device, steps=3, B=8):
                               f"{n} parameters with gradients, Adam; loss {float(logs['train/loss']):.3f}"}
 
 
+def ssc_extras(device, steps=3, B=8):
+    """BASELINE configs[3], second stage: one BEV-SSC training step (train_ssc.py) -- TerrainNet in training mode
+    (encoder + depth-guided splat + ResNet-18 BEV heads), the six SSC losses, backward through the splat into
+    features and depth, Adam -- batch 8 of 1216x608 -> 256x256 BEV on the HIP training kernels."""
+    from creste_public_amd import harness, synth
+    from creste_public_amd.creste.models.terrainnet import TerrainNet
+    from creste_public_amd.creste.utils.loss_utils import LossManager
+    cfg = harness.ssc_cfg((IMG_H, IMG_W), class_weights=[0.5, 0.2, 0.1, 0.1, 0.05, 0.05])
+    torch.manual_seed(0)
+    model = TerrainNet(cfg).to(device)
+    synth.randomize_bn(model, seed=1)
+    rgbd, p2p = synth.make_frames(B, IMG_H, IMG_W, seed=2)
+    g = torch.Generator().manual_seed(3)
+    G, Hs, Ws = 256, IMG_H // 4, IMG_W // 4
+    data = {"image": rgbd, "p2p": p2p, "depth_label": torch.rand(B, 1, Hs, Ws, generator=g) * 26000.0,
+            "fimg_label": torch.randn(B, 1, 128, Hs, Ws, generator=g),
+            "3d_sam_label": torch.randint(0, 5, (B, 1, G // 16, G // 16), generator=g).repeat_interleave(16, 2)
+            .repeat_interleave(16, 3),
+            "3d_sam_dynamic_label": torch.stack([torch.zeros(B, G, G), torch.randint(0, 6, (B, G // 8, G // 8), generator=g)
+                                                 .float().repeat_interleave(8, 1).repeat_interleave(8, 2)], dim=1),
+            "fov_mask": torch.rand(B, G, G, generator=g) > 0.5, "elevation_label": torch.randn(B, 2, G, G, generator=g)}
+    batch = {"joint": {k: v.to(device) for k, v in data.items()}}
+    tr = harness.SSCTrainer(model, LossManager(cfg).to(device), cfg)
+    tr.training_step(batch); tr.training_step(batch); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        logs = tr.training_step(batch)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    n = sum(p.numel() for p in model.parameters() if p.grad is not None)
+    del tr, model, batch
+    torch.cuda.empty_cache()
+    return {"ssc_train_step_ms": round(ms, 1), "ssc_frames_per_s": round(B / ms * 1e3, 1),
+            "ssc_config": f"batch {B}, {IMG_W}x{IMG_H} -> 256x256 BEV, TerrainNet in training mode, SupPixelCon + CE + MSE + "
+                          f"depth CE + depth SmoothL1 + elevation SmoothL1, {n} parameters with gradients, Adam; "
+                          f"loss {float(logs['train/loss']):.3f}"}
+
+
 def irl_extras(model_infer, device, steps=3):
     """The second half of BASELINE.json's metric: IRL train-step time (configs[2]).  Reference-config
     step: batch 8 frames, 64x128 IRL grid (map_ds 2 + front-half crop), frozen HIP backbone, reward net
@@ -377,6 +415,7 @@ def main():
         if args.gpus == 1 and not args.no_irl:
             line["irl"] = irl_extras(model, device)
             line["distill"] = distill_extras(device)
+            line["ssc"] = ssc_extras(device)
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
