@@ -1170,6 +1170,67 @@ __global__ __launch_bounds__(256) void pixel_geometry_bwd_kernel(
                  gx2 * (M[8] * fu + M[9] * fv + M[10]);
   }
 }
+
+// The shipped z-MLP (1 -> 64 -> 32): one 32-lane half-wave per pixel.  Lane j owns output j in the forward recompute
+// (every lane evaluates the 64 hidden units itself: 128 FMAs, no exchange) and hidden units {j, j+32} in the
+// backward (the 32 masked output cotangents arrive by shuffle); W2 sits in LDS in both orientations so either
+// access pattern is conflict-free; all stores are coalesced rows.  15 ms -> well under 1 ms per SSC step.
+__global__ __launch_bounds__(256) void pixel_geometry_bwd32_kernel(
+    const float* __restrict__ depth, const float* __restrict__ p2p, int B, int Hs, int Ws, const float* __restrict__ w1,
+    const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+    const float* __restrict__ g_xyz, const float* __restrict__ g_zf, int gz_cs, float* __restrict__ g_depth,
+    float* __restrict__ gq, float* __restrict__ ghp, float* __restrict__ hbuf, float* __restrict__ zbuf) {
+  constexpr int ZH = 64, ZD = 32;
+  __shared__ float s_w1[ZH], s_b1[ZH], s_b2[ZD], s_w2[ZD * ZH], s_w2t[ZH * ZD];
+  for (int i = threadIdx.x; i < ZH; i += 256) { s_w1[i] = w1[i]; s_b1[i] = b1[i]; }
+  for (int i = threadIdx.x; i < ZD; i += 256) s_b2[i] = b2[i];
+  for (int i = threadIdx.x; i < ZD * ZH; i += 256) {
+    s_w2[i] = w2[i];                                   // [j][h]
+    s_w2t[(i % ZH) * ZD + i / ZH] = w2[i];             // [h][j]
+  }
+  __syncthreads();
+  const int sub = threadIdx.x & 31;
+  const long P = (long)Hs * Ws, total = (long)B * P;
+  const long half = (blockIdx.x * 256L + threadIdx.x) >> 5, nhalf = ((long)gridDim.x * 256) >> 5;
+  for (long g = half; g < total; g += nhalf) {
+    const int b = (int)(g / P); const long p = g % P;
+    const int v = (int)(p / Ws), u = (int)(p % Ws);
+    const float d = depth[g];
+    const float* M = p2p + (long)b * 16;
+    const float z = __fmaf_rn(M[11], 1.0f, __fmaf_rn(M[10], d, __fmaf_rn(M[9], (float)v * d, __fmul_rn(M[8], (float)u * d))));
+    float s = s_b2[sub];
+#pragma unroll 8
+    for (int h = 0; h < ZH; ++h) {
+      const float hv = fmaxf(__fmaf_rn(s_w1[h], z, s_b1[h]), 0.f);
+      s = __fmaf_rn(s_w2t[h * ZD + sub], hv, s);
+    }
+    const float q = s > 0.f ? g_zf[g * gz_cs + sub] : 0.f;
+    gq[g * ZD + sub] = q;
+    const float h0 = fmaxf(__fmaf_rn(s_w1[sub], z, s_b1[sub]), 0.f);
+    const float h1 = fmaxf(__fmaf_rn(s_w1[sub + 32], z, s_b1[sub + 32]), 0.f);
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < ZD; ++j) {
+      const float qj = __shfl(q, j, 32);
+      a0 += s_w2[j * ZH + sub] * qj;
+      a1 += s_w2[j * ZH + sub + 32] * qj;
+    }
+    a0 = h0 > 0.f ? a0 : 0.f;
+    a1 = h1 > 0.f ? a1 : 0.f;
+    hbuf[g * ZH + sub] = h0; hbuf[g * ZH + sub + 32] = h1;
+    ghp[g * ZH + sub] = a0; ghp[g * ZH + sub + 32] = a1;
+    float gz = s_w1[sub] * a0 + s_w1[sub + 32] * a1;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) gz += __shfl_xor(gz, o);
+    if (sub == 0) {
+      zbuf[g] = z;
+      const float gx0 = g_xyz[g * 3], gx1 = g_xyz[g * 3 + 1], gx2 = g_xyz[g * 3 + 2] + gz;
+      const float fu = (float)u, fv = (float)v;
+      g_depth[g] = gx0 * (M[0] * fu + M[1] * fv + M[2]) + gx1 * (M[4] * fu + M[5] * fv + M[6]) +
+                   gx2 * (M[8] * fu + M[9] * fv + M[10]);
+    }
+  }
+}
 }  // namespace creste
 
 extern "C" int creste_pixel_geometry_bwd_f32(const float* depth, const float* p2p, int B, int Hs, int Ws, const float* w1,
@@ -1179,6 +1240,12 @@ extern "C" int creste_pixel_geometry_bwd_f32(const float* depth, const float* p2
   CRESTE_REQUIRE(depth && p2p && w1 && b1 && w2 && b2 && g_xyz && g_zf && g_depth && gq && ghp && hbuf && zbuf,
                  "pixel_geometry_bwd: null pointer");
   CRESTE_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && zhid > 0 && zdim > 0, "pixel_geometry_bwd: bad dims");
+  if (zhid == 64 && zdim == 32) {
+    pixel_geometry_bwd32_kernel<<<grid1d((long)B * Hs * Ws * 32), 256, 0, (hipStream_t)stream>>>(
+        depth, p2p, B, Hs, Ws, w1, b1, w2, b2, g_xyz, g_zf, gz_cs, g_depth, gq, ghp, hbuf, zbuf);
+    CRESTE_CHECK_LAUNCH("pixel_geometry_bwd32");
+    return CRESTE_OK;
+  }
   const size_t smem = (size_t)(2 * zhid + zdim * zhid + zdim) * sizeof(float);
   pixel_geometry_bwd_kernel<<<grid1d((long)B * Hs * Ws), 256, smem, (hipStream_t)stream>>>(
       depth, p2p, B, Hs, Ws, w1, b1, w2, b2, zhid, zdim, g_xyz, g_zf, gz_cs, g_depth, gq, ghp, hbuf, zbuf);
