@@ -98,6 +98,9 @@ SIGNATURES = {
     "creste_zero_insert_nhwc_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "creste_pixel_geometry_bwd_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp,
                                            _vp, _vp, _vp]),
+    "creste_multipos_con_workspace_bytes": (_i64, [_i, _i, _i]),
+    "creste_multipos_con_forward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "creste_multipos_con_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "creste_expected_svf_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp,
                                       _vp]),
 }

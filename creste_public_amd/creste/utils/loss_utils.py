@@ -254,6 +254,16 @@ class MultiPosConLoss(nn.Module):
             rank = dist.get_rank()
         else:
             all_feats, all_labels = feats, labels
+        if feats.is_cuda and feats.shape[1] in (8, 16, 32, 64):
+            # fused HIP path (no N x M tensors).  The reference's stale-mask behaviour is kept by remembering the LABELS
+            # the mask was built from: positives follow those, the class weights follow the current labels.
+            from ...loss_ops import MultiPosConFn
+            if n != self._last_n:
+                self._mask_labels, self._mask_all_labels, self._last_n = labels.clone(), all_labels.clone(), n
+            rw = self.class_weights[labels] if self.class_weights is not None else None
+            loss = MultiPosConFn.apply(feats, all_feats, self._mask_labels, self._mask_all_labels, rw, n * rank,
+                                       self.temperature)
+            return {"loss": loss, "image_loss": loss}
         if n != self._last_n:
             mask = torch.eq(labels.view(-1, 1), all_labels.contiguous().view(1, -1)).float()
             self.logits_mask = torch.scatter(torch.ones_like(mask), 1,

@@ -59,3 +59,38 @@ class MSEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gl):
         return ctx.g * gl, None
+
+
+class MultiPosConFn(torch.autograd.Function):
+    """fused multi-positive contrastive loss (csrc/losses.hip): feats [N,D] and all_feats [M,D] are the L2-normalised
+    local / all-gathered features; mask_labels [N] / all_labels [M] decide the positives, row_weights [N] (or None)
+    scale the rows.  No N x M tensor is formed."""
+
+    @staticmethod
+    def forward(ctx, feats, all_feats, mask_labels, all_labels, row_weights, self_offset, temperature):
+        lib = _lib.load()
+        f, a = feats.detach().float().contiguous(), all_feats.detach().float().contiguous()
+        lf, la = mask_labels.detach().long().contiguous(), all_labels.detach().long().contiguous()
+        rw = row_weights.detach().float().contiguous() if row_weights is not None else None
+        N, D = f.shape
+        M = a.shape[0]
+        dev = f.device
+        work = torch.empty(lib.creste_multipos_con_workspace_bytes(N, M, D), dtype=torch.uint8, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        _lib.check(lib.creste_multipos_con_forward_f32(f.data_ptr(), a.data_ptr(), lf.data_ptr(), la.data_ptr(),
+                                                       rw.data_ptr() if rw is not None else None, N, M, D,
+                                                       int(self_offset), float(temperature), loss.data_ptr(),
+                                                       work.data_ptr(), _stream()), "multipos_con_forward")
+        ctx.saved = (f, a, lf, la, rw, work, int(self_offset), float(temperature))
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gl):
+        f, a, lf, la, rw, work, off, T = ctx.saved
+        lib = _lib.load()
+        gf, ga = torch.empty_like(f), torch.empty_like(a)
+        _lib.check(lib.creste_multipos_con_backward_f32(f.data_ptr(), a.data_ptr(), lf.data_ptr(), la.data_ptr(),
+                                                        rw.data_ptr() if rw is not None else None, f.shape[0], a.shape[0],
+                                                        f.shape[1], off, T, 1.0, work.data_ptr(), gf.data_ptr(),
+                                                        ga.data_ptr(), _stream()), "multipos_con_backward")
+        return gf * gl, ga * gl, None, None, None, None, None

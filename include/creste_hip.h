@@ -355,6 +355,22 @@ int creste_pixel_geometry_bwd_f32(const float* depth, const float* p2p, int B, i
                                   const float* g_xyz, const float* g_zf, int gz_cs, float* g_depth, float* gq,
                                   float* ghp, float* hbuf, float* zbuf, void* stream);
 
+/* Multi-positive contrastive loss (reference models/losses/supcon_loss.py:56-115) without the N x M similarity
+ * matrix: feats [N][D] local L2-normalised features, all_feats [M][D] the all-gathered ones (== feats on one rank),
+ * int64 labels, optional per-row weights row_weights [N] (= class_weights[label]), self_offset = N * rank (the
+ * column of row i's own sample).
+ * forward: *loss = mean_i w_i * (logsumexp_{j != self} z_ij - mean_{j in P_i} z_ij), rows without positives count 0;
+ * backward (same workspace, after forward): g_feats [N][D], g_all [M][D] = grad_scale * d loss / d (feats, all_feats).
+ * D in {8,16,32,64}; work: creste_multipos_con_workspace_bytes(N, M, D). */
+int64_t creste_multipos_con_workspace_bytes(int N, int M, int D);
+int creste_multipos_con_forward_f32(const float* feats, const float* all_feats, const int64_t* labels,
+                                    const int64_t* all_labels, const float* row_weights, int N, int M, int D,
+                                    int self_offset, float temperature, float* loss, void* work, void* stream);
+int creste_multipos_con_backward_f32(const float* feats, const float* all_feats, const int64_t* labels,
+                                     const int64_t* all_labels, const float* row_weights, int N, int M, int D,
+                                     int self_offset, float temperature, float grad_scale, void* work, float* g_feats,
+                                     float* g_all, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

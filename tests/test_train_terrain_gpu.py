@@ -188,3 +188,69 @@ def test_ssc_trainer_steps_freeze_schedule_and_checkpoint(tmp_path):
     tr2.load_checkpoint(str(path))
     for (k, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
         assert torch.equal(a.cpu(), b), k
+
+
+@pytest.mark.parametrize("N,D,ncls,weights", [(700, 32, 9, False), (2500, 32, 40, True), (300, 8, 3, True), (1030, 64, 1, False)])
+def test_fused_multipos_contrastive_loss(N, D, ncls, weights):
+    """csrc/losses.hip (no N x N tensors) against the tensor-code restatement of MultiPosConLoss evaluated in float64
+    on the CPU: loss and gradient w.r.t. the un-normalised features (classes with a single member, i.e. rows without
+    positives, included)."""
+    from creste_public_amd.creste.utils.loss_utils import MultiPosConLoss
+    g = torch.Generator().manual_seed(N)
+    feats = torch.randn(N, D, generator=g)
+    labels = torch.randint(0, ncls, (N,), generator=g)
+    labels[0] = ncls + 5                                        # a singleton class: no positives for row 0
+    cw = (torch.rand(ncls + 6, generator=g) + 0.5) if weights else None
+    ref = MultiPosConLoss(0.1, cw.double() if weights else None)
+    fr = feats.double().requires_grad_(True)
+    lr = ref({"feats": fr, "labels": labels})["loss"]
+    lr.backward()
+    hip = MultiPosConLoss(0.1, cw.cuda() if weights else None)
+    fg = feats.cuda().requires_grad_(True)
+    out = hip({"feats": fg, "labels": labels.cuda()})
+    (out["loss"] * 1.7).backward()
+    torch.cuda.synchronize()
+    assert abs(float(out["loss"]) - float(lr)) < 2e-6 * abs(float(lr))
+    assert _rel(fg.grad, 1.7 * fr.grad) < 2e-5
+    # the reference's mask caching: a second batch of the SAME size reuses the first batch's positives
+    labels2 = torch.randint(0, ncls, (N,), generator=g)
+    l2r = ref({"feats": fr.detach(), "labels": labels2})["loss"]
+    l2h = hip({"feats": fg.detach(), "labels": labels2.cuda()})["loss"]
+    assert abs(float(l2h) - float(l2r)) < 2e-6 * abs(float(l2r))
+
+
+def test_ssc_losses_on_gpu_match_reference_golden(tmp_path):
+    """the SSC objective as the GPU runs it (fused contrastive + depth-CE/MSE kernels where they apply) against the
+    reference's own LossManager outputs."""
+    import os
+    import numpy as np
+    from creste_public_amd.creste.utils.loss_utils import LossManager
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "ssc_losses.npz"))
+    t = lambda k: torch.from_numpy(d[k]).cuda()          # noqa: E731
+    wfile = tmp_path / "w6.txt"
+    np.savetxt(wfile, d["class_freq"])
+    disc = dict(mode="UD", num_bins=128, depth_min=300, depth_max=25600)
+    lm = LossManager({"loss": [
+        dict(name="SupPixelConLoss", views=1, weight=1.0, pred_key="outputs/inpainting_sam_preds",
+             lab_key="inputs/3d_sam_label", ignore_index=0, temperature=0.1, task="joint", contrast_mode="batch_all"),
+        dict(name="CrossEntropy", weight=2.0, pred_key="outputs/inpainting_sam_dynamic_preds",
+             lab_key="inputs/3d_sam_dynamic_label", num_class=6, class_weights=str(wfile), class_dim=1, task="joint"),
+        dict(name="SmoothL1Depth", weight=0.1, pred_key="outputs/depth_preds_metric", lab_key="inputs/depth_label",
+             beta=0.5, discretize=disc),
+        dict(name="SmoothL1", weight=3.0, beta=0.2, pred_key="outputs/elevation_preds", lab_key="inputs/elevation_label",
+             absolute=False, task="joint")]}).cuda()
+    preds = {k: t(k).clone().requires_grad_(True) for k in ("sam_pred", "dyn_pred", "depth_pred", "elev_pred")}
+    td = {"outputs/inpainting_sam_preds": preds["sam_pred"], "inputs/3d_sam_label": t("sam_label"),
+          "outputs/inpainting_sam_dynamic_preds": preds["dyn_pred"], "inputs/3d_sam_dynamic_label": t("dyn_label"),
+          "inputs/fov_mask": t("fov"), "outputs/depth_preds_metric": preds["depth_pred"],
+          "inputs/depth_label": t("depth_label"), "outputs/elevation_preds": preds["elev_pred"],
+          "inputs/elevation_label": t("elev_label"), "task": "joint"}
+    torch.manual_seed(77)
+    ld, meta = lm(td)
+    total = sum(w * v for w, v in ld.values())
+    total.backward()
+    for k, (w, v) in ld.items():
+        assert abs(float(v) - float(d[f"loss/{k}"])) < 2e-5 * abs(float(d[f"loss/{k}"])), k
+    assert abs(float(total) - float(d["total"])) < 2e-5 * float(d["total"])
+    for k, gk in (("sam_pred", "g_sam"), ("dyn_pred", "g_dyn"), ("depth_pred", "g_depth"), ("elev_pred", "g_elev")):
+        assert _rel(preds[k].grad, torch.from_numpy(d[gk])) < 5e-5, k
