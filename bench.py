@@ -41,9 +41,12 @@ def build_model(device):
     torch.manual_seed(1337)
     model = MaxEntIRL(maxent_irl_cfg((IMG_H, IMG_W), solve_mdp=False))
     synth.randomize_bn(model, seed=1337)
-    with torch.no_grad():   # raw millimetre depth enters the stem un-normalised: give BN a matching scale
-        model.backbone.depthcomp.depthcomp.vision_backbone.model.trunk._bn0.running_var.fill_(1.0e7)
-    return model.to(device).eval()
+    model = model.to(device).eval()
+    # statistics of a trained network (see synth.calibrate_bn_hip): varied depths, ~21 % of the BEV cells occupied --
+    # a random-init network would splat nothing and run the BEV heads on zeros
+    rgbd, p2p = synth.make_frames(2, IMG_H, IMG_W, seed=4321)
+    synth.calibrate_bn_hip(model, rgbd.to(device), p2p.to(device))
+    return model
 
 
 def kernel_symbol(pc):
@@ -179,6 +182,7 @@ def ssc_extras(device, steps=3, B=8):
     torch.manual_seed(0)
     model = TerrainNet(cfg).to(device)
     synth.randomize_bn(model, seed=1)
+    synth.peak_depth_head(model)                 # varied depths -> a populated BEV map (see synth.calibrate_bn_hip)
     rgbd, p2p = synth.make_frames(B, IMG_H, IMG_W, seed=2)
     g = torch.Generator().manual_seed(3)
     G, Hs, Ws = 256, IMG_H // 4, IMG_W // 4

@@ -16,6 +16,7 @@ harness.seed_everything(0)
 cfg = harness.ssc_cfg((H, W), class_weights=[0.5, 0.2, 0.1, 0.1, 0.05, 0.05])
 model = TerrainNet(cfg).cuda()
 synth.randomize_bn(model, seed=1)
+synth.peak_depth_head(model)
 tr = harness.SSCTrainer(model, LossManager(cfg).cuda(), cfg)
 batch = _ssc_batch(B, H, W)
 def T():
