@@ -125,13 +125,17 @@ def calibrate_bn_hip(model: torch.nn.Module, rgbd: torch.Tensor, p2p: torch.Tens
         m.momentum = 1.0
     backbone = getattr(model, "backbone", model)
     was_training = model.training
-    try:
+    from . import hipnn
+    prec = hipnn.get_precision()
+    hipnn.set_precision("f32")        # exact fp32 engine for the one-off pass (also keeps its launches out of the
+    try:                              # timed kernels' rocprof statistics: different kernel symbols)
         backbone.train()
         backbone((rgbd, p2p))
         if backbone is not model:
             model.train()                       # the reward head's BatchNorms (the backbone itself stays in eval here)
             model((rgbd, p2p))
     finally:
+        hipnn.set_precision(prec)
         for m, mo in zip(bns, saved):
             m.momentum = mo
         model.train(was_training)

@@ -66,5 +66,9 @@ for r in stats[:24]:
     hb = f"{c['hbm_bytes_per_launch'] / 1e6:.1f}" if c else ""
     lines.append(f"| `{k[:70]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | "
                  f"{float(r['AverageNs']) / 1e3:.1f} | {100 * float(r['TotalDurationNs']) / tot:.1f} | {hb} |")
+lines += ["", "Note: `bench.py` first gives the random-init network trained-network statistics with ONE training-mode pass at batch 2 "
+          "(`synth.calibrate_bn_hip`) on the exact-fp32 engine; those launches are the extra `conv_igemm_f32_kernel` / "
+          "`moments_kernel` / `bn_elementwise_kernel` rows above and are outside the timed steps. The f16x3 kernels (`conv_patch*`) "
+          "only run inside the warm-up + timed steps, so their averages are per timed launch."]
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[:14]))
