@@ -133,7 +133,12 @@ def calibrate_bn_hip(model: torch.nn.Module, rgbd: torch.Tensor, p2p: torch.Tens
         backbone((rgbd, p2p))
         if backbone is not model:
             model.train()                       # the reward head's BatchNorms (the backbone itself stays in eval here)
-            model((rgbd, p2p))
+            solve = getattr(model, "solve_mdp", False)
+            model.solve_mdp = False             # costmap only: no expert needed for the statistics
+            try:
+                model((rgbd, p2p))
+            finally:
+                model.solve_mdp = solve
     finally:
         hipnn.set_precision(prec)
         for m, mo in zip(bns, saved):

@@ -332,3 +332,39 @@ def test_reference_resolution_512x612():
         for k in ("bev_features", "inpainting_sam_preds", "elevation_preds", "traversability_preds"):
             g, r = got[k].detach().double().cpu(), ref[k].detach().double()
             assert _rms(g - r) <= 2e-2 * max(_rms(r), 1e-9), f"{prec}:{k}: rel rms {_rms(g - r) / _rms(r):.2e}"
+
+
+def test_512_grid_bf16_encoder_pipeline():
+    """BASELINE configs[4] shape: 5 cm voxels -> 512x512 BEV grid, bf16 encoder operands, fp32 IRL sweep on the
+    128x256 MDP grid.  Geometry and splat stay exact (voxel coordinates and densities against the oracle on the HIP
+    path's own depth / features are covered by the stage tests; here: shapes, a populated map, a converged MDP)."""
+    import creste_public_amd
+    from creste_public_amd import MaxEntIRL
+    Hh, Ww, Bb = 128, 192, 2
+    creste_public_amd.set_precision("bf16")
+    try:
+        torch.manual_seed(8)
+        cfg = maxent_irl_cfg((Hh, Ww), solve_mdp=True, map_size=(128, 256))
+        cfg["vision_backbone"]["camera_projector"]["voxel_size"] = [0.05, 0.05, 3]
+        model = MaxEntIRL(cfg)
+        synth.randomize_bn(model, seed=1)
+        model = model.cuda().eval()
+        rgbd, p2p = synth.make_frames(Bb, Hh, Ww, seed=2)
+        rgbd, p2p = rgbd.cuda(), p2p.cuda()
+        synth.calibrate_bn_hip(model, rgbd, p2p)
+        expert = synth.make_experts(Bb, 50, 512, seed=3).cuda()
+        with torch.no_grad():
+            out = model((rgbd, p2p, expert))
+        torch.cuda.synchronize()
+    finally:
+        creste_public_amd.set_precision("f32")
+    assert tuple(out["bev_features"].shape) == (Bb, 96, 512, 512)
+    assert tuple(out["traversability_preds"].shape) == (Bb, 1, 128, 256)
+    assert tuple(out["traversability_preds_full"].shape) == (Bb, 1, 512, 512)
+    assert tuple(out["policy"].shape) == (Bb, 8, 128, 256) and tuple(out["exp_svf"].shape) == (Bb, 128, 256)
+    assert all(torch.isfinite(v).all() for v in out.values() if v.dtype.is_floating_point)
+    assert float((out["bev_densities"] > 0).float().mean()) > 0.01
+    assert torch.allclose(out["policy"].sum(1), torch.ones_like(out["policy"][:, 0]), atol=1e-5)
+    assert float(out["exp_svf"].sum(dim=(1, 2)).max()) <= 50 + 1e-3
+    X = out["bev_coords"][..., 0]
+    assert float(X.max()) > 300                       # coordinates in 5 cm cells
