@@ -224,24 +224,24 @@ __global__ __launch_bounds__(256) void wgrad_f16_kernel(
   const int u = tid & 127, quad = u & 31, loct = u >> 5;
   const int ch = (isB ? ci0 : co0) + quad * 4;
   const bool ch_ok = ch < (isB ? Cin : Cout);
+  // BRANCH-FREE loads: an out-of-range pixel reads the tensor's first element and is zeroed at conversion time (a
+  // predicated load compiles to a branch with an s_waitcnt behind every load, which serialises the eight latencies)
   f32x4 rv[8];
+  unsigned okmask = 0;
   auto load = [&](int p) __attribute__((always_inline)) {
     int q = p + loct * 8;
     int rowi = q / Wo;
     int ox = q - rowi * Wo;
     int n = rowi / Ho;
     int oy = rowi - n * Ho;
+    okmask = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j, ++q) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (q < p1 && ch_ok) {
-        if (!isB) v = ld4(gy + (long)q * gy_cs + ch);
-        else {
-          const int iy = oy * stride + ky, ix = ox * stride + kx;
-          if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = ld4(x + (((long)n * H + iy) * W + ix) * x_cs + ch);
-        }
-      }
-      rv[j] = v;
+      const int iy = oy * stride + ky, ix = ox * stride + kx;
+      const bool ok = q < p1 && ch_ok && (!isB || ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W));
+      const float* ptr = isB ? x + (((long)n * H + iy) * W + ix) * x_cs + ch : gy + (long)q * gy_cs + ch;
+      rv[j] = ld4(ok ? ptr : (isB ? x : gy));
+      okmask |= (unsigned)ok << j;
       if (++ox == Wo) { ox = 0; if (++oy == Ho) { oy = 0; ++n; } }
     }
   };
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void wgrad_f16_kernel(
       h8 hi, lo;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float v = rv[j][c] * mul;
+        const float v = rv[j][c] * ((okmask >> j & 1) ? mul : 0.f);
         hi[j] = (_Float16)v;
         lo[j] = (_Float16)(v - (float)hi[j]);
       }
@@ -314,6 +314,143 @@ __global__ __launch_bounds__(256) void wgrad_f16_kernel(
         if (row < Cout && col < Cin) out[(size_t)row * Cin + col] = c[i][j][r] * sc;
       }
     }
+}
+
+// 3x3 stride-1 "same" convs (the bulk of the network): one workgroup owns a whole KERNEL ROW -- the three taps
+// kx = -1, 0, +1 of one ky -- for its 128 x 128 (co x ci) block and walks a band of 32 image rows column by column.
+// The MFMA's K dimension runs DOWN a column (32 pixels at fixed x), so a horizontal tap shift is simply a
+// neighbouring column image in LDS: the gy column and ONE new x column per step serve all three taps (a ring of four
+// x-column images; the per-tap kernel above streams every operand 9 x tiles times through L2: 55 GB for the
+// 496 -> 496 layer), every fragment stays an aligned ds_read_b128, and both loader halves do the same amount of
+// conversion work.  36 MFMAs per wave and step (two waves per SIMD), one barrier per column.
+constexpr int W3_KS = 32, W3_NOCT = W3_KS / 8, W3_OCT = 128 * 16, W3_PLANE = W3_NOCT * W3_OCT, W3_IMG = 2 * W3_PLANE;
+constexpr int W3_SMEM = 2 * W3_IMG + 4 * W3_IMG;           // gy column double buffer + ring of four x columns
+__global__ __launch_bounds__(512, 1) void wgrad_f16_col3_kernel(
+    const float* __restrict__ x, int x_cs, const float* __restrict__ gy, int gy_cs, float* __restrict__ partial,
+    const float* __restrict__ x_amax, const float* __restrict__ gy_amax, int N, int H, int W, int Cin, int Cout,
+    int pad_t, int pad_l, int nbands, int nseg, int seg_w, int tiles_co, int tiles_ci) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Aimg = smem;                                   // [2][W3_IMG]
+  char* const Bimg = smem + 2 * W3_IMG;                      // [4][W3_IMG], slot = (source column + 1) & 3
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;                  // 8 waves: 4 (co strips of 32) x 2 (ci halves of 64)
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int kyi = id % 3; id /= 3;
+  const int tci = id % tiles_ci; id /= tiles_ci;
+  const int tco = id % tiles_co; id /= tiles_co;
+  const int chunk = id;                                      // (n * nbands + band) * nseg + seg
+  const int seg = id % nseg; id /= nseg;
+  const int band = id % nbands;
+  const int n = id / nbands;
+  const int ky = kyi - pad_t;
+  const int co0 = tco * 128, ci0 = tci * 128;
+  const int y0 = band * W3_KS;
+  const int xs = seg * seg_w, xe = min(W, xs + seg_w);
+  float a_inv, b_inv;
+  const float a_mul = f16_operand_scale(*gy_amax, &a_inv), b_mul = f16_operand_scale(*x_amax, &b_inv);
+
+  // loader: waves 0..3 (one per SIMD; the other wave of each SIMD only issues MFMAs, so conversion VALU work and
+  // matrix work overlap): threads 0..127 stage the next gy column, 128..255 the next x column; a thread owns one
+  // channel quad and 8 consecutive rows (a k-octet): 8 float4 loads (lanes = consecutive quads: coalesced),
+  // transposed in registers
+  const bool loader = tid < 256;
+  const bool isB = tid >= 128;
+  const int u = tid & 127, quad = u & 31, loct = u >> 5;
+  const int ch = (isB ? ci0 : co0) + quad * 4;
+  const bool ch_ok = ch < (isB ? Cin : Cout);
+  const float* src = isB ? x : gy;
+  const int cs = isB ? x_cs : gy_cs;
+  const float mul = isB ? b_mul : a_mul;
+  const int yk = y0 + loct * 8 + (isB ? ky : 0);             // first source row of this thread's octet
+  f32x4 rv[8];                                               // branch-free loads, see wgrad_f16_kernel
+  unsigned okmask = 0;
+  auto load = [&](int col) __attribute__((always_inline)) {  // col: gy column (A) or x SOURCE column (B)
+    const bool col_ok = ch_ok && (unsigned)col < (unsigned)W;
+    okmask = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int yy = yk + j;
+      const bool ok = col_ok && (unsigned)yy < (unsigned)H;
+      rv[j] = ld4(ok ? src + (((long)n * H + yy) * W + col) * cs + ch : src);
+      okmask |= (unsigned)ok << j;
+    }
+  };
+  auto store = [&](char* img) __attribute__((always_inline)) {
+    char* base = img + loct * W3_OCT + quad * 4 * 16;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      h8 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = rv[j][c] * ((okmask >> j & 1) ? mul : 0.f);
+        hi[j] = (_Float16)v;
+        lo[j] = (_Float16)(v - (float)hi[j]);
+      }
+      *reinterpret_cast<h8*>(base + c * 16) = hi;
+      *reinterpret_cast<h8*>(base + W3_PLANE + c * 16) = lo;
+    }
+  };
+  auto bslot = [&](int srccol) { return Bimg + ((srccol + 1) & 3) * W3_IMG; };
+
+  f32x16 c[3][2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[k][j][r] = 0.f;
+
+  // prologue: gy column xs; x source columns xs - pad_l + {0, 1, 2} (kx = 0..2 of output column xs)
+  if (loader) {
+    if (!isB) { load(xs); store(Aimg); }
+    else {
+      for (int t = 0; t < 3; ++t) { load(xs - pad_l + t); store(bslot(xs - pad_l + t)); }
+    }
+  }
+  __syncthreads();
+  for (int col = xs; col < xe; ++col) {
+    const bool more = loader && col + 1 < xe;
+    if (more) load(isB ? col + 1 - pad_l + 2 : col + 1);      // next gy column / the one new x source column it needs
+    const char* A = Aimg + ((col - xs) & 1) * W3_IMG;
+#pragma unroll
+    for (int ks = 0; ks < W3_KS / 16; ++ks) {
+      h8 a[2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        a[pl] = *reinterpret_cast<const h8*>(A + pl * W3_PLANE + (ks * 2 + lh) * W3_OCT + (wm * 32 + li) * 16);
+#pragma unroll
+      for (int kxi = 0; kxi < 3; ++kxi) {
+        const char* B = bslot(col - pad_l + kxi);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          h8 b[2];
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+            b[pl] = *reinterpret_cast<const h8*>(B + pl * W3_PLANE + (ks * 2 + lh) * W3_OCT + (wn * 64 + j * 32 + li) * 16);
+          c[kxi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], c[kxi][j], 0, 0, 0);
+          c[kxi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], c[kxi][j], 0, 0, 0);
+          c[kxi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], c[kxi][j], 0, 0, 0);
+        }
+      }
+    }
+    if (more) store(isB ? bslot(col + 1 - pad_l + 2) : Aimg + ((col + 1 - xs) & 1) * W3_IMG);
+    __syncthreads();
+  }
+  const float sc = a_inv * b_inv;
+#pragma unroll
+  for (int kxi = 0; kxi < 3; ++kxi) {
+    float* out = partial + ((size_t)chunk * 9 + kyi * 3 + kxi) * Cout * Cin;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int colc = ci0 + wn * 64 + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < Cout && colc < Cin) out[(size_t)row * Cin + colc] = c[kxi][j][r] * sc;
+      }
+    }
+  }
 }
 
 __global__ void wgrad_strided_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw, int nchunk,
@@ -791,6 +928,35 @@ extern "C" int creste_conv_wgrad_f16x3(const float* x, int x_cs, const float* gy
   CRESTE_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0 && x_cs % 4 == 0 && gy_cs % 4 == 0 &&
                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0,
                  "conv_wgrad_f16x3: channel counts / strides must be multiples of 4, tensors 16-byte aligned");
+  if (K == 3 && stride == 1 && Ho == H && Wo == W && Cin >= 64 && Cout >= 64) {          // kernel-row / column-walk variant
+    static bool attr_set = false;
+    if (!attr_set) {
+      CRESTE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16_col3_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, W3_SMEM));
+      attr_set = true;
+    }
+    const int nbands = (H + W3_KS - 1) / W3_KS;
+    const long base = (long)N * nbands;                            // chunks before column segmentation
+    const long tiles3 = (long)tiles_co * tiles_ci * 3;
+    long nseg = (1024 + tiles3 * base - 1) / (tiles3 * base);      // ~1024 workgroups in flight
+    const long seg_cap = cap / base > 0 ? cap / base : 1;          // the workspace holds `cap` partial sets
+    nseg = nseg < 1 ? 1 : (nseg > seg_cap ? seg_cap : nseg);
+    if (nseg > W) nseg = W;
+    CRESTE_REQUIRE(base * nseg <= cap || nseg == 1, "conv_wgrad_f16x3: workspace too small");
+    if (base <= cap) {
+      const int seg_w = (int)((W + nseg - 1) / nseg);
+      nseg = (W + seg_w - 1) / seg_w;
+      const int nchunk3 = (int)(base * nseg);
+      wgrad_f16_col3_kernel<<<(unsigned)(nchunk3 * tiles3), 512, W3_SMEM, s>>>(x, x_cs, gy, gy_cs, (float*)work, x_amax, gy_amax,
+                                                                             N, H, W, Cin, Cout, pad_t, pad_l, nbands,
+                                                                             (int)nseg, seg_w, tiles_co, tiles_ci);
+      CRESTE_CHECK_LAUNCH("wgrad_f16_col3");
+      wgrad_strided_reduce_kernel<<<grid1d((long)Cout * Cin * 9, 1024), 256, 0, s>>>((const float*)work, gw, nchunk3, Cout,
+                                                                                 Cin, 9, accumulate);
+      CRESTE_CHECK_LAUNCH("wgrad_strided_reduce");
+      return CRESTE_OK;
+    }
+  }
   wgrad_f16_kernel<<<nchunk * tiles_co * tiles_ci * K * K, 256, 0, s>>>(
       x, x_cs, gy, gy_cs, (float*)work, x_amax, gy_amax, N, H, W, Ho, Wo, Cin, Cout, K, stride, pad_t, pad_l,
       (int)chunk_px, tiles_co, tiles_ci);
