@@ -325,6 +325,9 @@ __global__ __launch_bounds__(256) void wgrad_f16_kernel(
 // conversion work.  36 MFMAs per wave and step (two waves per SIMD), one barrier per column.
 constexpr int W3_KS = 32, W3_NOCT = W3_KS / 8, W3_OCT = 128 * 16, W3_PLANE = W3_NOCT * W3_OCT, W3_IMG = 2 * W3_PLANE;
 constexpr int W3_SMEM = 2 * W3_IMG + 4 * W3_IMG;           // gy column double buffer + ring of four x columns
+// channel row r of an octet image sits at 16-byte slot r ^ ((r >> 4) & 3): the loader's rows 4q + c (fixed c) and the
+// MFMA fragment reads' consecutive rows both fall on 16 distinct slots per ds_*_b128 lane group
+__device__ __forceinline__ int w3_swz(int r) { return r ^ ((r >> 4) & 3); }
 __global__ __launch_bounds__(512, 1) void wgrad_f16_col3_kernel(
     const float* __restrict__ x, int x_cs, const float* __restrict__ gy, int gy_cs, float* __restrict__ partial,
     const float* __restrict__ x_amax, const float* __restrict__ gy_amax, int N, int H, int W, int Cin, int Cout,
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16_col3_kernel(
     }
   };
   auto store = [&](char* img) __attribute__((always_inline)) {
-    char* base = img + loct * W3_OCT + quad * 4 * 16;
+    char* base = img + loct * W3_OCT;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       h8 hi, lo;
@@ -387,8 +390,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16_col3_kernel(
         hi[j] = (_Float16)v;
         lo[j] = (_Float16)(v - (float)hi[j]);
       }
-      *reinterpret_cast<h8*>(base + c * 16) = hi;
-      *reinterpret_cast<h8*>(base + W3_PLANE + c * 16) = lo;
+      const int pos = w3_swz(quad * 4 + c) * 16;
+      *reinterpret_cast<h8*>(base + pos) = hi;
+      *reinterpret_cast<h8*>(base + W3_PLANE + pos) = lo;
     }
   };
   auto bslot = [&](int srccol) { return Bimg + ((srccol + 1) & 3) * W3_IMG; };
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16_col3_kernel(
       h8 a[2];
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl)
-        a[pl] = *reinterpret_cast<const h8*>(A + pl * W3_PLANE + (ks * 2 + lh) * W3_OCT + (wm * 32 + li) * 16);
+        a[pl] = *reinterpret_cast<const h8*>(A + pl * W3_PLANE + (ks * 2 + lh) * W3_OCT + w3_swz(wm * 32 + li) * 16);
 #pragma unroll
       for (int kxi = 0; kxi < 3; ++kxi) {
         const char* B = bslot(col - pad_l + kxi);
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16_col3_kernel(
           h8 b[2];
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl)
-            b[pl] = *reinterpret_cast<const h8*>(B + pl * W3_PLANE + (ks * 2 + lh) * W3_OCT + (wn * 64 + j * 32 + li) * 16);
+            b[pl] = *reinterpret_cast<const h8*>(B + pl * W3_PLANE + (ks * 2 + lh) * W3_OCT + w3_swz(wn * 64 + j * 32 + li) * 16);
           c[kxi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], c[kxi][j], 0, 0, 0);
           c[kxi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], c[kxi][j], 0, 0, 0);
           c[kxi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], c[kxi][j], 0, 0, 0);
