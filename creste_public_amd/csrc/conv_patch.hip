@@ -210,19 +210,27 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
     }
   };
 
+  // BRANCH-FREE prefetch: a halo / channel-tail element reads the tensor's first quad and is zeroed when the value
+  // is converted (a predicated load compiles to a branch with `s_waitcnt vmcnt(0)` behind it: the whole load
+  // latency -- and that of the weight DMA issued before it -- sat in front of the MFMAs of every step); the operand
+  // scale, the squeeze-excite gate and the zeroing are applied after the MFMAs, in store_a
   auto load_a = [&](int r, int c) __attribute__((always_inline)) -> f32x4 {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const int ch = c * PT_CK + cq * 4;
-    if (a_gpix[r] >= 0 && ch < p.Cin) {
-      v = *reinterpret_cast<const f32x4*>(p.in + (size_t)a_gpix[r] * p.in_cs + ch);
-      if (p.a_scale) v *= *reinterpret_cast<const f32x4*>(p.a_scale + (size_t)img * p.Cin + ch);
-      if (F16) v *= a_mul;
-    }
-    return v;
+    const bool ok = a_gpix[r] >= 0 && ch < p.Cin;
+    return *reinterpret_cast<const f32x4*>(ok ? p.in + (size_t)a_gpix[r] * p.in_cs + ch : p.in);
   };
-  auto store_a = [&](int r, f32x4 v, char* buf) __attribute__((always_inline)) {
+  auto load_gate = [&](int c) __attribute__((always_inline)) -> f32x4 {
+    const int ch = c * PT_CK + cq * 4;
+    return *reinterpret_cast<const f32x4*>(p.a_scale + (size_t)img * p.Cin + (ch < p.Cin ? ch : 0));
+  };
+  f32x4 gate = {1.f, 1.f, 1.f, 1.f};                        // squeeze-excite gate of the chunk being staged
+  auto store_a = [&](int r, int c, f32x4 v, char* buf) __attribute__((always_inline)) {
     if (r * 128 + (tid >> 2) >= NPIX) return;
     char* dst = buf + a_lofs0 + r * (128 * 16);
+    const bool ok = a_gpix[r] >= 0 && c * PT_CK + cq * 4 < p.Cin;
+    if (p.a_scale) v *= gate;
+    if (F16) v *= a_mul;
+    if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 rem = v;
 #pragma unroll
     for (int pl = 0; pl < SPLIT; ++pl) {           // hi, then the bf16 of what is left, ...
@@ -241,8 +249,9 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // ---- prologue: chunk 0 of A, weight tile (0,0)
+  if (p.a_scale) gate = load_gate(0);
 #pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) store_a(r, load_a(r, 0), abase);
+  for (int r = 0; r < ROUNDS; ++r) store_a(r, 0, load_a(r, 0), abase);
   dma_b(0);
   __syncthreads();
 
@@ -261,6 +270,7 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
 #pragma unroll
       for (int r = 0; r < ROUNDS; ++r)
         if ((r < T ? r : T - 1) == t && more_a) ra[r] = load_a(r, c + 1);
+      if (t == 0 && more_a && p.a_scale) gate = load_gate(c + 1);
 
       // ---- MFMAs of (chunk c, tap t)
       const int ky = t / K, kx = t % K;
@@ -289,7 +299,7 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
       // ---- land the prefetched tiles in the other buffers
 #pragma unroll
       for (int r = 0; r < ROUNDS; ++r)
-        if ((r < T ? r : T - 1) == t && more_a) store_a(r, ra[r], Anext);
+        if ((r < T ? r : T - 1) == t && more_a) store_a(r, c + 1, ra[r], Anext);
       __syncthreads();
     }
   }
@@ -357,9 +367,15 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
     a_yx[r] = ok ? (iy << 16) | ix : -1;
   }
   const int c_skip = UP ? p.Cin - p.up_C : p.Cin;           // channels below this come from `in`
+  // plain kernels: BRANCH-FREE prefetch (see conv_patch_kernel) -- scale, gate and zeroing happen in store_a
   auto load_a = [&](int r, int c) __attribute__((always_inline)) -> f32x4 {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const int ch = c * PT_CK + cq * 4;
+    if constexpr (!UP) {
+      const bool ok = a_yx[r] >= 0 && ch < p.Cin;
+      const int iy = a_yx[r] >> 16, ix = a_yx[r] & 0xffff;
+      return *reinterpret_cast<const f32x4*>(ok ? p.in + ((size_t)(img * p.H + iy) * p.W + ix) * p.in_cs + ch : p.in);
+    }
     if (a_yx[r] >= 0 && ch < p.Cin) {
       const int iy = a_yx[r] >> 16, ix = a_yx[r] & 0xffff;
       if (!UP || ch < c_skip) {
@@ -383,9 +399,20 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
     }
     return v;
   };
-  auto store_a = [&](int r, f32x4 v) __attribute__((always_inline)) {
+  auto load_gate = [&](int c) __attribute__((always_inline)) -> f32x4 {
+    const int ch = c * PT_CK + cq * 4;
+    return *reinterpret_cast<const f32x4*>(p.a_scale + (size_t)img * p.Cin + (ch < p.Cin ? ch : 0));
+  };
+  f32x4 gate = {1.f, 1.f, 1.f, 1.f};
+  auto store_a = [&](int r, int c, f32x4 v) __attribute__((always_inline)) {
     if (r * 128 + (tid >> 2) >= NPIX) return;
     char* dst = abuf + a_lofs0 + r * (128 * 16);
+    if constexpr (!UP) {
+      const bool ok = a_yx[r] >= 0 && c * PT_CK + cq * 4 < p.Cin;
+      if (p.a_scale) v *= gate;
+      if (F16) v *= a_mul;
+      if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     f32x4 rem = v;
 #pragma unroll
     for (int pl = 0; pl < SPLIT; ++pl) {           // hi, then the bf16 of what is left, ...
@@ -417,8 +444,9 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   dma_row(0);
+  if (!UP && p.a_scale) gate = load_gate(0);
 #pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) store_a(r, load_a(r, 0));
+  for (int r = 0; r < ROUNDS; ++r) store_a(r, 0, load_a(r, 0));
   __syncthreads();
 
   const int nrows = p.nchunk * 3;
@@ -430,6 +458,7 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
     for (int ky = 0; ky < 3; ++ky, ++g) {
       if (g + 1 < nrows) dma_row(g + 1);
       if (more_a) ra[ky] = load_a(ky, c + 1);
+      if (!UP && ky == 0 && more_a && p.a_scale) gate = load_gate(c + 1);
       const char* Brow = bbase + (g & 1) * ROW_BYTES;
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
@@ -457,7 +486,7 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
     }
     if (more_a) {
 #pragma unroll
-      for (int r = 0; r < ROUNDS; ++r) store_a(r, ra[r]);
+      for (int r = 0; r < ROUNDS; ++r) store_a(r, c + 1, ra[r]);
       __syncthreads();
     }
   }
