@@ -5,7 +5,8 @@ Camera2MapMulti (:53-354) -- same buffers/parameters (point_cloud_range, max_bou
 voxel_size, grid_size, lidar2map, z_proj.{0,2}, vision_fusion.convs.{0,1}) and the same output dict
 (`bev_features [B,F,GH,GW]`, `bev_densities [B,1,GH,GW]`, `bev_coords [B,P,2]`).
 
-Pipeline (single camera, scatter_mode 'mean', mode 'bilinear' -- what TerrainNet configures,
+Pipeline (mode 'bilinear'; scatter_mode 'mean' | 'sum' | 'max'; NC cameras of a frame are concatenated into
+one point set before the splat, reference :227-234 -- TerrainNet configures one camera and 'mean',
 terrainnet.py:74-77):
   creste_pixel_geometry_f32  xyz (bit-exact fma chain), range mask, z-MLP features -> channels
                              [F, F+Z) of the fusion conv's input buffer (no concat copy)
@@ -86,15 +87,21 @@ class Camera2MapMulti(nn.Module):
 
     def forward_act(self, depth: torch.Tensor, fbuf: Act, p2p: torch.Tensor):
         """depth [B,Hs,Ws] metres, fbuf = fusion_buffer with features in [0,F), p2p [B,4,4]."""
-        if self.NC != 1 or self.scatter_mode != "mean" or self.mode != "bilinear":
-            raise NotImplementedError("HIP splat: single camera, bilinear, mean (the shipped config)")
+        if self.mode != "bilinear":
+            raise Exception("Unknown splat mode:", self.mode)
         g = self._geo.get()
         F = fbuf.cs - self.z_dim
         xyz, mask = ops.pixel_geometry(depth, p2p, g["bounds"], g["w1"], g["b1"], g["w2"], g["b2"],
                                        fbuf.slice(F, self.z_dim))
         fused = self.vision_fusion.forward_act(Act(fbuf.buf, fbuf.cs, 0), row_mask=mask)
         gh, gw = g["grid"]
-        coords, bev, dens = ops.bev_splat(xyz, fused, g["off"], g["vox"], gh, gw, self.min_weight)
+        # NC cameras per frame: views (b, s, c) are consecutive, so the reference's concatenation of the cameras'
+        # points ([B*NS, NC*H*W, .], :227-234) is a reshape of the per-view buffers
+        BN = xyz.shape[0]
+        assert BN % self.NC == 0, f"Number of frames must be divisible by {self.NC}"
+        pts = xyz.reshape(BN // self.NC, -1, 3)
+        fl = Act(fused.buf.view(BN // self.NC, self.NC * fused.H, fused.W, fused.cs), fused.C, fused.co)
+        coords, bev, dens = ops.bev_splat(pts, fl, g["off"], g["vox"], gh, gw, self.min_weight, self.scatter_mode)
         return dict(bev=bev, dens=dens, coords=coords, xyz=xyz, mask=mask, fused=fused)
 
     def forward(self, x):

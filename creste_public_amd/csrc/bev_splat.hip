@@ -159,7 +159,10 @@ __global__ __launch_bounds__(256) void splat_sort_kernel(const int* __restrict__
   }
 }
 
-template <int LANES>   // lanes per BEV cell (>= F/4, power of two)
+// MODE = the reference's scatter_mode (splat_projection.py:334-352): 0 'mean' (sum / clamp(density, min_weight)),
+// 1 'sum', 2 'max' (torch_scatter's scatter-max of w*f per tap, empty cells 0, folded with torch.maximum against the
+// zero-initialised volume: max(0, max over taps and points of w*f)); the density is the tap-weight sum in all three
+template <int LANES, int MODE>   // lanes per BEV cell (>= F/4, power of two)
 __global__ __launch_bounds__(256) void splat_gather_kernel(
     const float* __restrict__ feats, int feats_cs, const float* __restrict__ coords,
     const int* __restrict__ offset, const int* __restrict__ list, int B, int P, int F, int GH, int GW,
@@ -198,7 +201,8 @@ __global__ __launch_bounds__(256) void splat_gather_kernel(
           if (lane_on) {
             const f32x4 f = *reinterpret_cast<const f32x4*>(fb + (long)p * feats_cs);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __fadd_rn(acc[j], __fmul_rn(w, f[j]));
+            for (int j = 0; j < 4; ++j)
+              acc[j] = MODE == 2 ? fmaxf(acc[j], __fmul_rn(w, f[j])) : __fadd_rn(acc[j], __fmul_rn(w, f[j]));
           }
         }
       }
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(256) void splat_gather_kernel(
     if (lane_on) {
       f32x4 o;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = __fdiv_rn(acc[j], den);
+      for (int j = 0; j < 4; ++j) o[j] = MODE == 0 ? __fdiv_rn(acc[j], den) : acc[j];
       *reinterpret_cast<f32x4*>(bev + cell * F + sub * 4) = o;
     }
     if (sub == 0) dens[cell] = d;
@@ -225,11 +229,13 @@ extern "C" int64_t creste_bev_splat_workspace_bytes(int B, int P, int GH, int GW
                    align256((size_t)B * (E + 1) * 4) + align256((size_t)B * ((E + 1023) / 1024) * 4));
 }
 
-extern "C" int creste_bev_splat_f32(const float* xyz, const float* feats, int feats_cs, int B, int P,
-                                    int F, float off_x, float off_y, float vox_x, float vox_y, int GH,
-                                    int GW, float min_weight, float* coords, float* bev, float* dens,
-                                    void* work, void* stream) {
+extern "C" int creste_bev_splat_mode_f32(const float* xyz, const float* feats, int feats_cs, int B, int P,
+                                         int F, float off_x, float off_y, float vox_x, float vox_y, int GH,
+                                         int GW, float min_weight, int mode, float* coords, float* bev,
+                                         float* dens, void* work, void* stream) {
   CRESTE_REQUIRE(xyz && feats && coords && bev && dens && work, "bev_splat: null pointer");
+  CRESTE_REQUIRE(mode == CRESTE_SPLAT_MEAN || mode == CRESTE_SPLAT_SUM || mode == CRESTE_SPLAT_MAX,
+                 "bev_splat: unknown scatter mode %d", mode);
   CRESTE_REQUIRE(B > 0 && P > 0 && F > 0 && F % 4 == 0 && F <= 256 && feats_cs % 4 == 0 && feats_cs >= F,
                  "bev_splat: F must be a multiple of 4 and <= 256");
   CRESTE_REQUIRE(GH > 0 && GW > 0 && vox_x > 0.f && vox_y > 0.f, "bev_splat: bad grid");
@@ -256,19 +262,31 @@ extern "C" int creste_bev_splat_f32(const float* xyz, const float* feats, int fe
   }
   const long ncell = (long)B * GH * GW;
   const int fq = F / 4;
-  if (fq <= 8) {
-    const int g = (int)((ncell + 31) / 32 > 16384 ? 16384 : (ncell + 31) / 32);
-    splat_gather_kernel<8><<<g, 256, 0, s>>>(feats, feats_cs, coords, w.offset, w.list, B, P, F, GH, GW, min_weight, bev, dens);
-  } else if (fq <= 16) {
-    const int g = (int)((ncell + 15) / 16 > 16384 ? 16384 : (ncell + 15) / 16);
-    splat_gather_kernel<16><<<g, 256, 0, s>>>(feats, feats_cs, coords, w.offset, w.list, B, P, F, GH, GW, min_weight, bev, dens);
-  } else if (fq <= 32) {
-    const int g = (int)((ncell + 7) / 8 > 16384 ? 16384 : (ncell + 7) / 8);
-    splat_gather_kernel<32><<<g, 256, 0, s>>>(feats, feats_cs, coords, w.offset, w.list, B, P, F, GH, GW, min_weight, bev, dens);
-  } else {
-    const int g = (int)((ncell + 3) / 4 > 16384 ? 16384 : (ncell + 3) / 4);
-    splat_gather_kernel<64><<<g, 256, 0, s>>>(feats, feats_cs, coords, w.offset, w.list, B, P, F, GH, GW, min_weight, bev, dens);
+#define CRESTE_SPLAT_GATHER(L, M)                                                                                   \
+  {                                                                                                                 \
+    const long per = 256 / L;                                                                                       \
+    const int g = (int)((ncell + per - 1) / per > 16384 ? 16384 : (ncell + per - 1) / per);                         \
+    splat_gather_kernel<L, M><<<g, 256, 0, s>>>(feats, feats_cs, coords, w.offset, w.list, B, P, F, GH, GW,        \
+                                                min_weight, bev, dens);                                             \
   }
+#define CRESTE_SPLAT_LANES(M)                                                                                       \
+  {                                                                                                                 \
+    if (fq <= 8) CRESTE_SPLAT_GATHER(8, M) else if (fq <= 16) CRESTE_SPLAT_GATHER(16, M)                            \
+    else if (fq <= 32) CRESTE_SPLAT_GATHER(32, M) else CRESTE_SPLAT_GATHER(64, M)                                   \
+  }
+  if (mode == CRESTE_SPLAT_MEAN) CRESTE_SPLAT_LANES(0)
+  else if (mode == CRESTE_SPLAT_SUM) CRESTE_SPLAT_LANES(1)
+  else CRESTE_SPLAT_LANES(2)
+#undef CRESTE_SPLAT_LANES
+#undef CRESTE_SPLAT_GATHER
   CRESTE_CHECK_LAUNCH("splat_gather");
   return CRESTE_OK;
+}
+
+extern "C" int creste_bev_splat_f32(const float* xyz, const float* feats, int feats_cs, int B, int P,
+                                    int F, float off_x, float off_y, float vox_x, float vox_y, int GH,
+                                    int GW, float min_weight, float* coords, float* bev, float* dens,
+                                    void* work, void* stream) {
+  return creste_bev_splat_mode_f32(xyz, feats, feats_cs, B, P, F, off_x, off_y, vox_x, vox_y, GH, GW, min_weight,
+                                   CRESTE_SPLAT_MEAN, coords, bev, dens, work, stream);
 }

@@ -383,9 +383,15 @@ def pixel_geometry(depth, p2p, bounds6, w1, b1, w2, b2, zfeat: Act):
     return xyz, mask
 
 
-def bev_splat(xyz, feats: Act, off_xy, vox_xy, GH, GW, min_weight=1.0):
-    """xyz [B,P,3], feats Act viewed as [B,P,F] -> (coords [B,P,2], bev Act [B,GH,GW,F], dens [B,GH,GW])."""
+SPLAT_MODES = {"mean": 0, "sum": 1, "max": 2}
+
+
+def bev_splat(xyz, feats: Act, off_xy, vox_xy, GH, GW, min_weight=1.0, scatter_mode="mean"):
+    """xyz [B,P,3], feats Act viewed as [B,P,F] -> (coords [B,P,2], bev Act [B,GH,GW,F], dens [B,GH,GW]).
+    scatter_mode: the reference's 'mean' | 'sum' | 'max' (splat_projection.py:334-352)."""
     lib = _lib.load()
+    if scatter_mode not in SPLAT_MODES:
+        raise Exception("Unknown splat scatter mode:", scatter_mode)
     B, P, _ = xyz.shape
     F = feats.C
     dev = xyz.device
@@ -393,10 +399,11 @@ def bev_splat(xyz, feats: Act, off_xy, vox_xy, GH, GW, min_weight=1.0):
     bev = Act.empty(B, GH, GW, F, dev)
     dens = torch.empty((B, GH, GW), dtype=torch.float32, device=dev)
     work = torch.empty(lib.creste_bev_splat_workspace_bytes(B, P, GH, GW), dtype=torch.uint8, device=dev)
-    _lib.check(lib.creste_bev_splat_f32(_chk(xyz).data_ptr(), feats.ptr, feats.cs, B, P, F,
-                                        float(off_xy[0]), float(off_xy[1]), float(vox_xy[0]),
-                                        float(vox_xy[1]), GH, GW, float(min_weight), coords.data_ptr(),
-                                        bev.ptr, dens.data_ptr(), work.data_ptr(), _stream()), "bev_splat")
+    _lib.check(lib.creste_bev_splat_mode_f32(_chk(xyz).data_ptr(), feats.ptr, feats.cs, B, P, F,
+                                             float(off_xy[0]), float(off_xy[1]), float(vox_xy[0]),
+                                             float(vox_xy[1]), GH, GW, float(min_weight),
+                                             SPLAT_MODES[scatter_mode], coords.data_ptr(),
+                                             bev.ptr, dens.data_ptr(), work.data_ptr(), _stream()), "bev_splat")
     return coords, bev, dens
 
 

@@ -206,6 +206,18 @@ int creste_bev_splat_f32(const float* xyz, const float* feats, int feats_cs, int
                          float off_x, float off_y, float vox_x, float vox_y, int GH, int GW,
                          float min_weight, float* coords, float* bev, float* dens, void* work,
                          void* stream);
+/* The same with the reference's `scatter_mode` (splat_projection.py:334-352): MEAN as above; SUM without the
+ * normalisation; MAX = torch_scatter's scatter(..., reduce='max') of w*f per tap folded with torch.maximum
+ * against the zero volume, i.e. max(0, max over taps and points of w*f).  dens is the tap-weight sum in all modes.
+ * Several cameras (Camera2MapMulti.NC > 1, :227-234) are one call with P = NC*H*W: the reference concatenates the
+ * cameras' points of a frame before the splat. */
+#define CRESTE_SPLAT_MEAN 0
+#define CRESTE_SPLAT_SUM 1
+#define CRESTE_SPLAT_MAX 2
+int creste_bev_splat_mode_f32(const float* xyz, const float* feats, int feats_cs, int B, int P, int F,
+                              float off_x, float off_y, float vox_x, float vox_y, int GH, int GW,
+                              float min_weight, int mode, float* coords, float* bev, float* dens, void* work,
+                              void* stream);
 
 /* Value iteration on the 8-connected grid MDP.  reference vin.py:36-46 (transition kernel),
  * :48-80 (Jacobi sweeps, hard-max backup, batch-global convergence test, final q + softmax).

@@ -88,8 +88,9 @@ class Camera2MapMulti(nn.Module):
     """pixel*depth -> LiDAR xyz -> z-MLP + 1x1 fuse -> range mask -> 4-tap bilinear scatter-add
     with mean normalisation (splat_projection.py:53-354)."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, scatter_mode="mean"):
         super().__init__()
+        self.scatter_mode = scatter_mode
         pcr = torch.tensor(cfg["point_cloud_range"])
         self.register_buffer("point_cloud_range", pcr)
         self.register_buffer("max_bound", pcr[3:].reshape(1, -1))
@@ -160,9 +161,22 @@ class Camera2MapMulti(nn.Module):
                 idx = torch.where(valid, Y_ * W + X_, torch.zeros_like(X_))
                 w = (wX * wY) * valid.type_as(rX)
                 dens.scatter_add_(1, idx, w)
-                vol.scatter_add_(2, idx.view(B, 1, P).expand(B, Fd, P), w.view(B, 1, P) * feats)
+                idx_f = idx.view(B, 1, P).expand(B, Fd, P)
+                if self.scatter_mode in ("mean", "sum"):
+                    vol.scatter_add_(2, idx_f, w.view(B, 1, P) * feats)
+                elif self.scatter_mode == "max":
+                    # torch_scatter.scatter(src, idx, dim=2, reduce='max', dim_size=G) (third-party, absent here:
+                    # PARITY UNPINNED for this mode): per-cell max of src, 0 where no point lands; then
+                    # torch.maximum with the running volume (:340-344)
+                    tap = torch.full_like(vol, float("-inf")).scatter_reduce_(
+                        2, idx_f, w.view(B, 1, P) * feats, reduce="amax", include_self=True)
+                    tap = torch.where(torch.isinf(tap), torch.zeros_like(tap), tap)
+                    vol = torch.maximum(tap, vol)
+                else:
+                    raise Exception("Unknown splat scatter mode:", self.scatter_mode)
                 taps.append((Y_ * W + X_).squeeze(-1))
-        vol = vol / dens.view(B, 1, G).clamp(self.min_weight)
+        if self.scatter_mode == "mean":
+            vol = vol / dens.view(B, 1, G).clamp(self.min_weight)
         return vol, dens, torch.stack(taps, dim=1)
 
     def forward(self, x):

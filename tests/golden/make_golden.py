@@ -140,6 +140,34 @@ def gen_splat():
         npz(f"splat_{tag}.npz", **arrs)
 
 
+def gen_splat_modes():
+    """Camera2MapMulti with scatter_mode 'sum' (splat_projection.py:334-352), several frames per batch element.
+    Not generated: 'max' needs torch_scatter (absent here); num_cams > 1 raises inside the reference itself
+    (`.view` of a permuted tensor at :228), so the multi-camera concatenation has no reference output to pin."""
+    from creste.models.blocks.splat_projection import Camera2MapMulti
+    from creste_public_amd.config import terrainnet_cfg
+    base = terrainnet_cfg().to_dict()["camera_projector"]
+    g = torch.Generator().manual_seed(4242)
+    for tag, (nc, smode, B, N, hs, ws) in {"onecam_sum": (1, "sum", 2, 2, 14, 18)}.items():
+        cfgd = dict(base); cfgd["num_cams"] = nc
+        torch.manual_seed(7)
+        m = Camera2MapMulti(wrap(cfgd), mode="bilinear", scatter_mode=smode)
+        randomise_bn(m, g)
+        m.eval()
+        depth = torch.rand(B, N, hs, ws, generator=g) * 14.0 + 0.3
+        depth[:, :, :1, :2] = 30.0
+        feats = torch.randn(B, N, 256, hs, ws, generator=g)
+        p2p = make_p2p(B, hs, ws).repeat(1, N, 1, 1)
+        p2p[:, :, :3, 3] += torch.randn(B, N, 3, generator=g) * 0.3      # every view its own extrinsic
+        with torch.no_grad():
+            out = m([depth, feats, p2p])
+        bf, dens = out["bev_features"], out["bev_densities"]
+        touched = (dens[:, 0] != 0) | (bf != 0).any(dim=1)
+        npz(f"splat_{tag}.npz", depth=depth, feats=feats, p2p=p2p, bev_coords=out["bev_coords"], bev_densities=dens,
+            touched_idx=touched.nonzero(), touched_feats=bf.permute(0, 2, 3, 1)[touched],
+            bev_features_abs_sum=bf.abs().sum(), num_cams=torch.tensor(nc), **sd_arrays(m))
+
+
 def gen_vin_svf_loss():
     import creste.models.blocks.vin as vin_mod
     from creste.models.blocks.vin import VIN
@@ -430,6 +458,7 @@ if __name__ == "__main__":
     with torch.no_grad():
         pass
     gen_splat()
+    gen_splat_modes()
     gen_vin_svf_loss()
     gen_blocks_and_utils()
     gen_distill_losses()

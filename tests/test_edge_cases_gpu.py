@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from creste_public_amd.config import maxent_irl_cfg, terrainnet_cfg
+from creste_public_amd.config import Cfg, maxent_irl_cfg, terrainnet_cfg
 from oracle import irl as oi
 from oracle import perception as op
 
@@ -66,6 +66,68 @@ def test_splat_edge_cases(ops, case):
         assert torch.equal(bev.buf.cpu(), ref_bev)
     if case == "all_outside":
         assert float(bev.buf.abs().sum()) == 0.0 and float(dens.sum()) == 0.0
+
+
+@pytest.mark.parametrize("mode", ["mean", "sum", "max"])
+def test_splat_scatter_modes(ops, mode):
+    """The reference's scatter_mode (splat_projection.py:334-352) on the gather kernel vs the oracle; negative
+    features exercise the max(0, .) floor of the 'max' mode."""
+    g = torch.Generator().manual_seed(3)
+    B, P, Fd = 2, 5000, 96
+    xyz = torch.zeros(B, P, 3)
+    xyz[..., :2] = torch.rand(B, P, 2, generator=g) * 8 - 4          # dense: many points per cell
+    xyz[:, :300, 0] = 12.75 + torch.rand(B, 300, generator=g) * 0.2  # straddle the border
+    feats = torch.randn(B, P, Fd, generator=g)
+    m = op.Camera2MapMulti(terrainnet_cfg()["camera_projector"], scatter_mode=mode)
+    xy = m.to_voxel_coords(xyz)
+    vol, rdens, _ = m.splat_mean(xy, feats.permute(0, 2, 1).contiguous(), m.grid_size[:2])
+    ref = vol.view(B, Fd, 256, 256).permute(0, 2, 3, 1)
+    fa = ops.Act(feats.view(B, 1, P, Fd).cuda().contiguous(), Fd)
+    coords, bev, dens = ops.bev_splat(xyz.cuda(), fa, (12.8, 12.8), (np.float32(0.1), np.float32(0.1)), 256, 256,
+                                      scatter_mode=mode)
+    assert torch.equal(coords.cpu(), xy)
+    assert torch.equal(dens.cpu(), rdens.view(B, 256, 256))
+    if mode == "max":
+        assert torch.equal(bev.buf.cpu(), ref)                        # a max has no summation order
+        assert (bev.buf >= 0).all()
+    else:
+        torch.testing.assert_close(bev.buf.cpu(), ref, rtol=1e-6, atol=1e-6)
+    with pytest.raises(Exception, match="Unknown splat scatter mode"):
+        ops.bev_splat(xyz.cuda(), fa, (12.8, 12.8), (np.float32(0.1), np.float32(0.1)), 256, 256, scatter_mode="min")
+
+
+def test_camera2map_sum_mode_golden_and_multi_camera(golden):
+    """Module level: scatter_mode='sum' against the reference's own output (two frames per batch element), and
+    num_cams=2 (the reference raises inside `.view` at :228; the intended concatenation is checked against the
+    oracle)."""
+    from creste_public_amd.creste.models.blocks.splat_projection import Camera2MapMulti
+    g = golden("splat_onecam_sum.npz")
+    cfg = terrainnet_cfg()["camera_projector"]
+    m = Camera2MapMulti(cfg, mode="bilinear", scatter_mode="sum")
+    m.load_state_dict(g.sd(), strict=True)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        out = m([g.t("depth").cuda(), g.t("feats").cuda(), g.t("p2p").cuda()])
+    assert torch.equal(out["bev_coords"].cpu(), g.t("bev_coords"))
+    torch.testing.assert_close(out["bev_densities"].cpu(), g.t("bev_densities"), rtol=0, atol=1e-6)
+    idx = g.t("touched_idx")
+    got = out["bev_features"].cpu().permute(0, 2, 3, 1)[idx[:, 0], idx[:, 1], idx[:, 2]]
+    torch.testing.assert_close(got, g.t("touched_feats"), rtol=2e-4, atol=2e-4)
+
+    cfg2 = dict(cfg.to_dict()); cfg2["num_cams"] = 2
+    for mode in ("mean", "max"):
+        o = op.Camera2MapMulti(cfg2, scatter_mode=mode)
+        o.load_state_dict(g.sd(), strict=True); o.eval()
+        h = Camera2MapMulti(Cfg(cfg2), mode="bilinear", scatter_mode=mode)
+        h.load_state_dict(g.sd(), strict=True)
+        h = h.cuda().eval()
+        with torch.no_grad():
+            want = o([g.t("depth"), g.t("feats"), g.t("p2p")])
+            have = h([g.t("depth").cuda(), g.t("feats").cuda(), g.t("p2p").cuda()])
+        assert have["bev_features"].shape == want["bev_features"].shape == (2, 96, 256, 256)
+        assert torch.equal(have["bev_coords"].cpu(), want["bev_coords"])
+        torch.testing.assert_close(have["bev_densities"].cpu(), want["bev_densities"], rtol=0, atol=1e-6)
+        torch.testing.assert_close(have["bev_features"].cpu(), want["bev_features"], rtol=2e-4, atol=2e-4)
 
 
 @pytest.mark.parametrize("shape,kind", [((2, 37, 53), "rand"), ((1, 5, 7), "rand"), ((2, 64, 128), "zero"),

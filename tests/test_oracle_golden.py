@@ -38,6 +38,63 @@ def test_splat_matches_reference(golden):
         assert out["bev_densities"].shape[1:] == (1, 256, 256)
 
 
+def test_splat_sum_mode_matches_reference(golden):
+    """scatter_mode='sum' with two frames per batch element (reference splat_projection.py:334-352)."""
+    g = golden("splat_onecam_sum.npz")
+    m = op.Camera2MapMulti(terrainnet_cfg()["camera_projector"], scatter_mode="sum")
+    m.load_state_dict(g.sd(), strict=True)
+    m.eval()
+    with torch.no_grad():
+        out = m([g.t("depth"), g.t("feats"), g.t("p2p")])
+    assert torch.equal(out["bev_coords"], g.t("bev_coords"))
+    torch.testing.assert_close(out["bev_densities"], g.t("bev_densities"), rtol=0, atol=1e-6)
+    idx = g.t("touched_idx")
+    got = out["bev_features"].permute(0, 2, 3, 1)[idx[:, 0], idx[:, 1], idx[:, 2]]
+    torch.testing.assert_close(got, g.t("touched_feats"), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out["bev_features"].abs().sum(), g.t("bev_features_abs_sum"), rtol=1e-5, atol=0)
+
+
+def test_splat_max_mode_and_multi_camera_semantics(golden):
+    """'max' (torch_scatter is absent: parity unpinned) and num_cams > 1 (the reference raises at :228) are
+    pinned to their definitions on a brute-force loop over points."""
+    g = golden("splat_small.npz")
+    cfg = dict(terrainnet_cfg()["camera_projector"].to_dict())
+    depth, feats, p2p = g.t("depth")[:1, :, :6, :7], g.t("feats")[:1, :, :, :6, :7], g.t("p2p")[:1]
+    for mode in ("max", "sum"):
+        m = op.Camera2MapMulti(cfg, scatter_mode=mode)
+        m.load_state_dict(golden("splat_small.npz").sd(), strict=True)
+        m.eval()
+        with torch.no_grad():
+            out = m([depth, feats, p2p])
+            xyz, mask, f = m.fuse(depth, feats, p2p)
+        f = (f * mask)[0, 0].reshape(f.shape[2], -1)                        # [F,P]
+        xy = out["bev_coords"][0]
+        want = torch.zeros(f.shape[0], 256, 256)
+        for p in range(xy.shape[0]):
+            X0, Y0 = int(xy[p, 0].floor()), int(xy[p, 1].floor())
+            rx, ry = xy[p, 0] - X0, xy[p, 1] - Y0
+            for xd in (0, 1):
+                for yd in (0, 1):
+                    X, Y = X0 + xd, Y0 + yd
+                    if 0 <= X < 256 and 0 <= Y < 256:
+                        w = (rx if xd else 1 - rx) * (ry if yd else 1 - ry)
+                        want[:, Y, X] = torch.maximum(want[:, Y, X], w * f[:, p]) if mode == "max" \
+                            else want[:, Y, X] + w * f[:, p]
+        torch.testing.assert_close(out["bev_features"][0], want, rtol=1e-5, atol=1e-6)
+    # two cameras: the cameras' points of a frame land in ONE map
+    cfg2 = dict(cfg); cfg2["num_cams"] = 2
+    m1 = op.Camera2MapMulti(cfg, scatter_mode="sum"); m2 = op.Camera2MapMulti(cfg2, scatter_mode="sum")
+    for m in (m1, m2):
+        m.load_state_dict(golden("splat_small.npz").sd(), strict=True); m.eval()
+    d2, f2 = torch.cat([depth, depth * 0.7], 1), torch.cat([feats, feats.flip(3)], 1)
+    with torch.no_grad():
+        a = m1([d2, f2, p2p.repeat(1, 2, 1, 1)])
+        b = m2([d2, f2, p2p.repeat(1, 2, 1, 1)])
+    assert b["bev_features"].shape[0] == 1 and a["bev_features"].shape[0] == 2
+    torch.testing.assert_close(b["bev_features"][0], a["bev_features"].sum(0), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(b["bev_densities"][0], a["bev_densities"].sum(0), rtol=1e-5, atol=1e-6)
+
+
 def test_splat_invariants(golden):
     g = golden("splat_small.npz")
     m = _splat_module(golden)
