@@ -49,14 +49,19 @@ def build_model(device):
     return model
 
 
-def kernel_symbol(pc):
-    """The kernel a packed conv dispatches to (mirrors csrc/conv_igemm.hip / conv_patch.hip), named as
+def kernel_symbol(pc, N, Ho, Wo):
+    """The kernel a packed conv dispatches to (mirrors csrc/conv_igemm.hip / conv_patch.hip: patch_tn), named as
     rocprofv3 prints it, so bench numbers and profiles/ line up kernel by kernel."""
     if pc.prec == 0:
         return ("f32", "conv_igemm_f32_kernel<2, 2, 2, 2>" if pc.Cout > 64 else
                 "conv_igemm_f32_kernel<2, 2, 2, 1>" if pc.Cout > 32 else "conv_igemm_f32_kernel<4, 1, 1, 1>")
     split = {1: 1, 2: 2, 3: 3, 4: 2}[pc.prec]
-    tn = 4 if (pc.prec == 4 and pc.Cout > 128) else 2 if pc.Cout > 64 else 1
+    tn = (4 if pc.prec == 4 else 2) if pc.Cout > 128 else 2 if pc.Cout > 64 else 1
+    if pc.KH == 1 and pc.Cin < 256 and tn == 4:
+        tn = 2
+    px_tiles = N * ((Ho + 7) // 8) * ((Wo + 31) // 32)
+    while tn > 1 and px_tiles * ((pc.Cout + 64 * tn - 1) // (64 * tn)) < 400:
+        tn //= 2
     f16 = "true" if pc.prec == 4 else "false"
     name = (f"conv_patch3_kernel<{split}, {tn}, {f16}, false>" if pc.KH == 3
             else f"conv_patch_kernel<1, {split}, {tn}, {f16}>")
@@ -80,7 +85,7 @@ class ConvProfiler:
             y = prof._orig(x, pc, **kw)
             e1.record()
             flops = 2.0 * y.N * y.H * y.W * pc.Cout * pc.Cin * pc.KH * pc.KW
-            prof.records.append((e0, e1, flops, kernel_symbol(pc), (pc.Cin, pc.Cout, pc.KH, y.H, y.W)))
+            prof.records.append((e0, e1, flops, kernel_symbol(pc, y.N, y.H, y.W), (pc.Cin, pc.Cout, pc.KH, y.H, y.W)))
             return y
         import creste_public_amd.hipnn as hipnn
         ops.conv2d = timed

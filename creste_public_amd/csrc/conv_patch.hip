@@ -154,9 +154,10 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
   constexpr int A_OCT = NPIXP * 16;             // bytes of one k-octet plane of A
   constexpr int A_PLANE = 2 * A_OCT;            // hi (or lo) plane
   constexpr int A_BYTES = SPLIT * A_PLANE;
-  constexpr int B_OCT = BN * 16;
-  constexpr int B_PLANE = 2 * B_OCT;
-  constexpr int B_BYTES = SPLIT * B_PLANE;
+  // weights are packed in UNITS of 64 output channels ([unit][chunk][tap][plane][k-octet][64][8 elements]); a
+  // workgroup stages TN consecutive units, so the tile width is a LAUNCH-time choice (patch_tn) on one packed image
+  constexpr int U_OCT = 64 * 16, U_PLANE = 2 * U_OCT, U_BYTES = SPLIT * U_PLANE, U_INSTR = U_BYTES / 1024;
+  constexpr int B_BYTES = TN * U_BYTES;
   constexpr int NF4 = NPIX * 4;                 // float4 loads per chunk of the A patch
   constexpr int ROUNDS = (NF4 + 511) / 512;
 
@@ -195,18 +196,21 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
     const bool ok = pix < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
     a_gpix[r] = ok ? (img * p.H + iy) * p.W + ix : -1;
   }
-  // weight tile of step g: B_BYTES contiguous bytes, copied by LDS-DMA in 1 KiB pieces
-  const char* wbase = p.wpk + (size_t)tn * p.nchunk * T * B_BYTES;
+  // weight tile of step g: U_BYTES contiguous bytes per unit, copied by LDS-DMA in 1 KiB pieces
+  const size_t nsteps_w = (size_t)p.nchunk * T;
+  const char* wbase = p.wpk + (size_t)tn * TN * nsteps_w * U_BYTES;
   constexpr int B_INSTR = B_BYTES / 1024;
   auto dma_b = [&](int g) __attribute__((always_inline)) {
-    const char* src = wbase + (size_t)g * B_BYTES + lane * 16;
     char* dst = bbase + (g & 1) * B_BYTES;
 #pragma unroll
     for (int j = 0; j < (B_INSTR + 7) / 8; ++j) {
       const int i = wave + 8 * j;
-      if (i < B_INSTR)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+      if (i < B_INSTR) {
+        const int u = i / U_INSTR, r = i % U_INSTR;
+        const char* src = wbase + ((size_t)u * nsteps_w + g) * U_BYTES + r * 1024 + lane * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+      }
     }
   };
 
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
         const int n = (wn * TN + nt) * 32 + li;
 #pragma unroll
         for (int pl = 0; pl < SPLIT; ++pl)
-          bfr[nt][pl] = *reinterpret_cast<const V8*>(B + pl * B_PLANE + lh * B_OCT + n * 16);
+          bfr[nt][pl] = *reinterpret_cast<const V8*>(B + (n >> 6) * U_BYTES + pl * U_PLANE + lh * U_OCT + (n & 63) * 16);
       }
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -327,8 +331,10 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
   constexpr int NPIXP = (NPIX + 15) / 16 * 16;
   constexpr int BN = 64 * TN;
   constexpr int A_OCT = NPIXP * 16, A_PLANE = 2 * A_OCT, A_BYTES = SPLIT * A_PLANE;
-  constexpr int B_OCT = BN * 16, B_PLANE = 2 * B_OCT, B_BYTES = SPLIT * B_PLANE;
-  constexpr int ROW_BYTES = 3 * B_BYTES;               // weight tiles of one kernel row
+  constexpr int U_OCT = 64 * 16, U_PLANE = 2 * U_OCT, U_BYTES = SPLIT * U_PLANE;   // 64-channel weight units
+  constexpr int UROW_BYTES = 3 * U_BYTES, UROW_INSTR = UROW_BYTES / 1024;          // one unit's kernel row
+  constexpr int B_BYTES = TN * U_BYTES;
+  constexpr int ROW_BYTES = 3 * B_BYTES;               // weight tiles of one kernel row: [unit][kx][plane][oct][64]
   constexpr int ROW_INSTR = ROW_BYTES / 1024;          // 1 KiB LDS-DMA pieces
   constexpr int ROUNDS = 3;                            // 340 px * 4 float4 over 512 threads
   static_assert(NPIX * 4 <= ROUNDS * 512, "A patch does not fit the staging rounds");
@@ -421,17 +427,20 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
       if (pl + 1 < SPLIT) rem -= __builtin_convertvector(piece, f32x4);
     }
   };
-  // weight rows of this channel tile: [chunk][row(ky)] -> ROW_BYTES each, contiguous
-  const char* wrow0 = p.wpk + (size_t)tn * p.nchunk * 3 * ROW_BYTES;
+  // weight rows of this channel tile: per unit [chunk][row(ky)] -> UROW_BYTES each, contiguous
+  const size_t nrows_w = (size_t)p.nchunk * 3;
+  const char* wrow0 = p.wpk + (size_t)tn * TN * nrows_w * UROW_BYTES;
   auto dma_row = [&](int g) __attribute__((always_inline)) {
-    const char* src = wrow0 + (size_t)g * ROW_BYTES + lane * 16;
     char* dst = bbase + (g & 1) * ROW_BYTES;
 #pragma unroll
     for (int j = 0; j < (ROW_INSTR + 7) / 8; ++j) {
       const int i = wave + 8 * j;
-      if (i < ROW_INSTR)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+      if (i < ROW_INSTR) {
+        const int u = i / UROW_INSTR, r = i % UROW_INSTR;
+        const char* src = wrow0 + ((size_t)u * nrows_w + g) * UROW_BYTES + r * 1024 + lane * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+      }
     }
   };
 
@@ -462,7 +471,7 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
       const char* Brow = bbase + (g & 1) * ROW_BYTES;
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        const char* B = Brow + kx * B_BYTES;
+        const char* B = Brow + kx * U_BYTES;
         V8 af[2][SPLIT];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -477,7 +486,7 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
           const int n = (wn * TN + nt) * 32 + li;
 #pragma unroll
           for (int pl = 0; pl < SPLIT; ++pl)
-            bfr[pl] = *reinterpret_cast<const V8*>(B + pl * B_PLANE + lh * B_OCT + n * 16);
+            bfr[pl] = *reinterpret_cast<const V8*>(B + (n >> 6) * UROW_BYTES + pl * U_PLANE + lh * U_OCT + (n & 63) * 16);
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = split_mfma<SPLIT, V8>(bfr, af[mt], acc[mt][nt]);
         }
@@ -538,7 +547,7 @@ __global__ void weight_unscale_kernel(const float* __restrict__ w, const float* 
   }
 }
 
-// weight packing: OIHW fp32 (x scale[co]) -> [ntile][chunk][tap][plane][k-octet][BN][8] bf16 / fp16
+// weight packing: OIHW fp32 (x scale[co]) -> [unit][chunk][tap][plane][k-octet][BN = 64][8] bf16 / fp16
 template <typename ET>
 __global__ void pack_weight_patch_kernel(const float* __restrict__ w, const float* __restrict__ scale,
                                          const float* __restrict__ unscale, ET* __restrict__ out, int Cout,
@@ -566,13 +575,21 @@ __global__ void pack_weight_patch_kernel(const float* __restrict__ w, const floa
   }
 }
 
-// output channels per workgroup.  f16x3 takes 256-wide tiles when the layer has them: 72 MFMAs per wave and
-// barrier interval (the bf16x6 kernel's ratio of MFMA to LDS traffic), and the halo patch is staged, split
-// and written to LDS once per 256 channels instead of once per 128.
-static inline int patch_bn(int cout, int prec) {
-  if (prec == CRESTE_PREC_F16X3 && cout > 128) return 256;
-  return cout > 64 ? 128 : 64;
+// 64-channel weight units per workgroup (tile width = 64 * TN), chosen per LAUNCH on one packed weight image.
+// f16x3 takes 256-wide tiles where the layer has them AND enough pixel tiles to fill the chip: 72 MFMAs per wave
+// and barrier interval, and the halo patch is staged, split and written to LDS once per 256 channels.  Layers with
+// few pixel tiles (the deep 19x38 / 38x76 maps) or few input channels (MBConv expand convs: one or two chunks per
+// tile, bound by the output write) take narrower tiles: more, lighter workgroups, two to a CU.
+static inline int patch_tn(int cout, int prec, int cin, int K, long px_tiles) {
+  static const int exp_tn = getenv("CRESTE_EXP_TN") ? atoi(getenv("CRESTE_EXP_TN")) : 0;   // tuning aid
+  const int max_tn = cout > 128 ? (prec == CRESTE_PREC_F16X3 ? 4 : 2) : (cout > 64 ? 2 : 1);
+  if (exp_tn) return exp_tn < max_tn ? exp_tn : max_tn;
+  int tn = max_tn;
+  if (K == 1 && cin < 256 && tn == 4) tn = 2;            // write-bound expand convs: 256-wide tiles only add latency
+  while (tn > 1 && px_tiles * ((cout + 64 * tn - 1) / (64 * tn)) < 400) tn >>= 1;   // < ~1.5 workgroups per CU
+  return tn;
 }
+constexpr int PATCH_UNIT_PAD = 4;     // packed units are padded to a multiple of the widest tile
 static inline int patch_split(int prec) {
   return prec == CRESTE_PREC_BF16X6 ? 3 : (prec == CRESTE_PREC_BF16X3 || prec == CRESTE_PREC_F16X3 ? 2 : 1);
 }
@@ -599,14 +616,14 @@ bool conv_patch_supported(int prec, int KH, int KW, int stride) {
 }
 
 int64_t conv_patch_weight_bytes(int Cout, int Cin, int K, int prec) {
-  const int bn = patch_bn(Cout, prec);
-  const long tiles = (Cout + bn - 1) / bn, nchunk = (Cin + PT_CK - 1) / PT_CK;
-  return tiles * nchunk * K * K * patch_split(prec) * 2 * bn * 16;
+  const long units = ((Cout + 63) / 64 + PATCH_UNIT_PAD - 1) / PATCH_UNIT_PAD * PATCH_UNIT_PAD;
+  const long nchunk = (Cin + PT_CK - 1) / PT_CK;
+  return units * nchunk * K * K * patch_split(prec) * 2 * 64 * 16;
 }
 
 int conv_patch_pack(const float* w, const float* scale, void* wpk, float* w_unscale, int Cout, int Cin, int K,
                     int prec, hipStream_t s) {
-  const int bn = patch_bn(Cout, prec), split = patch_split(prec), nchunk = (Cin + PT_CK - 1) / PT_CK;
+  const int bn = 64, split = patch_split(prec), nchunk = (Cin + PT_CK - 1) / PT_CK;   // 64-channel units
   const long total = conv_patch_weight_bytes(Cout, Cin, K, prec) / 2;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   if (prec == CRESTE_PREC_F16X3) {
@@ -633,10 +650,10 @@ int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.out_cs = d->out_cs; a.out_co = d->out_co;
   a.res_cs = d->res_cs; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.act = d->act;
   a.nchunk = (d->Cin + PT_CK - 1) / PT_CK;
-  const int bn = patch_bn(d->Cout, d->prec);
-  a.tiles_n = (d->Cout + bn - 1) / bn;
   a.tiles_x = (d->Wo + PT_TW - 1) / PT_TW;
   a.tiles_y = (d->Ho + PT_TH - 1) / PT_TH;
+  const int bn = 64 * patch_tn(d->Cout, d->prec, d->Cin, d->KH, (long)a.tiles_x * a.tiles_y * d->N);
+  a.tiles_n = (d->Cout + bn - 1) / bn;
   const int split = patch_split(d->prec);
   const int K = d->KH;
   if (d->prec == CRESTE_PREC_F16X3) {
