@@ -364,6 +364,49 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
   }
 }
 
+// exact 2x case (every Upsample in the network): input row yi receives output rows 2yi-1, 2yi, 2yi+1, 2yi+2 with
+// weights 1/4, 3/4, 3/4, 1/4 (align_corners=False); at the borders the clamped source rows fold the outer weight
+// into the edge (row 0 gets output row 0 with weight 1, no row -1; likewise at the far edge).  One thread per pixel
+// and channel quad, 16 branch-free float4 loads.
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ gy, int gy_cs, float* __restrict__ gx,
+                                                             int gx_cs, int N, int H1, int W1, int C) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int Cq = C >> 2, Ho = 2 * H1, Wo = 2 * W1;
+  const long total = (long)N * H1 * W1 * Cq;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int q = (int)(i % Cq);
+    long t = i / Cq;
+    const int xi = (int)(t % W1); t /= W1;
+    const int yi = (int)(t % H1);
+    const int n = (int)(t / H1);
+    float wy[4], wx[4];
+    int yo[4], xo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int y = 2 * yi - 1 + k, xx = 2 * xi - 1 + k;
+      const float base = (k == 0 || k == 3) ? 0.25f : 0.75f;
+      // the outermost output row/column of the image maps wholly onto the edge input row/column
+      wy[k] = (y < 0 || y >= Ho) ? 0.f : ((y == 0 || y == Ho - 1) ? 1.f : base);
+      wx[k] = (xx < 0 || xx >= Wo) ? 0.f : ((xx == 0 || xx == Wo - 1) ? 1.f : base);
+      yo[k] = min(max(y, 0), Ho - 1);
+      xo[k] = min(max(xx, 0), Wo - 1);
+    }
+    const float* g = gy + (long)n * Ho * Wo * gy_cs + q * 4;
+    f32x4 v[16];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        v[a * 4 + b] = *reinterpret_cast<const f32x4*>(g + ((long)yo[a] * Wo + xo[b]) * gy_cs);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) s += (wy[a] * wx[b]) * v[a * 4 + b];
+    *reinterpret_cast<f32x4*>(gx + (((long)n * H1 + yi) * W1 + xi) * gx_cs + q * 4) = s;
+  }
+}
+
 // pixel chunks of the wgrad reduction: ~2048 workgroups over (chunk, tap), at least 256 pixels per chunk
 static inline int wgrad_chunks(long M, int K) {
   long n = 2048 / (K * K);
@@ -547,6 +590,13 @@ extern "C" int creste_upsample_bwd_nhwc_f32(const float* gy, int gy_cs, int Ho, 
                                             int H1, int W1, int C, float rh, float rw, void* stream) {
   CRESTE_REQUIRE(gy && gx && N > 0 && H1 > 0 && W1 > 0 && Ho > 0 && Wo > 0 && C > 0 && rh > 0.f && rw > 0.f,
                  "upsample_bwd: bad args");
+  if (Ho == 2 * H1 && Wo == 2 * W1 && rh == 0.5f && rw == 0.5f && C % 4 == 0 && gy_cs % 4 == 0 && gx_cs % 4 == 0 &&
+      H1 > 1 && W1 > 1 && ((uintptr_t)gy & 15) == 0 && ((uintptr_t)gx & 15) == 0) {
+    upsample2x_bwd_kernel<<<grid1d((long)N * H1 * W1 * (C / 4), 8192), 256, 0, (hipStream_t)stream>>>(gy, gy_cs, gx, gx_cs,
+                                                                                                     N, H1, W1, C);
+    CRESTE_CHECK_LAUNCH("upsample2x_bwd");
+    return CRESTE_OK;
+  }
   const int span_h = (int)(1.f / rh) + 2, span_w = (int)(1.f / rw) + 2;
   upsample_bwd_kernel<<<grid1d((long)N * H1 * W1 * C), 256, 0, (hipStream_t)stream>>>(gy, gy_cs, Ho, Wo, gx, gx_cs, N, H1,
                                                                                       W1, C, rh, rw, span_h, span_w);

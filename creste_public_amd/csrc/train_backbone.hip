@@ -530,14 +530,20 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
         const long r = q / Wo;
         const int oy = (int)(r % Ho), n = (int)(r / Ho);
         const float g = gy[q * C + c];
+        // BRANCH-FREE taps: an out-of-image tap reads a clamped address with weight 0 -- K*K independent loads in
+        // flight instead of K*K (branch, load, s_waitcnt) round trips
+        const float* xn = x + (long)n * H * W * C + c;
 #pragma unroll
         for (int ky = 0; ky < K; ++ky) {
           const int iy = oy * stride + ky - pad_t;
-          if ((unsigned)iy >= (unsigned)H) continue;
+          const bool yok = (unsigned)iy < (unsigned)H;
+          const int iyc = yok ? iy : 0;
 #pragma unroll
           for (int kx = 0; kx < K; ++kx) {
             const int ix = ox * stride + kx - pad_l;
-            if ((unsigned)ix < (unsigned)W) s[ky * K + kx] += g * x[(((long)n * H + iy) * W + ix) * C + c];
+            const bool ok = yok && (unsigned)ix < (unsigned)W;
+            const float xv = xn[((long)iyc * W + (ok ? ix : 0)) * C];
+            s[ky * K + kx] += (ok ? g : 0.f) * xv;
           }
         }
       }
