@@ -525,27 +525,50 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
 #pragma unroll
     for (int t = 0; t < K * K; ++t) s[t] = 0.f;
     if (active) {
-      for (long q = (long)blockIdx.x * rows + row; q < M; q += (long)gridDim.x * rows) {
-        const int ox = (int)(q % Wo);
-        const long r = q / Wo;
-        const int oy = (int)(r % Ho), n = (int)(r / Ho);
+      // every (block, row slot) owns a CONTIGUOUS range of output pixels and slides a K x K register window along
+      // the image row: per output pixel only the `stride` new columns are loaded (K or 2K loads instead of K*K --
+      // the strided block-cyclic walk re-fetched every tap from L2: 100 B of L2 traffic per output element)
+      const long nslot = (long)gridDim.x * rows;
+      const long per = (M + nslot - 1) / nslot;
+      const long q0 = ((long)blockIdx.x * rows + row) * per, q1 = min(M, q0 + per);
+      float win[K][K];
+      int ox = 0, oy = 0, n = 0;
+      if (q0 < q1) { ox = (int)(q0 % Wo); const long r = q0 / Wo; oy = (int)(r % Ho); n = (int)(r / Ho); }
+      bool fresh = true;
+      for (long q = q0; q < q1; ++q) {
         const float g = gy[q * C + c];
-        // BRANCH-FREE taps: an out-of-image tap reads a clamped address with weight 0 -- K*K independent loads in
-        // flight instead of K*K (branch, load, s_waitcnt) round trips
         const float* xn = x + (long)n * H * W * C + c;
+        const int ix0 = ox * stride - pad_l;
+        // columns [first_new, K) of the window are loaded; the others slide over from the previous pixel
+        const int first_new = fresh ? 0 : K - stride;
+        if (!fresh) {
+#pragma unroll
+          for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+              win[ky][kx] = (stride == 1) ? (kx + 1 < K ? win[ky][kx + 1] : 0.f) : (kx + 2 < K ? win[ky][kx + 2] : 0.f);
+        }
 #pragma unroll
         for (int ky = 0; ky < K; ++ky) {
           const int iy = oy * stride + ky - pad_t;
           const bool yok = (unsigned)iy < (unsigned)H;
-          const int iyc = yok ? iy : 0;
+          const long rowoff = (long)(yok ? iy : 0) * W;
 #pragma unroll
           for (int kx = 0; kx < K; ++kx) {
-            const int ix = ox * stride + kx - pad_l;
-            const bool ok = yok && (unsigned)ix < (unsigned)W;
-            const float xv = xn[((long)iyc * W + (ok ? ix : 0)) * C];
-            s[ky * K + kx] += (ok ? g : 0.f) * xv;
+            if (kx >= first_new) {                       // wave-uniform (fresh / stride are uniform)
+              const int ix = ix0 + kx;
+              const bool ok = yok && (unsigned)ix < (unsigned)W;
+              const float xv = xn[(rowoff + (ok ? ix : 0)) * C];
+              win[ky][kx] = ok ? xv : 0.f;
+            }
           }
         }
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) s[ky * K + kx] += g * win[ky][kx];
+        fresh = false;
+        if (++ox == Wo) { ox = 0; fresh = true; if (++oy == Ho) { oy = 0; ++n; } }
       }
     }
     const int cw = Ct;                           // channels handled by this block
