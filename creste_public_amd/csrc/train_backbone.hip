@@ -625,6 +625,46 @@ __global__ __launch_bounds__(256) void train_pointwise_kernel(int op, const floa
   }
 }
 
+// float4 variant (C, strides multiples of 4; 16-byte aligned; < 2^31 quads), op as a template parameter
+template <int OP>
+__global__ __launch_bounds__(256) void train_pointwise4_kernel(const float* __restrict__ a, int a_cs,
+                                                               const float* __restrict__ b, int b_cs,
+                                                               const float* __restrict__ g, int g_c,
+                                                               const float* __restrict__ r, float* __restrict__ o,
+                                                               int o_cs, unsigned HW, unsigned P, int C) {
+  const unsigned Cq = (unsigned)C >> 2, total = P * Cq;
+  const float inv_hw = 1.f / (float)HW;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const unsigned p = i / Cq;
+    const int c = (int)(i - p * Cq) << 2;
+    const unsigned n = p / HW;
+    const f32x4 av = ld4(a + (long)p * a_cs + c);
+    f32x4 v;
+    if (OP == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = av[j] / (1.f + expf(-av[j]));
+    } else if (OP == 1) {
+      const f32x4 bv = ld4(b + (long)p * b_cs + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sg = 1.f / (1.f + expf(-av[j]));
+        v[j] = bv[j] * (sg + av[j] * sg * (1.f - sg));
+      }
+    } else {
+      f32x4 gv;
+      if (g_c == 1) { const float g1 = g[n]; gv = f32x4{g1, g1, g1, g1}; }
+      else gv = ld4(g + (long)n * g_c + c);
+      if (OP == 2) v = av * gv;
+      else if (OP == 3) v = ld4(b + (long)p * b_cs + c) + av * gv;
+      else {
+        v = ld4(b + (long)p * b_cs + c) * gv;
+        if (r) v += ld4(r + (long)n * C + c) * inv_hw;
+      }
+    }
+    *reinterpret_cast<f32x4*>(o + (long)p * o_cs + c) = v;
+  }
+}
+
 // per-sample channel sums: out[n][c] = scale * sum_hw a[n,p,c] * (b ? b[n,p,c] : 1); grid (chunks, N)
 constexpr int SR_CHUNKS = 256;
 __global__ __launch_bounds__(256) void sample_reduce_kernel(const float* __restrict__ a, int a_cs,
@@ -1040,6 +1080,19 @@ extern "C" int creste_train_pointwise_f32(int op, const float* a, int a_cs, cons
   CRESTE_REQUIRE(a && o && op >= 0 && op <= 4 && P > 0 && C > 0 && HW > 0, "train_pointwise: bad args");
   CRESTE_REQUIRE((op != 1 && op != 3 && op != 4) || b, "train_pointwise: op %d needs b", op);
   CRESTE_REQUIRE(op < 2 || g, "train_pointwise: op %d needs the gate", op);
+  const bool vec = C % 4 == 0 && a_cs % 4 == 0 && o_cs % 4 == 0 && (!b || b_cs % 4 == 0) && (!g || g_c == 1 || g_c % 4 == 0) &&
+                   P * (C / 4) < 2147483647L && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)o | (uintptr_t)r) & 15) == 0 &&
+                   (!g || g_c == 1 || ((uintptr_t)g & 15) == 0);
+  if (vec) {
+    hipStream_t s = (hipStream_t)stream;
+    const int g4 = grid1d(P * C / 4, 8192);
+#define CRESTE_TP4(OP) train_pointwise4_kernel<OP><<<g4, 256, 0, s>>>(a, a_cs, b, b_cs, g, g_c, r, o, o_cs, (unsigned)HW, (unsigned)P, C)
+    if (op == 0) CRESTE_TP4(0); else if (op == 1) CRESTE_TP4(1); else if (op == 2) CRESTE_TP4(2);
+    else if (op == 3) CRESTE_TP4(3); else CRESTE_TP4(4);
+#undef CRESTE_TP4
+    CRESTE_CHECK_LAUNCH("train_pointwise4");
+    return CRESTE_OK;
+  }
   train_pointwise_kernel<<<grid1d(P * C), 256, 0, (hipStream_t)stream>>>(op, a, a_cs, b, b_cs, g, g_c, r, o, o_cs, HW, P, C);
   CRESTE_CHECK_LAUNCH("train_pointwise");
   return CRESTE_OK;
