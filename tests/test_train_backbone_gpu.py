@@ -367,7 +367,11 @@ def test_depth_expectation_backward():
 
 @pytest.mark.parametrize("N,Cin,H,W,Cout,K,s,pad,gscale", [
     (2, 96, 19, 23, 136, 3, 1, (1, 1, 1, 1), 1.0), (1, 200, 9, 31, 72, 1, 1, (0, 0, 0, 0), 1e-7),
-    (2, 48, 21, 18, 40, 5, 1, (2, 2, 2, 2), 1e4), (2, 64, 20, 24, 64, 3, 2, (0, 1, 0, 1), 1e-3)])
+    (2, 48, 21, 18, 40, 5, 1, (2, 2, 2, 2), 1e4), (2, 64, 20, 24, 64, 3, 2, (0, 1, 0, 1), 1e-3),
+    # column-walk 3x3 kernel: several row bands with a partial last one, column segments, partial channel tiles,
+    # one-sided padding
+    (1, 64, 70, 50, 64, 3, 1, (1, 1, 1, 1), 1.0), (3, 160, 33, 40, 200, 3, 1, (1, 1, 1, 1), 1e-3),
+    (1, 64, 40, 37, 72, 3, 1, (0, 2, 2, 0), 1.0)])
 def test_conv_backward_f16x3(N, Cin, H, W, Cout, K, s, pad, gscale):
     """the training convs in the f16x3 operand mode: forward / dgrad on the patch engine, wgrad on the fp16-split
     MFMA kernel; gradient tensors of any magnitude (1e-7 .. 1e4) keep fp32-grade accuracy through the |max| scaling"""
