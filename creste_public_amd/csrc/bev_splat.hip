@@ -138,33 +138,81 @@ __global__ __launch_bounds__(256) void splat_fill_kernel(const int* __restrict__
   }
 }
 
-// Sort every base cell's list by point id (serial insertion sort per list; lists are short except
-// for degenerate depth maps, which are left in atomic order above kMaxSortedList entries).
-// One thread per extended cell.
+// Sort every base cell's list by point id.  One thread per extended cell for the short lists (<= 4 entries: an
+// unrolled insertion); longer lists are then taken one at a time by the whole wave: every lane holds one entry, its
+// rank is the number of smaller ids (n shuffle steps), and the entry is stored at its rank -- a 43-entry list costs
+// 43 shuffle steps instead of ~460 dependent global-memory steps of a one-thread insertion sort (which made one
+// crowded cell hold up its whole wave).  Lists beyond 64 entries (degenerate pile-ups) fall back to the serial
+// insertion sort up to kMaxSortedList entries and are left in atomic order beyond that (still the exact set).
 constexpr int kMaxSortedList = 2048;
 __global__ __launch_bounds__(256) void splat_sort_kernel(const int* __restrict__ offset,
                                                          int* __restrict__ list, int B, int P, int E) {
   const long total = (long)B * E;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int b = (int)(i / E), k = (int)(i % E);
-    const int lo = offset[(long)b * (E + 1) + k], hi = offset[(long)b * (E + 1) + k + 1];
-    int* l = list + (long)b * P;
-    if (hi - lo > kMaxSortedList) continue;   // degenerate pile-up: keep the atomic order (still exact set)
-    for (int a = lo + 1; a < hi; ++a) {
-      const int v = l[a];
-      int j = a - 1;
-      while (j >= lo && l[j] > v) { l[j + 1] = l[j]; --j; }
-      l[j + 1] = v;
+  const int lane = threadIdx.x & 63;
+  for (long i0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) - lane; i0 < total; i0 += (long)gridDim.x * blockDim.x) {
+    const long i = i0 + lane;
+    int lo = 0, n = 0;
+    int* l = list;
+    if (i < total) {
+      const int b = (int)(i / E), k = (int)(i % E);
+      lo = offset[(long)b * (E + 1) + k];
+      n = offset[(long)b * (E + 1) + k + 1] - lo;
+      l = list + (long)b * P;
+    }
+    if (n >= 2 && n <= 4) {
+      for (int a = lo + 1; a < lo + n; ++a) {
+        const int v = l[a];
+        int j = a - 1;
+        while (j >= lo && l[j] > v) { l[j + 1] = l[j]; --j; }
+        l[j + 1] = v;
+      }
+    }
+    unsigned long long heavy = __ballot(n > 4);
+    while (heavy) {
+      const int src = __ffsll((long long)heavy) - 1;
+      heavy &= heavy - 1;
+      const int hlo = __shfl(lo, src, 64), hn = __shfl(n, src, 64);
+      // the owning lane's list base (64-bit pointer as two shuffles)
+      const unsigned long long lp = (unsigned long long)l;
+      int* hl = (int*)(((unsigned long long)(unsigned)__shfl((int)(lp >> 32), src, 64) << 32) |
+                       (unsigned)__shfl((int)(lp & 0xffffffffu), src, 64));
+      if (hn <= 64) {
+        const int v = lane < hn ? hl[hlo + lane] : 0x7fffffff;
+        int rank = 0;
+        for (int e = 0; e < hn; ++e) rank += __shfl(v, e, 64) < v ? 1 : 0;     // ids are distinct
+        if (lane < hn) hl[hlo + rank] = v;
+      } else if (lane == 0 && hn <= kMaxSortedList) {
+        for (int a = hlo + 1; a < hlo + hn; ++a) {
+          const int v = hl[a];
+          int j = a - 1;
+          while (j >= hlo && hl[j] > v) { hl[j + 1] = hl[j]; --j; }
+          hl[j + 1] = v;
+        }
+      }
     }
   }
 }
 
-// MODE = the reference's scatter_mode (splat_projection.py:334-352): 0 'mean' (sum / clamp(density, min_weight)),
-// 1 'sum', 2 'max' (torch_scatter's scatter-max of w*f per tap, empty cells 0, folded with torch.maximum against the
-// zero-initialised volume: max(0, max over taps and points of w*f)); the density is the tap-weight sum in all three
+// After the sort: the fractional voxel coordinates of every CSR entry, in list order (the bin phase's key / rank
+// arrays are free by now) -- the gather then reads a point's id and its tap-weight factors side by side instead of
+// chasing id -> coords.
+__global__ __launch_bounds__(256) void splat_frac_kernel(const int* __restrict__ offset, const int* __restrict__ list,
+                                                         const float* __restrict__ coords, float* __restrict__ frx,
+                                                         float* __restrict__ fry, long BP, int P, int E) {
+  for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < BP; g += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(g / P), slot = (int)(g - (long)b * P);
+    if (slot >= offset[(long)b * (E + 1) + E]) continue;
+    const long q = (long)b * P + list[g];
+    const float Xf = coords[q * 2 + 0], Yf = coords[q * 2 + 1];
+    frx[g] = __fsub_rn(Xf, floorf(Xf));
+    fry[g] = __fsub_rn(Yf, floorf(Yf));
+  }
+}
+
+constexpr int SPLAT_CPG = 4;     // consecutive BEV cells per lane group
 template <int LANES, int MODE>   // lanes per BEV cell (>= F/4, power of two)
 __global__ __launch_bounds__(256) void splat_gather_kernel(
-    const float* __restrict__ feats, int feats_cs, const float* __restrict__ coords,
+    const float* __restrict__ feats, int feats_cs, const float* __restrict__ frx, const float* __restrict__ fry,
     const int* __restrict__ offset, const int* __restrict__ list, int B, int P, int F, int GH, int GW,
     float min_weight, float* __restrict__ bev, float* __restrict__ dens) {
   const int EW = GW + 1, E = (GH + 1) * (GW + 1);
@@ -173,36 +221,88 @@ __global__ __launch_bounds__(256) void splat_gather_kernel(
   const bool lane_on = sub < fq;
   const long ncell = (long)B * GH * GW;
   constexpr int CELLS_PER_BLOCK = 256 / LANES;
-  for (long cell = (long)blockIdx.x * CELLS_PER_BLOCK + threadIdx.x / LANES; cell < ncell;
-       cell += (long)gridDim.x * CELLS_PER_BLOCK) {
-    const int X = (int)(cell % GW);
-    const int Y = (int)((cell / GW) % GH);
-    const int b = (int)(cell / ((long)GW * GH));
-    const int* off = offset + (long)b * (E + 1);
+  // a lane group walks SPLAT_CPG consecutive cells (wave launches are not free: one cell per group left the chip at
+  // 3.5 of 8 waves per SIMD, bound by the dispatcher); the CSR offsets of the next cell are fetched while the
+  // current one is accumulated
+  // contiguous cell ranges per XCD: a point's four cells (X, X+1 on rows Y, Y+1) are then served by ONE L2
+  const long cell0 = ((long)xcd_remap(blockIdx.x, gridDim.x) * CELLS_PER_BLOCK + threadIdx.x / LANES) * SPLAT_CPG;
+  if (cell0 >= ncell) return;
+  // (frame, row, column) of the group's first cell: ONE division, then increments (64-bit div/mod per cell was
+  // most of the kernel's instruction count)
+  int X, Y, b;
+  {
+    const long rowi = cell0 / GW;
+    X = (int)(cell0 - rowi * GW);
+    b = (int)(rowi / GH);
+    Y = (int)(rowi - (long)b * GH);
+  }
+  auto fetch_ranges = [&](int bb, int yy, int xx, int* lo, int* cnt) __attribute__((always_inline)) {
+    const int* off = offset + (long)bb * (E + 1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k = (yy - (t & 1) + 1) * EW + (xx - (t >> 1) + 1);
+      lo[t] = off[k];
+      cnt[t] = off[k + 1] - lo[t];
+    }
+  };
+  int nlo[4], ncnt[4];
+  fetch_ranges(b, Y, X, nlo, ncnt);
+  for (int ci = 0; ci < SPLAT_CPG; ++ci) {
+    const long cell = cell0 + ci;
+    if (cell >= ncell) break;
+    int lo[4], cnt[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { lo[t] = nlo[t]; cnt[t] = ncnt[t]; }
     const int* lst = list + (long)b * P;
-    const float* fb = feats + (long)b * P * feats_cs + sub * 4;
-    const float* cb = coords + (long)b * P * 2;
+    const float* fb = feats + (long)b * P * feats_cs + (lane_on ? sub : 0) * 4;
+    const float* rxb = frx + (long)b * P;
+    const float* ryb = fry + (long)b * P;
+    if (++X == GW) { X = 0; if (++Y == GH) { Y = 0; ++b; } }          // next cell (prefetch its CSR ranges)
+    if (ci + 1 < SPLAT_CPG && cell + 1 < ncell) fetch_ranges(b, Y, X, nlo, ncnt);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float d = 0.f;
+    // the (<= 4) base cells whose taps land here, in the reference's tap order (xd,yd) = (0,0),(0,1),(1,0),(1,1):
+    // their CSR ranges are fetched together and walked as ONE concatenated sequence, LANES entries at a time.
+    // Every lane fetches one entry's point id and coordinates and forms its tap weight, then the group steps through
+    // the batch with shuffles: the offset -> id -> coords -> features chain of dependent loads is paid once per
+    // batch (not once per point and tap), and the feature loads of consecutive points are independent.  The
+    // accumulation order is the reference's (tap-major, point id ascending).
+    const int c0 = cnt[0], c01 = c0 + cnt[1], c012 = c01 + cnt[2], T = c012 + cnt[3];
+    for (int base = 0; base < T; base += LANES) {
+      const int v = base + sub;
+      int p_l = 0;
+      float w_l = 0.f;
+      if (v < T) {
+        const int tap = (v >= c0) + (v >= c01) + (v >= c012);
+        const int idx = tap == 0 ? lo[0] + v : tap == 1 ? lo[1] + v - c0 : tap == 2 ? lo[2] + v - c01 : lo[3] + v - c012;
+        p_l = lst[idx];
+        const float rX = rxb[idx], rY = ryb[idx];
+        const float wX = (tap >> 1) ? rX : __fsub_rn(1.f, rX);
+        const float wY = (tap & 1) ? rY : __fsub_rn(1.f, rY);
+        w_l = __fmul_rn(wX, wY);
+      }
+      const int n = min(LANES, T - base);
+      // four points per step, BRANCH-FREE: the four feature rows are loaded before the first is used (lanes beyond
+      // F/4 and steps beyond n read a valid row and contribute an exact +0), so four loads are in flight instead of
+      // one (load, s_waitcnt) round trip per point
+      for (int e0 = 0; e0 < n; e0 += 4) {
+        f32x4 f[4];
+        float w[4];
 #pragma unroll
-    for (int xd = 0; xd < 2; ++xd) {
+        for (int u = 0; u < 4; ++u) {
+          const int ee = e0 + u;
+          const int pp = __shfl(p_l, ee & (LANES - 1), LANES);
+          const float ww = __shfl(w_l, ee & (LANES - 1), LANES);
+          w[u] = ee < n ? ww : 0.f;
+          f[u] = *reinterpret_cast<const f32x4*>(fb + (unsigned)((ee < n ? pp : 0) * feats_cs));
+        }
 #pragma unroll
-      for (int yd = 0; yd < 2; ++yd) {
-        const int k = (Y - yd + 1) * EW + (X - xd + 1);
-        const int lo = off[k], hi = off[k + 1];
-        for (int e = lo; e < hi; ++e) {
-          const int p = lst[e];
-          const float Xf = cb[p * 2 + 0], Yf = cb[p * 2 + 1];
-          const float rX = __fsub_rn(Xf, floorf(Xf)), rY = __fsub_rn(Yf, floorf(Yf));
-          const float wX = xd ? rX : __fsub_rn(1.f, rX);
-          const float wY = yd ? rY : __fsub_rn(1.f, rY);
-          const float w = __fmul_rn(wX, wY);
-          d = __fadd_rn(d, w);
-          if (lane_on) {
-            const f32x4 f = *reinterpret_cast<const f32x4*>(fb + (long)p * feats_cs);
+        for (int u = 0; u < 4; ++u) {
+          if (e0 + u < n) {                              // group-uniform; keeps the sums bit-identical
+            d = __fadd_rn(d, w[u]);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              acc[j] = MODE == 2 ? fmaxf(acc[j], __fmul_rn(w, f[j])) : __fadd_rn(acc[j], __fmul_rn(w, f[j]));
+              acc[j] = MODE == 2 ? fmaxf(acc[j], __fmul_rn(w[u], f[u][j])) : __fadd_rn(acc[j], __fmul_rn(w[u], f[u][j]));
           }
         }
       }
@@ -239,6 +339,7 @@ extern "C" int creste_bev_splat_mode_f32(const float* xyz, const float* feats, i
   CRESTE_REQUIRE(B > 0 && P > 0 && F > 0 && F % 4 == 0 && F <= 256 && feats_cs % 4 == 0 && feats_cs >= F,
                  "bev_splat: F must be a multiple of 4 and <= 256");
   CRESTE_REQUIRE(GH > 0 && GW > 0 && vox_x > 0.f && vox_y > 0.f, "bev_splat: bad grid");
+  CRESTE_REQUIRE((long)P * feats_cs < (1L << 31), "bev_splat: P * feature stride overflows the 32-bit point offset");
   const int E = (GH + 1) * (GW + 1);
   const long BP = (long)B * P;
   hipStream_t s = (hipStream_t)stream;
@@ -260,13 +361,18 @@ extern "C" int creste_bev_splat_mode_f32(const float* xyz, const float* feats, i
     splat_sort_kernel<<<g, 256, 0, s>>>(w.offset, w.list, B, P, E);
     CRESTE_CHECK_LAUNCH("splat_sort");
   }
+  splat_frac_kernel<<<g1, 256, 0, s>>>(w.offset, w.list, coords, (float*)w.key, (float*)w.rank, BP, P, E);
+  CRESTE_CHECK_LAUNCH("splat_frac");
   const long ncell = (long)B * GH * GW;
   const int fq = F / 4;
 #define CRESTE_SPLAT_GATHER(L, M)                                                                                   \
   {                                                                                                                 \
-    const long per = 256 / L;                                                                                       \
-    const int g = (int)((ncell + per - 1) / per > 16384 ? 16384 : (ncell + per - 1) / per);                         \
-    splat_gather_kernel<L, M><<<g, 256, 0, s>>>(feats, feats_cs, coords, w.offset, w.list, B, P, F, GH, GW,        \
+    const long per = (256 / L) * SPLAT_CPG;                                                                         \
+    /* one pass per workgroup (no grid-stride): crowded cells sit at the same map position in every frame, and a \
+       strided walk hands all of them to the same few workgroups */                                              \
+    const int g = (int)((ncell + per - 1) / per > 4194304 ? 4194304 : (ncell + per - 1) / per);                     \
+    splat_gather_kernel<L, M><<<g, 256, 0, s>>>(feats, feats_cs, (const float*)w.key, (const float*)w.rank, w.offset, \
+                                                w.list, B, P, F, GH, GW,                                            \
                                                 min_weight, bev, dens);                                             \
   }
 #define CRESTE_SPLAT_LANES(M)                                                                                       \

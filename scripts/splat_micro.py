@@ -1,16 +1,29 @@
-"""BEV splat micro-benchmark at the bench shape (GPU box): B=16, P=46208, F=96, 256x256 grid."""
+"""BEV splat micro-benchmark at the bench shape (GPU box): B=16, P=46208, F=96, 256x256 grid.
+usage: splat_micro.py [uniform|frustum]   uniform: points uniform over the map (short cell lists);
+frustum: a camera frustum with per-pixel depths U(0.3, 25.4) m through the bench's p2p (cells near the sensor
+collect hundreds of points -- the representative case)."""
 import sys, os, torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-from creste_public_amd import ops
-B, P, F, G = 16, 152 * 304, 96, 256
+from creste_public_amd import ops, synth
+mode = sys.argv[1] if len(sys.argv) > 1 else "frustum"
+B, Hs, Ws, F, G = 16, 152, 304, 96, 256
+P = Hs * Ws
 torch.manual_seed(0)
-xyz = torch.empty(B, P, 3, device="cuda")
-xyz[..., 0] = torch.rand(B, P, device="cuda") * 30 - 2       # forward 0..28 m (part out of range)
-xyz[..., 1] = torch.rand(B, P, device="cuda") * 30 - 15
-xyz[..., 2] = torch.rand(B, P, device="cuda") * 3 - 2
-feats = ops.Act(torch.randn(B, 152, 304, F, device="cuda"), F)
+if mode == "uniform":
+    xyz = torch.empty(B, P, 3, device="cuda")
+    xyz[..., 0] = torch.rand(B, P, device="cuda") * 30 - 2       # forward 0..28 m (part out of range)
+    xyz[..., 1] = torch.rand(B, P, device="cuda") * 30 - 15
+    xyz[..., 2] = torch.rand(B, P, device="cuda") * 3 - 2
+else:
+    depth = torch.rand(B, Hs, Ws, device="cuda") * 25.1 + 0.3
+    p2p = synth.make_p2p(B, 608, 1216).to("cuda")[:, 0]
+    dummy = torch.zeros(1, device="cuda"); one = torch.zeros(1, 1, device="cuda")
+    bounds = torch.tensor([-3e38] * 3 + [3e38] * 3, device="cuda")
+    xyz, _ = ops.pixel_geometry(depth, p2p.contiguous().float(), bounds, dummy, dummy, one, dummy, ops.Act.empty(B, Hs, Ws, 1, "cuda"))
+    xyz = xyz.reshape(B, P, 3)
+feats = ops.Act(torch.randn(B, Hs, Ws, F, device="cuda"), F)
 for _ in range(3):
-    out = ops.bev_splat(xyz, feats, (12.8, 12.8), (0.1, 0.1), G, G)
+    coords, bev, dens = ops.bev_splat(xyz, feats, (12.8, 12.8), (0.1, 0.1), G, G)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
@@ -19,4 +32,12 @@ for _ in range(20):
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
 alg = 4.0 * (F * P + 2 * P + F * G * G + G * G) * B
+cell = coords.floor().long()
+ok = (cell >= -1).all(-1) & (cell[..., 0] <= G - 1) & (cell[..., 1] <= G - 1)
+key = ((cell[..., 1] + 1) * (G + 1) + cell[..., 0] + 1 + torch.arange(B, device="cuda").view(B, 1) * (G + 1) ** 2)[ok]
+cnt = torch.bincount(key)
+cnt = cnt[cnt > 0]
+print(f"{mode}: {int(ok.sum())} of {B * P} points own in-grid taps; occupied base cells {cnt.numel()}, points per occupied "
+      f"cell mean {cnt.float().mean():.1f} p99 {cnt.float().quantile(0.99):.0f} max {int(cnt.max())}; occupied BEV cells "
+      f"{100 * float((dens > 0).float().mean()):.1f} %")
 print(f"bev_splat B={B} P={P} F={F}: {ms * 1e3:.1f} us  algorithmic {alg / 1e6:.1f} MB -> {alg / ms / 1e9:.2f} TB/s = {alg / ms / 1e9 / 8 * 100:.1f}% of 8 TB/s")
