@@ -411,11 +411,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16_col3_kernel(
     else {
       for (int t = 0; t < 3; ++t) { load(xs - pad_l + t); store(bslot(xs - pad_l + t)); }
     }
+    if (xs + 1 < xe) load(isB ? xs + 1 - pad_l + 2 : xs + 1);   // registers: the data of the second column
   }
   __syncthreads();
   for (int col = xs; col < xe; ++col) {
-    const bool more = loader && col + 1 < xe;
-    if (more) load(isB ? col + 1 - pad_l + 2 : col + 1);      // next gy column / the one new x source column it needs
+    // loader waves FIRST convert and store the column fetched during the previous step (into the buffers the next
+    // step reads), then issue the loads for the step after -- their conversion VALU work runs while the other wave of
+    // the SIMD issues its MFMAs, and a load has a whole step to land
+    if (loader && col + 1 < xe) {
+      store(isB ? bslot(col + 1 - pad_l + 2) : Aimg + ((col + 1 - xs) & 1) * W3_IMG);
+      if (col + 2 < xe) load(isB ? col + 2 - pad_l + 2 : col + 2);
+    }
     const char* A = Aimg + ((col - xs) & 1) * W3_IMG;
 #pragma unroll
     for (int ks = 0; ks < W3_KS / 16; ++ks) {
@@ -438,7 +444,6 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16_col3_kernel(
         }
       }
     }
-    if (more) store(isB ? bslot(col + 1 - pad_l + 2) : Aimg + ((col + 1 - xs) & 1) * W3_IMG);
     __syncthreads();
   }
   const float sc = a_inv * b_inv;
