@@ -992,6 +992,9 @@ extern "C" int creste_conv_wgrad_f16x3(const float* x, int x_cs, const float* gy
   CRESTE_REQUIRE(x && gy && gw && work && x_amax && gy_amax, "conv_wgrad_f16x3: null pointer");
   CRESTE_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cout > 0 && K > 0 && stride > 0 &&
                      K * K <= 65535, "conv_wgrad_f16x3: bad dims");
+  CRESTE_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0 && x_cs % 4 == 0 && gy_cs % 4 == 0 && ((uintptr_t)x & 15) == 0 &&
+                     ((uintptr_t)gy & 15) == 0,
+                 "conv_wgrad_f16x3: channel counts and pixel strides must be multiples of 4 (16-byte operand quads)");
   const long M = (long)N * Ho * Wo;
   CRESTE_REQUIRE(M < (1L << 31), "conv_wgrad_f16x3: N*Ho*Wo overflows int32");
   const int tiles_co = (Cout + 127) / 128, tiles_ci = (Cin + 127) / 128;

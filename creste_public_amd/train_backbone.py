@@ -115,7 +115,8 @@ class ConvG:
             gw, acc = _acc(grads, w)
             work = torch.empty(lib.creste_conv_wgrad_strided_workspace_bytes(gy.N, gy.H, gy.W, Cin, Cout, self.K),
                                dtype=torch.uint8, device=w.device)
-            if hipnn._precision == ops.PREC_F16X3 and Cin >= 32 and Cout >= 32:
+            if (hipnn._precision == ops.PREC_F16X3 and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 8 and Cout >= 8
+                    and x.cs % 4 == 0 and gy.cs % 4 == 0 and x.co % 4 == 0 and gy.co % 4 == 0):
                 # f16x3 wgrad: fp16 hi+lo operands from the tensors' |max| bounds, fp32 accumulation
                 _lib.check(lib.creste_conv_wgrad_f16x3(x.ptr, x.cs, gy.ptr, gy.cs, gw.data_ptr(),
                                                        ops.absmax(x).data_ptr(), ops.absmax(gy).data_ptr(), x.N, x.H,
