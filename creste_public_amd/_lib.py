@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libcreste_hip.so")
 
-ABI_VERSION = 2          # creste_abi_version() of the library this binding was written against
+ABI_VERSION = 3          # creste_abi_version() of the library this binding was written against
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
 
@@ -71,10 +71,10 @@ SIGNATURES = {
     "creste_conv_flip_weight_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "creste_bn_workspace_bytes": (_i64, [_i]),
     "creste_bn_train_forward_f32": (_i, [_vp, _i, _i64, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
-                                         _vp, _vp]),
+                                         _vp, _vp, _vp]),
     "creste_bn_train_tangent_f32": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "creste_bn_train_backward_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp,
-                                          _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+                                          _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "creste_pointwise2_f32": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
     "creste_maxpool2_idx_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "creste_maxpool2_route_f32": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -85,7 +85,7 @@ SIGNATURES = {
     "creste_dwconv_dgrad_f32": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "creste_dwconv_wgrad_workspace_bytes": (_i64, [_i, _i]),
     "creste_dwconv_wgrad_f32": (_i, [_vp, _vp, _vp] + [_i] * 11 + [_vp, _vp]),
-    "creste_train_pointwise_f32": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i64, _i64, _i, _vp]),
+    "creste_train_pointwise_f32": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i64, _i64, _i, _vp, _vp]),
     "creste_sample_reduce_workspace_bytes": (_i64, [_i, _i]),
     "creste_sample_reduce_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _f, _vp, _vp]),
     "creste_se_fc_forward_f32": (_i, [_vp] * 8 + [_i, _i, _i, _vp]),

@@ -245,6 +245,7 @@ struct EwArgs {
   const float *mom_t;     // tangent moments [2][C]: m(xd), c = m(xh*xd)
   const float *mom_b;     // backward moments [5][C]
   float *o0, *o1;         // outputs
+  float* amax;            // optional running max|o0| (MODE 0 and 2), see block_amax_update
   int o0_cs, o1_cs;
   long P;
   int C, relu;
@@ -255,6 +256,8 @@ struct EwArgs {
 //   MODE 2  bn backward     o0 = gx, o1 = gxd (joint; G may be null -> plain first-order backward)
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_elementwise_kernel(const EwArgs a) {
+  __shared__ float amax_scratch[4];
+  float vmax = 0.f;
   const long total = a.P * a.C;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long p = i / a.C;
@@ -264,6 +267,7 @@ __global__ __launch_bounds__(256) void bn_elementwise_kernel(const EwArgs a) {
     if (MODE == 0) {
       float y = g * xh + (a.beta ? a.beta[c] : 0.f);
       if (a.relu) y = fmaxf(y, 0.f);
+      vmax = fmaxf(vmax, fabsf(y));
       a.o0[p * a.o0_cs + c] = y;
     } else if (MODE == 1) {
       const float t = (a.xd[p * a.xd_cs + c] - a.mom_t[c]) - xh * a.mom_t[a.C + c];
@@ -278,9 +282,11 @@ __global__ __launch_bounds__(256) void bn_elementwise_kernel(const EwArgs a) {
         gx -= g * is * is * (a.mom_b[4 * a.C + c] * xh + cc * pg + a.mom_b[3 * a.C + c] * t);
         a.o1[p * a.o1_cs + c] = g * is * pg;
       }
+      vmax = fmaxf(vmax, fabsf(gx));
       a.o0[p * a.o0_cs + c] = gx;
     }
   }
+  if (MODE != 1 && a.amax) block_amax_update(vmax, a.amax, amax_scratch);
 }
 
 // float4 variants of the streaming kernels (C and every pixel stride multiples of 4, 16-byte aligned bases, fewer
@@ -293,6 +299,9 @@ __device__ __forceinline__ ew4 relu4(ew4 v) { return ew4{fmaxf(v[0], 0.f), fmaxf
 
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_elementwise4_kernel(const EwArgs a) {
+  __shared__ float amax_scratch[4];
+  float vmax = 0.f;
+  auto amax4 = [](ew4 v) { return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))); };
   const unsigned Cq = (unsigned)a.C >> 2, total = (unsigned)a.P * Cq;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const unsigned p = i / Cq;
@@ -302,6 +311,7 @@ __global__ __launch_bounds__(256) void bn_elementwise4_kernel(const EwArgs a) {
     if (MODE == 0) {
       ew4 y = g * xh + (a.beta ? ld4e(a.beta + c) : splat4(0.f));
       if (a.relu) y = relu4(y);
+      vmax = fmaxf(vmax, amax4(y));
       st4e(a.o0 + (long)p * a.o0_cs + c, y);
     } else if (MODE == 1) {
       const ew4 t = (ld4e(a.xd + (long)p * a.xd_cs + c) - ld4e(a.mom_t + c)) - xh * ld4e(a.mom_t + a.C + c);
@@ -316,9 +326,11 @@ __global__ __launch_bounds__(256) void bn_elementwise4_kernel(const EwArgs a) {
         gx -= g * is * is * (ld4e(a.mom_b + 4 * a.C + c) * xh + cc * pg + ld4e(a.mom_b + 3 * a.C + c) * t);
         st4e(a.o1 + (long)p * a.o1_cs + c, g * is * pg);
       }
+      vmax = fmaxf(vmax, amax4(gx));
       st4e(a.o0 + (long)p * a.o0_cs + c, gx);
     }
   }
+  if (MODE != 1 && a.amax) block_amax_update(vmax, a.amax, amax_scratch);
 }
 
 static inline bool ew_vec_ok(const EwArgs& e) {
@@ -618,7 +630,7 @@ extern "C" int64_t creste_bn_workspace_bytes(int C) { return C > 0 ? (int64_t)mo
 extern "C" int creste_bn_train_forward_f32(const float* x, int x_cs, int64_t P, int C, const float* gamma,
                                            const float* beta, float eps, float momentum, float* running_mean,
                                            float* running_var, float* mean, float* invstd, float* var_scratch,
-                                           float* y, int y_cs, int relu, void* work, void* stream) {
+                                           float* y, int y_cs, int relu, float* out_amax, void* work, void* stream) {
   CRESTE_REQUIRE(x && mean && invstd && var_scratch && y && work && P > 1, "bn_train_forward: bad args");
   hipStream_t s = (hipStream_t)stream;
   MomArgs a = {};
@@ -633,8 +645,8 @@ extern "C" int creste_bn_train_forward_f32(const float* x, int x_cs, int64_t P, 
   CRESTE_CHECK_LAUNCH("bn_finish_stats");
   EwArgs e = {};
   e.x = x; e.x_cs = x_cs; e.gamma = gamma; e.beta = beta; e.mean = mean; e.invstd = invstd;
-  e.o0 = y; e.o0_cs = y_cs; e.P = P; e.C = C; e.relu = relu;
-  if (ew_vec_ok(e)) bn_elementwise4_kernel<0><<<grid1d(P * C / 4, 8192), 256, 0, s>>>(e);
+  e.o0 = y; e.o0_cs = y_cs; e.P = P; e.C = C; e.relu = relu; e.amax = out_amax;
+  if (ew_vec_ok(e)) bn_elementwise4_kernel<0><<<grid1d(P * C / 4, 1024), 256, 0, s>>>(e);
   else bn_elementwise_kernel<0><<<grid1d(P * C), 256, 0, s>>>(e);
   CRESTE_CHECK_LAUNCH("bn_forward");
   return CRESTE_OK;
@@ -662,8 +674,8 @@ extern "C" int creste_bn_train_backward_f32(const float* x, int x_cs, const floa
                                             int gy_cs, const float* gyd, int gyd_cs, int64_t P, int C,
                                             const float* gamma, const float* mean, const float* invstd,
                                             const float* mom_t, float* mom_b, float* gx, int gx_cs, float* gxd,
-                                            int gxd_cs, float* g_gamma, float* g_beta, int accumulate, void* work,
-                                            void* stream) {
+                                            int gxd_cs, float* g_gamma, float* g_beta, int accumulate,
+                                            float* gx_amax, void* work, void* stream) {
   CRESTE_REQUIRE(x && mean && invstd && mom_b && gx && work && (gy || gyd), "bn_train_backward: null pointer");
   CRESTE_REQUIRE(!gyd || (xd && mom_t && gxd), "bn_train_backward: the tangent cotangent needs xd, mom_t and gxd");
   hipStream_t s = (hipStream_t)stream;
@@ -676,8 +688,8 @@ extern "C" int creste_bn_train_backward_f32(const float* x, int x_cs, const floa
   EwArgs e = {};
   e.x = x; e.x_cs = x_cs; e.xd = xd; e.xd_cs = xd_cs; e.gy = gy; e.gy_cs = gy_cs; e.G = gyd; e.G_cs = gyd_cs;
   e.gamma = gamma; e.mean = mean; e.invstd = invstd; e.mom_t = mom_t; e.mom_b = mom_b;
-  e.o0 = gx; e.o0_cs = gx_cs; e.o1 = gxd; e.o1_cs = gxd_cs; e.P = P; e.C = C;
-  if (ew_vec_ok(e)) bn_elementwise4_kernel<2><<<grid1d(P * C / 4, 8192), 256, 0, s>>>(e);
+  e.o0 = gx; e.o0_cs = gx_cs; e.o1 = gxd; e.o1_cs = gxd_cs; e.P = P; e.C = C; e.amax = gx_amax;
+  if (ew_vec_ok(e)) bn_elementwise4_kernel<2><<<grid1d(P * C / 4, 1024), 256, 0, s>>>(e);
   else bn_elementwise_kernel<2><<<grid1d(P * C), 256, 0, s>>>(e);
   CRESTE_CHECK_LAUNCH("bn_backward");
   if (g_gamma && g_beta) {

@@ -611,7 +611,9 @@ __global__ __launch_bounds__(256) void train_pointwise_kernel(int op, const floa
                                                               const float* __restrict__ b, int b_cs,
                                                               const float* __restrict__ g, int g_c,
                                                               const float* __restrict__ r, float* __restrict__ o,
-                                                              int o_cs, long HW, long P, int C) {
+                                                              int o_cs, long HW, long P, int C, float* out_amax) {
+  __shared__ float amax_scratch[4];
+  float vmax = 0.f;
   const long total = P * C;
   const float inv_hw = 1.f / (float)HW;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -626,8 +628,10 @@ __global__ __launch_bounds__(256) void train_pointwise_kernel(int op, const floa
     } else if (op == 2) v = a[p * a_cs + c] * g[n * g_c + (g_c == 1 ? 0 : c)];
     else if (op == 3) v = b[p * b_cs + c] + a[p * a_cs + c] * g[n * g_c + (g_c == 1 ? 0 : c)];
     else v = b[p * b_cs + c] * g[n * g_c + (g_c == 1 ? 0 : c)] + (r ? r[n * C + c] * inv_hw : 0.f);
+    vmax = fmaxf(vmax, fabsf(v));
     o[p * o_cs + c] = v;
   }
+  if (out_amax) block_amax_update(vmax, out_amax, amax_scratch);
 }
 
 // float4 variant (C, strides multiples of 4; 16-byte aligned; < 2^31 quads), op as a template parameter
@@ -636,7 +640,9 @@ __global__ __launch_bounds__(256) void train_pointwise4_kernel(const float* __re
                                                                const float* __restrict__ b, int b_cs,
                                                                const float* __restrict__ g, int g_c,
                                                                const float* __restrict__ r, float* __restrict__ o,
-                                                               int o_cs, unsigned HW, unsigned P, int C) {
+                                                               int o_cs, unsigned HW, unsigned P, int C, float* out_amax) {
+  __shared__ float amax_scratch[4];
+  float vmax = 0.f;
   const unsigned Cq = (unsigned)C >> 2, total = P * Cq;
   const float inv_hw = 1.f / (float)HW;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
@@ -666,8 +672,10 @@ __global__ __launch_bounds__(256) void train_pointwise4_kernel(const float* __re
         if (r) v += ld4(r + (long)n * C + c) * inv_hw;
       }
     }
+    vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
     *reinterpret_cast<f32x4*>(o + (long)p * o_cs + c) = v;
   }
+  if (out_amax) block_amax_update(vmax, out_amax, amax_scratch);
 }
 
 // per-sample channel sums: out[n][c] = scale * sum_hw a[n,p,c] * (b ? b[n,p,c] : 1); grid (chunks, N)
@@ -1084,7 +1092,7 @@ extern "C" int creste_dwconv_wgrad_f32(const float* x, const float* gy, float* g
 
 extern "C" int creste_train_pointwise_f32(int op, const float* a, int a_cs, const float* b, int b_cs, const float* g,
                                           int g_c, const float* r, float* o, int o_cs, int64_t HW, int64_t P, int C,
-                                          void* stream) {
+                                          float* out_amax, void* stream) {
   CRESTE_REQUIRE(a && o && op >= 0 && op <= 4 && P > 0 && C > 0 && HW > 0, "train_pointwise: bad args");
   CRESTE_REQUIRE((op != 1 && op != 3 && op != 4) || b, "train_pointwise: op %d needs b", op);
   CRESTE_REQUIRE(op < 2 || g, "train_pointwise: op %d needs the gate", op);
@@ -1093,15 +1101,15 @@ extern "C" int creste_train_pointwise_f32(int op, const float* a, int a_cs, cons
                    (!g || g_c == 1 || ((uintptr_t)g & 15) == 0);
   if (vec) {
     hipStream_t s = (hipStream_t)stream;
-    const int g4 = grid1d(P * C / 4, 8192);
-#define CRESTE_TP4(OP) train_pointwise4_kernel<OP><<<g4, 256, 0, s>>>(a, a_cs, b, b_cs, g, g_c, r, o, o_cs, (unsigned)HW, (unsigned)P, C)
+    const int g4 = grid1d(P * C / 4, 1024);
+#define CRESTE_TP4(OP) train_pointwise4_kernel<OP><<<g4, 256, 0, s>>>(a, a_cs, b, b_cs, g, g_c, r, o, o_cs, (unsigned)HW, (unsigned)P, C, out_amax)
     if (op == 0) CRESTE_TP4(0); else if (op == 1) CRESTE_TP4(1); else if (op == 2) CRESTE_TP4(2);
     else if (op == 3) CRESTE_TP4(3); else CRESTE_TP4(4);
 #undef CRESTE_TP4
     CRESTE_CHECK_LAUNCH("train_pointwise4");
     return CRESTE_OK;
   }
-  train_pointwise_kernel<<<grid1d(P * C), 256, 0, (hipStream_t)stream>>>(op, a, a_cs, b, b_cs, g, g_c, r, o, o_cs, HW, P, C);
+  train_pointwise_kernel<<<grid1d(P * C), 256, 0, (hipStream_t)stream>>>(op, a, a_cs, b, b_cs, g, g_c, r, o, o_cs, HW, P, C, out_amax);
   CRESTE_CHECK_LAUNCH("train_pointwise");
   return CRESTE_OK;
 }

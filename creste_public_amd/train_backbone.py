@@ -20,7 +20,7 @@ from torch import nn
 
 from . import _lib, hipnn, ops
 from .ops import Act, HipLibraryError, _stream
-from .train_ops import BNT, UpT, _new, _px, as_act, pointwise2
+from .train_ops import BNT, UpT, _amax_slot, _new, _px, as_act, pointwise2
 from .train_ops import grad_slot as _acc
 
 DROP_CONNECT = 0.2          # efficientnet_pytorch global_params.drop_connect_rate of efficientnet-b0
@@ -36,10 +36,12 @@ def tpoint(op: int, a: Act, b: Act | None = None, gate: torch.Tensor | None = No
     per-pixel one (the splat's range mask)."""
     out = out or _new(a)
     HW = hw or a.H * a.W
+    out.amax = _amax_slot(a.buf.device)
     _lib.check(_lib_().creste_train_pointwise_f32(
         op, a.ptr, a.cs, b.ptr if b is not None else None, b.cs if b is not None else 0,
         gate.data_ptr() if gate is not None else None, gate.shape[1] if gate is not None else 0,
-        r.data_ptr() if r is not None else None, out.ptr, out.cs, HW, _px(a), a.C, _stream()), "train_pointwise")
+        r.data_ptr() if r is not None else None, out.ptr, out.cs, HW, _px(a), a.C,
+        out.amax.data_ptr() if out.amax is not None else None, _stream()), "train_pointwise")
     return out
 
 

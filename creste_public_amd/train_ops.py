@@ -39,6 +39,13 @@ def _px(a: Act) -> int:
     return a.N * a.H * a.W
 
 
+def _amax_slot(dev):
+    """A zeroed device float for a producer to raise to max|out| -- only in the f16x3 operand mode, where the convs
+    consuming the tensor need the bound (otherwise None: the kernels skip the reduction)."""
+    from . import hipnn
+    return ops._AmaxPool.slot(dev) if (hipnn._precision == ops.PREC_F16X3 or ops.TRACK_AMAX) else None
+
+
 def as_act(t: torch.Tensor, pad_to4=False) -> Act:
     """[B,C,H,W] tensor (any strides) -> NHWC Act, zero-copy when it already is a view of an NHWC buffer."""
     if not t.is_cuda:
@@ -69,6 +76,7 @@ def grad_slot(grads: dict, p: torch.Tensor):
 
 def pointwise2(op: int, a: Act, b: Act | None, out: Act | None = None) -> Act:
     out = out or _new(a)
+    out.amax = None                            # rewritten without tracking: a cached bound would be stale
     _lib.check(_lib_().creste_pointwise2_f32(op, a.ptr, a.cs, b.ptr if b is not None else None,
                                              b.cs if b is not None else 0, out.ptr, out.cs, _px(a), a.C, _stream()),
                "pointwise2")
@@ -164,10 +172,12 @@ class BNT:
         self.invstd = torch.empty(Cn, device=dev)
         var = torch.empty(Cn, device=dev)
         y = out or _new(x)
+        y.amax = _amax_slot(dev)               # max|y| for an f16x3 conv consuming it (None outside that mode)
         _lib.check(_lib_().creste_bn_train_forward_f32(
             x.ptr, x.cs, _px(x), Cn, bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), float(bn.momentum),
             bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.mean.data_ptr(), self.invstd.data_ptr(),
-            var.data_ptr(), y.ptr, y.cs, int(self.relu), self._work(dev).data_ptr(), _stream()), "bn_train_forward")
+            var.data_ptr(), y.ptr, y.cs, int(self.relu), y.amax.data_ptr() if y.amax is not None else None,
+            self._work(dev).data_ptr(), _stream()), "bn_train_forward")
         bn.num_batches_tracked += 1
         self.y = y
         return y
@@ -193,6 +203,7 @@ class BNT:
             gyd = pointwise2(1, self.y, gyd) if gyd is not None else None
         ref = gy if gy is not None else gyd
         gx = _new(ref)
+        gx.amax = _amax_slot(dev)
         gxd = _new(ref) if gyd is not None else None
         mom_b = torch.empty((5, bn.num_features), device=dev)
         gg = gb = None
@@ -209,7 +220,8 @@ class BNT:
             self.mom_t.data_ptr() if has_t else None, mom_b.data_ptr(), gx.ptr, gx.cs,
             gxd.ptr if has_t else None, gxd.cs if has_t else 0,
             gg.data_ptr() if gg is not None else None, gb.data_ptr() if gb is not None else None, acc,
-            self._work(dev).data_ptr(), _stream()), "bn_train_backward")
+            gx.amax.data_ptr() if gx.amax is not None else None, self._work(dev).data_ptr(), _stream()),
+            "bn_train_backward")
         return gx, gxd
 
 

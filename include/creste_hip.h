@@ -263,12 +263,14 @@ int creste_conv_flip_weight_f32(const float* w, float* wt, int Cout, int Cin, in
  *   tangent : yd = gamma*invstd*((xd - m(xd)) - xh*m(xh*xd)); mom_t[2][C] keeps the two moments.
  *   backward: cotangents gy (of y) and/or gyd (of yd) -> gx, gxd, g_gamma, g_beta ((+)= with
  *             accumulate); mom_b[5][C] scratch.  gyd == NULL is the ordinary first-order backward.
+ *   out_amax / gx_amax (optional): device float raised to max|y| / max|gx| (zero it first) -- the operand bound
+ *             the f16x3 convs consuming the tensor need (creste_conv_desc.a_amax), without a separate pass.
  *   work: creste_bn_workspace_bytes(C). */
 int64_t creste_bn_workspace_bytes(int C);
 int creste_bn_train_forward_f32(const float* x, int x_cs, int64_t P, int C, const float* gamma, const float* beta,
                                 float eps, float momentum, float* running_mean, float* running_var, float* mean,
-                                float* invstd, float* var_scratch, float* y, int y_cs, int relu, void* work,
-                                void* stream);
+                                float* invstd, float* var_scratch, float* y, int y_cs, int relu, float* out_amax,
+                                void* work, void* stream);
 int creste_bn_train_tangent_f32(const float* x, int x_cs, const float* xd, int xd_cs, int64_t P, int C,
                                 const float* gamma, const float* mean, const float* invstd, float* mom_t,
                                 float* yd, int yd_cs, void* work, void* stream);
@@ -276,7 +278,7 @@ int creste_bn_train_backward_f32(const float* x, int x_cs, const float* xd, int 
                                  const float* gyd, int gyd_cs, int64_t P, int C, const float* gamma,
                                  const float* mean, const float* invstd, const float* mom_t, float* mom_b,
                                  float* gx, int gx_cs, float* gxd, int gxd_cs, float* g_gamma, float* g_beta,
-                                 int accumulate, void* work, void* stream);
+                                 int accumulate, float* gx_amax, void* work, void* stream);
 
 /* op 0: o = max(a, 0) | op 1: o = a > 0 ? b : 0 (ReLU backward / tangent with a = the ReLU output) |
  * op 2: o = a + b.  [P][C] with pixel strides. */
@@ -317,9 +319,11 @@ int64_t creste_dwconv_wgrad_workspace_bytes(int C, int K);
 int creste_dwconv_wgrad_f32(const float* x, const float* gy, float* gw_taps, int N, int H, int W, int C, int Ho,
                             int Wo, int K, int stride, int pad_t, int pad_l, int accumulate, void* work, void* stream);
 /* op 0 swish(a) | 1 swish'(a)*b | 2 a*g[n][c] | 3 b + a*g[n][c] | 4 b*g[n][c] + r[n][c]/HW.
- * g is [N][g_c] with g_c == C (squeeze-excite gate) or 1 (per-sample scalar: drop-connect). */
+ * g is [N][g_c] with g_c == C (squeeze-excite gate) or 1 (per-sample scalar: drop-connect); out_amax (optional):
+ * device float raised to max|o|. */
 int creste_train_pointwise_f32(int op, const float* a, int a_cs, const float* b, int b_cs, const float* g, int g_c,
-                               const float* r, float* o, int o_cs, int64_t HW, int64_t P, int C, void* stream);
+                               const float* r, float* o, int o_cs, int64_t HW, int64_t P, int C, float* out_amax,
+                               void* stream);
 /* out[n][c] = scale * sum_hw a[n,p,c] * (b ? b[n,p,c] : 1)  (squeeze-excite pool and its gate gradient). */
 int64_t creste_sample_reduce_workspace_bytes(int N, int C);
 int creste_sample_reduce_f32(const float* a, int a_cs, const float* b, int b_cs, float* out, int N, int64_t HW, int C,
