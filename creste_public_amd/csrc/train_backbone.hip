@@ -709,14 +709,19 @@ __global__ __launch_bounds__(256) void sample_reduce_kernel(const float* __restr
   }
 }
 
-__global__ void sample_reduce_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int chunks,
-                                              int NC, int C, float scale) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per output: lane l sums chunks l, l+64, ... in order, then a fixed xor tree (a thread per output walked
+// the 256 chunks as 256 dependent loads: 60 us for a 9 KB result)
+__global__ __launch_bounds__(256) void sample_reduce_finalize_kernel(const float* __restrict__ partial,
+                                                                     float* __restrict__ out, int chunks, int NC, int C,
+                                                                     float scale) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= NC) return;
   const int n = i / C, c = i % C;
   float s = 0.f;
-  for (int k = 0; k < chunks; ++k) s += partial[((size_t)n * chunks + k) * C + c];
-  out[i] = s * scale;
+  for (int k = lane; k < chunks; k += 64) s += partial[((size_t)n * chunks + k) * C + c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) out[i] = s * scale;
 }
 
 // ------------------------------------------------------------------------------------ squeeze-excite FCs
@@ -1128,7 +1133,7 @@ extern "C" int creste_sample_reduce_f32(const float* a, int a_cs, const float* b
   hipStream_t s = (hipStream_t)stream;
   sample_reduce_kernel<<<dim3(chunks, N), 256, smem, s>>>(a, a_cs, b, b_cs, (float*)work, HW, C);
   CRESTE_CHECK_LAUNCH("sample_reduce");
-  sample_reduce_finalize_kernel<<<(N * C + 255) / 256, 256, 0, s>>>((const float*)work, out, chunks, N * C, C, scale);
+  sample_reduce_finalize_kernel<<<(N * C + 3) / 4, 256, 0, s>>>((const float*)work, out, chunks, N * C, C, scale);
   CRESTE_CHECK_LAUNCH("sample_reduce_finalize");
   return CRESTE_OK;
 }

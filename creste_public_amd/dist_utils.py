@@ -49,6 +49,8 @@ def allreduce_mean_grads(params) -> int:
     params = [p for p in params if p.requires_grad]
     if not params:
         return 0
+    if not is_dist():                 # one rank: nothing to average (and no flat copy / 300 per-parameter copies)
+        return sum(p.numel() for p in params)
     dev, dt = params[0].device, params[0].dtype
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(dt)
                       for p in params])
