@@ -581,9 +581,7 @@ __global__ void pack_weight_patch_kernel(const float* __restrict__ w, const floa
 // few pixel tiles (the deep 19x38 / 38x76 maps) or few input channels (MBConv expand convs: one or two chunks per
 // tile, bound by the output write) take narrower tiles: more, lighter workgroups, two to a CU.
 static inline int patch_tn(int cout, int prec, int cin, int K, long px_tiles) {
-  static const int exp_tn = getenv("CRESTE_EXP_TN") ? atoi(getenv("CRESTE_EXP_TN")) : 0;   // tuning aid
   const int max_tn = cout > 128 ? (prec == CRESTE_PREC_F16X3 ? 4 : 2) : (cout > 64 ? 2 : 1);
-  if (exp_tn) return exp_tn < max_tn ? exp_tn : max_tn;
   int tn = max_tn;
   if (K == 1 && cin < 256 && tn == 4) tn = 2;            // write-bound expand convs: 256-wide tiles only add latency
   while (tn > 1 && px_tiles * ((cout + 64 * tn - 1) / (64 * tn)) < 400) tn >>= 1;   // < ~1.5 workgroups per CU
