@@ -20,9 +20,18 @@ constexpr int MPC_TILE = 64;
 
 template <int D>
 __device__ __forceinline__ float mpc_dot(const float (&r)[D], const float* __restrict__ c) {
-  float s = 0.f;
+  // four independent partial sums (two packed-fp32 FMA chains) instead of one D-long dependent chain; the forward
+  // statistics and the gradient sweeps both come through here, so they see bit-identical logits
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
 #pragma unroll
-  for (int d = 0; d < D; ++d) s = __fmaf_rn(r[d], c[d], s);
+  for (int d = 0; d + 3 < D; d += 4) {
+    s0 = __builtin_elementwise_fma(f2{r[d], r[d + 1]}, f2{c[d], c[d + 1]}, s0);
+    s1 = __builtin_elementwise_fma(f2{r[d + 2], r[d + 3]}, f2{c[d + 2], c[d + 3]}, s1);
+  }
+  float s = (s0[0] + s0[1]) + (s1[0] + s1[1]);
+#pragma unroll
+  for (int d = D & ~3; d < D; ++d) s = __fmaf_rn(r[d], c[d], s);
   return s;
 }
 
