@@ -141,6 +141,9 @@ __global__ __launch_bounds__(256) void mpc_grad_kernel(const float* __restrict__
   float4 st = make_float4(0.f, 1.f, 0.f, 0.f);
   float wi = 0.f;
   if (ROWS && ok) { st = stats[t]; wi = (rw ? rw[t] : 1.f) * gscale; }
+  // (max, 1/sumexp, count, 1/count): the pair loop multiplies instead of dividing twice per pair
+  auto recip = [](float4 v) { return make_float4(v.x, 1.f / v.y, v.z, v.z > 0.f ? 1.f / v.z : 0.f); };
+  st = recip(st);
   const int o_lo = blockIdx.y * per_split, o_hi = min(oth_n, o_lo + per_split);
   for (int k0 = o_lo; k0 < o_hi; k0 += MPC_TILE) {
     __syncthreads();
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void mpc_grad_kernel(const float* __restrict__
       const int k = k0 + threadIdx.x;
       tlab[threadIdx.x] = k < o_hi ? oth_lab[k] : -2;
       if (!ROWS) {
-        tst[threadIdx.x] = k < o_hi ? stats[k] : make_float4(0.f, 1.f, 0.f, 0.f);
+        tst[threadIdx.x] = recip(k < o_hi ? stats[k] : make_float4(0.f, 1.f, 0.f, 0.f));
         trw[threadIdx.x] = (k < o_hi && rw) ? rw[k] : 1.f;
       }
     }
@@ -166,8 +169,8 @@ __global__ __launch_bounds__(256) void mpc_grad_kernel(const float* __restrict__
       if (s.z <= 0.f) continue;                                   // a row without positives contributes nothing
       const float z = mpc_dot<D>(r, tile[kk]) * inv_t;
       const float w = ROWS ? wi : trw[kk] * gscale;
-      float gij = expf(z - s.x) / s.y;
-      if (tlab[kk] == lt) gij -= 1.f / s.z;
+      float gij = expf(z - s.x) * s.y;
+      if (tlab[kk] == lt) gij -= s.w;
       gij *= w * inv_t;
 #pragma unroll
       for (int d = 0; d < D; ++d) g[d] = __fmaf_rn(gij, tile[kk][d], g[d]);
