@@ -55,6 +55,8 @@ def kernel_symbol(pc, N, Ho, Wo):
     if pc.prec == 0:
         return ("f32", "conv_igemm_f32_kernel<2, 2, 2, 2>" if pc.Cout > 64 else
                 "conv_igemm_f32_kernel<2, 2, 2, 1>" if pc.Cout > 32 else "conv_igemm_f32_kernel<4, 1, 1, 1>")
+    if pc.stride == 2:                          # f16x3 only: row-at-a-time stride-2 kernel
+        return (PREC_NAME[pc.prec], f"conv_patch_s2_kernel<{pc.KH}, {2 if pc.Cout > 64 and pc.KH != 7 else 1}>")
     split = {1: 1, 2: 2, 3: 3, 4: 2}[pc.prec]
     tn = (4 if pc.prec == 4 else 2) if pc.Cout > 128 else 2 if pc.Cout > 64 else 1
     if pc.KH == 1 and pc.Cin < 256 and tn == 4:

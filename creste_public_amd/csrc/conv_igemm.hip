@@ -253,7 +253,8 @@ extern "C" int creste_conv_supported_upsample(int prec, int KH, int KW, int stri
 extern "C" int64_t creste_conv_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int prec) {
   if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return -1;
   if (prec != CRESTE_PREC_F32)
-    return conv_patch_supported(prec, KH, KW, 1) ? conv_patch_weight_bytes(Cout, Cin, KH, prec) : -1;
+    return conv_patch_supported(prec, KH, KW, 1) || conv_patch_supported(prec, KH, KW, 2)
+               ? conv_patch_weight_bytes(Cout, Cin, KH, prec) : -1;
   const int bn = pick_bn(Cout);
   return (int64_t)round_up(Cout, bn) * KH * KW * round_up(Cin, BK) * 4;
 }
@@ -278,7 +279,8 @@ extern "C" int creste_conv_pack_weight(const float* w, const float* scale, void*
 extern "C" int creste_conv_pack_weight_f16(const float* w, const float* scale, void* wpk, float* w_unscale,
                                            int Cout, int Cin, int KH, int KW, void* stream) {
   CRESTE_REQUIRE(w && wpk && w_unscale && Cout > 0 && Cin > 0, "conv_pack_weight_f16: bad args");
-  CRESTE_REQUIRE(conv_patch_supported(CRESTE_PREC_F16X3, KH, KW, 1), "conv_pack_weight_f16: %dx%d not built", KH, KW);
+  CRESTE_REQUIRE(conv_patch_supported(CRESTE_PREC_F16X3, KH, KW, 1) || conv_patch_supported(CRESTE_PREC_F16X3, KH, KW, 2),
+                 "conv_pack_weight_f16: %dx%d not built", KH, KW);
   return conv_patch_pack(w, scale, wpk, w_unscale, Cout, Cin, KH, CRESTE_PREC_F16X3, (hipStream_t)stream);
 }
 
@@ -307,6 +309,8 @@ extern "C" int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream) {
   // forward never sampled), but not further than one kernel beyond the input
   CRESTE_REQUIRE((d->Ho - 1) * d->stride - d->pad_t < d->H + d->KH && (d->Wo - 1) * d->stride - d->pad_l < d->W + d->KW,
                  "conv2d: output extent outside the input");
+  CRESTE_REQUIRE(d->prec == CRESTE_PREC_F32 || d->stride == 1 || !d->a_scale,
+                 "conv2d: the per-sample input gate is built for stride-1 convs only on the split-operand engines");
   CRESTE_REQUIRE(d->prec != CRESTE_PREC_F16X3 || (d->a_amax && d->w_unscale),
                  "conv2d: F16X3 needs a_amax (device bound of |in|) and w_unscale (from creste_conv_pack_weight_f16)");
   if (d->prec != CRESTE_PREC_F32) return conv_patch_run(d, (hipStream_t)stream);

@@ -527,6 +527,177 @@ static int launch_patch3(const PatchArgs& a, hipStream_t s) {
   return launch_patch3_up<SPLIT, TN, F16, false>(a, s);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stride-2 convs (K = 1, 3, 7: the encoder stem, the BEV stem 7x7/2, the ResNet 3x3/2 and 1x1/2 downsamples) in the
+// f16x3 operand mode -- the row-at-a-time structure of conv_patch3_kernel for an 8 x 32 OUTPUT tile:
+//   * the halo patch covers (16 + K - 2) x (64 + K - 2) INPUT pixels of one 16-channel chunk (single-buffered, as
+//     fp16 hi + lo); even and odd input columns sit in separate halves of a patch row, so the 32 lanes of an MFMA
+//     fragment (32 consecutive output columns = every other input column) read consecutive 16-byte slots;
+//   * the K weight tiles of one kernel row arrive by LDS-DMA, double-buffered; K * 6 * TN MFMAs per wave and barrier
+//     interval; the next chunk's patch is prefetched branch-free during the K row steps and converted once.
+template <int K, int TN>
+__global__ __launch_bounds__(512, 1) void conv_patch_s2_kernel(const PatchArgs p) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  constexpr int S = 2;
+  constexpr int PH = S * PT_TH + K - S, PW = S * PT_TW + K - S;    // input patch extent
+  constexpr int PWH = (PW + 1) / 2, PROW = 2 * PWH;                // slots per column parity / per patch row
+  constexpr int NSLOT = PH * PROW, NSLOTP = (NSLOT + 15) / 16 * 16;
+  constexpr int NPIX = PH * PW;
+  constexpr int BN = 64 * TN;
+  constexpr int A_OCT = NSLOTP * 16, A_PLANE = 2 * A_OCT, A_BYTES = 2 * A_PLANE;
+  constexpr int U_OCT = 64 * 16, U_PLANE = 2 * U_OCT, U_BYTES = 2 * U_PLANE;
+  constexpr int UROW_BYTES = K * U_BYTES, UROW_INSTR = UROW_BYTES / 1024;
+  constexpr int B_BYTES = TN * U_BYTES;
+  constexpr int ROW_BYTES = K * B_BYTES, ROW_INSTR = ROW_BYTES / 1024;
+  constexpr int ROUNDS = (NPIX * 4 + 511) / 512;
+  constexpr int RPS = (ROUNDS + K - 1) / K;                        // prefetch rounds per row step
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const abuf = smem;
+  char* const bbase = smem + A_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int nblk = p.tiles_n * p.tiles_x * p.tiles_y * p.N;
+  int id = xcd_remap(blockIdx.x, nblk);
+  const int tn = id % p.tiles_n; id /= p.tiles_n;
+  const int tx = id % p.tiles_x; id /= p.tiles_x;
+  const int ty = id % p.tiles_y;
+  const int img = id / p.tiles_y;
+  const int oy0 = ty * PT_TH, ox0 = tx * PT_TW;
+
+  float o_mul = 1.f;
+  const float a_mul = f16_operand_scale(*p.a_amax, &o_mul);
+
+  // staging slots: thread = (patch pixel, channel quad); rounds of 128 pixels
+  const int cq = tid & 3;
+  int a_yx[ROUNDS];          // (iy << 16) | ix, or -1
+  int a_lofs[ROUNDS];        // LDS byte offset of the pixel's slot (+ octet / half-octet of the quad)
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int pix = r * 128 + (tid >> 2);
+    const int py = pix / PW, px = pix - py * PW;
+    const int iy = oy0 * S + py - p.pad_t, ix = ox0 * S + px - p.pad_l;
+    const bool ok = pix < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    a_yx[r] = ok ? (iy << 16) | ix : -1;
+    const int slot = py * PROW + (px & 1) * PWH + (px >> 1);
+    a_lofs[r] = pix < NPIX ? (cq >> 1) * A_OCT + slot * 16 + (cq & 1) * 8 : -1;
+  }
+  auto load_a = [&](int r, int c) __attribute__((always_inline)) -> f32x4 {
+    const int ch = c * PT_CK + cq * 4;
+    const bool ok = a_yx[r] >= 0 && ch < p.Cin;
+    const int iy = a_yx[r] >> 16, ix = a_yx[r] & 0xffff;
+    return *reinterpret_cast<const f32x4*>(ok ? p.in + ((size_t)(img * p.H + iy) * p.W + ix) * p.in_cs + ch : p.in);
+  };
+  auto store_a = [&](int r, int c, f32x4 v) __attribute__((always_inline)) {
+    if (a_lofs[r] < 0) return;
+    const bool ok = a_yx[r] >= 0 && c * PT_CK + cq * 4 < p.Cin;
+    v *= a_mul;
+    if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    const h4 hi = __builtin_convertvector(v, h4);
+    const h4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), h4);
+    *reinterpret_cast<h4*>(abuf + a_lofs[r]) = hi;
+    *reinterpret_cast<h4*>(abuf + A_PLANE + a_lofs[r]) = lo;
+  };
+  const size_t nrows_w = (size_t)p.nchunk * K;
+  const char* wrow0 = p.wpk + (size_t)tn * TN * nrows_w * UROW_BYTES;
+  auto dma_row = [&](int g) __attribute__((always_inline)) {
+    char* dst = bbase + (g & 1) * ROW_BYTES;
+#pragma unroll
+    for (int j = 0; j < (ROW_INSTR + 7) / 8; ++j) {
+      const int i = wave + 8 * j;
+      if (i < ROW_INSTR) {
+        const int u = i / UROW_INSTR, r = i % UROW_INSTR;
+        const char* src = wrow0 + ((size_t)u * nrows_w + g) * UROW_BYTES + r * 1024 + lane * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  dma_row(0);
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) store_a(r, 0, load_a(r, 0));
+  __syncthreads();
+
+  const int nrows = p.nchunk * K;
+  int g = 0;
+  for (int c = 0; c < p.nchunk; ++c) {
+    const bool more_a = c + 1 < p.nchunk;
+    f32x4 ra[ROUNDS];
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky, ++g) {
+      if (g + 1 < nrows) dma_row(g + 1);
+      if (more_a) {
+#pragma unroll
+        for (int q = 0; q < RPS; ++q)
+          if (ky * RPS + q < ROUNDS) ra[ky * RPS + q] = load_a(ky * RPS + q, c + 1);
+      }
+      const char* Brow = bbase + (g & 1) * ROW_BYTES;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        h8 af[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int slot = (S * (wm * 2 + mt) + ky) * PROW + (kx & 1) * PWH + li + (kx >> 1);
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+            af[mt][pl] = *reinterpret_cast<const h8*>(abuf + pl * A_PLANE + lh * A_OCT + slot * 16);
+        }
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+          h8 bfr[2];
+          const int n = (wn * TN + nt) * 32 + li;
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+            bfr[pl] = *reinterpret_cast<const h8*>(Brow + (n >> 6) * UROW_BYTES + kx * U_BYTES + pl * U_PLANE + lh * U_OCT +
+                                                   (n & 63) * 16);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = split_mfma<2, h8>(bfr, af[mt], acc[mt][nt]);
+        }
+      }
+      __syncthreads();
+    }
+    if (more_a) {
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) store_a(r, c + 1, ra[r]);
+      __syncthreads();
+    }
+  }
+  patch_epilogue<TN, true>(acc, p, img, oy0, ox0, tn * BN, wm, wn, li, lh, o_mul, reinterpret_cast<float*>(smem));
+}
+
+template <int K, int TN>
+static int launch_patch_s2(const PatchArgs& a, hipStream_t s) {
+  constexpr int PH = 2 * PT_TH + K - 2, PW = 2 * PT_TW + K - 2, PROW = 2 * ((PW + 1) / 2);
+  constexpr int NSLOTP = (PH * PROW + 15) / 16 * 16;
+  constexpr int smem = 2 * 2 * NSLOTP * 16 + 2 * K * (2 * 2 * 64 * TN * 16);
+  static_assert(smem <= 160 * 1024, "stride-2 patch does not fit the LDS");
+  static bool attr_set = false;
+  if (!attr_set) {
+    CRESTE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_s2_kernel<K, TN>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  const int nblk = a.tiles_n * a.tiles_x * a.tiles_y * a.N;
+  conv_patch_s2_kernel<K, TN><<<nblk, 512, smem, s>>>(a);
+  CRESTE_CHECK_LAUNCH("conv_patch_s2");
+  return CRESTE_OK;
+}
+
 // F16X3: per output channel, the inverse of the power of two that brings max|w*scale| into [2^7, 2^8)
 __global__ void weight_unscale_kernel(const float* __restrict__ w, const float* __restrict__ scale,
                                       float* __restrict__ unscale, int per_co) {
@@ -609,6 +780,7 @@ static int launch_patch(const PatchArgs& a, hipStream_t s) {
 }
 
 bool conv_patch_supported(int prec, int KH, int KW, int stride) {
+  if (prec == CRESTE_PREC_F16X3 && KH == KW && (KH == 1 || KH == 3 || KH == 7) && stride == 2) return true;
   return (prec == CRESTE_PREC_BF16 || prec == CRESTE_PREC_BF16X3 || prec == CRESTE_PREC_BF16X6 ||
           prec == CRESTE_PREC_F16X3) && KH == KW && (KH == 1 || KH == 3) && stride == 1;
 }
@@ -654,6 +826,13 @@ int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
   a.tiles_n = (d->Cout + bn - 1) / bn;
   const int split = patch_split(d->prec);
   const int K = d->KH;
+  if (d->stride == 2) {                                  // f16x3 only (conv_patch_supported); tiles of 64 or 128 channels
+    const int tn2 = d->Cout > 64 && K != 7 ? 2 : 1;
+    a.tiles_n = (d->Cout + 64 * tn2 - 1) / (64 * tn2);
+    if (K == 7) return launch_patch_s2<7, 1>(a, s);
+    if (K == 3) return tn2 == 2 ? launch_patch_s2<3, 2>(a, s) : launch_patch_s2<3, 1>(a, s);
+    return tn2 == 2 ? launch_patch_s2<1, 2>(a, s) : launch_patch_s2<1, 1>(a, s);
+  }
   if (d->prec == CRESTE_PREC_F16X3) {
     if (K == 3)
       return bn == 256 ? launch_patch3<2, 4, true>(a, s)

@@ -91,7 +91,7 @@ class ConvUnit:
 
     def packed(self) -> ops.PackedConv:
         k = self.conv.kernel_size[0]
-        prec = _precision if ops.conv_supported(_precision, k, self.conv.stride[0]) else ops.PREC_F32
+        prec = ops.conv_precision(_precision, k, self.conv.stride[0], self.conv.in_channels)
         key = (_sig(self._tensors()), prec)
         if self._packed is None or key != self._key:
             require_hip(self.conv.weight, "conv weight")

@@ -82,7 +82,7 @@ class ConvG:
 
     def _prec(self):
         p = hipnn._precision
-        return p if ops.conv_supported(p, self.K, self.s) else ops.PREC_F32
+        return ops.conv_precision(p, self.K, self.s, self.conv.in_channels)
 
     def _packed(self, want_bw):
         w, b = self.conv.weight, self.conv.bias

@@ -110,6 +110,44 @@ def test_conv_patch_bf16(ops, case, prec, tol):
     assert float((got - ref).abs().max()) < 60 * tol * float(ref.abs().max().clamp_min(1.0))
 
 
+S2_CASES = [c for c in CONV_CASES if c[6] == 2] + [
+    (2, 96, 64, 70, 64, 7, 2, (3, 3, 3, 3), 1, False, True, False),    # BEV stem, several tiles, partial in x
+    (1, 64, 33, 65, 128, 3, 2, (1, 1, 1, 1), 1, False, True, True),    # odd extents, residual, two 64-channel units
+    (2, 64, 16, 40, 128, 1, 2, (0, 0, 0, 0), 0, False, True, False),   # ResNet 1x1/2 downsample
+    (1, 20, 21, 35, 200, 3, 2, (0, 1, 0, 1), 2, True, False, False),   # ragged chunk, bias, static 'same' padding
+]
+
+
+@pytest.mark.parametrize("case", S2_CASES)
+def test_conv_patch_stride2_f16x3(ops, case):
+    """stride-2 convs (K = 1, 3, 7) on the f16x3 engine vs a float64 conv: fp32-grade, like the stride-1 kernels"""
+    N, Cin, H, W, Cout, K, s, pad, act, use_bias, use_bn, use_res = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g) if use_bias else None
+    bn = (torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1,
+          torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5, 1e-3) if use_bn else None
+    ref = F.conv2d(F.pad(x, (pad[2], pad[3], pad[0], pad[1])).double(), w.double(),
+                   None if b is None else b.double(), stride=s)
+    if bn is not None:
+        ref = F.batch_norm(ref, bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(), False, 0.0, bn[4])
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if res is not None:
+        ref = ref + res.double()
+    ref = {0: lambda t: t, 1: F.relu, 2: lambda t: t * torch.sigmoid(t)}[act](ref)
+    assert ops.conv_supported(ops.PREC_F16X3, K, s)
+    pc = ops.pack_conv(dev(w), None if b is None else dev(b),
+                       None if bn is None else tuple(dev(t) if isinstance(t, torch.Tensor) else t for t in bn),
+                       s, pad, act, ops.PREC_F16X3)
+    out = ops.conv2d(to_act(ops, x), pc, res=None if res is None else to_act(ops, res))
+    got = out.nchw().cpu().double()
+    assert got.shape == ref.shape
+    err = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-30))
+    assert err < 2e-6, err
+    assert float(out.amax.cpu()) >= float(got.abs().max()) * (1 - 1e-6)
+
+
 @pytest.mark.parametrize("xs,ws", [(1e-20, 1.0), (1e-6, 1e3), (1.0, 1e-12), (3e4, 1.0), (1e15, 1e15), ("outlier", 1.0),
                                    ("zero", 1.0)])
 @pytest.mark.parametrize("K", [1, 3])
