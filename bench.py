@@ -55,8 +55,9 @@ def kernel_symbol(pc, N, Ho, Wo):
     if pc.prec == 0:
         return ("f32", "conv_igemm_f32_kernel<2, 2, 2, 2>" if pc.Cout > 64 else
                 "conv_igemm_f32_kernel<2, 2, 2, 1>" if pc.Cout > 32 else "conv_igemm_f32_kernel<4, 1, 1, 1>")
-    if pc.stride == 2:                          # f16x3 only: row-at-a-time stride-2 kernel
-        return (PREC_NAME[pc.prec], f"conv_patch_s2_kernel<{pc.KH}, {2 if pc.Cout > 64 and pc.KH != 7 else 1}>")
+    if pc.stride == 2 or pc.KH > 3:             # f16x3 only: row-at-a-time kernel
+        tn2 = 2 if pc.Cout > 64 and not (pc.KH == 7 and pc.stride == 2) else 1
+        return (PREC_NAME[pc.prec], f"conv_patch_row_kernel<{pc.KH}, {pc.stride}, {tn2}>")
     split = {1: 1, 2: 2, 3: 3, 4: 2}[pc.prec]
     tn = (4 if pc.prec == 4 else 2) if pc.Cout > 128 else 2 if pc.Cout > 64 else 1
     if pc.KH == 1 and pc.Cin < 256 and tn == 4:
@@ -155,6 +156,7 @@ def distill_extras(device, steps=3, B=8):
     from creste_public_amd.creste.models.distillation import DistillationBackbone
     from creste_public_amd.creste.utils.loss_utils import LossManager
     cfg = harness.distillation_cfg((IMG_H, IMG_W))
+    torch.cuda.empty_cache()                   # the inference / IRL runs before this leave a fragmented cache
     torch.manual_seed(0)
     model = DistillationBackbone(cfg).to(device)
     synth.randomize_bn(model, seed=1)

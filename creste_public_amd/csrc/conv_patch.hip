@@ -528,20 +528,21 @@ static int launch_patch3(const PatchArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Stride-2 convs (K = 1, 3, 7: the encoder stem, the BEV stem 7x7/2, the ResNet 3x3/2 and 1x1/2 downsamples) in the
-// f16x3 operand mode -- the row-at-a-time structure of conv_patch3_kernel for an 8 x 32 OUTPUT tile:
+// Stride-2 convs (K = 1, 3, 7: the BEV stem 7x7/2, the ResNet 3x3/2 and 1x1/2 downsamples) and stride-1 5x5 / 7x7
+// convs (reward network, the input gradient of the 7x7/2 stem) in the f16x3 operand mode -- the row-at-a-time
+// structure of conv_patch3_kernel for an 8 x 32 OUTPUT tile (described for stride 2; stride 1 needs no parity split):
 //   * the halo patch covers (16 + K - 2) x (64 + K - 2) INPUT pixels of one 16-channel chunk (single-buffered, as
 //     fp16 hi + lo); even and odd input columns sit in separate halves of a patch row, so the 32 lanes of an MFMA
 //     fragment (32 consecutive output columns = every other input column) read consecutive 16-byte slots;
 //   * the K weight tiles of one kernel row arrive by LDS-DMA, double-buffered; K * 6 * TN MFMAs per wave and barrier
 //     interval; the next chunk's patch is prefetched branch-free during the K row steps and converted once.
-template <int K, int TN>
-__global__ __launch_bounds__(512, 1) void conv_patch_s2_kernel(const PatchArgs p) {
+template <int K, int S, int TN>
+__global__ __launch_bounds__(512, 1) void conv_patch_row_kernel(const PatchArgs p) {
   typedef _Float16 h8 __attribute__((ext_vector_type(8)));
   typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-  constexpr int S = 2;
+  static_assert(S == 1 || S == 2, "stride 1 or 2");
   constexpr int PH = S * PT_TH + K - S, PW = S * PT_TW + K - S;    // input patch extent
-  constexpr int PWH = (PW + 1) / 2, PROW = 2 * PWH;                // slots per column parity / per patch row
+  constexpr int PWH = (PW + 1) / 2, PROW = S == 2 ? 2 * PWH : PW;  // slots per column parity / per patch row
   constexpr int NSLOT = PH * PROW, NSLOTP = (NSLOT + 15) / 16 * 16;
   constexpr int NPIX = PH * PW;
   constexpr int BN = 64 * TN;
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(512, 1) void conv_patch_s2_kernel(const PatchArgs p
     const int iy = oy0 * S + py - p.pad_t, ix = ox0 * S + px - p.pad_l;
     const bool ok = pix < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
     a_yx[r] = ok ? (iy << 16) | ix : -1;
-    const int slot = py * PROW + (px & 1) * PWH + (px >> 1);
+    const int slot = S == 2 ? py * PROW + (px & 1) * PWH + (px >> 1) : py * PROW + px;
     a_lofs[r] = pix < NPIX ? (cq >> 1) * A_OCT + slot * 16 + (cq & 1) * 8 : -1;
   }
   auto load_a = [&](int r, int c) __attribute__((always_inline)) -> f32x4 {
@@ -652,7 +653,8 @@ __global__ __launch_bounds__(512, 1) void conv_patch_s2_kernel(const PatchArgs p
         h8 af[2][2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-          const int slot = (S * (wm * 2 + mt) + ky) * PROW + (kx & 1) * PWH + li + (kx >> 1);
+          const int slot = S == 2 ? (S * (wm * 2 + mt) + ky) * PROW + (kx & 1) * PWH + li + (kx >> 1)
+                                  : (wm * 2 + mt + ky) * PROW + li + kx;
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl)
             af[mt][pl] = *reinterpret_cast<const h8*>(abuf + pl * A_PLANE + lh * A_OCT + slot * 16);
@@ -680,21 +682,21 @@ __global__ __launch_bounds__(512, 1) void conv_patch_s2_kernel(const PatchArgs p
   patch_epilogue<TN, true>(acc, p, img, oy0, ox0, tn * BN, wm, wn, li, lh, o_mul, reinterpret_cast<float*>(smem));
 }
 
-template <int K, int TN>
-static int launch_patch_s2(const PatchArgs& a, hipStream_t s) {
-  constexpr int PH = 2 * PT_TH + K - 2, PW = 2 * PT_TW + K - 2, PROW = 2 * ((PW + 1) / 2);
+template <int K, int S, int TN>
+static int launch_patch_row(const PatchArgs& a, hipStream_t s) {
+  constexpr int PH = S * PT_TH + K - S, PW = S * PT_TW + K - S, PROW = S == 2 ? 2 * ((PW + 1) / 2) : PW;
   constexpr int NSLOTP = (PH * PROW + 15) / 16 * 16;
   constexpr int smem = 2 * 2 * NSLOTP * 16 + 2 * K * (2 * 2 * 64 * TN * 16);
   static_assert(smem <= 160 * 1024, "stride-2 patch does not fit the LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    CRESTE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_s2_kernel<K, TN>),
+    CRESTE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_row_kernel<K, S, TN>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   const int nblk = a.tiles_n * a.tiles_x * a.tiles_y * a.N;
-  conv_patch_s2_kernel<K, TN><<<nblk, 512, smem, s>>>(a);
-  CRESTE_CHECK_LAUNCH("conv_patch_s2");
+  conv_patch_row_kernel<K, S, TN><<<nblk, 512, smem, s>>>(a);
+  CRESTE_CHECK_LAUNCH("conv_patch_row");
   return CRESTE_OK;
 }
 
@@ -781,6 +783,7 @@ static int launch_patch(const PatchArgs& a, hipStream_t s) {
 
 bool conv_patch_supported(int prec, int KH, int KW, int stride) {
   if (prec == CRESTE_PREC_F16X3 && KH == KW && (KH == 1 || KH == 3 || KH == 7) && stride == 2) return true;
+  if (prec == CRESTE_PREC_F16X3 && KH == KW && (KH == 5 || KH == 7) && stride == 1) return true;
   return (prec == CRESTE_PREC_BF16 || prec == CRESTE_PREC_BF16X3 || prec == CRESTE_PREC_BF16X6 ||
           prec == CRESTE_PREC_F16X3) && KH == KW && (KH == 1 || KH == 3) && stride == 1;
 }
@@ -826,12 +829,16 @@ int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
   a.tiles_n = (d->Cout + bn - 1) / bn;
   const int split = patch_split(d->prec);
   const int K = d->KH;
-  if (d->stride == 2) {                                  // f16x3 only (conv_patch_supported); tiles of 64 or 128 channels
-    const int tn2 = d->Cout > 64 && K != 7 ? 2 : 1;
+  if (d->stride == 2 || K > 3) {        // f16x3 only (conv_patch_supported): the row-at-a-time kernels
+    const int tn2 = d->Cout > 64 && !(K == 7 && d->stride == 2) ? 2 : 1;      // tiles of 64 or 128 channels
     a.tiles_n = (d->Cout + 64 * tn2 - 1) / (64 * tn2);
-    if (K == 7) return launch_patch_s2<7, 1>(a, s);
-    if (K == 3) return tn2 == 2 ? launch_patch_s2<3, 2>(a, s) : launch_patch_s2<3, 1>(a, s);
-    return tn2 == 2 ? launch_patch_s2<1, 2>(a, s) : launch_patch_s2<1, 1>(a, s);
+    if (d->stride == 1) {
+      if (K == 7) return tn2 == 2 ? launch_patch_row<7, 1, 2>(a, s) : launch_patch_row<7, 1, 1>(a, s);
+      return tn2 == 2 ? launch_patch_row<5, 1, 2>(a, s) : launch_patch_row<5, 1, 1>(a, s);
+    }
+    if (K == 7) return launch_patch_row<7, 2, 1>(a, s);
+    if (K == 3) return tn2 == 2 ? launch_patch_row<3, 2, 2>(a, s) : launch_patch_row<3, 2, 1>(a, s);
+    return tn2 == 2 ? launch_patch_row<1, 2, 2>(a, s) : launch_patch_row<1, 2, 1>(a, s);
   }
   if (d->prec == CRESTE_PREC_F16X3) {
     if (K == 3)

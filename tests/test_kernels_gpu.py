@@ -115,12 +115,16 @@ S2_CASES = [c for c in CONV_CASES if c[6] == 2] + [
     (1, 64, 33, 65, 128, 3, 2, (1, 1, 1, 1), 1, False, True, True),    # odd extents, residual, two 64-channel units
     (2, 64, 16, 40, 128, 1, 2, (0, 0, 0, 0), 0, False, True, False),   # ResNet 1x1/2 downsample
     (1, 20, 21, 35, 200, 3, 2, (0, 1, 0, 1), 2, True, False, False),   # ragged chunk, bias, static 'same' padding
+    # stride-1 5x5 / 7x7 on the same row-at-a-time kernel (reward network, input gradient of the 7x7/2 stem)
+    (3, 40, 8, 16, 64, 5, 1, (2, 2, 2, 2), 1, False, True, False),
+    (1, 64, 41, 70, 96, 7, 1, (3, 4, 3, 4), 0, False, False, False),   # zero-inserted cotangent, one-sided extra pad
+    (2, 48, 19, 37, 40, 5, 1, (2, 2, 2, 2), 1, True, True, True),
 ]
 
 
 @pytest.mark.parametrize("case", S2_CASES)
 def test_conv_patch_stride2_f16x3(ops, case):
-    """stride-2 convs (K = 1, 3, 7) on the f16x3 engine vs a float64 conv: fp32-grade, like the stride-1 kernels"""
+    """stride-2 convs (K = 1, 3, 7) and stride-1 5x5 / 7x7 convs on the f16x3 row kernel vs a float64 conv: fp32-grade"""
     N, Cin, H, W, Cout, K, s, pad, act, use_bias, use_bn, use_res = case
     g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
     x = torch.randn(N, Cin, H, W, generator=g)
