@@ -143,6 +143,58 @@ __device__ __forceinline__ void patch_epilogue(const f32x16 (&acc)[2][TN], const
   if (p.out_amax) block_amax_update(vmax, p.out_amax, scratch);
 }
 
+// Epilogue through LDS for the write-bound 1x1 convs (MBConv expand / project, heads): every 32 pixel x 32 channel
+// accumulator tile is transposed in a per-wave LDS tile so that EIGHT lanes write 128 contiguous bytes of one pixel
+// (and read bias / residual the same way) -- the register epilogue above stores 16 bytes per lane at a pixel stride,
+// 64 separate memory transactions per instruction, and the store tail of a K = 16..48 conv IS the kernel.
+// `tile`: 32 rows of 36 floats per wave (144-byte rows: conflict-free for both access patterns).
+constexpr int EPI_ROW = 36;
+template <int TN>
+__device__ __forceinline__ void patch_epilogue_lds(const f32x16 (&acc)[2][TN], const PatchArgs& p, int img, int oy0,
+                                                   int ox0, int nbase, int wm, int wn, int lane, float o_mul,
+                                                   float* smem_f) {
+  const int li = lane & 31, lh = lane >> 5;
+  const int wave = wm * 2 + wn;
+  float* tile = smem_f + wave * (32 * EPI_ROW);
+  float* scratch = smem_f + 8 * 32 * EPI_ROW;
+  const int rp = lane >> 3, rq = lane & 7;                     // read-back: pixel row (of 8) and channel quad
+  float vmax = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int oy = oy0 + wm * 2 + mt;
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(tile + li * EPI_ROW + 8 * g + 4 * lh) =
+            f32x4{acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+      __syncthreads();
+      const int n = nbase + (wn * TN + nt) * 32 + rq * 4;
+      if (oy < p.Ho && n < p.Cout) {
+        const f32x4 us = *reinterpret_cast<const f32x4*>(p.w_unscale + n) * o_mul;       // exact: powers of two
+        const f32x4 bs = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int px = rp + 8 * k, ox = ox0 + px;
+          if (ox >= p.Wo) continue;
+          const long m = ((long)img * p.Ho + oy) * p.Wo + ox;
+          f32x4 v = *reinterpret_cast<const f32x4*>(tile + px * EPI_ROW + rq * 4) * us + bs;
+          if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * p.res_cs + n);
+          const float rmask = p.row_mask ? p.row_mask[m] : 1.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = act_apply(v[j], p.act) * rmask;
+            vmax = fmaxf(vmax, fabsf(v[j]));
+          }
+          *reinterpret_cast<f32x4*>(p.out + m * p.out_cs + p.out_co + n) = v;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (p.out_amax) block_amax_update(vmax, p.out_amax, scratch);
+}
+
 template <int K, int SPLIT, int TN, bool F16>
 __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) void conv_patch_kernel(const PatchArgs p) {
   typedef typename Piece<F16>::V8 V8;
@@ -308,6 +360,14 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
     }
   }
 
+  if constexpr (K == 1 && F16) {
+    // all waves are past the last barrier of the main loop: the operand buffers are free for the transpose tiles
+    const bool vec_ok = (p.Cout & 3) == 0 && (p.out_cs & 3) == 0 && (p.out_co & 3) == 0 && (!p.res || (p.res_cs & 3) == 0);
+    if (vec_ok) {
+      patch_epilogue_lds<TN>(acc, p, img, oy0, ox0, tn * BN, wm, wn, lane, o_mul, reinterpret_cast<float*>(smem));
+      return;
+    }
+  }
   patch_epilogue<TN, F16>(acc, p, img, oy0, ox0, tn * BN, wm, wn, li, lh, o_mul, reinterpret_cast<float*>(smem));
 }
 
