@@ -746,7 +746,9 @@ __global__ __launch_bounds__(512, 1) void conv_patch_row_kernel(const PatchArgs 
       __syncthreads();
     }
   }
-  patch_epilogue<TN, true>(acc, p, img, oy0, ox0, tn * BN, wm, wn, li, lh, o_mul, reinterpret_cast<float*>(smem));
+  const bool vec_ok = (p.Cout & 3) == 0 && (p.out_cs & 3) == 0 && (p.out_co & 3) == 0 && (!p.res || (p.res_cs & 3) == 0);
+  if (vec_ok) patch_epilogue_lds<TN>(acc, p, img, oy0, ox0, tn * BN, wm, wn, lane, o_mul, reinterpret_cast<float*>(smem));
+  else patch_epilogue<TN, true>(acc, p, img, oy0, ox0, tn * BN, wm, wn, li, lh, o_mul, reinterpret_cast<float*>(smem));
 }
 
 template <int K, int S, int TN>
