@@ -97,7 +97,9 @@ typedef struct creste_conv_desc {
 } creste_conv_desc;
 
 int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream);
-/* 1 when (precision, kernel, stride) is built: F32 covers everything, BF16/BF16X3 cover stride-1 1x1/3x3. */
+/* 1 when (precision, kernel, stride) is built: F32 covers everything; BF16 / BF16X3 / BF16X6 cover stride-1 1x1 and
+ * 3x3; F16X3 covers stride-1 1x1, 3x3, 5x5, 7x7 and stride-2 1x1, 3x3, 7x7 (every dense conv of the reference path:
+ * effnet.py / inpainting.py / conv.py). */
 int creste_conv_supported(int prec, int KH, int KW, int stride);
 /* 1 when the fused bilinear-upsample+concat input (up_src) is built for this configuration. */
 int creste_conv_supported_upsample(int prec, int KH, int KW, int stride);
