@@ -256,29 +256,35 @@ __global__ __launch_bounds__(256) void upsample_concat_kernel(
   const int y0 = (int)sy;
   const int y1 = y0 + (y0 < H1 - 1 ? 1 : 0);
   const float ly = sy - (float)y0, hy = 1.f - ly;
-  const float* r0 = x1 + ((long)n * H1 + y0) * W1 * x1_cs;
-  const float* r1 = x1 + ((long)n * H1 + y1) * W1 * x1_cs;
   const long orow = ((long)n * Ho + oy) * Wo;
-  const int row_items = Wo * cq;
   float vmax = 0.f;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < row_items; i += gridDim.x * 256) {
-    const int ox = i / cq, q = i - ox * cq;
-    f32x4 v;
-    if (q < c2q) {
-      v = ld4(skip + (orow + ox) * skip_cs + q * 4);
-    } else {
-      const int c = (q - c2q) * 4;
+  // a thread keeps ONE channel quad and walks output columns (no per-element division); a skip-connection quad takes
+  // the same four-tap path with all taps on its own pixel and weights (1, 0, 0, 0) -- no divergent branch around loads
+  const int qpp = cq < 256 ? cq : 256;                       // quads handled per pass of the workgroup
+  const int xpp = 256 / qpp;                                 // output columns per pass
+  for (int q0 = 0; q0 < cq; q0 += qpp) {
+    const int q = q0 + (int)threadIdx.x % qpp, xs = (int)threadIdx.x / qpp;
+    if (q >= cq || xs >= xpp) continue;
+    const bool is_skip = q < c2q;
+    const int c = is_skip ? q * 4 : (q - c2q) * 4;
+    const float* r0 = is_skip ? skip + orow * skip_cs + c : x1 + ((long)n * H1 + y0) * W1 * x1_cs + c;
+    const float* r1 = is_skip ? r0 : x1 + ((long)n * H1 + y1) * W1 * x1_cs + c;
+    const int cs = is_skip ? skip_cs : x1_cs;
+    for (int ox = blockIdx.x * xpp + xs; ox < Wo; ox += gridDim.x * xpp) {
       float sx = rw * ((float)ox + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
-      const int x0 = (int)sx;
-      const int x1i = x0 + (x0 < W1 - 1 ? 1 : 0);
-      const float lx = sx - (float)x0, hx = 1.f - lx;
-      const f32x4 v00 = ld4(r0 + (long)x0 * x1_cs + c), v01 = ld4(r0 + (long)x1i * x1_cs + c);
-      const f32x4 v10 = ld4(r1 + (long)x0 * x1_cs + c), v11 = ld4(r1 + (long)x1i * x1_cs + c);
-      v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+      int x0 = (int)sx;
+      int x1i = x0 + (x0 < W1 - 1 ? 1 : 0);
+      float lx = sx - (float)x0, wy1 = ly;
+      if (is_skip) { x0 = x1i = ox; lx = 0.f; wy1 = 0.f; }
+      const float hx = 1.f - lx, wy0 = 1.f - wy1;
+      const f32x4 v00 = ld4(r0 + (long)x0 * cs), v01 = ld4(r0 + (long)x1i * cs);
+      const f32x4 v10 = ld4(r1 + (long)x0 * cs), v11 = ld4(r1 + (long)x1i * cs);
+      const f32x4 v = is_skip ? v00 : wy0 * (hx * v00 + lx * v01) + wy1 * (hx * v10 + lx * v11);
+      vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      st4(out + (orow + ox) * out_cs + out_co + q * 4, v);
     }
-    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    st4(out + (orow + ox) * out_cs + out_co + q * 4, v);
   }
+  (void)hy;
   if (amax) block_amax_update(vmax, amax, scratch);
 }
 
@@ -539,8 +545,11 @@ extern "C" int creste_upsample_concat_nhwc_f32(const float* x1, int N, int H1, i
                  "upsample_concat: channel counts/strides must be multiples of 4");
   CRESTE_REQUIRE(out_cs >= out_co + C1 + C2, "upsample_concat: output slice exceeds out_cs");
   CRESTE_REQUIRE((long)N * Ho < 65536 * 32768L && (long)Wo * ((C1 + C2) / 4) < (1L << 30), "upsample_concat: extent too large");
-  const int row_items = Wo * ((C1 + C2) / 4);
-  const int bx = (row_items + 4 * 256 - 1) / (4 * 256);          // ~4 quads per thread
+  const int cq_all = (C1 + C2) / 4, qpp = cq_all < 256 ? cq_all : 256, xpp = 256 / qpp;
+  const int passes = (cq_all + qpp - 1) / qpp;                    // quad passes per workgroup (1 unless C > 1024)
+  int bx = (Wo + 2 * xpp - 1) / (2 * xpp);                        // ~2 columns per thread and pass
+  if (bx < 1) bx = 1;
+  (void)passes;
   upsample_concat_kernel<<<dim3(bx, N * Ho), 256, 0, (hipStream_t)stream>>>(
       x1, H1, W1, C1, x1_cs, skip, C2, skip_cs, out, Ho, Wo, out_cs, out_co, rh, rw, out_amax);
   CRESTE_CHECK_LAUNCH("upsample_concat");
