@@ -290,12 +290,19 @@ def upsample_concat(x1: Act, skip: Act | None, Ho, Wo, rh, rw, out: Act | None =
     if out is None:
         out = Act.empty(x1.N, Ho, Wo, x1.C + C2, x1.buf.device)
     assert out.C == x1.C + C2 and (out.H, out.W) == (Ho, Wo)
-    if fresh and TRACK_AMAX:
+    # max|out| without a reduction over the output: bilinear interpolation is a convex combination, so
+    # max|out| <= max(max|x1|, max|skip|) -- and the sources' bounds are usually already known (the kernel's own
+    # |max| update costs its 65k small workgroups a barrier pair and a contended L2 access each: ~9 % of its time)
+    out.amax = None
+    if fresh and TRACK_AMAX and x1.amax is not None and (skip is None or skip.amax is not None):
+        out.amax = x1.amax if skip is None else torch.maximum(x1.amax, skip.amax)
+    track = fresh and TRACK_AMAX and out.amax is None
+    if track:
         out.amax = _AmaxPool.slot(x1.buf.device)
     _lib.check(lib.creste_upsample_concat_nhwc_f32(
         x1.ptr, x1.N, x1.H, x1.W, x1.C, x1.cs, skip.ptr if skip is not None else None, C2,
         skip.cs if skip is not None else 0, out.buf.data_ptr(), Ho, Wo, out.cs, out.co, float(rh),
-        float(rw), out.amax.data_ptr() if fresh and TRACK_AMAX else None, _stream()), "upsample_concat")
+        float(rw), out.amax.data_ptr() if track else None, _stream()), "upsample_concat")
     return out
 
 
