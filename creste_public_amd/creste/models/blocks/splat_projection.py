@@ -100,7 +100,7 @@ class Camera2MapMulti(nn.Module):
         BN = xyz.shape[0]
         assert BN % self.NC == 0, f"Number of frames must be divisible by {self.NC}"
         pts = xyz.reshape(BN // self.NC, -1, 3)
-        fl = Act(fused.buf.view(BN // self.NC, self.NC * fused.H, fused.W, fused.cs), fused.C, fused.co)
+        fl = Act(fused.buf.view(BN // self.NC, self.NC * fused.H, fused.W, fused.cs), fused.C, fused.co, fused.amax)
         coords, bev, dens = ops.bev_splat(pts, fl, g["off"], g["vox"], gh, gw, self.min_weight, self.scatter_mode)
         return dict(bev=bev, dens=dens, coords=coords, xyz=xyz, mask=mask, fused=fused)
 

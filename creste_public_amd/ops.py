@@ -420,6 +420,10 @@ def bev_splat(xyz, feats: Act, off_xy, vox_xy, GH, GW, min_weight=1.0, scatter_m
                                              float(vox_xy[1]), GH, GW, float(min_weight),
                                              SPLAT_MODES[scatter_mode], coords.data_ptr(),
                                              bev.ptr, dens.data_ptr(), work.data_ptr(), _stream()), "bev_splat")
+    # |bev| <= max|feats|: 'mean' divides the tap-weighted sum by max(sum of weights, min_weight >= 1), 'max' takes
+    # w * f with w <= 1 -- the consumer's operand bound needs no pass over the 25 MB/frame map
+    if scatter_mode in ("mean", "max") and min_weight >= 1.0 and feats.amax is not None:
+        bev.amax = feats.amax
     return coords, bev, dens
 
 
