@@ -18,6 +18,7 @@ from torch import nn
 
 from .... import ops
 from ....hipnn import Act, Cached, require_hip
+from ....hipnn import get_precision as hipnn_precision
 from .conv import ConvEncoder, _cfg_get
 
 
@@ -85,15 +86,20 @@ class Camera2MapMulti(nn.Module):
         the encoder's last conv) and whose last Z channels receive the z-MLP features."""
         return Act.empty(N, H, W, F + self.z_dim, device)
 
-    def forward_act(self, depth: torch.Tensor, fbuf: Act, p2p: torch.Tensor):
-        """depth [B,Hs,Ws] metres, fbuf = fusion_buffer with features in [0,F), p2p [B,4,4]."""
+    def forward_act(self, depth: torch.Tensor, fbuf: Act, p2p: torch.Tensor, feats_amax=None):
+        """depth [B,Hs,Ws] metres, fbuf = fusion_buffer with features in [0,F), p2p [B,4,4]; feats_amax: device
+        float >= max|features| when the producer tracked it (then only the 32 z channels are scanned for the fusion
+        conv's operand bound instead of all 288)."""
         if self.mode != "bilinear":
             raise Exception("Unknown splat mode:", self.mode)
         g = self._geo.get()
         F = fbuf.cs - self.z_dim
         xyz, mask = ops.pixel_geometry(depth, p2p, g["bounds"], g["w1"], g["b1"], g["w2"], g["b2"],
                                        fbuf.slice(F, self.z_dim))
-        fused = self.vision_fusion.forward_act(Act(fbuf.buf, fbuf.cs, 0), row_mask=mask)
+        whole = Act(fbuf.buf, fbuf.cs, 0)
+        if feats_amax is not None and (ops.TRACK_AMAX or hipnn_precision() == "f16x3"):
+            whole.amax = torch.maximum(feats_amax, ops.absmax(fbuf.slice(F, self.z_dim)))
+        fused = self.vision_fusion.forward_act(whole, row_mask=mask)
         gh, gw = g["grid"]
         # NC cameras per frame: views (b, s, c) are consecutive, so the reference's concatenation of the cameras'
         # points ([B*NS, NC*H*W, .], :227-234) is a reshape of the per-view buffers

@@ -126,8 +126,10 @@ class TerrainNet(nn.Module):
         F = self.vision_cfg["effnet_cfgs"]["out_channels"]
         assert H % ds == 0 and W % ds == 0, "image size must be a multiple of the encoder downsample"
         fbuf = self.cam2map.fusion_buffer(B * N, H // ds, W // ds, F, rgbd.device)
-        r = self.depthcomp.forward_act(x, feats_out=fbuf.slice(0, F))
-        sp = self.cam2map.forward_act(r["depth"], fbuf, p2p.reshape(B * N, 4, 4).contiguous().float())
+        fslice = fbuf.slice(0, F)                # the encoder's last conv leaves max|features| on this slice
+        r = self.depthcomp.forward_act(x, feats_out=fslice)
+        sp = self.cam2map.forward_act(r["depth"], fbuf, p2p.reshape(B * N, 4, 4).contiguous().float(),
+                                      feats_amax=fslice.amax)
         r.update(sp)
         if self.bevclassifier is not None:
             nc = self.bevclassifier.num_classes

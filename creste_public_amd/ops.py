@@ -227,7 +227,7 @@ def conv2d(x: Act | None, pc: PackedConv, out: Act | None = None, res: Act | Non
         if up is not None:
             raise HipLibraryError("conv2d: the fused upsample loader is not built for f16x3")
         d.a_amax, d.w_unscale = absmax(x).data_ptr(), pc.w_unscale.data_ptr()
-    if fresh and (TRACK_AMAX or pc.prec == PREC_F16X3):     # a slice written by several producers is not tracked
+    if TRACK_AMAX or pc.prec == PREC_F16X3:     # also into a caller's slice: the bound of THAT slice (its Act object)
         out.amax = _AmaxPool.slot(dev)
         d.out_amax = out.amax.data_ptr()
     _lib.check(lib.creste_conv2d_nhwc(C.byref(d), _stream()), "conv2d_nhwc")
