@@ -529,6 +529,7 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
       if (more_a) ra[ky] = load_a(ky, c + 1);
       if (!UP && ky == 0 && more_a && p.a_scale) gate = load_gate(c + 1);
       const char* Brow = bbase + (g & 1) * ROW_BYTES;
+      __builtin_amdgcn_s_setprio(1);            // the matrix phase outranks the other wave's staging work (+0.7 %)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const char* B = Brow + kx * U_BYTES;
@@ -551,6 +552,7 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
           for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = split_mfma<SPLIT, V8>(bfr, af[mt], acc[mt][nt]);
         }
       }
+      __builtin_amdgcn_s_setprio(0);
       __syncthreads();     // row g consumed by every wave; DMA of row g+1 landed (vmcnt drained)
     }
     if (more_a) {
