@@ -400,9 +400,13 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
   static_assert(NPIX * 4 <= ROUNDS * 512, "A patch does not fit the staging rounds");
   static_assert(ROW_BYTES % 1024 == 0, "weight row must be a whole number of 1 KiB pieces");
 
+  // 256-channel f16x3 tiles run one workgroup per CU anyway (118 KB): a SECOND halo-patch buffer (+22 KB) lets every
+  // wave convert and store its prefetched patch rows right after the row step that loaded them -- the conversion VALU
+  // work overlaps the other wave's MFMAs and the chunk-boundary barrier disappears (3 barriers per chunk, not 4)
+  constexpr bool DBA = F16 && !UP && TN == 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const abuf = smem;
-  char* const bbase = smem + A_BYTES;
+  char* const abuf0 = smem;
+  char* const bbase = smem + (DBA ? 2 : 1) * A_BYTES;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
   f32x4 gate = {1.f, 1.f, 1.f, 1.f};
   auto store_a = [&](int r, int c, f32x4 v) __attribute__((always_inline)) {
     if (r * 128 + (tid >> 2) >= NPIX) return;
-    char* dst = abuf + a_lofs0 + r * (128 * 16);
+    char* dst = abuf0 + (DBA ? (c & 1) * A_BYTES : 0) + a_lofs0 + r * (128 * 16);
     if constexpr (!UP) {
       const bool ok = a_yx[r] >= 0 && c * PT_CK + cq * 4 < p.Cin;
       if (p.a_scale) v *= gate;
@@ -522,6 +526,7 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
   int g = 0;
   for (int c = 0; c < p.nchunk; ++c) {
     const bool more_a = c + 1 < p.nchunk;
+    const char* abuf = abuf0 + (DBA ? (c & 1) * A_BYTES : 0);
     f32x4 ra[ROUNDS];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky, ++g) {
@@ -553,9 +558,10 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
         }
       }
       __builtin_amdgcn_s_setprio(0);
+      if (DBA && more_a) store_a(ky, c + 1, ra[ky]);       // into the other patch buffer
       __syncthreads();     // row g consumed by every wave; DMA of row g+1 landed (vmcnt drained)
     }
-    if (more_a) {
+    if (!DBA && more_a) {
 #pragma unroll
       for (int r = 0; r < ROUNDS; ++r) store_a(r, c + 1, ra[r]);
       __syncthreads();
@@ -575,7 +581,7 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
 template <int SPLIT, int TN, bool F16, bool UP>
 static int launch_patch3_up(const PatchArgs& a, hipStream_t s) {
   constexpr int NPIXP = ((PT_TH + 2) * (PT_TW + 2) + 15) / 16 * 16;
-  constexpr int smem = SPLIT * 2 * NPIXP * 16 + 2 * 3 * (SPLIT * 2 * 64 * TN * 16);
+  constexpr int smem = ((F16 && !UP && TN == 4) ? 2 : 1) * SPLIT * 2 * NPIXP * 16 + 2 * 3 * (SPLIT * 2 * 64 * TN * 16);
   static bool attr_set = false;
   if (!attr_set && smem > 64 * 1024) {
     CRESTE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch3_kernel<SPLIT, TN, F16, UP>),
