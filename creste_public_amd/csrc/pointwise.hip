@@ -407,6 +407,10 @@ __global__ __launch_bounds__(256) void pixel_geometry_kernel(
   const long P = (long)Hs * Ws, total = (long)B * P;
   const int per = blockDim.x / zdim;                       // pixels per block iteration
   const int j = threadIdx.x % zdim, slot = threadIdx.x / zdim;
+  const bool fast = zhid == 64 && zdim == 32;
+  float w2r[64];                                            // this lane's column of W2 (fast path)
+#pragma unroll
+  for (int h = 0; h < 64; ++h) w2r[h] = fast ? s_w2[h * 32 + j] : 0.f;
   for (long base = (long)blockIdx.x * per; base < total; base += (long)gridDim.x * per) {
     const long g = base + slot;
     if (g >= total || slot >= per) continue;
@@ -426,9 +430,21 @@ __global__ __launch_bounds__(256) void pixel_geometry_kernel(
       mask[g] = ok ? 1.f : 0.f;
     }
     float s = s_b2[j];
-    for (int h = 0; h < zhid; ++h) {
-      const float hv = fmaxf(__fmaf_rn(s_w1[h], q[2], s_b1[h]), 0.f);
-      s = __fmaf_rn(s_w2[h * zdim + j], hv, s);
+    if (fast) {
+      // the shipped z-MLP (1 -> 64 -> 32): lane j of a pixel's 32 lanes evaluates hidden units j and j + 32 once and
+      // the group walks them through shuffles -- one LDS-pipe operation (the shuffle) per hidden unit instead of three, W2's column in registers (the loop was
+      // LDS-bound: 0.33 ms per batch of 16); same operations in the same order, bit-identical
+      const float hv0 = fmaxf(__fmaf_rn(s_w1[j], q[2], s_b1[j]), 0.f);
+      const float hv1 = fmaxf(__fmaf_rn(s_w1[j + 32], q[2], s_b1[j + 32]), 0.f);
+#pragma unroll
+      for (int h = 0; h < 32; ++h) s = __fmaf_rn(w2r[h], __shfl(hv0, h, 32), s);
+#pragma unroll
+      for (int h = 0; h < 32; ++h) s = __fmaf_rn(w2r[h + 32], __shfl(hv1, h, 32), s);
+    } else {
+      for (int h = 0; h < zhid; ++h) {
+        const float hv = fmaxf(__fmaf_rn(s_w1[h], q[2], s_b1[h]), 0.f);
+        s = __fmaf_rn(s_w2[h * zdim + j], hv, s);
+      }
     }
     zfeat[g * z_cs + z_co + j] = fmaxf(s, 0.f);
   }
