@@ -411,18 +411,39 @@ __global__ __launch_bounds__(256) void pixel_geometry_kernel(
   float w2r[64];                                            // this lane's column of W2 (fast path)
 #pragma unroll
   for (int h = 0; h < 64; ++h) w2r[h] = fast ? s_w2[h * 32 + j] : 0.f;
-  for (long base = (long)blockIdx.x * per; base < total; base += (long)gridDim.x * per) {
+  // the depth of the NEXT pixel is fetched before the current one is processed (a workgroup walks ~20 pixels per
+  // lane group; un-prefetched, every step waited a full memory latency: that chain, not arithmetic, was the kernel)
+  const long stride = (long)gridDim.x * per;
+  float d_next = 0.f;
+  {
+    const long g0 = (long)blockIdx.x * per + slot;
+    if (g0 < total && slot < per) d_next = depth[g0];
+  }
+  int cur_b = -1;
+  float Mr[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Mr[k] = 0.f;
+  for (long base = (long)blockIdx.x * per; base < total; base += stride) {
     const long g = base + slot;
     if (g >= total || slot >= per) continue;
-    const int b = (int)(g / P); const long p = g % P;
-    const int v = (int)(p / Ws), u = (int)(p % Ws);
-    const float d = depth[g];
+    const float d = d_next;
+    if (g + stride < total) d_next = depth[g + stride];
+    // 32-bit index arithmetic (the host checks B*Hs*Ws < 2^31): three 64-bit divisions cost more than the z-MLP
+    const unsigned g32 = (unsigned)g, P32 = (unsigned)P;
+    const int b = (int)(g32 / P32);
+    const unsigned p = g32 - (unsigned)b * P32;
+    const int v = (int)(p / (unsigned)Ws), u = (int)(p - (unsigned)v * (unsigned)Ws);
     const float c0 = (float)u * d, c1 = (float)v * d;
-    const float* M = p2p + (long)b * 16;
+    if (b != cur_b) {                                         // frame changed: its projection matrix (rows 0..2)
+      const float* M = p2p + (long)b * 16;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) Mr[k] = M[k];
+      cur_b = b;
+    }
     float q[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
-      q[k] = __fmaf_rn(M[k * 4 + 3], 1.0f, __fmaf_rn(M[k * 4 + 2], d, __fmaf_rn(M[k * 4 + 1], c1, __fmul_rn(M[k * 4 + 0], c0))));
+      q[k] = __fmaf_rn(Mr[k * 4 + 3], 1.0f, __fmaf_rn(Mr[k * 4 + 2], d, __fmaf_rn(Mr[k * 4 + 1], c1, __fmul_rn(Mr[k * 4 + 0], c0))));
     if (j == 0) {
       xyz[g * 3 + 0] = q[0]; xyz[g * 3 + 1] = q[1]; xyz[g * 3 + 2] = q[2];
       const bool ok = q[0] >= bounds[0] && q[1] >= bounds[1] && q[2] >= bounds[2] &&
@@ -621,6 +642,7 @@ extern "C" int creste_pixel_geometry_f32(const float* depth, const float* p2p, i
   CRESTE_REQUIRE(depth && p2p && bounds6 && w1 && b1 && w2 && b2 && xyz && mask && zfeat,
                  "pixel_geometry: null pointer");
   CRESTE_REQUIRE(zdim > 0 && zdim <= 256 && 256 % zdim == 0 && zhid > 0, "pixel_geometry: zdim must divide 256");
+  CRESTE_REQUIRE((long)B * Hs * Ws < (1L << 31), "pixel_geometry: B*Hs*Ws overflows int32");
   const long total = (long)B * Hs * Ws;
   const int per = 256 / zdim;
   const size_t smem = (size_t)(2 * zhid + zdim * zhid + zdim) * sizeof(float);
