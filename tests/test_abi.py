@@ -37,6 +37,24 @@ def test_header_symbols_are_exported_and_bound():
     assert handle.creste_se_partial_count(4096, 96) == 26      # 10 pixel slices x 16 rows
 
 
+def test_conv_engine_routing_is_a_host_query():
+    """Which conv shapes each operand mode is built for (host-only query, creste_hip.h) and the host-side routing on
+    top of it: every dense conv of the reference path runs on the f16x3 engine except the 4 -> 32 strided stem."""
+    from creste_public_amd import ops
+    F32, BF16X6, F16X3 = ops.PREC_F32, ops.PREC_BF16X6, ops.PREC_F16X3
+    for k, s in ((1, 1), (3, 1), (5, 1), (7, 1), (1, 2), (3, 2), (7, 2)):
+        assert ops.conv_supported(F16X3, k, s), (k, s)
+        assert ops.conv_supported(F32, k, s)
+    assert not ops.conv_supported(F16X3, 5, 2) and not ops.conv_supported(F16X3, 9, 1)
+    assert ops.conv_supported(BF16X6, 3, 1) and not ops.conv_supported(BF16X6, 3, 2) and not ops.conv_supported(BF16X6, 7, 1)
+    assert ops.conv_precision(F16X3, 7, 2, 96) == F16X3          # BEV stem
+    assert ops.conv_precision(F16X3, 3, 2, 4) == F32             # encoder stem: one mostly-empty channel chunk
+    assert ops.conv_precision(F16X3, 5, 1, 40) == F16X3          # reward FCN
+    assert ops.conv_precision(BF16X6, 7, 2, 96) == F32
+    lib = _lib.load()
+    assert lib.creste_conv_packed_weight_bytes(64, 96, 7, 7, F16X3) == 4 * 6 * 49 * 2 * 2 * 64 * 16   # 4 padded units
+
+
 def test_argument_errors_are_reported_not_thrown():
     handle = _lib.load()
     rc = handle.creste_conv2d_nhwc(None, None)
