@@ -1080,6 +1080,7 @@ extern "C" int creste_dwconv_wgrad_f32(const float* x, const float* gy, float* g
                                        void* work, void* stream) {
   CRESTE_REQUIRE(x && gy && gw_taps && work && C > 0 && N > 0, "dwconv_wgrad: bad args");
   CRESTE_REQUIRE(K == 3 || K == 5, "dwconv_wgrad: kernel size %d not built (3 or 5)", K);
+  CRESTE_REQUIRE(stride == 1 || stride == 2, "dwconv_wgrad: stride %d not built (1 or 2: the window slides by it)", stride);
   const int rows = C >= 256 ? 1 : 256 / C;
   const long M = (long)N * Ho * Wo;
   const long per = (M + rows - 1) / rows;
