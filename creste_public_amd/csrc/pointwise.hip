@@ -339,6 +339,18 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
   }
 }
 
+// C == 4 (the RGB-D input): one thread per pixel -- four coalesced plane reads, one 16-byte store (the 32 x 32 tile
+// kernel above would run 4 of its 32 channel rows / write lanes)
+__global__ __launch_bounds__(256) void nchw4_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            long HW, int out_cs, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long n = i / HW, p = i - n * HW;
+    const float* src = in + n * 4 * HW + p;
+    const f32x4 v = {src[0], src[HW], src[2 * HW], src[3 * HW]};
+    st4(out + i * out_cs, v);
+  }
+}
+
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, int in_cs,
                                                            float* __restrict__ out, int C, long HW) {
   __shared__ float tile[32][33];
@@ -607,6 +619,11 @@ extern "C" int creste_nchw_to_nhwc_f32(const float* in, float* out, int out_cs, 
                                        void* stream) {
   CRESTE_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0 && out_cs >= C, "nchw_to_nhwc: bad args");
   const long HW = (long)H * W;
+  if (C == 4 && out_cs % 4 == 0 && ((uintptr_t)out & 15) == 0) {
+    nchw4_to_nhwc_kernel<<<grid_for((long)N * HW, 256, 256 * 64), 256, 0, (hipStream_t)stream>>>(in, out, HW, out_cs, (long)N * HW);
+    CRESTE_CHECK_LAUNCH("nchw4_to_nhwc");
+    return CRESTE_OK;
+  }
   const dim3 grid((unsigned)((HW + 31) / 32), (C + 31) / 32, N);
   nchw_to_nhwc_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(in, out, C, HW, out_cs);
   CRESTE_CHECK_LAUNCH("nchw_to_nhwc");
