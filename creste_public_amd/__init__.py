@@ -23,6 +23,14 @@ def get_precision() -> str:
     from . import hipnn
     return hipnn.get_precision()
 
+
+
+def invalidate_caches():
+    """Drop packed-weight / folded-BN caches after parameter updates made through `.data` (see hipnn)."""
+    from . import hipnn
+    hipnn.invalidate_caches()
+
+
 _MIRROR = ["creste", "creste.models", "creste.models.blocks", "creste.models.blocks.conv",
            "creste.models.blocks.effnet", "creste.models.blocks.inpainting",
            "creste.models.blocks.splat_projection", "creste.models.blocks.vin",

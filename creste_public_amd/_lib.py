@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libcreste_hip.so")
 
-ABI_VERSION = 3          # creste_abi_version() of the library this binding was written against
+ABI_VERSION = 4          # creste_abi_version() of the library this binding was written against
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
 
@@ -103,7 +103,7 @@ SIGNATURES = {
     "creste_multipos_con_workspace_bytes": (_i64, [_i, _i, _i]),
     "creste_multipos_con_forward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "creste_multipos_con_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
-    "creste_expected_svf_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp,
+    "creste_expected_svf_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp,
                                       _vp]),
 }
 

@@ -7,6 +7,7 @@ import os
 import torch
 from torch import nn
 
+from ... import hipnn as _hipnn
 from ... import ops
 from ...hipnn import Act, require_hip
 from .blocks.conv import MultiLayerConv, _cfg_get
@@ -16,6 +17,8 @@ from .depth import DepthCompletion
 class DistillationBackbone(nn.Module):
     def __init__(self, model_cfg):
         super().__init__()
+        # checkpoint loaders that write through `.data` do not bump tensor versions: drop derived-weight caches
+        self.register_load_state_dict_post_hook(lambda m, keys: _hipnn.invalidate_caches())
         self.model_cfg = model_cfg
         self.vision_cfg = model_cfg["vision_backbone"]
         self.depth_cfg = model_cfg["depth_head"]

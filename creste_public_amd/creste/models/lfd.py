@@ -12,6 +12,7 @@ import os
 import torch
 from torch import nn
 
+from ... import hipnn as _hipnn
 from ... import ops
 from ...hipnn import require_hip
 from ..utils import train_utils as tu
@@ -25,6 +26,8 @@ _DYNAMICS = [[-1, -1], [-1, 0], [-1, 1], [0, -1], [0, 1], [1, -1], [1, 0], [1, 1
 class MaxEntIRL(nn.Module):
     def __init__(self, model_cfg):
         super().__init__()
+        # checkpoint loaders that write through `.data` do not bump tensor versions: drop derived-weight caches
+        self.register_load_state_dict_post_hook(lambda m, keys: _hipnn.invalidate_caches())
         self.model_cfg = model_cfg
         self.backbone_cfg = model_cfg["vision_backbone"]
         self.traversability_head_cfg = model_cfg["traversability_head"]

@@ -13,6 +13,7 @@ import os
 import torch
 from torch import nn
 
+from ... import hipnn as _hipnn
 from ... import ops
 from ...hipnn import Act, require_hip
 from .blocks.conv import _cfg_get
@@ -31,6 +32,8 @@ def _plain(cfg):
 class TerrainNet(nn.Module):
     def __init__(self, model_cfg):
         super().__init__()
+        # checkpoint loaders that write through `.data` do not bump tensor versions: drop derived-weight caches
+        self.register_load_state_dict_post_hook(lambda m, keys: _hipnn.invalidate_caches())
         self.model_cfg = model_cfg
         self.views = _cfg_get(model_cfg, "views", 1)
         self.vision_cfg = model_cfg["vision_backbone"]

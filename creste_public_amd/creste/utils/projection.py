@@ -30,8 +30,10 @@ def get_pts2pixel_transform(calib_dict):
 
 def lidar_depth_images(points: torch.Tensor, lidar2camrect: torch.Tensor, IMG_H: int, IMG_W: int,
                        out: torch.Tensor = None, scale: float = 1.0, depth_priority: str = "max"):
-    """Batched GPU form of `pixels_to_depth(..., return_keys=['depth'])`: points [B,N,>=3] fp32 (CUDA),
-    lidar2camrect [B,4,4] float64 -> depth images [B,IMG_H,IMG_W] (z_cam * scale, 0 = no return)."""
+    """Batched GPU form of `pixels_to_depth(..., return_keys=['image_depth'], depth_priority=...)` -- the per-pixel
+    scatter-max / scatter-min path (projection.py:124-128) that `depth_utils.py:27-30` uses, NOT the last-write-wins
+    'depth' key (:116-118): points [B,N,>=3] fp32 (CUDA), lidar2camrect [B,4,4] float64 -> depth images
+    [B,IMG_H,IMG_W] (z_cam * scale, 0 = no return)."""
     if out is None:
         out = torch.empty((points.shape[0], IMG_H, IMG_W), dtype=torch.float32, device=points.device)
     return ops.lidar_depth_image(points.contiguous(), lidar2camrect.to(torch.float64).contiguous(), IMG_H,

@@ -1,6 +1,7 @@
 // Shared helpers for the gfx950 kernels of libcreste_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -88,6 +89,20 @@ __device__ __forceinline__ float f16_operand_scale(float amax, float* inv) {
   se = se > 253 ? 253 : (se < 1 ? 1 : se);
   *inv = __uint_as_float((unsigned)(254 - se) << 23);
   return __uint_as_float((unsigned)se << 23);
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize applies to the CURRENT device: remember per device (bit i of `mask`,
+// one static mask per kernel instantiation) whether the limit was raised there.  Thread-safe; devices >= 64 set it
+// on every launch.
+inline hipError_t ensure_dyn_smem(const void* fn, int bytes, std::atomic<uint64_t>& mask) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = dev < 64 ? (1ull << dev) : 0ull;
+  if (bit && (mask.load(std::memory_order_acquire) & bit)) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && bit) mask.fetch_or(bit, std::memory_order_release);
+  return e;
 }
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -309,8 +309,13 @@ extern "C" int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream) {
   // forward never sampled), but not further than one kernel beyond the input
   CRESTE_REQUIRE((d->Ho - 1) * d->stride - d->pad_t < d->H + d->KH && (d->Wo - 1) * d->stride - d->pad_l < d->W + d->KW,
                  "conv2d: output extent outside the input");
-  CRESTE_REQUIRE(d->prec == CRESTE_PREC_F32 || d->stride == 1 || !d->a_scale,
-                 "conv2d: the per-sample input gate is built for stride-1 convs only on the split-operand engines");
+  // split-operand engines: stride-2 and K>3 convs run on the row-at-a-time kernel, whose loader has no per-sample
+  // gate and packs (iy << 16) | ix into one register
+  const bool row_kernel = d->prec != CRESTE_PREC_F32 && (d->stride != 1 || d->KH > 3);
+  CRESTE_REQUIRE(!row_kernel || !d->a_scale,
+                 "conv2d: the per-sample input gate is built for stride-1 1x1/3x3 convs only on the split-operand engines");
+  CRESTE_REQUIRE(!row_kernel || (d->H < 32768 && d->W < 65536),
+                 "conv2d: %dx%d input exceeds the row kernel's packed coordinate range", d->H, d->W);
   CRESTE_REQUIRE(d->prec != CRESTE_PREC_F16X3 || (d->a_amax && d->w_unscale),
                  "conv2d: F16X3 needs a_amax (device bound of |in|) and w_unscale (from creste_conv_pack_weight_f16)");
   if (d->prec != CRESTE_PREC_F32) return conv_patch_run(d, (hipStream_t)stream);

@@ -582,12 +582,8 @@ template <int SPLIT, int TN, bool F16, bool UP>
 static int launch_patch3_up(const PatchArgs& a, hipStream_t s) {
   constexpr int NPIXP = ((PT_TH + 2) * (PT_TW + 2) + 15) / 16 * 16;
   constexpr int smem = ((F16 && !UP && TN == 4) ? 2 : 1) * SPLIT * 2 * NPIXP * 16 + 2 * 3 * (SPLIT * 2 * 64 * TN * 16);
-  static bool attr_set = false;
-  if (!attr_set && smem > 64 * 1024) {
-    CRESTE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch3_kernel<SPLIT, TN, F16, UP>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_devs{0};
+  if (smem > 64 * 1024) CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(conv_patch3_kernel<SPLIT, TN, F16, UP>), smem, attr_devs));
   const int nblk = a.tiles_n * a.tiles_x * a.tiles_y * a.N;
   conv_patch3_kernel<SPLIT, TN, F16, UP><<<nblk, 512, smem, s>>>(a);
   CRESTE_CHECK_LAUNCH("conv_patch3");
@@ -765,12 +761,8 @@ static int launch_patch_row(const PatchArgs& a, hipStream_t s) {
   constexpr int NSLOTP = (PH * PROW + 15) / 16 * 16;
   constexpr int smem = 2 * 2 * NSLOTP * 16 + 2 * K * (2 * 2 * 64 * TN * 16);
   static_assert(smem <= 160 * 1024, "stride-2 patch does not fit the LDS");
-  static bool attr_set = false;
-  if (!attr_set) {
-    CRESTE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_row_kernel<K, S, TN>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_devs{0};
+  CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(conv_patch_row_kernel<K, S, TN>), smem, attr_devs));
   const int nblk = a.tiles_n * a.tiles_x * a.tiles_y * a.N;
   conv_patch_row_kernel<K, S, TN><<<nblk, 512, smem, s>>>(a);
   CRESTE_CHECK_LAUNCH("conv_patch_row");
@@ -846,12 +838,8 @@ template <int K, int SPLIT, int TN, bool F16>
 static int launch_patch(const PatchArgs& a, hipStream_t s) {
   constexpr int PH = PT_TH + K - 1, PW = PT_TW + K - 1, NPIXP = (PH * PW + 15) / 16 * 16;
   constexpr int smem = 2 * (SPLIT * 2 * NPIXP * 16) + 2 * (SPLIT * 2 * 64 * TN * 16);
-  static bool attr_set = false;
-  if (!attr_set && smem > 64 * 1024) {
-    CRESTE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_patch_kernel<K, SPLIT, TN, F16>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_devs{0};
+  if (smem > 64 * 1024) CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(conv_patch_kernel<K, SPLIT, TN, F16>), smem, attr_devs));
   const int nblk = a.tiles_n * a.tiles_x * a.tiles_y * a.N;
   conv_patch_kernel<K, SPLIT, TN, F16><<<nblk, 512, smem, s>>>(a);
   CRESTE_CHECK_LAUNCH("conv_patch");

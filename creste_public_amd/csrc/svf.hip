@@ -66,7 +66,7 @@ __global__ __launch_bounds__(1024) void svf_kernel(const float* __restrict__ pi,
                                                    const float* __restrict__ spi,
                                                    const float* __restrict__ expert_xy,
                                                    const uint8_t* __restrict__ fov, int H, int W, int T,
-                                                   float ds, int zero_terminal,
+                                                   int Te, float ds, int zero_terminal,
                                                    float* __restrict__ exp_svf,
                                                    int64_t* __restrict__ state_preds,
                                                    float* __restrict__ state_grid) {
@@ -74,13 +74,13 @@ __global__ __launch_bounds__(1024) void svf_kernel(const float* __restrict__ pi,
   __shared__ int s_start[2], s_term[2];
   const int b = blockIdx.x, tid = threadIdx.x;
   const long HW = (long)H * W;
-  const float* exb = expert_xy + (long)b * T * 2;
+  const float* exb = expert_xy + (long)b * Te * 2;
 
   if (tid == 0) {
     int r0 = H - 1, c0 = W / 2;
     bool found = false;
     int lr = 0, lc = 0;
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < Te; ++t) {
       long r = (long)floor_div(exb[t * 2 + 0], ds), c = (long)floor_div(exb[t * 2 + 1], ds);
       r = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
       c = c < 0 ? 0 : (c > W - 1 ? W - 1 : c);
@@ -173,13 +173,13 @@ __global__ __launch_bounds__(1024) void svf_kernel(const float* __restrict__ pi,
 using namespace creste;
 
 extern "C" int creste_expected_svf_f32(const float* policy, const float* expert_xy, const uint8_t* fov,
-                                       int B, int H, int W, int T, float ds, float temperature,
+                                       int B, int H, int W, int T, int T_expert, float ds, float temperature,
                                        int sharpen, int zero_terminal, float* sharp_policy,
                                        float* exp_svf, int64_t* state_preds, float* state_grid,
                                        void* stream) {
   CRESTE_REQUIRE(policy && expert_xy && fov && sharp_policy && exp_svf && state_preds && state_grid,
                  "expected_svf: null pointer");
-  CRESTE_REQUIRE(B > 0 && H > 0 && W > 0 && T > 0 && ds > 0.f, "expected_svf: bad dims");
+  CRESTE_REQUIRE(B > 0 && H > 0 && W > 0 && T > 0 && T_expert > 0 && ds > 0.f, "expected_svf: bad dims");
   CRESTE_REQUIRE(!sharpen || temperature > 0.f, "expected_svf: temperature must be positive");
   const long win = (long)(2 * T - 1);
   const long wn = (win < H ? win : H) * (win < W ? win : W);
@@ -190,11 +190,10 @@ extern "C" int creste_expected_svf_f32(const float* policy, const float* expert_
   sharpen_policy_kernel<<<(int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256), 256, 0, s>>>(
       policy, sharp_policy, B, (long)H * W, temperature, sharpen);
   CRESTE_CHECK_LAUNCH("sharpen_policy");
-  if (smem > 64 * 1024) {
+  if (smem > 64 * 1024)     // the size depends on T: set per call (per-device attribute, cheap)
     CRESTE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(svf_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  }
-  svf_kernel<<<B, 1024, smem, s>>>(policy, sharp_policy, expert_xy, fov, H, W, T, ds, zero_terminal,
+  svf_kernel<<<B, 1024, smem, s>>>(policy, sharp_policy, expert_xy, fov, H, W, T, T_expert, ds, zero_terminal,
                                    exp_svf, state_preds, state_grid);
   CRESTE_CHECK_LAUNCH("svf");
   return CRESTE_OK;

@@ -1023,12 +1023,8 @@ extern "C" int creste_conv_wgrad_f16x3(const float* x, int x_cs, const float* gy
                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0,
                  "conv_wgrad_f16x3: channel counts / strides must be multiples of 4, tensors 16-byte aligned");
   if (K == 3 && stride == 1 && Ho == H && Wo == W && Cin >= 64 && Cout >= 64) {          // kernel-row / column-walk variant
-    static bool attr_set = false;
-    if (!attr_set) {
-      CRESTE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16_col3_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, W3_SMEM));
-      attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_devs{0};
+    CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wgrad_f16_col3_kernel), W3_SMEM, attr_devs));
     const int nbands = (H + W3_KS - 1) / W3_KS;
     const long base = (long)N * nbands;                            // chunks before column segmentation
     const long tiles3 = (long)tiles_co * tiles_ci * 3;

@@ -68,7 +68,7 @@ __device__ __forceinline__ void load_x_tile(float (*xs)[TW + 2], const float* __
 //   * sweep k's batch-global delta is an atomicMax over the tile interiors, as before.  Launch l checks
 //     the deltas of chunk l-1 after the kernel boundary; if the test failed at sweep j of that chunk,
 //     launch l REDOES chunk l-1 from its (untouched) input buffer with exactly j+1 sweeps, publishes
-//     `done`, and every later launch is a no-op.  The result is bit-identical to single-sweep launches.
+//     `done` = l+1, and every later launch is a no-op.  The result is bit-identical to single-sweep launches.
 constexpr int VM_THREADS = 1024, VM_CPT = 8;     // region <= 8192 cells
 
 struct VmState { int done, converged_at, final_buf, pad; };
@@ -79,7 +79,9 @@ __global__ __launch_bounds__(VM_THREADS) void vi_multi_kernel(const float* __res
                                                              int halo, float gamma, float threshold) {
   extern __shared__ float lds[];
   __shared__ int s_mode[2];
-  if (st->done) return;
+  // `done` holds (index of the launch that published it) + 1: only LATER launches may skip -- a block of the redo
+  // launch itself that is dispatched after block 0 retired must still redo its tile
+  { const int d = st->done; if (d != 0 && d <= l) return; }
   const int tid = threadIdx.x;
   if (tid == 0) {
     int first = -1;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(VM_THREADS) void vi_multi_kernel(const float* __res
     st->converged_at = (l - 1) * S + first + 1;
     st->final_buf = l & 1;
     __threadfence();
-    st->done = 1;
+    st->done = l + 1;
   }
 }
 

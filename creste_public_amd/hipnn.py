@@ -47,8 +47,18 @@ def get_precision() -> str:
     return {v: k for k, v in PRECISIONS.items()}[_precision]
 
 
+def invalidate_caches():
+    """Forget every packed weight / folded-BN tensor derived from module parameters.
+
+    The caches are keyed on (data_ptr, tensor._version): `load_state_dict`, optimiser steps and any in-place op on
+    the parameter bump the version and re-pack automatically.  Writes THROUGH `.data` (`p.data.copy_(..)`,
+    `p.data.mul_(..)`, EMA updates, BN running statistics edited via `.data`) do not -- call this after such an
+    update.  The mirror modules call it from `load_state_dict` / `train()` / `eval()` as well."""
+    ops.CACHE_EPOCH += 1
+
+
 def _sig(tensors):
-    return tuple((t.data_ptr(), t._version, t.device.index) for t in tensors if t is not None)
+    return (ops.CACHE_EPOCH,) + tuple((t.data_ptr(), t._version, t.device.index) for t in tensors if t is not None)
 
 
 def require_hip(t: torch.Tensor, what: str):

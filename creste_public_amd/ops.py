@@ -20,6 +20,10 @@ from ._lib import (ACT_NONE, ACT_RELU, ACT_SWISH, PREC_BF16, PREC_BF16X3, PREC_B
 # pass over the tensor.  hipnn.set_precision('f16x3') turns it on.
 TRACK_AMAX = False
 
+# Bumped by hipnn.invalidate_caches(): part of the key of every cache of tensors derived from module parameters
+# (packed / flipped weights, folded BatchNorm), for updates that do not bump `tensor._version` (writes through `.data`).
+CACHE_EPOCH = 0
+
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
@@ -478,13 +482,16 @@ def expected_svf(policy, expert_xy, fov_u8, T, ds, temperature, sharpen=True, ze
     lib = _lib.load()
     B, A, H, W = policy.shape
     assert A == 8
+    if expert_xy.dim() != 3 or expert_xy.shape[0] != B or expert_xy.shape[2] != 2:
+        raise HipLibraryError(f"expected_svf: expert_xy must be [B,T_expert,2], got {tuple(expert_xy.shape)}")
+    Te = expert_xy.shape[1]        # poses per expert trajectory; independent of the rollout horizon T (lfd.py:171-177)
     dev = policy.device
     sharp = torch.empty_like(policy)
     svf = torch.empty((B, H, W), dtype=torch.float32, device=dev)
     states = torch.empty((B, T, 2), dtype=torch.int64, device=dev)
     grid = torch.empty((B, H, W), dtype=torch.float32, device=dev)
     _lib.check(lib.creste_expected_svf_f32(_chk(policy).data_ptr(), _chk(expert_xy).data_ptr(),
-                                           _chk(fov_u8, torch.uint8).data_ptr(), B, H, W, T, float(ds),
+                                           _chk(fov_u8, torch.uint8).data_ptr(), B, H, W, T, Te, float(ds),
                                            float(temperature), int(sharpen), int(zero_terminal),
                                            sharp.data_ptr(), svf.data_ptr(), states.data_ptr(),
                                            grid.data_ptr(), _stream()), "expected_svf")

@@ -86,7 +86,7 @@ class ConvG:
 
     def _packed(self, want_bw):
         w, b = self.conv.weight, self.conv.bias
-        key = (w.data_ptr(), w._version, b._version if b is not None else None, self._prec())
+        key = (w.data_ptr(), w._version, b._version if b is not None else None, self._prec(), ops.CACHE_EPOCH)
         if key != self._key:
             self._fw = ops.pack_conv(w, b, None, self.s, self.pad, ops.ACT_NONE, self._prec())
             self._bw, self._key = None, key
@@ -196,7 +196,7 @@ class DwConvT:
 
     def _taps(self):
         w = self.conv.weight
-        key = (w.data_ptr(), w._version)
+        key = (w.data_ptr(), w._version, ops.CACHE_EPOCH)
         if key != self._key:
             Cn = w.shape[0]
             self._w = w.detach()[:, 0].reshape(Cn, -1).t().contiguous()          # [K*K, C] tap-major

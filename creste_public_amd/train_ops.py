@@ -100,7 +100,7 @@ class ConvT:
 
     def _packed(self):
         w = self.conv.weight
-        key = (w.data_ptr(), w._version)
+        key = (w.data_ptr(), w._version, ops.CACHE_EPOCH)
         if key != self._key:
             Cout, Cin = w.shape[:2]
             self._fw = ops.pack_conv(w, None, None, 1, self.K // 2, ops.ACT_NONE, ops.PREC_F32)
@@ -250,6 +250,7 @@ class PoolT:
     def fwd(self, x, out=None):
         self.shape = (x.N, x.H, x.W, x.C)
         y = out or _new(x, H=x.H // 2, W=x.W // 2)
+        y.amax = None                              # (re)written without tracking: a cached bound would be stale
         self.idx = torch.empty((x.N, x.H // 2, x.W // 2, x.C), dtype=torch.uint8, device=x.buf.device)
         _lib.check(_lib_().creste_maxpool2_idx_f32(x.ptr, x.cs, x.N, x.H, x.W, x.C, y.ptr, y.cs, self.idx.data_ptr(),
                                                    _stream()), "maxpool2_idx")
@@ -258,6 +259,7 @@ class PoolT:
     def _route(self, backward, t: Act, out=None):
         N, H, W, Cn = self.shape
         o = out or (Act.empty(N, H, W, Cn, t.buf.device) if backward else Act.empty(N, H // 2, W // 2, Cn, t.buf.device))
+        o.amax = None
         _lib.check(_lib_().creste_maxpool2_route_f32(int(backward), t.ptr, t.cs, self.idx.data_ptr(), o.ptr, o.cs, N,
                                                      H, W, Cn, _stream()), "maxpool2_route")
         return o

@@ -232,11 +232,14 @@ int creste_value_iteration_f32(const float* r, int B, int H, int W, float discou
 
 /* Expected state-visitation frequency + greedy rollout.  reference lfd.py:156-277,
  * train_utils.py:765-803.
- *   policy [B,8,H,W]; expert_xy [B,T,2] (full-resolution BEV row,col as float); fov [H,W] u8.
+ *   policy [B,8,H,W]; expert_xy [B,T_expert,2] (full-resolution BEV row,col as float); fov [H,W] u8.
+ *   T = rollout horizon (action_horizon), T_expert = poses per expert trajectory: the start state is the
+ *   earliest expert pose in the field of view, the terminal state the LAST expert pose (lfd.py:171-177) -- the
+ *   reference indexes them independently of the horizon.
  *   -> exp_svf [B,H,W], state_preds [B,T,2] int64, state_grid [B,H,W].
  *   sharp_policy: workspace [B,8,H,W] floats (the temperature-sharpened policy). */
 int creste_expected_svf_f32(const float* policy, const float* expert_xy, const uint8_t* fov, int B,
-                            int H, int W, int T, float ds, float temperature, int sharpen,
+                            int H, int W, int T, int T_expert, float ds, float temperature, int sharpen,
                             int zero_terminal, float* sharp_policy, float* exp_svf,
                             int64_t* state_preds, float* state_grid, void* stream);
 

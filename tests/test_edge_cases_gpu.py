@@ -186,3 +186,39 @@ def test_svf_window_clipping_and_terminal(ops, start, zts):
     assert torch.equal(grid.cpu(), ref["state_preds_grid"])
     torch.testing.assert_close(svf.cpu(), ref["exp_svf"], rtol=1e-4, atol=1e-6)
     assert float(svf.sum(dim=(1, 2)).max()) <= T + 1e-3
+
+
+@pytest.mark.parametrize("Te,zts", [(20, True), (80, False), (1, True)])
+def test_svf_expert_length_differs_from_horizon(ops, Te, zts):
+    """The reference indexes the expert trajectory [B,Te,..] independently of action_horizon T (lfd.py:171-177): start =
+    earliest in-fov pose over Te, terminal = pose Te-1; rollout / propagation run T steps.  Samples b>0 used to read
+    the wrong poses when Te != T."""
+    H, W, T, B = 64, 128, 50, 3
+    g = torch.Generator().manual_seed(Te)
+    pol = torch.softmax(torch.randn(B, 8, H, W, generator=g) * 2, dim=1)
+    t = torch.linspace(0, 1, Te).view(1, Te, 1)
+    xy = torch.tensor([[100.0, 128.0], [90.0, 60.0], [120.0, 200.0]]).unsqueeze(1) + \
+        t * torch.tensor([[[-60.0, 40.0]], [[-50.0, -30.0]], [[-80.0, 10.0]]])
+    expert = torch.eye(3).repeat(B, Te, 1, 1)
+    expert[:, :, :2, 2] = xy
+    ref = _svf_oracle(pol.clone(), expert.clone(), T, H, W, zts)
+    fov = torch.ones(H, W, dtype=torch.uint8)
+    svf, states, grid = ops.expected_svf(pol.cuda(), xy.contiguous().cuda(), fov.cuda(), T, 2.0, 0.005, True, zts)
+    assert states.shape == (B, T, 2)
+    assert torch.equal(states.cpu(), ref["state_preds"])
+    assert torch.equal(grid.cpu(), ref["state_preds_grid"])
+    torch.testing.assert_close(svf.cpu(), ref["exp_svf"], rtol=1e-4, atol=1e-6)
+
+
+def test_value_iteration_many_tiles_deterministic(ops):
+    """Grid larger than residency (B*tiles >> CUs): every tile of the redo launch must run the same sweep count --
+    a block dispatched after block 0 published `done` used to skip its redo.  Two runs are bit-identical
+    and the result is a fixed point of one more Jacobi sweep within the convergence threshold."""
+    B, H, W = 48, 256, 256
+    r = torch.rand(B, H, W, generator=torch.Generator().manual_seed(5)).cuda()
+    v1, q1, p1, s1 = ops.value_iteration(r, 0.99, 1e-3)
+    v2, q2, p2, s2 = ops.value_iteration(r, 0.99, 1e-3)
+    assert int(s1) == int(s2) > 0
+    assert torch.equal(v1, v2) and torch.equal(q1, q2) and torch.equal(p1, p2)
+    # the last sweep moved no cell by more than the threshold: v' = max_a q(v) differs from v by <= ~1e-3 everywhere
+    assert float((q1.max(dim=1).values - v1).abs().max()) <= 1.05e-3
