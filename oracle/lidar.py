@@ -2,10 +2,11 @@
 the pixel->LiDAR transform.
 
 Follows /root/reference/creste/utils/projection.py:11-34 (`get_pixel2pts_transform`) and :64-155
-(`pixels_to_depth`).  PARITY UNPINNED for `pixels_to_depth`: the reference function calls
-`torch_scatter.scatter(reduce=...)` (requirements.txt:1, un-vendored, absent here) and holds no golden
-vectors; the per-pixel reduction is restated from torch_scatter's documented semantics (reduce over
-equal indices, empty slots filled with 0).
+(`pixels_to_depth`).  `pixels_to_depth` calls `torch_scatter.scatter(reduce=...)` (requirements.txt:1, un-vendored,
+absent here) and the reference holds no golden vectors, so the function cannot be run: the per-pixel reduction is
+restated from torch_scatter's documented semantics (reduce over equal indices, empty slots filled with 0) and
+INDEPENDENTLY CROSS-CHECKED bit for bit against torch's own `scatter_reduce('amax'/'amin')`
+(tests/test_trunk_hf.py::test_oracle_lidar_depth_image_matches_torch_scatter_reduce).
 """
 import numpy as np
 
