@@ -29,10 +29,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 IMG_H, IMG_W, BATCH = 608, 1216, 16
-# TFLOP/s dense (MI355X_MICROARCH.md): fp32 MFMA 157.3; bf16 MFMA 2500.  bf16x3 issues 3 bf16 MFMAs per
-# algorithmic product, so its ceiling in algorithmic FLOPs is 2500/3.
-PEAK = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0 / 3.0, "bf16x6": 2500.0 / 6.0, "f16x3": 2500.0 / 3.0}
+# TFLOP/s dense (MI355X_MICROARCH.md): the peak of the MFMA instruction each mode ISSUES -- v_mfma_f32_32x32x2_f32
+# 157.3, v_mfma_f32_32x32x16_{bf16,f16} 2500.  `roofline.frac` = algorithmic conv FLOP/s / that peak; the split modes
+# issue PRODUCTS[mode] MFMA products per algorithmic multiply, so the pipe's issue utilisation (`mfma_issue_util`) is
+# PRODUCTS x frac.
+PEAK = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0, "bf16x6": 2500.0, "f16x3": 2500.0}
+PRODUCTS = {"f32": 1, "bf16": 1, "bf16x3": 3, "bf16x6": 6, "f16x3": 3}
 PREC_NAME = {0: "f32", 1: "bf16", 2: "bf16x3", 3: "bf16x6", 4: "f16x3"}
+DTYPE = {"f32": "f32 (exact fp32 products on v_mfma_f32_32x32x2_f32, fp32 accumulate)",
+         "bf16x6": "bf16x6 (fp32 operands as 3 bf16 pieces = 24 significand bits, 6 piece products per multiply on the "
+                   "bf16 MFMA, fp32 accumulate: fp32-equivalent products)",
+         "f16x3": "f16x3 (fp32 operands rescaled by exact powers of two and split into fp16 hi+lo = 22 significand "
+                  "bits, 3 piece products per multiply on the f16 MFMA, fp32 accumulate; product error <= 2^-21 -- "
+                  "narrower than fp32 operands, inside the north-star tolerances: tests/test_fullsize_gpu.py)",
+         "bf16x3": "bf16x3 (fp32 operands as 2 bf16 pieces = 16 significand bits, 3 piece products, fp32 accumulate)",
+         "bf16": "bf16 operands, fp32 accumulate / activations"}
 HBM_PEAK_GBS = 8000.0
 
 
@@ -108,10 +119,14 @@ class ConvProfiler:
         return by
 
 
-def cpu_baseline(sample_frames=1, runs=3):
-    """The oracle (CPU restatement of the reference's PyTorch path) on this host's cores."""
+def cpu_baseline(batches=(1, 16), runs=5, budget_s=150.0):
+    """The oracle (CPU restatement of the reference's PyTorch path) on this host's cores: batch 1 and batch 16,
+    median of `runs` timed runs after 1 warm-up each (SURVEY 8d / BASELINE.md section 2).  `value` is the better of the
+    two batch sizes in frames/s.  `budget_s` bounds the batch-16 leg: if its warm-up shows that `runs` runs would not
+    fit, fewer runs are timed and the count is reported."""
     from creste_public_amd import maxent_irl_cfg, synth
     from oracle.irl import MaxEntIRL as OracleIRL
+    from oracle import lidar as olidar
     cores = os.cpu_count() or 1
     try:
         import psutil
@@ -121,31 +136,42 @@ def cpu_baseline(sample_frames=1, runs=3):
     torch.set_num_threads(cores)
     torch.manual_seed(1337)
     model = OracleIRL(maxent_irl_cfg((IMG_H, IMG_W), solve_mdp=False)).eval()
-    from oracle import lidar as olidar
-    gen = torch.Generator().manual_seed(1337)
-    rgbd = torch.zeros(sample_frames, 1, 4, IMG_H, IMG_W)
-    rgbd[:, 0, :3] = torch.rand(sample_frames, 3, IMG_H, IMG_W, generator=gen)
-    scan = synth.lidar_scan(sample_frames, gen).numpy()
-    l2c = synth.lidar2camrect(sample_frames, IMG_H, IMG_W).numpy()
-    p2p = synth.make_p2p(sample_frames, IMG_H, IMG_W)
+    blas = " ".join(l.strip() for l in torch.__config__.show().splitlines()
+                    if any(k in l for k in ("MKL", "oneDNN", "BLAS", "OpenMP", "LAPACK")) and "flags" not in l)[:300]
+    per = {}
+    for nb in batches:
+        gen = torch.Generator().manual_seed(1337)
+        rgbd = torch.zeros(nb, 1, 4, IMG_H, IMG_W)
+        rgbd[:, 0, :3] = torch.rand(nb, 3, IMG_H, IMG_W, generator=gen)
+        scan = synth.lidar_scan(nb, gen).numpy()
+        l2c = synth.lidar2camrect(nb, IMG_H, IMG_W).numpy()
+        p2p = synth.make_p2p(nb, IMG_H, IMG_W)
 
-    def cpu_step():
-        for b in range(sample_frames):     # LiDAR scan -> sparse mm depth channel, then the forward
-            rgbd[b, 0, 3] = torch.from_numpy(olidar.depth_image(scan[b], l2c[b], IMG_H, IMG_W) * 1000.0).float()
-        return model((rgbd, p2p))
+        def cpu_step():
+            for b in range(nb):     # LiDAR scan -> sparse mm depth channel, then the forward
+                rgbd[b, 0, 3] = torch.from_numpy(olidar.depth_image(scan[b], l2c[b], IMG_H, IMG_W) * 1000.0).float()
+            return model((rgbd, p2p))
 
-    times = []
-    with torch.no_grad():
-        cpu_step()                               # warm-up
-        for _ in range(runs):
+        with torch.no_grad():
             t0 = time.perf_counter()
-            cpu_step()
-            times.append(time.perf_counter() - t0)
-    med = statistics.median(times)
-    return {"value": round(sample_frames / med, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (CPU PyTorch restatement of the reference path), batch={sample_frames} "
-                      f"frame of {IMG_W}x{IMG_H}, median of {runs} runs after 1 warm-up, "
-                      f"{cores} threads, fp32"}
+            cpu_step()                               # warm-up
+            warm = time.perf_counter() - t0
+            n = runs if nb == 1 else max(1, min(runs, int(budget_s / max(warm, 1e-3))))
+            times = []
+            for _ in range(n):
+                t0 = time.perf_counter()
+                cpu_step()
+                times.append(time.perf_counter() - t0)
+        per[nb] = {"frames_per_s": round(nb / statistics.median(times), 4), "runs": n,
+                   "median_s": round(statistics.median(times), 3)}
+    best = max(per, key=lambda k: per[k]["frames_per_s"])
+    return {"value": per[best]["frames_per_s"], "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (CPU PyTorch restatement of the reference path, fp32, eval, no_grad), {IMG_W}x{IMG_H} "
+                      f"frames incl. the LiDAR projection, {cores} threads (torch.set_num_threads), "
+                      + "; ".join(f"batch {nb}: {v['frames_per_s']} frames/s (median of {v['runs']} runs after 1 warm-up, "
+                                  f"{v['median_s']} s/run)" for nb, v in per.items())
+                      + f"; value = batch {best}",
+            "by_batch": {str(k): v for k, v in per.items()}, "blas": blas}
 
 
 def distill_extras(device, steps=3, B=8):
@@ -219,66 +245,113 @@ def ssc_extras(device, steps=3, B=8):
                           f"loss {float(logs['train/loss']):.3f}"}
 
 
-def irl_extras(model_infer, device, steps=3):
-    """The second half of BASELINE.json's metric: IRL train-step time (configs[2]).  Reference-config
-    step: batch 8 frames, 64x128 IRL grid (map_ds 2 + front-half crop), frozen HIP backbone, reward net
-    trained on the HIP kernels (train_ops.py, hipGraph replay), value iteration + expected SVF kernels, MaxEntIRLLoss with counterfactual mixing and
-    gradient penalty, Adam step (reference train_traversability.py:66-105).  Plus the MDP kernels alone
-    on the 8x256x256 grid BASELINE names."""
+IRL_VARIANTS = {
+    # reference config: 256x256 BEV (0.1 m voxels over +-12.8 m), map_ds 2 + front-half crop -> 64x128 MDP grid
+    "reference": dict(pcr=None, voxel=None, map_size=(64, 128), map_ds=2, bev=(256, 256), prec=None, B=8),
+    # BASELINE configs[2]: the MDP solved on a 256x256 grid.  The reference's geometry (max-pool by map_ds, front-half
+    # crop, vin.py:104-109) gives an (R/ds/2) x (C/ds) grid from an R x C BEV map: 256x256 = the front half of a
+    # 512x256 BEV map (0.1 m voxels, 51.2 m ahead/behind x 25.6 m across) with map_ds 1
+    "mdp256": dict(pcr=[-25.6, -12.8, -2, 25.6, 12.8, 1], voxel=None, map_size=(256, 256), map_ds=1, bev=(512, 256),
+                   prec=None, B=8),
+    # BASELINE configs[4], per-GPU part: counterfactual IRL on a 512x512 BEV grid (5 cm voxels) -> 128x256 MDP grid,
+    # bf16 encoder operands, fp32 reward network / value iteration / SVF
+    "cf512": dict(pcr=None, voxel=[0.05, 0.05, 3], map_size=(128, 256), map_ds=2, bev=(512, 512), prec="bf16", B=8),
+}
+
+
+def irl_step_bench(model_infer, device, variant, steps=3):
+    """One IRL training step (reference train_traversability.py:66-105): frozen HIP backbone forward, reward net
+    (train mode, hipGraph-replayed HIP kernels), value iteration + expected SVF, MaxEntIRLLoss with counterfactual
+    mixing (alpha 0.5) and gradient penalty, backward incl. the second-order term, Adam."""
     import numpy as np
-    from creste_public_amd import LossManager, MaxEntIRL, maxent_irl_cfg, ops, synth
-    B = 8
-    cfg = maxent_irl_cfg((IMG_H, IMG_W), solve_mdp=True)
-    model = MaxEntIRL(cfg)
-    model.load_state_dict(model_infer.state_dict(), strict=True)
-    with torch.no_grad():   # costmaps of O(1) as after training (random-init BN gains give rewards ~1e2)
-        model.traversability_head.r.postpool[0].norm.weight.mul_(0.01)
-        model.traversability_head.r.postpool[0].norm.bias.mul_(0.01)
-    model = model.to(device).train()
-    model.traversability_head.r.train_graphs = True      # reward-net launch sequences replayed from hipGraphs
-    lm = LossManager(cfg).to(device)
-    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-4, betas=(0.9, 0.999))
-    rgbd, p2p = synth.make_frames(B, IMG_H, IMG_W, seed=4242)
-    rgbd, p2p = rgbd.to(device), p2p.to(device)
-    expert = synth.make_experts(B, 50, 256, seed=5).to(device)
-    fov = torch.ones(B, 256, 256, dtype=torch.bool, device=device)
-    rng = np.random.RandomState(0)
-    cf = [dict(trajectories=(np.array([[100.0, 128.0]]) + np.linspace(0, 1, 20)[None, :, None] *
-                             rng.uniform(-80, 80, size=(2, 1, 2))).astype(np.float32), rank=np.array([0, 1]))
-          for _ in range(B)]
+    import creste_public_amd
+    from creste_public_amd import LossManager, MaxEntIRL, maxent_irl_cfg, synth
+    v = IRL_VARIANTS[variant]
+    B, (GH, GW) = v["B"], v["bev"]
+    prev = creste_public_amd.get_precision()
+    if v["prec"]:
+        creste_public_amd.set_precision(v["prec"])
+    try:
+        cfg = maxent_irl_cfg((IMG_H, IMG_W), solve_mdp=True, map_size=v["map_size"], map_ds=v["map_ds"],
+                             point_cloud_range=v["pcr"], voxel_size=v["voxel"])
+        model = MaxEntIRL(cfg)
+        sd = {k: t for k, t in model_infer.state_dict().items() if ".cam2map." not in k or "z_proj" in k
+              or "vision_fusion" in k}                         # keep this variant's grid buffers
+        model.load_state_dict(sd, strict=False)
+        with torch.no_grad():   # costmaps of O(1) as after training (random-init BN gains give rewards ~1e2)
+            model.traversability_head.r.postpool[0].norm.weight.mul_(0.01)
+            model.traversability_head.r.postpool[0].norm.bias.mul_(0.01)
+        model = model.to(device).train()
+        model.traversability_head.r.train_graphs = True      # reward-net launch sequences replayed from hipGraphs
+        lm = LossManager(cfg).to(device)
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-4, betas=(0.9, 0.999))
+        rgbd, p2p = synth.make_frames(B, IMG_H, IMG_W, seed=4242)
+        rgbd, p2p = rgbd.to(device), p2p.to(device)
+        expert = synth.make_experts(B, 50, (GH, GW), seed=5).to(device)
+        # the loss halves the field-of-view mask and crops it to the MDP grid (loss_utils.py:1134-1136)
+        fov = torch.ones(B, max(GH, 2 * v["map_size"][0]), max(GW, 2 * v["map_size"][1]), dtype=torch.bool, device=device)
+        rng = np.random.RandomState(0)
+        c0 = np.array([[GH / 2 - 28.0, GW / 2.0]])
+        cf = [dict(trajectories=(c0 + np.linspace(0, 1, 20)[None, :, None] *
+                                 rng.uniform(-0.3 * GW, 0.3 * GW, size=(2, 1, 2))).astype(np.float32),
+                   rank=np.array([0, 1])) for _ in range(B)]
 
-    def step():
-        opt.zero_grad()
-        out = model((rgbd, p2p, expert))
-        td = {f"outputs/{k}": v for k, v in out.items()}
-        td.update({"inputs/traversability_label": expert, "inputs/fov_mask": fov,
-                   "inputs/counterfactuals_label": cf, "task": "irl"})
-        ld, _ = lm(td)
-        loss = sum(w * v for w, v in ld.values())
-        loss.backward()
-        opt.step()
-        return loss
+        def step():
+            opt.zero_grad()
+            out = model((rgbd, p2p, expert))
+            td = {f"outputs/{k}": t for k, t in out.items()}
+            td.update({"inputs/traversability_label": expert, "inputs/fov_mask": fov,
+                       "inputs/counterfactuals_label": cf, "task": "irl"})
+            ld, _ = lm(td)
+            loss = sum(w * t for w, t in ld.values())
+            loss.backward()
+            opt.step()
+            return loss.detach(), out
 
-    step(); step(); torch.cuda.synchronize()              # eager step, then the capturing step
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    sweeps = int(model.traversability_head.last_sweeps.item())
-    # MDP kernels alone, 8 x 256 x 256, r ~ U[0,1)
-    r = torch.rand(8, 256, 256, device=device)
+        step(); step(); torch.cuda.synchronize()              # eager step, then the capturing step
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, out = step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        sweeps = int(model.traversability_head.last_sweeps.item())
+        occ = float((out["bev_densities"] > 0).float().mean())
+        res = {"train_step_ms": round(ms, 2), "batch": B, "bev_grid": [GH, GW], "mdp_grid": list(v["map_size"]),
+               "vi_sweeps": sweeps, "encoder_operands": creste_public_amd.get_precision(),
+               "loss": round(float(loss), 5), "bev_cells_occupied": round(occ, 3)}
+        del model, lm, opt
+        torch.cuda.empty_cache()
+        return res
+    finally:
+        creste_public_amd.set_precision(prev)
+
+
+def vi_kernel_bench(device, B, Hg, Wg):
+    """The MDP kernels alone on r ~ U[0,1): value iteration (gamma 0.99, threshold 1e-3)."""
+    from creste_public_amd import ops
+    r = torch.rand(B, Hg, Wg, device=device)
     ops.value_iteration(r, 0.99, 1e-3); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3):
         v, q, pi, sw = ops.value_iteration(r, 0.99, 1e-3)
     torch.cuda.synchronize()
-    vi_ms = (time.perf_counter() - t0) / 3 * 1e3
+    ms = (time.perf_counter() - t0) / 3 * 1e3
     n = int(sw.item())
-    return {"irl_train_step_ms": round(ms, 2), "irl_config": f"batch {B}, {IMG_W}x{IMG_H} frames, 64x128 IRL grid, "
-            f"{sweeps} VI sweeps, T=50 SVF, CF-IRL loss + gradient penalty + Adam; loss {float(loss):.4f}",
-            "vi_8x256x256_ms": round(vi_ms, 3), "vi_8x256x256_sweeps": n,
-            "vi_8x256x256_algorithmic_GBps": round(8 * 256 * 256 * (12 * n + 72) / vi_ms / 1e6, 1)}
+    gbs = B * Hg * Wg * (12 * n + 72) / ms / 1e6
+    return {"ms": round(ms, 3), "sweeps": n, "algorithmic_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 3)}
+
+
+def irl_extras(model_infer, device, steps=3):
+    """The second half of BASELINE.json's metric: IRL train-step time, at the reference config, at BASELINE configs[2]
+    (256x256 MDP grid) and at configs[4]'s per-GPU shape (512x512 BEV, bf16 encoder, counterfactual IRL)."""
+    out = {"config": "frames 1216x608; frozen HIP backbone + reward net training kernels + VI + SVF (T=50) + CF-IRL loss "
+                     "(alpha 0.5, 2 counterfactual trajectories per sample) + gradient penalty + Adam"}
+    for name in IRL_VARIANTS:
+        out[name] = irl_step_bench(model_infer, device, name, steps)
+    out["irl_train_step_ms"] = out["reference"]["train_step_ms"]
+    out["vi_8x256x256"] = vi_kernel_bench(device, 8, 256, 256)
+    out["vi_8x512x512"] = vi_kernel_bench(device, 8, 512, 512)
+    return out
 
 
 def main():
@@ -354,17 +427,17 @@ def main():
 
     modes = {}
     if args.gpus == 1 and not args.no_modes:
-        # the other conv operand modes, 3 steps each after 1 warm-up (same model, same inputs)
+        # every other conv operand mode over the SAME number of steps after 1 warm-up (same model, same inputs)
         for name in ("f32", "bf16x6", "f16x3", "bf16x3", "bf16"):
             if name == args.precision:
                 continue
             creste_public_amd.set_precision(name)
             step(); torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(3):
+            for _ in range(args.steps):
                 step()
             torch.cuda.synchronize()
-            modes[name] = round(3 * args.batch / (time.perf_counter() - t1), 2)
+            modes[name] = round(args.steps * args.batch / (time.perf_counter() - t1), 2)
         creste_public_amd.set_precision(args.precision)
 
     if rank == 0 and args.layers:
@@ -399,32 +472,32 @@ def main():
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16x3": "f32 (bf16x3 split products on the bf16 MFMA, fp32 accumulate)",
-                      "bf16x6": "f32 (fp32 operands as 3 bf16 pieces, 6 exact piece products per multiply on the "
-                                "bf16 MFMA, fp32 accumulate)",
-                      "f16x3": "f32 (fp32 operands, power-of-two rescaled, as fp16 hi+lo = 22 significand bits, 3 piece "
-                               "products per multiply on the f16 MFMA, fp32 accumulate)",
-                      "bf16": "bf16 operands, fp32 accumulate/activations"}[args.precision],
+            "dtype": DTYPE[args.precision],
             "data": "synthetic",
             "config": {"workload": f"inference: batch={args.batch}/GPU synthetic {IMG_W}x{IMG_H} RGB + 128x1024 "
                                    "LiDAR scan (projected to the sparse depth channel inside the step) -> 256x256 BEV costmap "
                                    "(MaxEntIRL solve_mdp=False; EfficientNet-B0 U-Net, BEV splat, ResNet-18 heads, "
                                    "reward FCN), random-init weights",
                        "batch_per_gpu": args.batch, "image": [IMG_H, IMG_W], "lidar": [128, 1024],
-                       "bev": [256, 256], "parallelism": f"{args.gpus} independent replicas (frame-sharded, no collective)"},
+                       "bev": [256, 256], "parallelism": f"{args.gpus} independent replicas (frame-sharded, no collective)",
+                       "inputs": "resident in HBM when the timed region starts (a host-resident batch of 189 MB would add "
+                                 "~3 ms per step over PCIe Gen5: excluded)"},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": round(PEAK[dprec], 1), "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK[dprec], 4), "traffic": traffic,
+                         "mfma_products_per_multiply": PRODUCTS[dprec],
+                         "mfma_issue_util": round(PRODUCTS[dprec] * achieved / PEAK[dprec], 4),
                          "launches": d["n"], "avg_launch_ms": round(d["ms"] / d["n"], 4),
-                         "conv_share_of_step": round(conv_ms / args.steps / (elapsed / args.steps * 1e3), 4)},
+                         "conv_share_of_step": round(conv_ms / args.steps / (elapsed / args.steps * 1e3), 4),
+                         "note": "achieved = algorithmic conv FLOPs (2*M*Cout*Cin*K*K) of every launch of this kernel "
+                                 "symbol in the timed steps / their HIP-event time; peak = dense peak of the MFMA "
+                                 "instruction issued; mfma_issue_util counts the piece products actually issued"},
         }
         if modes:
             line["modes_frames_per_s"] = dict(modes, **{args.precision: line["value"]})
-            line["modes_note"] = ("conv operand modes: f32 = exact fp32 MFMA; bf16x6 = fp32 operands as 3 bf16 pieces, "
-                                  "6 exact piece products (fp32-equivalent, parity suite green); f16x3 = fp32 operands "
-                                  "rescaled by exact powers of two and split into fp16 hi+lo, 3 piece products "
-                                  "(<=2^-21 per product, parity suite green); bf16x3 = 2 pieces "
-                                  "(~6e-5 rel per conv); bf16 = plain bf16 operands (~4e-3 rel per conv)")
+            line["modes_note"] = (f"every mode timed over the same {args.steps} steps after 1 warm-up; " +
+                                  "; ".join(f"{k} = {v}" for k, v in DTYPE.items()))
+            line["fp32_equivalent_frames_per_s"] = {k: line["modes_frames_per_s"][k] for k in ("f32", "bf16x6")}
         if args.gpus == 1 and not args.no_irl:
             line["irl"] = irl_extras(model, device)
             line["distill"] = distill_extras(device)

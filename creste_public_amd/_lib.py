@@ -51,6 +51,7 @@ SIGNATURES = {
     "creste_upsample_concat_nhwc_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i,
                                               _f, _f, _vp, _vp]),
     "creste_maxpool2_nhwc_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "creste_maxpool_nhwc_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "creste_affine_act_nhwc_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
     "creste_resize_plane_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _f, _f, _vp]),
     "creste_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

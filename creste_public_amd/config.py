@@ -130,9 +130,15 @@ def terrainnet_cfg(image_size=(512, 612), views: int = 1) -> Cfg:
 
 
 def maxent_irl_cfg(image_size=(512, 612), solve_mdp: bool = True,
-                   map_size=(64, 128), map_ds: int = 2) -> Cfg:
-    """MaxEntIRL (frozen TerrainNet + reward FCN + VI/SVF) hyper-parameters."""
+                   map_size=(64, 128), map_ds: int = 2, point_cloud_range=None, voxel_size=None) -> Cfg:
+    """MaxEntIRL (frozen TerrainNet + reward FCN + VI/SVF) hyper-parameters.  The MDP grid `map_size` must equal
+    ((rows / map_ds) // 2, cols / map_ds) of the BEV grid (max-pool by map_ds, front-half crop: vin.py:104-109);
+    the shipped config is a 256x256 BEV grid (0.1 m voxels over +-12.8 m), map_ds 2 -> 64x128."""
     backbone = terrainnet_cfg(image_size)
+    if point_cloud_range is not None:
+        backbone["camera_projector"]["point_cloud_range"] = list(point_cloud_range)
+    if voxel_size is not None:
+        backbone["camera_projector"]["voxel_size"] = list(voxel_size)
     backbone["load_setting"] = "strict_freeze"
     feats_dim = 40
     return Cfg(

@@ -47,10 +47,10 @@ class VIN(nn.Module):
 
     def input_view_act(self, preds: Act) -> Act:
         """cat(input_keys) -> max_pool2d(ds) -> front half rows (vin.py:104-109), one kernel pass."""
-        ds = self.reward_cfg["ds"]
-        if ds != 2:
-            raise NotImplementedError("HIP max-pool is 2x2/2 (reward_cfg.ds == 2)")
-        return ops.maxpool2(preds, Ho=(preds.H // 2) // 2, Wo=preds.W // 2)
+        ds = int(self.reward_cfg["ds"])
+        if ds not in (1, 2, 4):
+            raise NotImplementedError("HIP max-pool is built for reward_cfg.ds in {1, 2, 4}")
+        return ops.maxpool2(preds, Ho=(preds.H // ds) // 2, Wo=preds.W // ds, ds=ds)
 
     def forward_from_view(self, view: Act, Ho, Wo, S, solve_mdp=False):
         name = self.reward_cfg["output_prefix"][0]

@@ -288,11 +288,14 @@ __global__ __launch_bounds__(256) void upsample_concat_kernel(
   if (amax) block_amax_update(vmax, amax, scratch);
 }
 
-// ------------------------------------------------------------------------------ max-pool 2x2/2
-__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ in, int H, int W,
-                                                       int C, int in_cs, float* __restrict__ out,
-                                                       int N, int Ho, int Wo, int out_cs,
-                                                       float* __restrict__ amax) {
+// ------------------------------------------------------------------------------ max-pool DSxDS/DS
+// DS = 2: nn.MaxPool2d(2, 2) / F.max_pool2d(x, ds, ds) of the reward head (vin.py:104-106); DS = 1: the degenerate
+// pool of reward_cfg.ds == 1 (a row/column crop into the output slice).
+template <int DS>
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ in, int H, int W,
+                                                      int C, int in_cs, float* __restrict__ out,
+                                                      int N, int Ho, int Wo, int out_cs,
+                                                      float* __restrict__ amax) {
   __shared__ float scratch[4];
   float vmax = 0.f;
   const int cq = C >> 2;
@@ -304,15 +307,19 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__
     const int ox = (int)(t % Wo); t /= Wo;
     const int oy = (int)(t % Ho);
     const int n = (int)(t / Ho);
-    const float* b = in + (((long)n * H + 2 * oy) * W + 2 * ox) * in_cs + c;
-    const f32x4 a = ld4(b), bb = ld4(b + in_cs), cc = ld4(b + (long)W * in_cs),
-                d = ld4(b + (long)W * in_cs + in_cs);
-    f32x4 m;
+    const float* b = in + (((long)n * H + DS * oy) * W + DS * ox) * in_cs + c;
+    f32x4 m = ld4(b);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      m[j] = fmaxf(fmaxf(a[j], bb[j]), fmaxf(cc[j], d[j]));
-      vmax = fmaxf(vmax, fabsf(m[j]));
-    }
+    for (int dy = 0; dy < DS; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < DS; ++dx) {
+        if (dy == 0 && dx == 0) continue;
+        const f32x4 a = ld4(b + ((long)dy * W + dx) * in_cs);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], a[j]);
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vmax = fmaxf(vmax, fabsf(m[j]));
     st4(out + (((long)n * Ho + oy) * Wo + ox) * out_cs + c, m);
   }
   if (amax) block_amax_update(vmax, amax, scratch);
@@ -605,14 +612,23 @@ extern "C" int creste_upsample_concat_nhwc_f32(const float* x1, int N, int H1, i
   return CRESTE_OK;
 }
 
+extern "C" int creste_maxpool_nhwc_f32(const float* in, int N, int H, int W, int C, int in_cs, float* out,
+                                       int Ho, int Wo, int out_cs, int ds, float* out_amax, void* stream) {
+  CRESTE_REQUIRE(in && out && C % 4 == 0 && in_cs % 4 == 0 && out_cs % 4 == 0, "maxpool: bad args");
+  CRESTE_REQUIRE(ds == 1 || ds == 2 || ds == 4, "maxpool: window/stride %d not built (1, 2, 4)", ds);
+  CRESTE_REQUIRE(ds * Ho <= H && ds * Wo <= W, "maxpool: pooled extent exceeds input");
+  const long total = (long)N * Ho * Wo * (C / 4);
+  hipStream_t s = (hipStream_t)stream;
+  if (ds == 1) maxpool_kernel<1><<<grid_for(total), 256, 0, s>>>(in, H, W, C, in_cs, out, N, Ho, Wo, out_cs, out_amax);
+  else if (ds == 2) maxpool_kernel<2><<<grid_for(total), 256, 0, s>>>(in, H, W, C, in_cs, out, N, Ho, Wo, out_cs, out_amax);
+  else maxpool_kernel<4><<<grid_for(total), 256, 0, s>>>(in, H, W, C, in_cs, out, N, Ho, Wo, out_cs, out_amax);
+  CRESTE_CHECK_LAUNCH("maxpool");
+  return CRESTE_OK;
+}
+
 extern "C" int creste_maxpool2_nhwc_f32(const float* in, int N, int H, int W, int C, int in_cs, float* out,
                                         int Ho, int Wo, int out_cs, float* out_amax, void* stream) {
-  CRESTE_REQUIRE(in && out && C % 4 == 0 && in_cs % 4 == 0 && out_cs % 4 == 0, "maxpool2: bad args");
-  CRESTE_REQUIRE(2 * Ho <= H && 2 * Wo <= W, "maxpool2: pooled extent exceeds input");
-  const long total = (long)N * Ho * Wo * (C / 4);
-  maxpool2_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(in, H, W, C, in_cs, out, N, Ho, Wo, out_cs, out_amax);
-  CRESTE_CHECK_LAUNCH("maxpool2");
-  return CRESTE_OK;
+  return creste_maxpool_nhwc_f32(in, N, H, W, C, in_cs, out, Ho, Wo, out_cs, 2, out_amax, stream);
 }
 
 extern "C" int creste_nchw_to_nhwc_f32(const float* in, float* out, int out_cs, int N, int C, int H, int W,

@@ -310,15 +310,16 @@ def upsample_concat(x1: Act, skip: Act | None, Ho, Wo, rh, rw, out: Act | None =
     return out
 
 
-def maxpool2(x: Act, Ho=None, Wo=None) -> Act:
+def maxpool2(x: Act, Ho=None, Wo=None, ds: int = 2) -> Act:
+    """F.max_pool2d(x, ds, ds) restricted to the first Ho x Wo pooled pixels (ds in {1, 2, 4}; ds = 1 is a crop)."""
     lib = _lib.load()
-    Ho = Ho if Ho is not None else x.H // 2
-    Wo = Wo if Wo is not None else x.W // 2
+    Ho = Ho if Ho is not None else x.H // ds
+    Wo = Wo if Wo is not None else x.W // ds
     out = Act.empty(x.N, Ho, Wo, x.C, x.buf.device)
     if TRACK_AMAX:
         out.amax = _AmaxPool.slot(x.buf.device)
-    _lib.check(lib.creste_maxpool2_nhwc_f32(x.ptr, x.N, x.H, x.W, x.C, x.cs, out.ptr, Ho, Wo, out.cs,
-                                            out.amax.data_ptr() if TRACK_AMAX else None, _stream()), "maxpool2")
+    _lib.check(lib.creste_maxpool_nhwc_f32(x.ptr, x.N, x.H, x.W, x.C, x.cs, out.ptr, Ho, Wo, out.cs, int(ds),
+                                           out.amax.data_ptr() if TRACK_AMAX else None, _stream()), "maxpool")
     return out
 
 

@@ -84,14 +84,15 @@ def make_frames(B: int, H: int, W: int, seed: int = 1337):
     return rgbd, make_p2p(B, H, W)
 
 
-def make_experts(B: int, T: int = 50, grid: int = 256, seed: int = 7) -> torch.Tensor:
+def make_experts(B: int, T: int = 50, grid=256, seed: int = 7) -> torch.Tensor:
     """Straight-ish polylines from the bottom centre of the front half of the BEV map -> [B,T,3,3]
-    SE(2) poses in full-resolution BEV cells (row, col in [:, :, :2, 2])."""
+    SE(2) poses in full-resolution BEV cells (row, col in [:, :, :2, 2]).  grid = G or (rows, cols)."""
     g = torch.Generator().manual_seed(seed)
+    gh, gw = (grid, grid) if isinstance(grid, int) else grid
     t = torch.linspace(0, 1, T).view(1, T, 1)
-    start = torch.tensor([[grid / 2 - 6.0, grid / 2.0]]).repeat(B, 1)
-    delta = torch.stack([-(torch.rand(B, generator=g) * 0.3 + 0.5) * grid / 2,
-                         (torch.rand(B, generator=g) - 0.5) * grid / 3], dim=1)
+    start = torch.tensor([[gh / 2 - 6.0, gw / 2.0]]).repeat(B, 1)
+    delta = torch.stack([-(torch.rand(B, generator=g) * 0.3 + 0.5) * gh / 2,
+                         (torch.rand(B, generator=g) - 0.5) * gw / 3], dim=1)
     xy = start.unsqueeze(1) + t * delta.unsqueeze(1)
     P = torch.eye(3).repeat(B, T, 1, 1)
     P[:, :, :2, 2] = xy

@@ -151,6 +151,10 @@ int creste_upsample_concat_nhwc_f32(const float* x1, int N, int H1, int W1, int 
  * pooled map to its first H//2 rows -> pass Ho = H//4). */
 int creste_maxpool2_nhwc_f32(const float* in, int N, int H, int W, int C, int in_cs, float* out,
                              int Ho, int Wo, int out_cs, float* out_amax, void* stream);
+/* The same with a ds x ds window and stride ds, ds in {1, 2, 4} (reward_cfg.ds of vin.py:104-106; ds = 1 is the plain
+ * front-half crop: configurations whose MDP grid equals the BEV grid's front half). */
+int creste_maxpool_nhwc_f32(const float* in, int N, int H, int W, int C, int in_cs, float* out,
+                            int Ho, int Wo, int out_cs, int ds, float* out_amax, void* stream);
 
 /* y = act(x*scale[c] + shift[c]): an eval-mode BatchNorm that FOLLOWS a ReLU (MultiScaleFCN trunk,
  * reference conv.py:118-128: conv -> ReLU -> BN -> ReLU) and so cannot be folded into the conv. */

@@ -368,3 +368,77 @@ def test_512_grid_bf16_encoder_pipeline():
     assert float(out["exp_svf"].sum(dim=(1, 2)).max()) <= 50 + 1e-3
     X = out["bev_coords"][..., 0]
     assert float(X.max()) > 300                       # coordinates in 5 cm cells
+
+
+@pytest.mark.parametrize("variant", ["cf512", "mdp256"])
+def test_irl_training_step_on_large_mdp_grids(variant):
+    """BASELINE configs[4] (counterfactual IRL, 512x512 BEV grid at 5 cm -> 128x256 MDP grid, bf16 encoder operands,
+    fp32 reward net / value iteration / SVF) and configs[2] (256x256 MDP grid = front half of a 512x256 BEV map,
+    map_ds 1): one training step (reference train_traversability.py:66-105, loss_utils.py:1118-1259) on the HIP path,
+    then the objective on IDENTICAL inputs (the oracle's input_view / exp_svf) against the CPU oracle: loss and every
+    reward-net gradient, as test_irl_training_step does on the 64x128 grid."""
+    import copy
+    import numpy as np
+    import creste_public_amd
+    from creste_public_amd import LossManager, MaxEntIRL
+    from oracle import irl as oirl
+    Hh, Ww, Bb = 128, 192, 2
+    if variant == "cf512":
+        kw = dict(map_size=(128, 256), map_ds=2, voxel_size=[0.05, 0.05, 3])
+        bev, prec = (512, 512), "bf16"
+    else:
+        kw = dict(map_size=(256, 256), map_ds=1, point_cloud_range=[-25.6, -12.8, -2, 25.6, 12.8, 1])
+        bev, prec = (512, 256), "f16x3"
+    cfg = maxent_irl_cfg((Hh, Ww), solve_mdp=True, **kw)
+    torch.manual_seed(77)
+    oracle = oirl.MaxEntIRL(cfg)
+    rgbd, p2p = synth.make_frames(Bb, Hh, Ww, seed=12)
+    expert = synth.make_experts(Bb, 50, bev, seed=4)
+    calibrate_bn(oracle, lambda: oracle((rgbd, p2p, expert)))
+    with torch.no_grad():
+        oracle.traversability_head.r.postpool[0].norm.weight.mul_(0.01)
+        oracle.traversability_head.r.postpool[0].norm.bias.mul_(0.01)
+    oracle = _with_eval_backbone(oracle)
+    mh, mw = kw["map_size"]
+    fov = torch.ones(Bb, max(bev[0], 2 * mh), max(bev[1], 2 * mw), dtype=torch.bool)
+    rng = np.random.RandomState(1)
+    c0 = np.array([[bev[0] / 2 - 28.0, bev[1] / 2.0]])
+    cf = [dict(trajectories=(c0 + np.linspace(0, 1, 20)[None, :, None] *
+                             rng.uniform(-0.3 * bev[1], 0.3 * bev[1], size=(3, 1, 2))).astype(np.float32),
+               rank=np.array([0, 1, 2])), None]
+    batch = (rgbd, p2p, expert)
+    lo, go, _, out_o, _ = _irl_step(copy.deepcopy(oracle), oirl.LossManager(cfg), "cpu", batch, cf, fov)
+    assert tuple(out_o["traversability_preds"].shape) == (Bb, 1, mh, mw)
+    assert tuple(out_o["bev_features"].shape[-2:]) == bev
+    creste_public_amd.set_precision(prec)
+    try:
+        model = MaxEntIRL(maxent_irl_cfg((Hh, Ww), solve_mdp=True, **kw))
+        model.load_state_dict(oracle.state_dict(), strict=True)
+        model = model.cuda()
+        lh, gh, md, out_h, moved = _irl_step(copy.deepcopy(model), LossManager(cfg).cuda(), "cuda", batch, cf, fov)
+        assert moved > 0 and set(gh) == set(go)
+        assert tuple(out_h["traversability_preds"].shape) == (Bb, 1, mh, mw)
+        assert tuple(out_h["exp_svf"].shape) == (Bb, mh, mw) and tuple(out_h["policy"].shape) == (Bb, 8, mh, mw)
+        assert torch.isfinite(lh) and all(torch.isfinite(g).all() for g in gh.values())
+        assert float(out_h["exp_svf"].sum(dim=(1, 2)).max()) <= 50 + 1e-3
+        # identical inputs: reward net forward / backward / second-order term + loss arithmetic only
+        res = {}
+        for tag, m, lm, dev in (("hip", model, LossManager(cfg).cuda(), "cuda"), ("cpu", oracle, oirl.LossManager(cfg), "cpu")):
+            rnet = m.traversability_head.r
+            rnet.train()
+            rnet.zero_grad()
+            iv = out_o["input_view"].detach().to(dev).requires_grad_(True)
+            r = rnet(iv)
+            td = {"outputs/exp_svf": out_o["exp_svf"].to(dev), "outputs/traversability_preds": r,
+                  "outputs/input_view": iv, "inputs/traversability_label": expert.to(dev),
+                  "inputs/fov_mask": fov.to(dev), "inputs/counterfactuals_label": cf, "task": "irl"}
+            ld, _ = lm(td)
+            loss = sum(w * v for w, v in ld.values())
+            loss.backward()
+            res[tag] = (loss.detach().cpu(), {n: p.grad.detach().cpu() for n, p in rnet.named_parameters()})
+        torch.testing.assert_close(res["hip"][0], res["cpu"][0], rtol=1e-4, atol=1e-6)
+        for n in res["cpu"][1]:
+            a, b = res["hip"][1][n], res["cpu"][1][n]
+            assert _rms(a - b) <= 2e-3 * max(_rms(b), 1e-8) + 1e-9, n
+    finally:
+        creste_public_amd.set_precision("f32")
