@@ -108,7 +108,7 @@ class Camera2MapMulti(nn.Module):
         pts = xyz.reshape(BN // self.NC, -1, 3)
         fl = Act(fused.buf.view(BN // self.NC, self.NC * fused.H, fused.W, fused.cs), fused.C, fused.co, fused.amax)
         coords, bev, dens = ops.bev_splat(pts, fl, g["off"], g["vox"], gh, gw, self.min_weight, self.scatter_mode)
-        return dict(bev=bev, dens=dens, coords=coords, xyz=xyz, mask=mask, fused=fused)
+        return dict(bev=bev, dens=dens, coords=coords, xyz=xyz, mask=mask, fused=fused, fused_in=whole)
 
     def forward(self, x):
         assert len(x) >= 3, "Input must contain depth, features and camera projection matrix."
