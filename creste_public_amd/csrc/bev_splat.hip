@@ -6,12 +6,12 @@
 // The reference scatters: 8 scatter_add_ launches over a [B,F,P] tensor, a zero-filled [B,F,G]
 // accumulator, then a normalisation pass -- >= 3 passes over the 25 MB/frame BEV tensor plus
 // float atomics on a GPU.  Here the irregular part is reduced to INTEGER work on 4-byte keys:
-//   1. bin    : per point, voxel coords (bev_coords, bit-exact arithmetic), base cell (X0,Y0) on an
-//               extended (GH+1)x(GW+1) grid (X0,Y0 in [-1, G-1] still own in-grid taps), and its rank
-//               inside that cell (one int atomic on an L2-resident 264 KB/frame histogram)
-//   2. scan   : exclusive prefix sum of the histogram (one workgroup per frame)
-//   3. fill   : CSR list of point ids per base cell
-//   4. gather : each BEV cell visits the <=4 base cells whose taps land on it, in the reference's tap
+//   1. key    : per point, voxel coords (bev_coords, bit-exact arithmetic) and base cell (X0,Y0) on an
+//               extended (GH+1)x(GW+1) grid (X0,Y0 in [-1, G-1] still own in-grid taps)
+//      build  : a point's rank inside its cell (LDS atomic on a band histogram), the exclusive scan of the
+//               counts and the CSR fill -- one launch, no global atomics (splat_build_kernel)
+//   2. sort   : every cell's entries by point id, through LDS (splat_sort_rec_kernel)
+//   3. gather : each BEV cell visits the <=4 base cells whose taps land on it, in the reference's tap
 //               order (xd,yd) = (0,0),(0,1),(1,0),(1,1), accumulates w and w*f in registers, divides by
 //               max(density, min_weight) and writes its F channels exactly once (16-B stores).
 // HBM traffic = features read once (4x re-reads are L2 hits) + BEV written once = the algorithmic
@@ -26,6 +26,8 @@
 // `frac` pass is gone); (b) the gather loads the CSR ranges of its four cells with ONE load per lane, zero-fills empty
 // cells at once, fetches a whole batch of records with one 16-byte load per lane and keeps 8 feature rows in flight
 // per lane group (was 4 rows behind three dependent index loads).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace creste {
@@ -34,12 +36,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct SplatWork {
   int* key;      // [B*P]  extended base-cell id or -1
-  int* rank;     // [B*P]
-  int* count;    // [B*E]
-  int* offset;   // [B*(E+1)]
-  int* list;     // [B*P]
-  int* strip;    // [B*ceil(E/1024)] scan strip sums
-  int4* rec;     // [B*P]  {point id, frac x bits, frac y bits, 0} per CSR entry, in sorted list order
+  int* rank;     // [B*P]  a point's arrival rank inside its base cell (LDS atomic order)
+  int* offset;   // [B*(E+1)] CSR offsets of the extended base cells (exclusive scan of the per-cell counts)
+  int4* recu;    // [B*P]  {point id, frac x bits, frac y bits, 0} per CSR entry, arrival order inside a cell
+  int4* rec;     // [B*P]  the same, every cell's entries sorted by point id
 };
 
 static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -49,117 +49,238 @@ static SplatWork carve(void* work, int B, int P, int E) {
   SplatWork w;
   w.key = (int*)p;    p += align256((size_t)B * P * 4);
   w.rank = (int*)p;   p += align256((size_t)B * P * 4);
-  w.count = (int*)p;  p += align256((size_t)B * E * 4);
   w.offset = (int*)p; p += align256((size_t)B * (E + 1) * 4);
-  w.list = (int*)p;   p += align256((size_t)B * P * 4);
-  w.strip = (int*)p;  p += align256((size_t)B * ((E + 1023) / 1024) * 4);
+  w.recu = (int4*)p;  p += align256((size_t)B * P * 16);
   w.rec = (int4*)p;
   return w;
 }
 
-__global__ __launch_bounds__(256) void splat_bin_kernel(const float* __restrict__ xyz, long BP, int P,
-                                                        float off_x, float off_y, float vox_x,
-                                                        float vox_y, int GH, int GW,
-                                                        float* __restrict__ coords,
-                                                        int* __restrict__ key, int* __restrict__ rank,
-                                                        int* __restrict__ count) {
-  const int EW = GW + 1, E = (GH + 1) * (GW + 1);
+// Per point: voxel coordinates (bev_coords, one rounding per operation as the reference) and the extended base-cell id.
+__global__ __launch_bounds__(256) void splat_key_kernel(const float* __restrict__ xyz, long BP, float off_x,
+                                                        float off_y, float vox_x, float vox_y, int GH, int GW,
+                                                        float* __restrict__ coords, int* __restrict__ key) {
   for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < BP; g += (long)gridDim.x * blockDim.x) {
     const float x = xyz[g * 3 + 0], y = xyz[g * 3 + 1];
     // map = lidar2map @ [x,y,z,1]: rows (0,-1,0,off_x), (-1,0,0,off_y) -> one rounding each
     const float mx = __fadd_rn(-y, off_x), my = __fadd_rn(-x, off_y);
     const float X = __fdiv_rn(mx, vox_x), Y = __fdiv_rn(my, vox_y);
-    coords[g * 2 + 0] = X;
-    coords[g * 2 + 1] = Y;
+    *reinterpret_cast<float2*>(coords + g * 2) = make_float2(X, Y);
     const float fx = floorf(X), fy = floorf(Y);
     int k = -1;
-    if (fx >= -1.f && fx <= (float)(GW - 1) && fy >= -1.f && fy <= (float)(GH - 1)) {
-      const int b = (int)(g / P);
-      k = ((int)fy + 1) * EW + ((int)fx + 1);
-      rank[g] = atomicAdd(&count[(long)b * E + k], 1);
-    }
+    if (fx >= -1.f && fx <= (float)(GW - 1) && fy >= -1.f && fy <= (float)(GH - 1))
+      k = ((int)fy + 1) * (GW + 1) + ((int)fx + 1);
     key[g] = k;
   }
 }
 
-// offset[b][0..E] = exclusive scan of count[b][0..E), two launches over 1024-element strips:
-//   reduce: strip_sum[b][j] = sum of strip j            (grid = strips x frames, coalesced)
-//   apply : every strip adds the (<= 65) preceding strip sums to its local shuffle/LDS scan
-constexpr int SCAN_STRIP = 1024;
-__global__ __launch_bounds__(256) void splat_scan_reduce_kernel(const int* __restrict__ count,
-                                                                int* __restrict__ strip_sum, int E,
-                                                                int nstrip) {
-  __shared__ int ws[4];
-  const int b = blockIdx.y, j = blockIdx.x, t = threadIdx.x;
-  const int* c = count + (long)b * E + (long)j * SCAN_STRIP;
-  int s = 0;
-#pragma unroll
-  for (int k = 0; k < SCAN_STRIP / 256; ++k) {
-    const int i = k * 256 + t;
-    if (j * SCAN_STRIP + i < E) s += c[i];
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if ((t & 63) == 0) ws[t >> 6] = s;
+// Histogram + exclusive scan + CSR fill in ONE launch, without global atomics (round 1: memset + one device-scope
+// atomic per point + two scan launches + fill, ~50 us at batch 16).
+// A workgroup owns one BAND of extended base-cell rows of one frame: its histogram lives in LDS.  Every workgroup of a
+// frame walks the keys of ALL points of the frame (185 KB, L2 resident), keeps the ones in its band (rank = LDS atomic)
+// and COUNTS the ones in lower bands -- so the band's CSR base is known without any exchange between workgroups.  After
+// the in-LDS scan the offsets are final: they are written out and a second walk stores every kept point's record
+// {id, frac x, frac y} at offset + rank.
+constexpr int BUILD_THREADS = 1024, BUILD_MAX_CELLS = 8192;      // cells per band: <= 8 per thread, <= 14 bits
+__global__ __launch_bounds__(BUILD_THREADS) void splat_build_kernel(
+    const int* __restrict__ key, const float* __restrict__ coords, int P, int GH, int GW, int RPB,
+    int* __restrict__ rank, int* __restrict__ offset, int4* __restrict__ recu) {
+  extern __shared__ int s_hist[];                 // [band cells] counts, then absolute CSR offsets
+  __shared__ int s_wave[BUILD_THREADS / 64];
+  __shared__ int s_base;
+  const int q = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  const int EW = GW + 1, E = (GH + 1) * EW;
+  const int r0 = q * RPB, r1 = min(GH + 1, r0 + RPB);
+  const int k0 = r0 * EW, nk = (r1 - r0) * EW, k1 = k0 + nk;
+  for (int i = t; i < nk; i += BUILD_THREADS) s_hist[i] = 0;
   __syncthreads();
-  if (t == 0) strip_sum[(long)b * nstrip + j] = ws[0] + ws[1] + ws[2] + ws[3];
-}
-
-__global__ __launch_bounds__(1024) void splat_scan_apply_kernel(const int* __restrict__ count,
-                                                                const int* __restrict__ strip_sum,
-                                                                int* __restrict__ offset, int E, int nstrip) {
-  __shared__ int wsum[16];
-  __shared__ int base_s;
-  const int b = blockIdx.y, j = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (wave == 0) {                                   // prefix of the preceding strips (nstrip <= 128)
+  const int* kb = key + (long)b * P;
+  int* rk = rank + (long)b * P;
+  int lower = 0;
+  for (int g0 = t; g0 < P; g0 += 4 * BUILD_THREADS) {          // four points per trip: the loads are in flight together
+    int ks[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ks[u] = kb[min(g0 + u * BUILD_THREADS, P - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int g = g0 + u * BUILD_THREADS;
+      if (g < P && ks[u] >= 0) {
+        if (ks[u] < k0) ++lower;
+        else if (ks[u] < k1) rk[g] = atomicAdd(&s_hist[ks[u] - k0], 1);
+      }
+    }
+  }
+  // base = number of kept points of the frame in lower bands
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) lower += __shfl_xor(lower, o);
+  if ((t & 63) == 0) s_wave[t >> 6] = lower;
+  __syncthreads();                                 // also: histogram complete
+  if (t == 0) {
     int v = 0;
-    for (int k = lane; k < j; k += 64) v += strip_sum[(long)b * nstrip + k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if (lane == 0) base_s = v;
+    for (int i = 0; i < BUILD_THREADS / 64; ++i) v += s_wave[i];
+    s_base = v;
   }
-  const int i = j * SCAN_STRIP + t;
-  const int v = i < E ? count[(long)b * E + i] : 0;
-  int inc = v;
+  // exclusive scan of the band's counts: each thread owns IPT consecutive cells
+  const int IPT = (nk + BUILD_THREADS - 1) / BUILD_THREADS;
+  const int i0 = t * IPT, i1 = min(nk, i0 + IPT);
+  int mine = 0;
+  for (int i = i0; i < i1; ++i) mine += s_hist[i];
+  int inc = mine;
+  const int lane = t & 63, wave = t >> 6;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int up = __shfl_up(inc, d);
-    if (lane >= d) inc += up;
+  for (int dd = 1; dd < 64; dd <<= 1) {
+    const int up = __shfl_up(inc, dd);
+    if (lane >= dd) inc += up;
   }
-  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();                                 // s_base written, s_wave free again
+  const int base = s_base;
   __syncthreads();
-  int wave_off = 0;
-  for (int w = 0; w < wave; ++w) wave_off += wsum[w];
-  int* o = offset + (long)b * (E + 1);
-  if (i < E) o[i] = base_s + wave_off + inc - v;
-  if (i == E - 1) o[E] = base_s + wave_off + inc;
-}
-
-__global__ __launch_bounds__(256) void splat_fill_kernel(const int* __restrict__ key,
-                                                         const int* __restrict__ rank,
-                                                         const int* __restrict__ offset,
-                                                         int* __restrict__ list, long BP, int P, int E) {
-  for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < BP; g += (long)gridDim.x * blockDim.x) {
-    const int k = key[g];
-    if (k < 0) continue;
-    const int b = (int)(g / P);
-    list[(long)b * P + offset[(long)b * (E + 1) + k] + rank[g]] = (int)(g % P);
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  int run = base + inc - mine;
+  for (int w = 0; w < wave; ++w) run += s_wave[w];
+  int* ob = offset + (long)b * (E + 1) + k0;
+  for (int i = i0; i < i1; ++i) {
+    const int c = s_hist[i];
+    s_hist[i] = run;
+    ob[i] = run;
+    run += c;
+  }
+  if (r1 == GH + 1 && i1 == nk && i0 < i1) ob[nk] = run;       // offset[E]: the thread owning the last cell
+  __syncthreads();
+  int4* ru = recu + (long)b * P;
+  const float* cb = coords + (long)b * P * 2;
+  for (int g0 = t; g0 < P; g0 += 4 * BUILD_THREADS) {
+    int ks[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ks[u] = kb[min(g0 + u * BUILD_THREADS, P - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int g = g0 + u * BUILD_THREADS;
+      if (g < P && ks[u] >= k0 && ks[u] < k1) {
+        const float2 c = *reinterpret_cast<const float2*>(cb + (long)g * 2);
+        int4 r;
+        r.x = g;
+        r.y = __float_as_int(__fsub_rn(c.x, floorf(c.x)));
+        r.z = __float_as_int(__fsub_rn(c.y, floorf(c.y)));
+        r.w = 0;
+        ru[s_hist[ks[u] - k0] + rk[g]] = r;
+      }
+    }
   }
 }
 
-// Sort every base cell's list by point id and emit the gather's entry records.  One workgroup owns SORT_CELLS
-// consecutive extended cells of one frame = ONE contiguous chunk of the CSR list: the chunk is copied to LDS (coalesced),
-// every entry finds its rank inside its own cell's list as the number of smaller ids (LDS reads; the lanes of a wave
-// mostly scan the same list -> broadcasts), and is written straight to its sorted slot together with its record
-// {id, frac(X), frac(Y)} (the gather then needs ONE 16-byte load per entry instead of id -> coords chains).
-// A 43-entry list costs 43 LDS reads per entry; the old kernel walked heavy lists one at a time per wave through
-// global memory (a crowded wave: 64 lists x ~1.5 us -- the kernel's critical path, 84 us at batch 16).
-// Chunks beyond SORT_CAP entries (degenerate pile-ups) fall back to a one-thread insertion sort per list in global
-// memory up to kMaxSortedList entries; longer lists stay in atomic order (still the exact set).
+// The same with every point's key (then its packed {rank, cell}) held in REGISTERS: KPT points per thread, all key loads
+// in flight at once, no rank array, no second walk over the keys -- the generic kernel above pays two dependent global
+// round trips per four points (41 us at batch 16); this one pays one for the keys and one for the kept points' coords.
+// Needs P <= KPT * 1024 and P <= 65536 (rank << 14 | cell must fit an int).
+template <int KPT>
+__global__ __launch_bounds__(BUILD_THREADS) void splat_build_reg_kernel(
+    const int* __restrict__ key, const float* __restrict__ coords, int P, int GH, int GW, int RPB,
+    int* __restrict__ offset, int4* __restrict__ recu) {
+  extern __shared__ int s_hist[];                  // [nk] counts -> absolute CSR offsets
+  __shared__ int s_wave[BUILD_THREADS / 64];
+  const int q = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  const int EW = GW + 1, E = (GH + 1) * EW;
+  const int r0 = q * RPB, r1 = min(GH + 1, r0 + RPB);
+  const int k0 = r0 * EW, nk = (r1 - r0) * EW;
+  const int* kb = key + (long)b * P;
+  int pk[KPT];
+#pragma unroll
+  for (int u = 0; u < KPT; ++u) {
+    const int g = t + u * BUILD_THREADS;
+    pk[u] = g < P ? kb[g] : -1;
+  }
+  for (int i = t; i < nk; i += BUILD_THREADS) s_hist[i] = 0;
+  __syncthreads();
+  // (an all-lanes, branch-free form -- lanes outside the band adding 0 to a per-lane sink slot -- measured SLOWER:
+  // 39.8 vs 29.2 us; LDS atomics with a return value cost per active lane)
+  int lower = 0;
+#pragma unroll
+  for (int u = 0; u < KPT; ++u) {
+    const int k = pk[u];
+    lower += (unsigned)k < (unsigned)k0 ? 1 : 0;       // k == -1 compares as a huge unsigned
+    const unsigned rel = (unsigned)(k - k0);
+    int v = -1;
+    if (rel < (unsigned)nk) v = (atomicAdd(&s_hist[rel], 1) << 14) | (int)rel;
+    pk[u] = v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) lower += __shfl_xor(lower, o);
+  if ((t & 63) == 0) s_wave[t >> 6] = lower;
+  __syncthreads();                                 // also: histogram complete
+  int base = 0;
+#pragma unroll
+  for (int i = 0; i < BUILD_THREADS / 64; ++i) base += s_wave[i];
+  // exclusive scan of the band's counts: thread t owns cells [t*IPT, (t+1)*IPT), IPT <= 8
+  const int IPT = (nk + BUILD_THREADS - 1) / BUILD_THREADS;
+  const int i0 = t * IPT;
+  int cnt[8];
+  int mine = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    cnt[j] = (j < IPT && i0 + j < nk) ? s_hist[i0 + j] : 0;
+    mine += cnt[j];
+  }
+  int inc = mine;
+  const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+  for (int dd = 1; dd < 64; dd <<= 1) {
+    const int up = __shfl_up(inc, dd);
+    if (lane >= dd) inc += up;
+  }
+  __syncthreads();                                 // every thread has read s_wave and its counts
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  int run = base + inc - mine;
+  for (int w = 0; w < wave; ++w) run += s_wave[w];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j < IPT && i0 + j < nk) s_hist[i0 + j] = run;
+    run += cnt[j];
+  }
+  int* ob = offset + (long)b * (E + 1) + k0;
+  if (r1 == GH + 1 && t == BUILD_THREADS - 1) ob[nk] = run;    // offset[E] (trailing threads carry the total)
+  __syncthreads();
+  for (int i = t; i < nk; i += BUILD_THREADS) ob[i] = s_hist[i];          // coalesced
+  int4* ru = recu + (long)b * P;
+  const float* cb = coords + (long)b * P * 2;
+  // kept points: coordinates are fetched eight at a time BEFORE the first record is formed (a load inside each
+  // point's own branch would serialise 48 round trips)
+#pragma unroll
+  for (int u0 = 0; u0 < KPT; u0 += 8) {
+    float2 c[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      c[j] = make_float2(0.f, 0.f);
+      if (u0 + j < KPT && pk[u0 + j] >= 0)
+        c[j] = *reinterpret_cast<const float2*>(cb + (long)(t + (u0 + j) * BUILD_THREADS) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (u0 + j < KPT && pk[u0 + j] >= 0) {
+        int4 r;
+        r.x = t + (u0 + j) * BUILD_THREADS;
+        r.y = __float_as_int(__fsub_rn(c[j].x, floorf(c[j].x)));
+        r.z = __float_as_int(__fsub_rn(c[j].y, floorf(c[j].y)));
+        r.w = 0;
+        ru[s_hist[pk[u0 + j] & 16383] + (pk[u0 + j] >> 14)] = r;
+      }
+    }
+  }
+}
+
+// Sort every base cell's entries by point id.  One workgroup owns SORT_CELLS consecutive extended cells of one frame
+// = ONE contiguous chunk of the CSR: every thread loads one 16-byte record of the chunk (coalesced), the ids go to
+// LDS, every entry finds its rank inside its own cell's list as the number of smaller ids (LDS reads; the lanes of a
+// wave mostly scan the same list -> broadcasts) and its record is written straight to its sorted slot.  A 43-entry list
+// costs 43 LDS reads per entry; round 1 walked heavy lists one at a time per wave through global memory (a crowded
+// wave: 64 lists x ~1.5 us -- that kernel's critical path, 84 us at batch 16).
+// Chunks beyond SORT_CAP entries (degenerate pile-ups) rank through global memory; lists beyond kMaxSortedList entries
+// stay in arrival order (still the exact set).
 constexpr int kMaxSortedList = 2048;
 constexpr int SORT_CELLS = 128, SORT_CAP = 6144;
-__global__ __launch_bounds__(256) void splat_sort_rec_kernel(const int* __restrict__ offset, int* __restrict__ list,
-                                                             const float* __restrict__ coords,
+__global__ __launch_bounds__(256) void splat_sort_rec_kernel(const int* __restrict__ offset,
+                                                             const int4* __restrict__ recu,
                                                              int4* __restrict__ rec, int P, int E) {
   __shared__ int s_off[SORT_CELLS + 1];
   __shared__ int s_ids[SORT_CAP];
@@ -171,47 +292,36 @@ __global__ __launch_bounds__(256) void splat_sort_rec_kernel(const int* __restri
   __syncthreads();
   const int lo0 = s_off[0], n = s_off[nc] - lo0;
   if (n == 0) return;
-  int* l = list + (long)b * P;
-  int4* rb = rec + (long)b * P;
-  const float* cb = coords + (long)b * P * 2;
-  auto emit = [&](int pos, int id) __attribute__((always_inline)) {
-    const float Xf = cb[(long)id * 2 + 0], Yf = cb[(long)id * 2 + 1];
-    int4 r;
-    r.x = id;
-    r.y = __float_as_int(__fsub_rn(Xf, floorf(Xf)));
-    r.z = __float_as_int(__fsub_rn(Yf, floorf(Yf)));
-    r.w = 0;
-    rb[pos] = r;
-  };
+  const int4* ru = recu + (long)b * P + lo0;
+  int4* ro = rec + (long)b * P + lo0;
   if (n <= SORT_CAP) {
-    for (int e = t; e < n; e += 256) s_ids[e] = l[lo0 + e];
+    for (int e = t; e < n; e += 256) s_ids[e] = ru[e].x;
     if (t < nc)
       for (int e = s_off[t] - lo0; e < s_off[t + 1] - lo0; ++e) s_cell[e] = (unsigned char)t;
     __syncthreads();
     for (int e = t; e < n; e += 256) {
+      const int4 r = ru[e];
       const int c = s_cell[e], a = s_off[c] - lo0, z = s_off[c + 1] - lo0;
-      const int v = s_ids[e];
-      int rank = 0;
-      if (z - a <= kMaxSortedList)
-        for (int j = a; j < z; ++j) rank += s_ids[j] < v ? 1 : 0;          // ids of a list are distinct
-      else
-        rank = e - a;                                                      // degenerate list: atomic order
-      const int pos = lo0 + a + rank;
-      l[pos] = v;
-      emit(pos, v);
+      int rnk = e - a;                                                     // degenerate list: arrival order
+      if (z - a <= kMaxSortedList) {
+        rnk = 0;
+        for (int j = a; j < z; ++j) rnk += s_ids[j] < r.x ? 1 : 0;         // ids of a list are distinct
+      }
+      ro[a + rnk] = r;
     }
     return;
   }
-  if (t < nc) {                       // oversized chunk: serial insertion sort per list, in place
-    const int a = s_off[t], z = s_off[t + 1];
-    if (z - a >= 2 && z - a <= kMaxSortedList)
-      for (int i = a + 1; i < z; ++i) {
-        const int v = l[i];
-        int j = i - 1;
-        while (j >= a && l[j] > v) { l[j + 1] = l[j]; --j; }
-        l[j + 1] = v;
+  if (t < nc) {                       // oversized chunk: one thread per list, ranks through global memory
+    const int a = s_off[t] - lo0, z = s_off[t + 1] - lo0;
+    for (int e = a; e < z; ++e) {
+      const int4 r = ru[e];
+      int rnk = e - a;
+      if (z - a <= kMaxSortedList) {
+        rnk = 0;
+        for (int j = a; j < z; ++j) rnk += ru[j].x < r.x ? 1 : 0;
       }
-    for (int i = a; i < z; ++i) emit(i, l[i]);
+      ro[a + rnk] = r;
+    }
   }
 }
 
@@ -225,8 +335,9 @@ __global__ __launch_bounds__(256) void splat_sort_rec_kernel(const int* __restri
 // crowded blob of cells is spread over all groups.  Per entry: one broadcast 16-byte record load (id, frac x, frac y),
 // NQ feature loads; SPLAT_ROWS entries are in flight per lane group.  Sums run in the reference's order (tap-major,
 // point id ascending) -- bit-identical to the CPU scatter_add_.
-constexpr int SPLAT_ROWS = 4;    // entries (feature rows) in flight per lane group
-template <int NQ, int MODE>
+// (tuning: rows in flight per lane group = template parameter ROWS)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int NQ, int MODE, int ROWS>
 __global__ __launch_bounds__(256) void splat_gather8_kernel(
     const float* __restrict__ feats, int feats_cs, const int4* __restrict__ rec, const int* __restrict__ offset,
     int B, int P, int GH, int GW, float min_weight, float* __restrict__ bev, float* __restrict__ dens) {
@@ -254,37 +365,56 @@ __global__ __launch_bounds__(256) void splat_gather8_kernel(
     const int l3 = s_off[X], c3 = l1 - l3;
     const int c01 = c0 + c1, c012 = c01 + c2, T = c012 + c3;
     const int d1 = l1 - c0, d2 = l2 - c01, d3 = l3 - c012;      // list index = e + d_tap
-    f32x4 acc[NQ];
+    f32x2 acc[NQ][2];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < NQ; ++q) acc[q][0] = acc[q][1] = f32x2{0.f, 0.f};
     float d = 0.f;
-    for (int e0 = 0; e0 < T; e0 += SPLAT_ROWS) {
-      f32x4 f[SPLAT_ROWS][NQ];
-      float w[SPLAT_ROWS];
+    // the record (id, frac x, frac y) of entry e of the concatenated tap lists, and its tap weight; entries past the
+    // end repeat the last one (a valid load) and are never accumulated.  Records are fetched ONE STEP AHEAD of the
+    // feature rows they address, so a step's chain is one load latency, not two.
+    int rid[ROWS];
+    float rw[ROWS];
+#define CRESTE_SPLAT_FETCH(E0)                                                                    \
+  _Pragma("unroll") for (int u = 0; u < ROWS; ++u) {                                              \
+    const int e = min((E0) + u, T - 1);                                                           \
+    const bool t1 = e >= c0, t2 = e >= c01, t3 = e >= c012;                                       \
+    const int4 r = rb[e + (t3 ? d3 : t2 ? d2 : t1 ? d1 : l0)];                                    \
+    const float rX = __int_as_float(r.y), rY = __int_as_float(r.z);                               \
+    const float wX = t2 ? rX : __fsub_rn(1.f, rX);                      /* xd = tap >> 1 */       \
+    const float wY = ((t1 && !t2) || t3) ? rY : __fsub_rn(1.f, rY);     /* yd = tap & 1 */        \
+    rid[u] = r.x * feats_cs;                                                                      \
+    rw[u] = __fmul_rn(wX, wY);                                                                    \
+  }
+    if (T > 0) { CRESTE_SPLAT_FETCH(0) }
+    for (int e0 = 0; e0 < T; e0 += ROWS) {
+      f32x4 f[ROWS][NQ];
+      float w[ROWS];
 #pragma unroll
-      for (int u = 0; u < SPLAT_ROWS; ++u) {
-        const int e = min(e0 + u, T - 1);                         // past the end: a valid entry, never accumulated
-        const int t1 = e >= c0, t2 = e >= c01, t3 = e >= c012;
-        const int idx = e + (t3 ? d3 : t2 ? d2 : t1 ? d1 : l0);
-        const int4 r = rb[idx];
-        const float rX = __int_as_float(r.y), rY = __int_as_float(r.z);
-        const float wX = t2 ? rX : __fsub_rn(1.f, rX);            // xd = tap >> 1
-        const float wY = (t1 != t2 || t3) ? rY : __fsub_rn(1.f, rY);   // yd = tap & 1: taps 1 and 3
-        w[u] = __fmul_rn(wX, wY);
-        const float* fr = fb + (unsigned)(r.x * feats_cs);
+      for (int u = 0; u < ROWS; ++u) {
+        w[u] = rw[u];
+        const float* fr = fb + (unsigned)rid[u];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) f[u][q] = *reinterpret_cast<const f32x4*>(fr + q * 32);
       }
+      if (e0 + ROWS < T) { CRESTE_SPLAT_FETCH(e0 + ROWS) }
 #pragma unroll
-      for (int u = 0; u < SPLAT_ROWS; ++u) {
+      for (int u = 0; u < ROWS; ++u) {
         if (e0 + u < T) {
           d = __fadd_rn(d, w[u]);
+          const f32x2 w2 = {w[u], w[u]};
 #pragma unroll
           for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[q][j] = MODE == 2 ? fmaxf(acc[q][j], __fmul_rn(w[u], f[u][q][j]))
-                                    : __fadd_rn(acc[q][j], __fmul_rn(w[u], f[u][q][j]));
+            for (int h = 0; h < 2; ++h) {
+              const f32x2 fv = {f[u][q][2 * h], f[u][q][2 * h + 1]};
+              if (MODE == 2) {
+                acc[q][h][0] = fmaxf(acc[q][h][0], __fmul_rn(w[u], fv[0]));
+                acc[q][h][1] = fmaxf(acc[q][h][1], __fmul_rn(w[u], fv[1]));
+              } else {
+                const f32x2 pr = w2 * fv;              // v_pk_mul_f32 then v_pk_add_f32 (-ffp-contract=off): the same
+                acc[q][h] = acc[q][h] + pr;            // two IEEE roundings per element as the scalar form
+              }
+            }
         }
       }
     }
@@ -293,11 +423,12 @@ __global__ __launch_bounds__(256) void splat_gather8_kernel(
     for (int q = 0; q < NQ; ++q) {
       f32x4 o;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = MODE == 0 ? __fdiv_rn(acc[q][j], den) : acc[q][j];
+      for (int j = 0; j < 4; ++j) o[j] = MODE == 0 ? __fdiv_rn(acc[q][j >> 1][j & 1], den) : acc[q][j >> 1][j & 1];
       *reinterpret_cast<f32x4*>(orow + (long)X * F + q * 32) = o;
     }
     if (l == 0) drow[X] = d;
   }
+#undef CRESTE_SPLAT_FETCH
 }
 
 // Generic path (any F <= 256 that is a multiple of 4): LANES >= F/4 lanes per cell, SPLAT_CPG consecutive cells per lane
@@ -394,9 +525,7 @@ using namespace creste;
 extern "C" int64_t creste_bev_splat_workspace_bytes(int B, int P, int GH, int GW) {
   if (B <= 0 || P <= 0 || GH <= 0 || GW <= 0) return -1;
   const int E = (GH + 1) * (GW + 1);
-  return (int64_t)(3 * align256((size_t)B * P * 4) + align256((size_t)B * E * 4) +
-                   align256((size_t)B * (E + 1) * 4) + align256((size_t)B * ((E + 1023) / 1024) * 4) +
-                   align256((size_t)B * P * 16));
+  return (int64_t)(2 * align256((size_t)B * P * 4) + align256((size_t)B * (E + 1) * 4) + 2 * align256((size_t)B * P * 16));
 }
 
 extern "C" int creste_bev_splat_mode_f32(const float* xyz, const float* feats, int feats_cs, int B, int P,
@@ -414,18 +543,34 @@ extern "C" int creste_bev_splat_mode_f32(const float* xyz, const float* feats, i
   const long BP = (long)B * P;
   hipStream_t s = (hipStream_t)stream;
   SplatWork w = carve(work, B, P, E);
-  CRESTE_HIP(hipMemsetAsync(w.count, 0, (size_t)B * E * 4, s));
-  const int g1 = (int)((BP + 255) / 256 > 4096 ? 4096 : (BP + 255) / 256);
-  splat_bin_kernel<<<g1, 256, 0, s>>>(xyz, BP, P, off_x, off_y, vox_x, vox_y, GH, GW, coords, w.key,
-                                      w.rank, w.count);
-  CRESTE_CHECK_LAUNCH("splat_bin");
-  const int nstrip = (E + SCAN_STRIP - 1) / SCAN_STRIP;
-  splat_scan_reduce_kernel<<<dim3(nstrip, B), 256, 0, s>>>(w.count, w.strip, E, nstrip);
-  splat_scan_apply_kernel<<<dim3(nstrip, B), 1024, 0, s>>>(w.count, w.strip, w.offset, E, nstrip);
-  CRESTE_CHECK_LAUNCH("splat_scan");
-  splat_fill_kernel<<<g1, 256, 0, s>>>(w.key, w.rank, w.offset, w.list, BP, P, E);
-  CRESTE_CHECK_LAUNCH("splat_fill");
-  splat_sort_rec_kernel<<<dim3((E + SORT_CELLS - 1) / SORT_CELLS, B), 256, 0, s>>>(w.offset, w.list, coords, w.rec, P, E);
+  {
+    // bands of extended rows: as many workgroups as the chip has CUs, at most BUILD_MAX_CELLS cells of LDS each
+    const int EW = GW + 1;
+    int want = 256 / B;
+    if (want < 1) want = 1;
+    int rpb = (GH + 1 + want - 1) / want;                       // rows per band
+    const int cap_rows = BUILD_MAX_CELLS / EW;
+    CRESTE_REQUIRE(cap_rows >= 1, "bev_splat: grid width %d too large for the LDS histogram", GW);
+    if (rpb > cap_rows) rpb = cap_rows;
+    if (rpb < 1) rpb = 1;
+    const int Q = (GH + 1 + rpb - 1) / rpb;
+    const size_t smem = (size_t)rpb * EW * sizeof(int);
+    const int g1 = (int)((BP + 255) / 256 > 8192 ? 8192 : (BP + 255) / 256);
+    splat_key_kernel<<<g1, 256, 0, s>>>(xyz, BP, off_x, off_y, vox_x, vox_y, GH, GW, coords, w.key);
+    CRESTE_CHECK_LAUNCH("splat_key");
+    const int kpt = (P + BUILD_THREADS - 1) / BUILD_THREADS;
+    static_assert(BUILD_MAX_CELLS <= 16384, "the packed {rank, cell} word keeps 14 bits for the cell");
+    if (P <= 65536 && kpt <= 16)
+      splat_build_reg_kernel<16><<<dim3(Q, B), BUILD_THREADS, smem, s>>>(w.key, coords, P, GH, GW, rpb, w.offset, w.recu);
+    else if (P <= 65536 && kpt <= 32)
+      splat_build_reg_kernel<32><<<dim3(Q, B), BUILD_THREADS, smem, s>>>(w.key, coords, P, GH, GW, rpb, w.offset, w.recu);
+    else if (P <= 65536 && kpt <= 48)
+      splat_build_reg_kernel<48><<<dim3(Q, B), BUILD_THREADS, smem, s>>>(w.key, coords, P, GH, GW, rpb, w.offset, w.recu);
+    else
+      splat_build_kernel<<<dim3(Q, B), BUILD_THREADS, smem, s>>>(w.key, coords, P, GH, GW, rpb, w.rank, w.offset, w.recu);
+    CRESTE_CHECK_LAUNCH("splat_build");
+  }
+  splat_sort_rec_kernel<<<dim3((E + SORT_CELLS - 1) / SORT_CELLS, B), 256, 0, s>>>(w.offset, w.recu, w.rec, P, E);
   CRESTE_CHECK_LAUNCH("splat_sort_rec");
   const long ncell = (long)B * GH * GW;
   const int fq = F / 4;
@@ -433,15 +578,23 @@ extern "C" int creste_bev_splat_mode_f32(const float* xyz, const float* feats, i
     const int rows = B * GH;
     const size_t smem = 2 * (size_t)(GW + 2) * sizeof(int);
     CRESTE_REQUIRE(smem <= 64 * 1024, "bev_splat: grid width %d too large for the offset staging", GW);
-#define CRESTE_SPLAT_G8(NQ, M) splat_gather8_kernel<NQ, M><<<rows, 256, smem, s>>>(feats, feats_cs, w.rec, w.offset, B, P, GH, GW, min_weight, bev, dens)
-#define CRESTE_SPLAT_G8M(NQ)                                                     \
-    {                                                                            \
-      if (mode == CRESTE_SPLAT_MEAN) CRESTE_SPLAT_G8(NQ, 0);                     \
-      else if (mode == CRESTE_SPLAT_SUM) CRESTE_SPLAT_G8(NQ, 1);                 \
-      else CRESTE_SPLAT_G8(NQ, 2);                                               \
-    }
-    if (F == 32) CRESTE_SPLAT_G8M(1) else if (F == 64) CRESTE_SPLAT_G8M(2) else if (F == 96) CRESTE_SPLAT_G8M(3) else CRESTE_SPLAT_G8M(4)
+    static const int rif = getenv("CRESTE_SPLAT_ROWS") ? atoi(getenv("CRESTE_SPLAT_ROWS")) : 4;     // tuning knob
+#define CRESTE_SPLAT_G8(NQ, M, R) \
+  splat_gather8_kernel<NQ, M, R><<<rows, 256, smem, s>>>(feats, feats_cs, w.rec, w.offset, B, P, GH, GW, min_weight, bev, dens)
+#define CRESTE_SPLAT_G8R(NQ, M)                                                                         \
+    do {                                                                                                \
+      if (rif == 2) CRESTE_SPLAT_G8(NQ, M, 2); else if (rif == 3) CRESTE_SPLAT_G8(NQ, M, 3); else if (rif == 6) CRESTE_SPLAT_G8(NQ, M, 6); \
+      else if (rif == 8) CRESTE_SPLAT_G8(NQ, M, 8); else CRESTE_SPLAT_G8(NQ, M, 4);                     \
+    } while (0)
+#define CRESTE_SPLAT_G8M(NQ)                                                                            \
+    do {                                                                                                \
+      if (mode == CRESTE_SPLAT_MEAN) CRESTE_SPLAT_G8R(NQ, 0);                                           \
+      else if (mode == CRESTE_SPLAT_SUM) CRESTE_SPLAT_G8R(NQ, 1);                                       \
+      else CRESTE_SPLAT_G8R(NQ, 2);                                                                     \
+    } while (0)
+    if (F == 32) CRESTE_SPLAT_G8M(1); else if (F == 64) CRESTE_SPLAT_G8M(2); else if (F == 96) CRESTE_SPLAT_G8M(3); else CRESTE_SPLAT_G8M(4);
 #undef CRESTE_SPLAT_G8M
+#undef CRESTE_SPLAT_G8R
 #undef CRESTE_SPLAT_G8
     CRESTE_CHECK_LAUNCH("splat_gather8");
     return CRESTE_OK;
