@@ -119,7 +119,7 @@ class ConvProfiler:
         return by
 
 
-def cpu_baseline(batches=(1, 16), runs=5, budget_s=150.0):
+def cpu_baseline(batches=(1, 16), runs=5, budget_s=210.0):
     """The oracle (CPU restatement of the reference's PyTorch path) on this host's cores: batch 1 and batch 16,
     median of `runs` timed runs after 1 warm-up each (SURVEY 8d / BASELINE.md section 2).  `value` is the better of the
     two batch sizes in frames/s.  `budget_s` bounds the batch-16 leg: if its warm-up shows that `runs` runs would not

@@ -38,6 +38,12 @@ print(f"# full-size e2e noise, B={B} frames of {W}x{H}; {B * (H // 4) * (W // 4)
       f"{float((ref['bev_densities'] > 0).float().mean()):.3f}\n")
 print(f"voxel-cell flips vs float64: cpu-fp32 {flips(ref['bev_coords'])}, " +
       ", ".join(f"hip-{k} {flips(v['bev_coords'])}" for k, v in outs.items()) + "\n")
+def q999(err):
+    x = err.abs().flatten()
+    if x.numel() > 2_000_000:
+        x = x[::max(1, x.numel() // 2_000_000)]
+    return float(torch.kthvalue(x, max(1, int(0.999 * x.numel()))).values)
+print("rms error vs float64:\n")
 print("| key | rms(f64) | cpu fp32 | hip f32 | hip bf16x6 | hip f16x3 |\n|---|---|---|---|---|---|")
 for k, t in ref64.items():
     if k.startswith("_") or not torch.is_tensor(t) or not t.is_floating_point():
@@ -45,3 +51,16 @@ for k, t in ref64.items():
     t = t.double()
     row = [f"{_rms(t):.3e}", f"{_rms(ref[k].double() - t):.3e}"] + [f"{_rms(outs[mo][k].double() - t):.3e}" for mo in outs]
     print(f"| {k} | " + " | ".join(row) + " |")
+def quant(err, q):
+    x = err.abs().flatten()
+    if x.numel() > 2_000_000:
+        x = x[::max(1, x.numel() // 2_000_000)]
+    return float(torch.kthvalue(x, max(1, int(q * x.numel()))).values)
+for q in (0.5, 0.9, 0.999):
+    print(f"\n{q}-quantile of |error| vs float64\n\n| key | cpu fp32 | hip f32 | hip bf16x6 | hip f16x3 |\n|---|---|---|---|---|")
+    for k, t in ref64.items():
+        if k.startswith("_") or not torch.is_tensor(t) or not t.is_floating_point():
+            continue
+        t = t.double()
+        row = [f"{quant(ref[k].double() - t, q):.3e}"] + [f"{quant(outs[mo][k].double() - t, q):.3e}" for mo in outs]
+        print(f"| {k} | " + " | ".join(row) + " |")
