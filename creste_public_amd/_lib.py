@@ -52,6 +52,8 @@ SIGNATURES = {
                                               _f, _f, _vp, _vp]),
     "creste_maxpool2_nhwc_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "creste_maxpool_nhwc_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "creste_fill_u32": (_i, [_vp, C.c_uint32, _i64, _vp]),
+    "creste_max2_f32": (_i, [_vp, _vp, _vp, _vp]),
     "creste_affine_act_nhwc_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
     "creste_resize_plane_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _f, _f, _vp]),
     "creste_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -106,16 +108,70 @@ SIGNATURES = {
     "creste_multipos_con_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "creste_expected_svf_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp,
                                       _vp]),
+    "creste_hip_model_load": (_i, [C.c_char_p, _i, C.POINTER(_vp)]),
+    "creste_hip_model_free": (_i, [_vp]),
+    "creste_hip_model_info": (C.c_char_p, [_vp]),
+    "creste_hip_model_num_inputs": (_i, [_vp]),
+    "creste_hip_model_num_outputs": (_i, [_vp]),
+    "creste_hip_model_input": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i),
+                                    C.POINTER(_i64), C.POINTER(_i64)]),
+    "creste_hip_model_output": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i),
+                                     C.POINTER(_i64), C.POINTER(_i64)]),
+    "creste_hip_model_infer": (_i, [_vp, C.POINTER(_vp), _i, _vp]),
+    "creste_hip_memcpy_d2h": (_i, [_vp, _vp, _i64]),
 }
 
 _lib = None
+_recorder = None          # a list while deploy.export_plan traces a forward: (name, args) of every launching call
+
+
+class _RecordingLib:
+    """The ctypes handle with every LAUNCHING entry point (int return, trailing stream argument) wrapped: the call is
+    appended to the active recorder -- scalar arguments by value, a creste_conv_desc by a copy of its bytes -- and then
+    executed.  Host-side queries (workspace sizes, `*_supported`) pass through unrecorded."""
+
+    def __init__(self, lib, rec):
+        self._lib_, self._rec = lib, rec
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib_, name)
+        sig = SIGNATURES.get(name)
+        if sig is None or not is_launch(name):
+            return fn
+        rec = self._rec
+
+        def call(*args):
+            saved = []
+            for a, ty in zip(args[:-1], sig[1][:-1]):
+                if ty in (_vp,):
+                    saved.append(("p", int(a) if a is not None else 0))
+                elif ty in (_i, C.c_uint32):
+                    saved.append(("i", int(a)))
+                elif ty is _i64:
+                    saved.append(("l", int(a)))
+                elif ty is _f:
+                    saved.append(("f", float(a)))
+                elif ty is C.c_double:
+                    saved.append(("d", float(a)))
+                else:                                   # byref(ConvDesc)
+                    saved.append(("desc", bytes(a._obj)))
+            rec.append((name, saved))
+            return fn(*args)
+        return call
+
+
+def is_launch(name: str) -> bool:
+    """Entry points that launch work on a stream: int return and a trailing void* stream (csrc/plan_dispatch.inc)."""
+    res, args = SIGNATURES[name]
+    return (res is _i and bool(args) and args[-1] is _vp and not name.startswith("creste_hip_model")
+            and name not in ("creste_conv_supported", "creste_conv_supported_upsample", "creste_se_partial_count"))
 
 
 def load(path: str | None = None):
     """Load (once) and return the ctypes handle; raises HipLibraryError when unavailable."""
     global _lib
     if _lib is not None:
-        return _lib
+        return _lib if _recorder is None else _RecordingLib(_lib, _recorder)
     # torch ships its own libamdhip64; it must be in the process BEFORE this library is opened so that
     # both share ONE HIP runtime (otherwise the kernels register with a second runtime that owns no
     # device: "no ROCm-capable device is detected").

@@ -19,7 +19,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libcreste_hip.so")
 ARCH = "gfx950"
-SOURCES = ["error.cpp", "conv_igemm.hip", "conv_patch.hip", "pointwise.hip", "bev_splat.hip", "value_iteration.hip",
+SOURCES = ["error.cpp", "plan_runtime.cpp", "conv_igemm.hip", "conv_patch.hip", "pointwise.hip", "bev_splat.hip", "value_iteration.hip",
            "svf.hip", "lidar.hip", "train.hip", "train_backbone.hip", "losses.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}",
          "-Wall", "-Wno-unused-function"]
@@ -33,7 +33,7 @@ def _hipcc() -> str:
 
 
 def _deps_mtime() -> float:
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hdrs.append(os.path.join(HERE, "..", "include", "creste_hip.h"))
     return max(os.path.getmtime(h) for h in hdrs)
 

@@ -98,7 +98,7 @@ class Camera2MapMulti(nn.Module):
                                        fbuf.slice(F, self.z_dim))
         whole = Act(fbuf.buf, fbuf.cs, 0)
         if feats_amax is not None and (ops.TRACK_AMAX or hipnn_precision() == "f16x3"):
-            whole.amax = torch.maximum(feats_amax, ops.absmax(fbuf.slice(F, self.z_dim)))
+            whole.amax = ops.max2(feats_amax, ops.absmax(fbuf.slice(F, self.z_dim)))
         fused = self.vision_fusion.forward_act(whole, row_mask=mask)
         gh, gw = g["grid"]
         # NC cameras per frame: views (b, s, c) are consecutive, so the reference's concatenation of the cameras'

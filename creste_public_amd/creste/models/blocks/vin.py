@@ -62,7 +62,7 @@ class VIN(nn.Module):
         else:
             iv = view.nchw()
             r = self.r.forward_act(view).nchw()              # [B,1,h,w] (C == 1: dense)
-        full = torch.zeros((B, Ho, Wo), dtype=torch.float32, device=view.buf.device)
+        full = ops.fill_(torch.empty((B, Ho, Wo), dtype=torch.float32, device=view.buf.device), 0.0)
         rr = r.detach()[:, 0].contiguous()
         ops.resize_plane(rr, Ho // 2, Wo, Ho, rr.shape[1] / (Ho // 2), rr.shape[2] / Wo, full)
         outputs = {name: r, f"{name}_full": full.unsqueeze(1), "input_view": iv}

@@ -612,6 +612,28 @@ extern "C" int creste_upsample_concat_nhwc_f32(const float* x1, int N, int H1, i
   return CRESTE_OK;
 }
 
+// ------------------------------------------------------------------------------ small bookkeeping ops
+// (so that an inference forward is C-ABI launches only: what the plan runtime of csrc/plan_runtime.cpp replays)
+__global__ void fill_u32_kernel(uint32_t* __restrict__ p, uint32_t v, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void max2_f32_kernel(const float* a, const float* b, float* out) { *out = fmaxf(*a, *b); }
+
+extern "C" int creste_fill_u32(void* dst, uint32_t value, int64_t n, void* stream) {
+  CRESTE_REQUIRE(dst && n >= 0 && (reinterpret_cast<uintptr_t>(dst) & 3) == 0, "fill_u32: bad args");
+  if (n == 0) return CRESTE_OK;
+  fill_u32_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>((uint32_t*)dst, value, n);
+  CRESTE_CHECK_LAUNCH("fill_u32");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_max2_f32(const float* a, const float* b, float* out, void* stream) {
+  CRESTE_REQUIRE(a && b && out, "max2: null pointer");
+  max2_f32_kernel<<<1, 1, 0, (hipStream_t)stream>>>(a, b, out);
+  CRESTE_CHECK_LAUNCH("max2");
+  return CRESTE_OK;
+}
+
 extern "C" int creste_maxpool_nhwc_f32(const float* in, int N, int H, int W, int C, int in_cs, float* out,
                                        int Ho, int Wo, int out_cs, int ds, float* out_amax, void* stream) {
   CRESTE_REQUIRE(in && out && C % 4 == 0 && in_cs % 4 == 0 && out_cs % 4 == 0, "maxpool: bad args");

@@ -49,10 +49,28 @@ class _AmaxPool:
         key = (device.type, device.index)
         blk = cls._blocks.get(key)
         if blk is None or blk[1] >= blk[0].numel():
-            blk = [torch.zeros(1024, dtype=torch.float32, device=device), 0]
+            blk = [fill_(torch.empty(1024, dtype=torch.float32, device=device), 0.0), 0]
             cls._blocks[key] = blk
         blk[1] += 1
         return blk[0][blk[1] - 1:blk[1]]
+
+
+def fill_(t: torch.Tensor, value: float = 0.0) -> torch.Tensor:
+    """t[...] = value for a contiguous 4-byte-element tensor, as a launch of THIS library (torch.zeros / fill_ would be
+    a launch the plan recorder of deploy.export_plan cannot see)."""
+    import struct
+    if not t.is_cuda or not t.is_contiguous() or t.element_size() != 4:
+        raise HipLibraryError("fill_: contiguous CUDA tensor of 4-byte elements expected")
+    bits = struct.unpack("<I", struct.pack("<f", float(value)))[0] if t.dtype.is_floating_point else int(value) & 0xffffffff
+    _lib.check(_lib.load().creste_fill_u32(t.data_ptr(), bits, t.numel(), _stream()), "fill_u32")
+    return t
+
+
+def max2(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """device float max(a, b) -> a fresh |max| slot (the operand bound of a concatenation from its parts' bounds)."""
+    out = _AmaxPool.slot(a.device)
+    _lib.check(_lib.load().creste_max2_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), _stream()), "max2")
+    return out
 
 
 def reset_amax_pool():
@@ -299,7 +317,7 @@ def upsample_concat(x1: Act, skip: Act | None, Ho, Wo, rh, rw, out: Act | None =
     # |max| update costs its 65k small workgroups a barrier pair and a contended L2 access each: ~9 % of its time)
     out.amax = None
     if fresh and TRACK_AMAX and x1.amax is not None and (skip is None or skip.amax is not None):
-        out.amax = x1.amax if skip is None else torch.maximum(x1.amax, skip.amax)
+        out.amax = x1.amax if skip is None else max2(x1.amax, skip.amax)
     track = fresh and TRACK_AMAX and out.amax is None
     if track:
         out.amax = _AmaxPool.slot(x1.buf.device)

@@ -156,6 +156,12 @@ int creste_maxpool2_nhwc_f32(const float* in, int N, int H, int W, int C, int in
 int creste_maxpool_nhwc_f32(const float* in, int N, int H, int W, int C, int in_cs, float* out,
                             int Ho, int Wo, int out_cs, int ds, float* out_amax, void* stream);
 
+/* Bookkeeping launches, so that one inference forward consists of entry points of this library only (what
+ * creste_hip_model_infer replays): dst[0..n) = value (32-bit words); *out = max(*a, *b) on device floats (the operand
+ * bound of a concatenated tensor from its parts' bounds). */
+int creste_fill_u32(void* dst, uint32_t value, int64_t n, void* stream);
+int creste_max2_f32(const float* a, const float* b, float* out, void* stream);
+
 /* y = act(x*scale[c] + shift[c]): an eval-mode BatchNorm that FOLLOWS a ReLU (MultiScaleFCN trunk,
  * reference conv.py:118-128: conv -> ReLU -> BN -> ReLU) and so cannot be folded into the conv. */
 int creste_affine_act_nhwc_f32(const float* x, int x_cs, const float* scale, const float* shift,
@@ -395,6 +401,33 @@ int creste_multipos_con_backward_f32(const float* feats, const float* all_feats,
                                      const int64_t* all_labels, const float* row_weights, int N, int M, int D,
                                      int self_offset, float temperature, float grad_scale, void* work, float* g_feats,
                                      float* g_all, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Python-free deployment entry (csrc/plan_runtime.cpp).  reference scripts/runtime/compile.py:160-210 traces
+ * TraversabilityModel(solve_mdp=False) / TerrainNet with torch.jit.trace and saves a self-contained module that the
+ * C++ runtime stack loads without Python.  Here the artefact is a PLAN file written by
+ * creste_public_amd.deploy.export_plan: the memory arena, the constant blocks (packed BN-folded weights; raw bytes, no
+ * pickle) and the recorded sequence of entry-point calls of one forward at fixed shapes.
+ *   load   : allocates the arena on the current device, uploads the constants.  flags & 1: replay through a hipGraph
+ *            captured on the first infer call of a stream.
+ *   infer  : inputs[i] = DEVICE pointer to input i (rgbd [B,1,4,H,W] fp32, p2p [B,1,4,4] fp32; contiguous) or NULL
+ *            when the caller wrote it in place (creste_hip_model_input's pointer); asynchronous on `stream`.
+ *   output : index -> name (the reference's output-dict key, terrainnet.py:272-350 / vin.py:119-133), device pointer
+ *            into the arena, dtype (0 = f32, 1 = i64, 2 = u8/bool), rank, shape[6], stride[6] in ELEMENTS; valid after
+ *            the stream drained, overwritten by the next infer.
+ * Results are bit-identical to the Python host path (the same launches on the same arena layout). */
+int creste_hip_model_load(const char* path, int flags, void** handle);
+int creste_hip_model_free(void* handle);
+const char* creste_hip_model_info(void* handle);
+int creste_hip_model_num_inputs(void* handle);
+int creste_hip_model_num_outputs(void* handle);
+int creste_hip_model_input(void* handle, int index, const char** name, void** ptr, int* dtype, int* ndim,
+                           int64_t* shape, int64_t* stride);
+int creste_hip_model_output(void* handle, int index, const char** name, void** ptr, int* dtype, int* ndim,
+                            int64_t* shape, int64_t* stride);
+int creste_hip_model_infer(void* handle, const void* const* inputs, int n_inputs, void* stream);
+/* tooling helper of the plan exporter: synchronous device -> host copy of raw bytes */
+int creste_hip_memcpy_d2h(void* dst_host, const void* src_dev, int64_t nbytes);
 
 #ifdef __cplusplus
 }

@@ -75,3 +75,24 @@ def test_cpu_tensors_are_rejected():
     from creste_public_amd import ops
     with pytest.raises(_lib.HipLibraryError):
         ops.nchw_to_nhwc(torch.zeros(1, 4, 8, 8))
+
+
+def test_plan_dispatch_table_is_current_and_loader_rejects_garbage(tmp_path):
+    """csrc/plan_dispatch.inc (the marshalling thunks the Python-free runtime replays a plan through) is generated from
+    SIGNATURES: the committed file must be what the generator produces; creste_hip_model_load refuses a file that is not
+    a plan, and a plan naming an unknown entry point -- host-side parsing only, no GPU needed."""
+    import importlib.util
+    import struct
+    spec = importlib.util.spec_from_file_location("gen", os.path.join(ROOT, "scripts", "gen_plan_dispatch.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    committed = open(os.path.join(ROOT, "creste_public_amd", "csrc", "plan_dispatch.inc")).read()
+    assert gen.generate() == committed, "run scripts/gen_plan_dispatch.py"
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    bad = tmp_path / "bad.plan"
+    bad.write_bytes(b"not a plan at all")
+    assert lib.creste_hip_model_load(str(bad).encode(), 0, ctypes.byref(h)) != 0
+    assert b"not a creste plan" in lib.creste_last_error()
+    assert lib.creste_hip_model_load(b"/nonexistent.plan", 0, ctypes.byref(h)) != 0
+    assert lib.creste_hip_model_num_outputs(None) == -1
