@@ -402,6 +402,18 @@ int creste_multipos_con_backward_f32(const float* feats, const float* all_feats,
                                      int self_offset, float temperature, float grad_scale, void* work, float* g_feats,
                                      float* g_all, void* stream);
 
+/* Candidate-trajectory scoring against a costmap (the consumer of the path's output).
+ * reference loss_utils.py:1054-1116 (polyline rasterisation: max_steps = max over the call of ceil(segment length)
+ * samples of torch.linspace(0,1,max_steps) per segment + the last pose, clamp, truncate, each cell once) and
+ * :1197-1258 (trajectory reward = sum of the costmap over its visited cells).  Candidates: the Ackermann sampler of
+ * scripts/traversability/planner_utils/control.py:12-118 (creste_public_amd/planner.py).
+ *   xy [N,T,2] (row, col) in full-resolution BEV cells, divided by map_ds inside; costmap [.,H,W] with trajectory n
+ *   reading map (map_index ? map_index[n] : n) at stride map_stride floats (0 = one shared map);
+ *   -> scores [N]; visit [N,H,W] 0/1 (may be NULL); n_cells [N] visited-cell counts (may be NULL).  work: 1 int. */
+int creste_trajectory_scores_f32(const float* xy, int N, int T, float map_ds, int H, int W, const float* costmap,
+                                 const int* map_index, int64_t map_stride, float* scores, float* visit,
+                                 int* n_cells, int* work, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Python-free deployment entry (csrc/plan_runtime.cpp).  reference scripts/runtime/compile.py:160-210 traces
  * TraversabilityModel(solve_mdp=False) / TerrainNet with torch.jit.trace and saves a self-contained module that the
