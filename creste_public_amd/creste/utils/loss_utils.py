@@ -244,31 +244,25 @@ class MultiPosConLoss(nn.Module):
             self.class_weights = self.class_weights.to(feats.device)
         feats = torch.nn.functional.normalize(feats, dim=-1, p=2)
         n = feats.size(0)
-        rank = 0
-        if dist.is_available() and dist.is_initialized():
-            from torch.distributed.nn import all_gather as all_gather_with_grad
-            all_feats = torch.cat(all_gather_with_grad(feats), dim=0)
-            gathered = [torch.ones_like(labels) for _ in range(dist.get_world_size())]
-            dist.all_gather(gathered, labels)
-            all_labels = torch.cat(gathered, dim=0)
-            rank = dist.get_rank()
-        else:
-            all_feats, all_labels = feats, labels
+        # every rank contributes however many rows its data yields (padded all-gather, features with gradient);
+        # `row0` = position of this rank's first row in the gathered set (the reference's n * rank when counts agree)
+        from ...dist_utils import gather_varlen
+        all_feats, all_labels, row0 = gather_varlen(feats, labels)
         if feats.is_cuda and feats.shape[1] in (8, 16, 32, 64):
             # fused HIP path (no N x M tensors).  The reference's stale-mask behaviour is kept by remembering the LABELS
             # the mask was built from: positives follow those, the class weights follow the current labels.
             from ...loss_ops import MultiPosConFn
-            if n != self._last_n:
-                self._mask_labels, self._mask_all_labels, self._last_n = labels.clone(), all_labels.clone(), n
+            if (n, all_feats.size(0)) != self._last_n:
+                self._mask_labels, self._mask_all_labels, self._last_n = labels.clone(), all_labels.clone(), (n, all_feats.size(0))
             rw = self.class_weights[labels] if self.class_weights is not None else None
-            loss = MultiPosConFn.apply(feats, all_feats, self._mask_labels, self._mask_all_labels, rw, n * rank,
+            loss = MultiPosConFn.apply(feats, all_feats, self._mask_labels, self._mask_all_labels, rw, row0,
                                        self.temperature)
             return {"loss": loss, "image_loss": loss}
-        if n != self._last_n:
+        if (n, all_feats.size(0)) != self._last_n:
             mask = torch.eq(labels.view(-1, 1), all_labels.contiguous().view(1, -1)).float()
             self.logits_mask = torch.scatter(torch.ones_like(mask), 1,
-                                             torch.arange(n, device=feats.device).view(-1, 1) + n * rank, 0)
-            self._last_n = n
+                                             torch.arange(n, device=feats.device).view(-1, 1) + row0, 0)
+            self._last_n = (n, all_feats.size(0))
             self.mask = mask * self.logits_mask
         mask = self.mask
         logits = torch.matmul(feats, all_feats.T) / self.temperature

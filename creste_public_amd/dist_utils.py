@@ -133,3 +133,102 @@ class GradArena(dict):
         if is_dist():
             self.flat /= dist.get_world_size()
         return self
+
+
+class HookedArena:
+    """GradArena for a backward that torch autograd drives (the BEV-SSC step: BackboneFn <- SplatFn <- BevHeadFn chained
+    by ordinary tensors): every trainable parameter's `.grad` is a VIEW into one flat fp32 buffer laid out in reverse
+    registration order (~ the order in which the backward finishes them: heads first, encoder stem last), and a
+    post-accumulate-grad hook per parameter marks it final.  Whenever the finished PREFIX of the buffer has grown by a
+    bucket, that slice goes out as an async all-reduce -- the collective is enqueued behind the kernels that produced
+    the slice and runs on the communication stream while the rest of the backward (the encoder: ~60 ms of the step)
+    is still computing.  `finish()` sends the tail, waits, and divides by the world size; parameters that received no
+    gradient on this rank contribute zeros (the buffer is cleared by ONE memset per step).
+
+    Ring all-reduce over point-to-point xGMI is per-link bound: a few large buckets (default 32 MB) keep all seven
+    links busy; per-tensor calls (330 of them here) would be latency-bound.  A reduce-scatter + all-gather split
+    (what a sharded optimiser wants) moves the same bytes per link as the ring all-reduce RCCL runs for these sizes,
+    so with a replicated Adam state it buys nothing -- one collective per bucket it is."""
+
+    def __init__(self, params, bucket_bytes: int = 32 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.order = list(reversed(self.params))
+        dev = self.order[0].device
+        n, self.span = 0, {}
+        for p in self.order:
+            self.span[id(p)] = (n, n + p.numel())
+            n += p.numel()
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.pos = {id(p): i for i, p in enumerate(self.order)}
+        self.bucket = max(1, bucket_bytes // 4)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.order]
+        self.launched = 0                         # async collectives issued before finish() in the last step
+        self.begin()
+
+    def begin(self):
+        """start of a step: clear the buffer (one memset) and re-point every .grad at its slice"""
+        self.flat.zero_()
+        for p in self.order:
+            lo, hi = self.span[id(p)]
+            p.grad = self.flat[lo:hi].view_as(p)
+        self.finished = [False] * len(self.order)
+        self.prefix = self.sent = 0
+        self.handles = []
+
+    def _send(self, upto):
+        if upto > self.sent and is_dist():
+            self.handles.append(dist.all_reduce(self.flat[self.sent:upto], op=dist.ReduceOp.SUM, async_op=True))
+        self.sent = max(self.sent, upto)
+
+    @torch.no_grad()
+    def _on_grad(self, p):
+        lo, hi = self.span[id(p)]
+        if p.grad.data_ptr() != self.flat.data_ptr() + 4 * lo:      # autograd replaced the view (first accumulation)
+            self.flat[lo:hi].view_as(p).copy_(p.grad)
+            p.grad = self.flat[lo:hi].view_as(p)
+        self.finished[self.pos[id(p)]] = True
+        while self.prefix < len(self.order) and self.finished[self.prefix]:
+            self.prefix += 1
+        upto = self.span[id(self.order[self.prefix - 1])][1] if self.prefix else 0
+        if upto - self.sent >= self.bucket:
+            self._send(upto)
+
+    def finish(self):
+        self.launched = len(self.handles)
+        self._send(self.flat.numel())
+        for h in self.handles:
+            h.wait()
+        if is_dist():
+            self.flat /= dist.get_world_size()
+        return self
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def gather_varlen(feats: torch.Tensor, labels: torch.Tensor):
+    """All-gather rows whose COUNT differs between ranks (the per-class sample of the contrastive loss depends on the
+    rank's data; the reference all-gathers the raw tensors, supcon_loss.py:85-86, which only works while every rank
+    happens to draw the same count): counts are exchanged first, every rank pads to the maximum, the padded blocks
+    are gathered -- features WITH gradient -- and the padding is dropped.  -> (all_feats [sum n, D], all_labels
+    [sum n], offset of this rank's rows).  Without a process group: the inputs, offset 0."""
+    if not is_dist():
+        return feats, labels, 0
+    from torch.distributed.nn import all_gather as all_gather_with_grad
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = torch.tensor([feats.shape[0]], dtype=torch.int64, device=feats.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    n_max = max(counts)
+    pad = n_max - feats.shape[0]
+    f = torch.nn.functional.pad(feats, (0, 0, 0, pad)) if pad else feats
+    l = torch.nn.functional.pad(labels, (0, pad), value=-1) if pad else labels
+    parts = all_gather_with_grad(f.contiguous())
+    lab_parts = [torch.empty_like(l) for _ in range(world)]
+    dist.all_gather(lab_parts, l.contiguous())
+    all_feats = torch.cat([p_[:c] for p_, c in zip(parts, counts)], dim=0)
+    all_labels = torch.cat([p_[:c] for p_, c in zip(lab_parts, counts)], dim=0)
+    return all_feats, all_labels, sum(counts[:rank])

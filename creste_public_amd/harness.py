@@ -205,6 +205,22 @@ class SSCTrainer(DistillTrainer):
         self.params = [p for p in self.model.parameters() if p.requires_grad]
         self.optimizer = torch.optim.Adam(self.params, betas=(oc["beta1"], oc["beta2"]), lr=lr)
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=self.cfg["lr_scheduler"]["gamma"])
+        self._rebuild_arena()
+
+    def _rebuild_arena(self):
+        """Gradient exchange of the step.  The encoder's engine (train_backbone.BackboneFn) owns a GradArena of its
+        own: its ~64 MB of gradients are all-reduced bucket by bucket INSIDE its backward.  Everything else (BEV heads,
+        splat stage: ~38 MB, finished FIRST by the backward) lives in a HookedArena: the autograd hooks send those
+        buckets while the splat and encoder backward are still running."""
+        if getattr(self, "arena", None) is not None:
+            self.arena.close()
+        dc = getattr(self.model, "depthcomp", None)
+        self._engine_owned = {id(p) for p in dc.parameters()} if (dc is not None and self._hip_model()) else set()
+        rest = [p for p in self.params if id(p) not in self._engine_owned]
+        self.arena = dist_utils.HookedArena(rest, self.bucket_bytes) if rest else None
+
+    def _hip_model(self) -> bool:
+        return type(self.model).__module__.startswith("creste_public_amd.creste.")
 
     def on_train_epoch_start(self):
         if self.epoch >= self.freeze_backbone_epochs and self.backbone_frozen:
@@ -227,9 +243,16 @@ class SSCTrainer(DistillTrainer):
         """batch: {task: {'image', 'p2p', labels ...}}"""
         self.model.train()
         self.optimizer.zero_grad()
+        if not hasattr(self, "_engine_owned"):
+            self._rebuild_arena()
+        if self.arena is not None:
+            self.arena.begin()                            # .grad of the non-encoder parameters = views of one buffer
         total, logs = 0.0, {}
         for task, data in batch.items():
             outputs = self.model((data["image"], data["p2p"]))
+            eng = getattr(getattr(self.model, "depthcomp", None), "_train_engine", None)
+            if eng is not None and self._engine_owned:    # encoder gradients: flat arena, comm overlapped in its backward
+                eng.arena, eng.bucket_bytes = True, self.bucket_bytes
             with torch.no_grad():
                 merged = tu.merge_dict(("inputs", data), ("outputs", outputs))
                 merged["task"] = task
@@ -240,7 +263,8 @@ class SSCTrainer(DistillTrainer):
             logs.update({f"train/{k}": (w * v.detach()) for k, (w, v) in loss_dict.items()})
             logs.update({f"train/{k}": v.detach() for k, v in meta.items()})
         total.backward()
-        dist_utils.allreduce_mean_grads(self.params)          # one flat all-reduce over the trainable parameters
+        if self.arena is not None:
+            self.arena.finish()                           # tail bucket, wait, average
         self.optimizer.step()
         logs["train/loss"] = total.detach()
         self.global_step += 1
