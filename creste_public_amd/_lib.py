@@ -97,6 +97,8 @@ SIGNATURES = {
     "creste_loss_workspace_bytes": (_i64, []),
     "creste_depth_ce_loss_f32": (_i, [_vp, _i, _vp, _i64, _i, _f, _f, _f, _vp, _i, _vp, _vp, _vp]),
     "creste_mse_loss_f32": (_i, [_vp, _i, _vp, _i, _i64, _i, _f, _vp, _i, _vp, _vp, _vp]),
+    "creste_bev_ce_loss_f32": (_i, [_vp, _i, _i, _vp, _i, _i64, _i64, _vp, _vp, _i, _i, _f, _f, _vp, _i, _vp, _vp, _vp]),
+    "creste_smooth_l1_loss_f32": (_i, [_i, _vp, _i, _vp, _i64, _i64, _i, _f, _f, _f, _i, _f, _vp, _i, _vp, _vp, _vp]),
     "creste_bev_splat_bwd_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _i, _vp,
                                       _vp, _vp]),
     "creste_depth_expectation_bwd_f32": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _i, _i, _vp]),

@@ -264,3 +264,200 @@ extern "C" int creste_multipos_con_backward_f32(const float* feats, const float*
   CRESTE_CHECK_LAUNCH("mpc_grad");
   return CRESTE_OK;
 }
+
+// =====================================================================================================================
+// BEV classification and regression objectives of the SSC stage, fused (reference creste/utils/loss_utils.py:379-474
+// `CrossEntropy`, :576-603 `SmoothL1`, :530-573 `SmoothL1Depth`): masking, label extraction, the loss, its metric and the
+// gradient w.r.t. the prediction in streaming passes over the NHWC prediction -- the reference runs boolean-mask gathers
+// (`pred.permute(0,2,3,1)[fov, :]`), torch.nn.CrossEntropyLoss / SmoothL1Loss and a second softmax for the metric.
+// Deterministic: per-workgroup partial sums combined in index order.
+namespace creste {
+
+constexpr int BCE_MAXC = 64;
+
+__device__ __forceinline__ void block_sum4(float v0, float v1, float v2, float v3, float* __restrict__ partial) {
+  __shared__ float sm[4][4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    v0 += __shfl_xor(v0, o, 64); v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); v3 += __shfl_xor(v3, o, 64);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sm[w][0] = v0; sm[w][1] = v1; sm[w][2] = v2; sm[w][3] = v3; }
+  __syncthreads();
+  if (threadIdx.x < 4)
+    partial[(size_t)blockIdx.x * 4 + threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+// label of pixel p: class_dim >= 0 -> (long) gt[b, class_dim, y, x]; else argmax_c gt[b,c,y,x] / (sum_c gt + eps)
+__device__ __forceinline__ int bce_label(const float* __restrict__ gt, int Cg, long HW, long p, int class_dim, float eps) {
+  const long b = p / HW, q = p - b * HW;
+  const float* g = gt + b * Cg * HW + q;
+  if (class_dim >= 0) return (int)(long)g[(long)class_dim * HW];
+  float s = 0.f;
+  for (int c = 0; c < Cg; ++c) s = __fadd_rn(s, g[(long)c * HW]);
+  s = __fadd_rn(s, eps);
+  int best = 0;
+  float bv = __fdiv_rn(g[0], s);
+  for (int c = 1; c < Cg; ++c) {
+    const float v = __fdiv_rn(g[(long)c * HW], s);
+    if (v > bv) { bv = v; best = c; }
+  }
+  return best;
+}
+
+// MODE 0: partial sums (w*nll, w, correct, labelled);  MODE 1: gradient (needs out4[2] = sum of weights)
+template <int MODE>
+__global__ __launch_bounds__(256) void bev_ce_kernel(const float* __restrict__ pred, int cs, int C,
+                                                     const float* __restrict__ gt, int Cg, long HW, long P,
+                                                     const uint8_t* __restrict__ fov, const float* __restrict__ cw,
+                                                     int class_dim, int ignore_index, float eps,
+                                                     const float* __restrict__ out4, float gscale,
+                                                     float* __restrict__ g, int g_cs, float* __restrict__ partial) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const float inv_w = MODE == 1 ? gscale / out4[2] : 0.f;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+    const bool in = fov[p] != 0;
+    const float* x = pred + p * cs;
+    int y = 0;
+    bool use = false;
+    float mx = -3.0e38f, se = 0.f;
+    int am = 0;
+    if (in) {
+      y = bce_label(gt, Cg, HW, p, class_dim, eps);
+      use = y != ignore_index;
+      for (int c = 0; c < C; ++c) { const float v = x[c]; if (v > mx) { mx = v; am = c; } }
+      for (int c = 0; c < C; ++c) se += expf(x[c] - mx);
+    }
+    if (MODE == 0) {
+      if (in) {
+        if (use) {
+          const float w = cw ? cw[y] : 1.f;
+          a0 += w * (mx + logf(se) - x[y]);
+          a1 += w;
+        }
+        if (y != 0) { a3 += 1.f; a2 += am == y ? 1.f : 0.f; }            // metric: class 0 taken as unlabelled
+      }
+    } else {
+      float* go = g + p * g_cs;
+      if (in && use) {
+        const float w = (cw ? cw[y] : 1.f) * inv_w;
+        const float inv = 1.f / se;
+        for (int c = 0; c < C; ++c) go[c] = w * (expf(x[c] - mx) * inv - (c == y ? 1.f : 0.f));
+      } else {
+        for (int c = 0; c < C; ++c) go[c] = 0.f;
+      }
+    }
+  }
+  if (MODE == 0) block_sum4(a0, a1, a2, a3, partial);
+}
+
+__global__ void bev_ce_final_kernel(const float* __restrict__ partial, int nb, float eps, float* __restrict__ out4) {
+  if (threadIdx.x == 0) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < nb; ++b)
+      for (int k = 0; k < 4; ++k) s[k] += partial[(size_t)b * 4 + k];
+    out4[0] = s[0] / s[1];                 // weighted mean (torch.nn.CrossEntropyLoss, reduction='mean')
+    out4[1] = s[2] / (s[3] + eps);         // accuracy over labelled pixels (loss_utils.py:470-472)
+    out4[2] = s[1];
+    out4[3] = s[3];
+  }
+}
+
+// smooth-L1 (Huber with threshold beta): MODE 0 partial (sum, count), MODE 1 gradient.
+// KIND 0: elevation (loss_utils.py:576-603): pred NHWC [P][2] (pixel stride cs), gt NCHW [B][2][HW]; channel 1 of the label
+//         relative to channel 0 unless `absolute`; nan / inf labels masked per element.
+// KIND 1: metric depth (:530-573): pred [P] metres, gt [P] millimetres; valid where the label falls into a bin.
+template <int MODE, int KIND>
+__global__ __launch_bounds__(256) void smooth_l1_kernel(const float* __restrict__ pred, int cs, const float* __restrict__ gt,
+                                                        long HW, long P, int absolute, float beta, float dmin, float bin_size,
+                                                        int num_bins, const float* __restrict__ out2, float gscale,
+                                                        float* __restrict__ g, int g_cs, float* __restrict__ partial) {
+  float a0 = 0.f, a1 = 0.f;
+  const float inv_n = MODE == 1 ? gscale / out2[1] : 0.f;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+    float d[2], t[2];
+    bool ok[2] = {false, false};
+    int nch;
+    if (KIND == 0) {
+      nch = 2;
+      const long b = p / HW, q = p - b * HW;
+      const float g0 = gt[(b * 2) * HW + q], g1 = gt[(b * 2 + 1) * HW + q];
+      t[0] = g0;
+      t[1] = absolute ? g1 : __fsub_rn(g1, g0);
+      for (int c = 0; c < 2; ++c) { ok[c] = isfinite(t[c]); d[c] = pred[p * cs + c] - t[c]; }
+    } else {
+      nch = 1;
+      const float gm = gt[p];
+      const float idx = __fdiv_rn(__fsub_rn(gm, dmin), bin_size);
+      ok[0] = isfinite(idx) && idx >= 0.f && idx < (float)num_bins;        // the label's bin exists (depth_utils.bin_depths)
+      t[0] = __fdiv_rn(gm, 1000.f);
+      d[0] = pred[p] - t[0];
+    }
+    for (int c = 0; c < nch; ++c) {
+      const float ad = fabsf(d[c]);
+      if (MODE == 0) {
+        if (ok[c]) { a0 += ad < beta ? 0.5f * d[c] * d[c] / beta : ad - 0.5f * beta; a1 += 1.f; }
+      } else {
+        const float gv = ok[c] ? (ad < beta ? d[c] / beta : (d[c] > 0.f ? 1.f : -1.f)) * inv_n : 0.f;
+        if (KIND == 0) g[p * g_cs + c] = gv; else g[p] = gv;
+      }
+    }
+  }
+  if (MODE == 0) block_sum4(a0, a1, 0.f, 0.f, partial);
+}
+
+__global__ void smooth_l1_final_kernel(const float* __restrict__ partial, int nb, float* __restrict__ out2) {
+  if (threadIdx.x == 0) {
+    float s = 0.f, n = 0.f;
+    for (int b = 0; b < nb; ++b) { s += partial[(size_t)b * 4]; n += partial[(size_t)b * 4 + 1]; }
+    out2[0] = s / n;
+    out2[1] = n;
+  }
+}
+
+}  // namespace creste
+
+using namespace creste;
+
+static inline int loss_grid(long P) { long b = (P + 255) / 256; return (int)(b < 1 ? 1 : (b > 512 ? 512 : b)); }
+
+extern "C" int creste_bev_ce_loss_f32(const float* pred, int cs, int C, const float* gt, int Cg, int64_t HW, int64_t P,
+                                      const uint8_t* fov, const float* class_weights, int class_dim, int ignore_index,
+                                      float eps, float grad_scale, float* g_pred, int g_cs, float* out4, void* work,
+                                      void* stream) {
+  CRESTE_REQUIRE(pred && gt && fov && g_pred && out4 && work, "bev_ce_loss: null pointer");
+  CRESTE_REQUIRE(P > 0 && HW > 0 && P % HW == 0 && C > 0 && C <= BCE_MAXC && cs >= C && g_cs >= C && Cg > 0 && class_dim < Cg,
+                 "bev_ce_loss: bad dims");
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = loss_grid(P);
+  bev_ce_kernel<0><<<nb, 256, 0, s>>>(pred, cs, C, gt, Cg, HW, P, fov, class_weights, class_dim, ignore_index, eps, nullptr,
+                                       0.f, nullptr, 0, (float*)work);
+  bev_ce_final_kernel<<<1, 64, 0, s>>>((const float*)work, nb, eps, out4);
+  bev_ce_kernel<1><<<nb, 256, 0, s>>>(pred, cs, C, gt, Cg, HW, P, fov, class_weights, class_dim, ignore_index, eps, out4,
+                                       grad_scale, g_pred, g_cs, nullptr);
+  CRESTE_CHECK_LAUNCH("bev_ce_loss");
+  return CRESTE_OK;
+}
+
+extern "C" int creste_smooth_l1_loss_f32(int kind, const float* pred, int cs, const float* gt, int64_t HW, int64_t P,
+                                         int absolute, float beta, float depth_min, float depth_max, int num_bins,
+                                         float grad_scale, float* g_pred, int g_cs, float* out2, void* work, void* stream) {
+  CRESTE_REQUIRE(pred && gt && g_pred && out2 && work && P > 0 && beta > 0.f, "smooth_l1_loss: bad args");
+  CRESTE_REQUIRE(kind == 0 || kind == 1, "smooth_l1_loss: kind 0 (elevation) or 1 (metric depth)");
+  CRESTE_REQUIRE(kind == 1 || (HW > 0 && P % HW == 0 && cs >= 2 && g_cs >= 2), "smooth_l1_loss: bad elevation dims");
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = loss_grid(P);
+  const float bin = num_bins > 0 ? (depth_max - depth_min) / (float)num_bins : 1.f;
+  float* wk = (float*)work;
+  if (kind == 0) {
+    smooth_l1_kernel<0, 0><<<nb, 256, 0, s>>>(pred, cs, gt, HW, P, absolute, beta, 0.f, 1.f, 0, nullptr, 0.f, nullptr, 0, wk);
+    smooth_l1_final_kernel<<<1, 64, 0, s>>>(wk, nb, out2);
+    smooth_l1_kernel<1, 0><<<nb, 256, 0, s>>>(pred, cs, gt, HW, P, absolute, beta, 0.f, 1.f, 0, out2, grad_scale, g_pred, g_cs, nullptr);
+  } else {
+    smooth_l1_kernel<0, 1><<<nb, 256, 0, s>>>(pred, 1, gt, 1, P, 0, beta, depth_min, bin, num_bins, nullptr, 0.f, nullptr, 0, wk);
+    smooth_l1_final_kernel<<<1, 64, 0, s>>>(wk, nb, out2);
+    smooth_l1_kernel<1, 1><<<nb, 256, 0, s>>>(pred, 1, gt, 1, P, 0, beta, depth_min, bin, num_bins, out2, grad_scale, g_pred, 1, nullptr);
+  }
+  CRESTE_CHECK_LAUNCH("smooth_l1_loss");
+  return CRESTE_OK;
+}

@@ -361,6 +361,23 @@ int creste_depth_ce_loss_f32(const float* logits, int cs, const float* gt_mm, in
 int creste_mse_loss_f32(const float* pred, int p_cs, const float* gt, int g_cs, int64_t P, int C, float weight,
                         float* g_pred, int o_cs, float* out2, void* work, void* stream);
 
+/* BEV-stage objectives, fused (csrc/losses.hip).  work: creste_loss_workspace_bytes().  Deterministic reductions.
+ * creste_bev_ce_loss_f32 -- reference loss_utils.py:379-474 (`CrossEntropy`): pred NHWC [P][cs] with C classes, label
+ *   from gt NCHW [B,Cg,H,W] (class_dim >= 0: the class index stored in that channel; < 0: argmax_c gt/(sum+eps)), only
+ *   pixels with fov != 0, optional class weights and ignore_index (< -99999: none) as torch.nn.CrossEntropyLoss(weight,
+ *   ignore_index, reduction='mean').  out4 = (loss, accuracy over labelled (!= 0) pixels, sum of weights, labelled
+ *   count); g_pred [P][g_cs] = grad_scale * dloss/dpred (zeros outside the mask).
+ * creste_smooth_l1_loss_f32 -- kind 0: elevation regression (:576-603): pred NHWC [P][cs] (2 channels), gt NCHW
+ *   [B,2,H,W], channel 1 relative to channel 0 unless `absolute`, non-finite labels masked; kind 1: metric depth
+ *   (:530-573): pred [P] metres, gt [P] millimetres, valid where the label falls into one of num_bins uniform bins of
+ *   [depth_min, depth_max].  out2 = (mean smooth-L1 over valid elements, valid count); g_pred likewise. */
+int creste_bev_ce_loss_f32(const float* pred, int cs, int C, const float* gt, int Cg, int64_t HW, int64_t P,
+                           const uint8_t* fov, const float* class_weights, int class_dim, int ignore_index, float eps,
+                           float grad_scale, float* g_pred, int g_cs, float* out4, void* work, void* stream);
+int creste_smooth_l1_loss_f32(int kind, const float* pred, int cs, const float* gt, int64_t HW, int64_t P, int absolute,
+                              float beta, float depth_min, float depth_max, int num_bins, float grad_scale,
+                              float* g_pred, int g_cs, float* out2, void* work, void* stream);
+
 /* Backward of creste_bev_splat_f32 (reference autograd through splat_projection.py:262-354):
  * coords / bev / dens are the forward's outputs, feats its (range-masked) input.  g_feats [B*P][gf_cs] and
  * g_xyz [B*P][3] (LiDAR x, y; z gets 0) are gathers -- no atomics.  cell_work: B*GH*GW floats.  g_dens may be
