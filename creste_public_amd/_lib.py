@@ -99,6 +99,13 @@ SIGNATURES = {
     "creste_mse_loss_f32": (_i, [_vp, _i, _vp, _i, _i64, _i, _f, _vp, _i, _vp, _vp, _vp]),
     "creste_bev_ce_loss_f32": (_i, [_vp, _i, _i, _vp, _i, _i64, _i64, _vp, _vp, _i, _i, _f, _f, _vp, _i, _vp, _vp, _vp]),
     "creste_smooth_l1_loss_f32": (_i, [_i, _vp, _i, _vp, _i64, _i64, _i, _f, _f, _f, _i, _f, _vp, _i, _vp, _vp, _vp]),
+    "creste_label_minmax_i64": (_i, [_vp, _i64, _vp, _vp]),
+    "creste_remap_labels_i64": (_i, [_vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp]),
+    "creste_group_by_class_workspace_bytes": (_i64, [_i64, _i]),
+    "creste_group_by_class_i64": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "creste_pick_cells_i32": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "creste_gather_rows_f32": (_i, [_vp, _i, _i, _vp, _i64, _vp, _vp]),
+    "creste_scatter_rows_f32": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp]),
     "creste_bev_splat_bwd_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _i, _vp,
                                       _vp, _vp]),
     "creste_depth_expectation_bwd_f32": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _i, _i, _vp]),

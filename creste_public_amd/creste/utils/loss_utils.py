@@ -194,6 +194,10 @@ class SmoothL1Depth(Loss):
         # softmax-expectation backward (BackboneFn); `depth_preds_bins` (the distillation config) is an integer map
         d = self.config["discretize"]
         gt = _match_depth_label(pred.shape[-2:], gt)
+        if pred.is_cuda and d["mode"] == "UD":              # fused HIP kernel: mask, loss and gradient in two passes
+            from ...loss_ops import SmoothL1Fn
+            return {"depth/reg_loss": SmoothL1Fn.apply(1, pred.float(), gt, False, self.config["beta"], d["depth_min"],
+                                                       d["depth_max"], d["num_bins"])}, {}
         valid = _bin_depths_ud(gt, d["depth_min"], d["depth_max"], d["num_bins"]) != d["num_bins"]
         return {"depth/reg_loss": self.smoothl1_loss(pred[valid].float(), (gt / 1000.0)[valid].float())}, {}
 
@@ -311,6 +315,20 @@ class SupPixelConLoss(Loss):
         BV, Z, H, W = preds.shape
         B = BV // self.views
         gt_label = torch.argmax(gt_prob, dim=1) if C > 1 else gt_prob.squeeze(1)
+        if preds.is_cuda and self.views == 1 and gt_label.dtype == torch.int64:
+            # device path (label_ops / csrc/labels.hip): remap, class-wise grouping of the valid cells and the row gather
+            # are kernels; the host draws the per-class permutations with the reference's generator, in its order
+            from ... import label_ops
+            if self.lab_key == "inputs/3d_sam_label":
+                gt_label, nclass = label_ops.remap_labels_in_batch(gt_label.contiguous(), ignore_idx=0)
+                K = int(nclass.item())
+            else:
+                K = int(gt_label.max().item()) + 1
+            cell, sel_labels = label_ops.sample_cells_per_class(gt_label, fov_mask, K, self.ignore_index)
+            feats = label_ops.RowsFn.apply(preds, cell)
+            out = self.supcon_loss({"feats": feats, "labels": sel_labels})
+            k = f"{self.task}/{self.lab_suffix_key}/supcon"
+            return {f"{k}/sem_loss": out["loss"], f"{k}/img_loss": out["image_loss"]}, {}
         if self.lab_key == "inputs/3d_sam_label":
             gt_label = remap_labels_in_batch(gt_label, ignore_idx=0)
         valid = (gt_label != self.ignore_index) & fov_mask
@@ -353,6 +371,10 @@ class CrossEntropy(Loss):
 
     def loss(self, tensor_dict):
         pred, gt, fov = tensor_dict[self.pred_key], tensor_dict[self.lab_key], tensor_dict[self.mask_key]
+        if pred.is_cuda and pred.shape[1] <= 64:            # fused HIP kernel (mask, label, loss, metric, gradient)
+            from ...loss_ops import BevCEFn
+            loss, stats = BevCEFn.apply(pred, gt, fov, self.class_weights, self.class_dim, self.ignore_index, self.epsilon_w)
+            return {f"{self.task}/cls_loss": loss}, {f"{self.task}/mIoU": stats[1]}
         if self.class_dim < 0:
             gt_mode = torch.argmax(gt / (torch.sum(gt, dim=1, keepdim=True) + self.epsilon_w), dim=1)
         else:
@@ -381,6 +403,9 @@ class SmoothL1(Loss):
 
     def loss(self, tensor_dict):
         pred, gt = tensor_dict[self.pred_key], tensor_dict[self.lab_key]
+        if pred.is_cuda and not self.take_grad and pred.dim() == 4 and pred.shape[1] == 2:
+            from ...loss_ops import SmoothL1Fn
+            return {"val": SmoothL1Fn.apply(0, pred, gt, self.absolute, self.config["beta"], 0.0, 1.0, 0)}, {}
         if not self.absolute:
             gt = gt.clone()
             gt[:, 1, :, :] = gt[:, 1, :, :] - gt[:, 0, :, :]

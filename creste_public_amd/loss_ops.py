@@ -94,3 +94,71 @@ class MultiPosConFn(torch.autograd.Function):
                                                         f.shape[1], off, T, 1.0, work.data_ptr(), gf.data_ptr(),
                                                         ga.data_ptr(), _stream()), "multipos_con_backward")
         return gf * gl, ga * gl, None, None, None, None, None
+
+
+class BevCEFn(torch.autograd.Function):
+    """CrossEntropy over BEV cells (reference loss_utils.py:379-474): pred [B,C,H,W], gt [B,Cg,H,W] (class index in
+    channel `class_dim`, or a distribution when class_dim < 0), fov [B,H,W] bool -> (loss, stats[4] = loss, accuracy,
+    weight sum, labelled count); one fused HIP op (csrc/losses.hip) that also leaves dloss/dpred."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, fov, class_weights, class_dim, ignore_index, eps):
+        if not pred.is_cuda:
+            raise HipLibraryError("BEV cross-entropy runs on the HIP kernels only")
+        pa = as_act(pred)
+        B, C, H, W = pred.shape
+        g_ = gt.detach().float().contiguous()
+        f_ = fov.detach().to(torch.uint8).contiguous()
+        cw = class_weights.detach().float().contiguous() if class_weights is not None else None
+        dev = pred.device
+        g = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
+        out4 = torch.empty(4, dtype=torch.float32, device=dev)
+        _lib.check(_lib.load().creste_bev_ce_loss_f32(
+            pa.ptr, pa.cs, C, g_.data_ptr(), g_.shape[1], H * W, B * H * W, f_.data_ptr(),
+            cw.data_ptr() if cw is not None else None, int(class_dim), -1000000 if ignore_index is None else int(ignore_index),
+            float(eps), 1.0, g.data_ptr(), C, out4.data_ptr(), _work(dev).data_ptr(), _stream()), "bev_ce_loss")
+        ctx.g = g.permute(0, 3, 1, 2)
+        ctx.mark_non_differentiable(out4)
+        return out4[0].clone(), out4
+
+    @staticmethod
+    def backward(ctx, gl, _):
+        return ctx.g * gl, None, None, None, None, None, None
+
+
+class SmoothL1Fn(torch.autograd.Function):
+    """kind 0: elevation smooth-L1 (reference loss_utils.py:576-603; pred [B,2,H,W], gt [B,2,H,W]);
+    kind 1: metric-depth smooth-L1 (:530-573; pred [N,H,W] m, gt [N,H,W] mm).  Fused HIP op with gradient."""
+
+    @staticmethod
+    def forward(ctx, kind, pred, gt, absolute, beta, depth_min, depth_max, num_bins):
+        if not pred.is_cuda:
+            raise HipLibraryError("smooth-L1 runs on the HIP kernels only")
+        dev = pred.device
+        gt_ = gt.detach().float().contiguous()
+        out2 = torch.empty(2, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        if kind == 0:
+            pa = as_act(pred)
+            B, C, H, W = pred.shape
+            if C != 2 or tuple(gt_.shape) != (B, 2, H, W):
+                raise HipLibraryError("SmoothL1 (elevation): [B,2,H,W] prediction and label expected")
+            g = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev)
+            _lib.check(lib.creste_smooth_l1_loss_f32(0, pa.ptr, pa.cs, gt_.data_ptr(), H * W, B * H * W, int(bool(absolute)),
+                                                     float(beta), 0.0, 1.0, 0, 1.0, g.data_ptr(), 2, out2.data_ptr(),
+                                                     _work(dev).data_ptr(), _stream()), "smooth_l1_loss")
+            ctx.g = g.permute(0, 3, 1, 2)
+        else:
+            p_ = pred.detach().float().contiguous()
+            if p_.shape != gt_.shape:
+                raise HipLibraryError("SmoothL1Depth: prediction and label shapes differ")
+            g = torch.empty_like(p_)
+            _lib.check(lib.creste_smooth_l1_loss_f32(1, p_.data_ptr(), 1, gt_.data_ptr(), 1, p_.numel(), 0, float(beta),
+                                                     float(depth_min), float(depth_max), int(num_bins), 1.0, g.data_ptr(),
+                                                     1, out2.data_ptr(), _work(dev).data_ptr(), _stream()), "smooth_l1_loss")
+            ctx.g = g
+        return out2[0].clone()
+
+    @staticmethod
+    def backward(ctx, gl):
+        return None, ctx.g * gl, None, None, None, None, None, None

@@ -378,6 +378,31 @@ int creste_smooth_l1_loss_f32(int kind, const float* pred, int cs, const float* 
                               float beta, float depth_min, float depth_max, int num_bins, float grad_scale,
                               float* g_pred, int g_cs, float* out2, void* work, void* stream);
 
+/* Label bookkeeping of the supervised pixel-contrastive loss on the device (csrc/labels.hip; reference
+ * creste/utils/utils.py:59-77 `remap_labels_in_batch`, creste/utils/train_utils.py:324-352 `extract_max_per_class`,
+ * creste/utils/loss_utils.py:203-286).
+ *   label_minmax : out2 = (min, max) of n int64 labels (sizes the presence table).
+ *   remap_labels : gt [B,HW] int64 in [0,L) -> out: per sample, label -> (index in that sample's sorted unique labels)
+ *                  + running offset (offset += present non-ignore labels), ignore_idx kept; table: B*L ints of work;
+ *                  *nclass (device int) = largest new label + 1.
+ *   group_by_class: the cells with label in [0,K), != ignore_idx and fov != 0 (fov may be NULL), grouped by class in
+ *                  ascending class order, row-major order inside a class: counts [K], offsets [K+1], class_list [n]
+ *                  (cell indices); work: creste_group_by_class_workspace_bytes(n, K).
+ *   pick_cells   : cell[s] = class_list[offsets[sel_cls[s]] + sel_rank[s]] -- the host draws (class, rank) pairs with
+ *                  the reference's generator (torch.randperm per over-full class, in class order).
+ *   gather_rows / scatter_rows: rows [S][Z] <-> grid[cell[s]][0..Z) of an NHWC map with pixel stride cs (scatter into a
+ *                  zero-filled gradient map; the cells of one pick are distinct). */
+int creste_label_minmax_i64(const int64_t* labels, int64_t n, int64_t* out2, void* stream);
+int creste_remap_labels_i64(const int64_t* gt, int B, int64_t HW, int ignore_idx, int L, int* table, int64_t* out,
+                            int* nclass, void* stream);
+int64_t creste_group_by_class_workspace_bytes(int64_t n, int K);
+int creste_group_by_class_i64(const int64_t* labels, const uint8_t* fov, int64_t n, int K, int ignore_idx, int* counts,
+                              int* offsets, int* class_list, void* work, void* stream);
+int creste_pick_cells_i32(const int* class_list, const int* offsets, const int* sel_cls, const int* sel_rank, int S,
+                          int* cell, void* stream);
+int creste_gather_rows_f32(const float* grid, int cs, int Z, const int* cell, int64_t S, float* rows, void* stream);
+int creste_scatter_rows_f32(const float* rows, const int* cell, int64_t S, int Z, float* grid, int cs, void* stream);
+
 /* Backward of creste_bev_splat_f32 (reference autograd through splat_projection.py:262-354):
  * coords / bev / dens are the forward's outputs, feats its (range-masked) input.  g_feats [B*P][gf_cs] and
  * g_xyz [B*P][3] (LiDAR x, y; z gets 0) are gathers -- no atomics.  cell_work: B*GH*GW floats.  g_dens may be
