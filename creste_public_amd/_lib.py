@@ -118,6 +118,8 @@ SIGNATURES = {
     "creste_expected_svf_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp,
                                       _vp]),
     "creste_trajectory_scores_f32": (_i, [_vp, _i, _i, _f, _i, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "creste_trajectory_scores_grouped_f32": (_i, [_vp, _i, _i, _f, _i, _i, _vp, _vp, _i64, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "creste_irl_visitation_mix_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i64, _vp, _vp, _vp, _vp, _vp]),
     "creste_hip_model_load": (_i, [C.c_char_p, _i, C.POINTER(_vp)]),
     "creste_hip_model_free": (_i, [_vp]),
     "creste_hip_model_info": (C.c_char_p, [_vp]),

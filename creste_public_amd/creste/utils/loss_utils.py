@@ -75,17 +75,8 @@ class MaxEntIRLLoss(Loss):
         counts[counts > 1] = 1
         return pts, counts
 
-    def loss(self, tensor_dict):
-        exp_svf = tensor_dict[self.pred_key]
-        gt = tensor_dict[self.lab_key]
-        fov_mask = tensor_dict[self.fov_key]
-        reward = tensor_dict["outputs/traversability_preds"].squeeze(1)
-        state_features = tensor_dict["outputs/input_view"]
-        _, Ho, Wo = fov_mask.shape
-        _, H, W = exp_svf.shape
-        fov = tu.resize_and_crop(fov_mask.unsqueeze(1).byte(), (Ho // 2, Wo // 2), (0, H, 0, W))
-        fov = fov.squeeze(1).bool()
-
+    def _visitation_host(self, exp_svf, gt, fov, tensor_dict):
+        """reference loss_utils.py:1139-1186 as tensor code (CPU tensors: tests of the host logic)."""
         _, svf = self.compute_expert_visitation(gt, self.map_ds, self.map_sz)
         if self.use_fov_mask:
             svf = svf * fov.float()
@@ -108,6 +99,76 @@ class MaxEntIRLLoss(Loss):
                 cf_svf = cf_svf / (cf_svf.sum(dim=(0, 1), keepdim=True) + 1e-5)
                 exp_svf[i] = self.alpha * cf_svf + (1 - self.alpha) * exp_svf[i]
                 cf_total[i] = cf_svf
+        return svf, exp_svf, cf_total, policy_svf
+
+    def _visitation_hip(self, exp_svf, gt, fov, tensor_dict):
+        """The same on the device: the expert polylines and every sample's sub-optimal counterfactuals are rasterised
+        by ONE launch each of csrc/planner.hip (max_steps per reference call = per group), masking / normalisation /
+        mixing by one launch of creste_irl_visitation_mix_f32 -- instead of ~12 tensor ops and a host sync per sample."""
+        from ... import _lib
+        from ...ops import _stream
+        lib = _lib.load()
+        dev = exp_svf.device
+        H, W = self.map_sz
+        B = exp_svf.shape[0]
+        xy = (gt if gt.ndim == 3 else gt[:, :, :2, 2]).detach().float().contiguous()
+
+        def raster(xy_dev, group, ngroups):
+            n, T = xy_dev.shape[0], xy_dev.shape[1]
+            visit = torch.empty((n, H, W), dtype=torch.float32, device=dev)
+            scores = torch.empty(n, dtype=torch.float32, device=dev)
+            work = torch.empty(ngroups, dtype=torch.int32, device=dev)
+            _lib.check(lib.creste_trajectory_scores_grouped_f32(
+                xy_dev.data_ptr(), n, T, float(self.map_ds), H, W, None, None, 0,
+                group.data_ptr() if group is not None else None, ngroups, scores.data_ptr(), visit.data_ptr(), None,
+                work.data_ptr(), _stream()), "trajectory_scores")
+            return visit
+
+        visit_e = raster(xy, None, 1)
+        sets, ptr = [], [0] * (B + 1)
+        if self.cf_key is not None and self.alpha is not None:
+            for i, cf in enumerate(tensor_dict[self.cf_key]):
+                n = 0
+                if cf is not None:
+                    worse = np.asarray(cf["trajectories"])[np.asarray(cf["rank"]) > 0]
+                    n = worse.shape[0]
+                    if n:
+                        sets.append((i, worse.astype(np.float32)))
+                ptr[i + 1] = ptr[i] + n
+        visit_c = cf_ptr = None
+        if sets:
+            Ts = {w.shape[1] for _, w in sets}
+            if len(Ts) != 1:
+                raise NotImplementedError("counterfactual trajectories of different lengths in one batch")
+            allxy = torch.from_numpy(np.concatenate([w for _, w in sets], axis=0)).to(dev)
+            group = torch.from_numpy(np.concatenate([np.full(w.shape[0], j, dtype=np.int32) for j, (_, w) in enumerate(sets)])).to(dev)
+            visit_c = raster(allxy.contiguous(), group, len(sets))
+            cf_ptr = torch.tensor(ptr, dtype=torch.int32).to(dev)
+        f8 = fov.to(torch.uint8).contiguous() if self.use_fov_mask else None
+        er = exp_svf.detach().float().contiguous()
+        svf, ex, cft, pol = (torch.empty((B, H, W), dtype=torch.float32, device=dev) for _ in range(4))
+        _lib.check(lib.creste_irl_visitation_mix_f32(
+            er.data_ptr(), f8.data_ptr() if f8 is not None else None, visit_e.data_ptr(),
+            visit_c.data_ptr() if visit_c is not None else None, cf_ptr.data_ptr() if cf_ptr is not None else None,
+            float(self.alpha if self.alpha is not None else 0.0), B, H * W, svf.data_ptr(), ex.data_ptr(), cft.data_ptr(),
+            pol.data_ptr(), _stream()), "irl_visitation_mix")
+        return svf, ex, cft, pol
+
+    def loss(self, tensor_dict):
+        exp_svf = tensor_dict[self.pred_key]
+        gt = tensor_dict[self.lab_key]
+        fov_mask = tensor_dict[self.fov_key]
+        reward = tensor_dict["outputs/traversability_preds"].squeeze(1)
+        state_features = tensor_dict["outputs/input_view"]
+        _, Ho, Wo = fov_mask.shape
+        _, H, W = exp_svf.shape
+        fov = tu.resize_and_crop(fov_mask.unsqueeze(1).byte(), (Ho // 2, Wo // 2), (0, H, 0, W))
+        fov = fov.squeeze(1).bool()
+
+        if exp_svf.is_cuda:
+            svf, exp_svf, cf_total, policy_svf = self._visitation_hip(exp_svf, gt, fov, tensor_dict)
+        else:
+            svf, exp_svf, cf_total, policy_svf = self._visitation_host(exp_svf, gt, fov, tensor_dict)
         assert torch.all(exp_svf >= 0), "Negative expert visitation frequencies"
         assert torch.all(svf >= 0), "Negative predicted visitation frequencies"
 

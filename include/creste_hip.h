@@ -451,10 +451,27 @@ int creste_multipos_con_backward_f32(const float* feats, const float* all_feats,
  * scripts/traversability/planner_utils/control.py:12-118 (creste_public_amd/planner.py).
  *   xy [N,T,2] (row, col) in full-resolution BEV cells, divided by map_ds inside; costmap [.,H,W] with trajectory n
  *   reading map (map_index ? map_index[n] : n) at stride map_stride floats (0 = one shared map);
- *   -> scores [N]; visit [N,H,W] 0/1 (may be NULL); n_cells [N] visited-cell counts (may be NULL).  work: 1 int. */
+ *   -> scores [N]; visit [N,H,W] 0/1 (may be NULL); n_cells [N] visited-cell counts (may be NULL).  work: 1 int.
+ *   costmap may be NULL when only the visitation maps are wanted (scores = 0). */
 int creste_trajectory_scores_f32(const float* xy, int N, int T, float map_ds, int H, int W, const float* costmap,
                                  const int* map_index, int64_t map_stride, float* scores, float* visit,
                                  int* n_cells, int* work, void* stream);
+/* The same for a BATCH of reference calls in one launch: group[n] in [0, n_groups) names the call trajectory n
+ * belongs to; max_steps is taken per group (the expert set and every sample's counterfactual set of MaxEntIRLLoss,
+ * loss_utils.py:1139,1160-1170).  work: n_groups ints. */
+int creste_trajectory_scores_grouped_f32(const float* xy, int N, int T, float map_ds, int H, int W,
+                                         const float* costmap, const int* map_index, int64_t map_stride,
+                                         const int* group, int n_groups, float* scores, float* visit, int* n_cells,
+                                         int* work, void* stream);
+
+/* Visitation bookkeeping of MaxEntIRLLoss (reference loss_utils.py:1139-1186) in one launch: svf = normalise(fov *
+ * visit_expert), policy_svf = normalise(fov * exp_svf_raw) (L1, +1e-5), and for samples with counterfactual maps
+ * (visit_cf rows cf_ptr[b]..cf_ptr[b+1]): cf_total[b] = normalise(sum of those rows), exp_svf[b] = alpha * cf_total[b]
+ * + (1 - alpha) * policy_svf[b]; otherwise exp_svf[b] = policy_svf[b], cf_total[b] = 0.  fov / visit_cf / cf_ptr may be
+ * NULL.  All maps [B][HW] fp32. */
+int creste_irl_visitation_mix_f32(const float* exp_svf_raw, const uint8_t* fov, const float* visit_expert,
+                                  const float* visit_cf, const int* cf_ptr, float alpha, int B, int64_t HW, float* svf,
+                                  float* exp_svf, float* cf_total, float* policy_svf, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Python-free deployment entry (csrc/plan_runtime.cpp).  reference scripts/runtime/compile.py:160-210 traces
