@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void splat_key_kernel(const float* __restrict_
 constexpr int BUILD_THREADS = 1024, BUILD_MAX_CELLS = 8192;      // cells per band: <= 8 per thread, <= 14 bits
 __global__ __launch_bounds__(BUILD_THREADS) void splat_build_kernel(
     const int* __restrict__ key, const float* __restrict__ coords, int P, int GH, int GW, int RPB,
-    int* __restrict__ rank, int* __restrict__ offset, int4* __restrict__ recu) {
+    int* __restrict__ rank, int* __restrict__ offset) {
   extern __shared__ int s_hist[];                 // [band cells] counts, then absolute CSR offsets
   __shared__ int s_wave[BUILD_THREADS / 64];
   __shared__ int s_base;
@@ -146,27 +146,6 @@ __global__ __launch_bounds__(BUILD_THREADS) void splat_build_kernel(
     run += c;
   }
   if (r1 == GH + 1 && i1 == nk && i0 < i1) ob[nk] = run;       // offset[E]: the thread owning the last cell
-  __syncthreads();
-  int4* ru = recu + (long)b * P;
-  const float* cb = coords + (long)b * P * 2;
-  for (int g0 = t; g0 < P; g0 += 4 * BUILD_THREADS) {
-    int ks[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) ks[u] = kb[min(g0 + u * BUILD_THREADS, P - 1)];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int g = g0 + u * BUILD_THREADS;
-      if (g < P && ks[u] >= k0 && ks[u] < k1) {
-        const float2 c = *reinterpret_cast<const float2*>(cb + (long)g * 2);
-        int4 r;
-        r.x = g;
-        r.y = __float_as_int(__fsub_rn(c.x, floorf(c.x)));
-        r.z = __float_as_int(__fsub_rn(c.y, floorf(c.y)));
-        r.w = 0;
-        ru[s_hist[ks[u] - k0] + rk[g]] = r;
-      }
-    }
-  }
 }
 
 // The same with every point's key (then its packed {rank, cell}) held in REGISTERS: KPT points per thread, all key loads
@@ -176,7 +155,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void splat_build_kernel(
 template <int KPT>
 __global__ __launch_bounds__(BUILD_THREADS) void splat_build_reg_kernel(
     const int* __restrict__ key, const float* __restrict__ coords, int P, int GH, int GW, int RPB,
-    int* __restrict__ offset, int4* __restrict__ recu) {
+    int* __restrict__ rank, int* __restrict__ offset) {
   extern __shared__ int s_hist[];                  // [nk] counts -> absolute CSR offsets
   __shared__ int s_wave[BUILD_THREADS / 64];
   const int q = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
@@ -184,6 +163,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void splat_build_reg_kernel(
   const int r0 = q * RPB, r1 = min(GH + 1, r0 + RPB);
   const int k0 = r0 * EW, nk = (r1 - r0) * EW;
   const int* kb = key + (long)b * P;
+  int* rk = rank + (long)b * P;
   int pk[KPT];
 #pragma unroll
   for (int u = 0; u < KPT; ++u) {
@@ -200,9 +180,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void splat_build_reg_kernel(
     const int k = pk[u];
     lower += (unsigned)k < (unsigned)k0 ? 1 : 0;       // k == -1 compares as a huge unsigned
     const unsigned rel = (unsigned)(k - k0);
-    int v = -1;
-    if (rel < (unsigned)nk) v = (atomicAdd(&s_hist[rel], 1) << 14) | (int)rel;
-    pk[u] = v;
+    if (rel < (unsigned)nk) rk[t + u * BUILD_THREADS] = atomicAdd(&s_hist[rel], 1);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) lower += __shfl_xor(lower, o);
@@ -242,30 +220,25 @@ __global__ __launch_bounds__(BUILD_THREADS) void splat_build_reg_kernel(
   if (r1 == GH + 1 && t == BUILD_THREADS - 1) ob[nk] = run;    // offset[E] (trailing threads carry the total)
   __syncthreads();
   for (int i = t; i < nk; i += BUILD_THREADS) ob[i] = s_hist[i];          // coalesced
-  int4* ru = recu + (long)b * P;
-  const float* cb = coords + (long)b * P * 2;
-  // kept points: coordinates are fetched eight at a time BEFORE the first record is formed (a load inside each
-  // point's own branch would serialise 48 round trips)
-#pragma unroll
-  for (int u0 = 0; u0 < KPT; u0 += 8) {
-    float2 c[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      c[j] = make_float2(0.f, 0.f);
-      if (u0 + j < KPT && pk[u0 + j] >= 0)
-        c[j] = *reinterpret_cast<const float2*>(cb + (long)(t + (u0 + j) * BUILD_THREADS) * 2);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (u0 + j < KPT && pk[u0 + j] >= 0) {
-        int4 r;
-        r.x = t + (u0 + j) * BUILD_THREADS;
-        r.y = __float_as_int(__fsub_rn(c[j].x, floorf(c[j].x)));
-        r.z = __float_as_int(__fsub_rn(c[j].y, floorf(c[j].y)));
-        r.w = 0;
-        ru[s_hist[pk[u0 + j] & 16383] + (pk[u0 + j] >> 14)] = r;
-      }
-    }
+}
+
+// One thread per point: its record {id, frac x, frac y} goes to its CSR slot offset[key] + rank (full-chip parallel;
+// inside the band workgroups this step serialised a memory round trip per eight points: 24 of that kernel's 34 us).
+__global__ __launch_bounds__(256) void splat_fill_rec_kernel(const int* __restrict__ key, const int* __restrict__ rank,
+                                                             const int* __restrict__ offset,
+                                                             const float* __restrict__ coords,
+                                                             int4* __restrict__ recu, long BP, int P, int E) {
+  for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < BP; g += (long)gridDim.x * blockDim.x) {
+    const int k = key[g];
+    if (k < 0) continue;
+    const int b = (int)(g / P);
+    const float2 c = *reinterpret_cast<const float2*>(coords + g * 2);
+    int4 r;
+    r.x = (int)(g - (long)b * P);
+    r.y = __float_as_int(__fsub_rn(c.x, floorf(c.x)));
+    r.z = __float_as_int(__fsub_rn(c.y, floorf(c.y)));
+    r.w = 0;
+    recu[(long)b * P + offset[(long)b * (E + 1) + k] + rank[g]] = r;
   }
 }
 
@@ -335,9 +308,8 @@ __global__ __launch_bounds__(256) void splat_sort_rec_kernel(const int* __restri
 // crowded blob of cells is spread over all groups.  Per entry: one broadcast 16-byte record load (id, frac x, frac y),
 // NQ feature loads; SPLAT_ROWS entries are in flight per lane group.  Sums run in the reference's order (tap-major,
 // point id ascending) -- bit-identical to the CPU scatter_add_.
-// (tuning: rows in flight per lane group = template parameter ROWS)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int NQ, int MODE, int ROWS>
+template <int NQ, int MODE, int ROWS, bool NT = false>
 __global__ __launch_bounds__(256) void splat_gather8_kernel(
     const float* __restrict__ feats, int feats_cs, const int4* __restrict__ rec, const int* __restrict__ offset,
     int B, int P, int GH, int GW, float min_weight, float* __restrict__ bev, float* __restrict__ dens) {
@@ -424,7 +396,8 @@ __global__ __launch_bounds__(256) void splat_gather8_kernel(
       f32x4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = MODE == 0 ? __fdiv_rn(acc[q][j >> 1][j & 1], den) : acc[q][j >> 1][j & 1];
-      *reinterpret_cast<f32x4*>(orow + (long)X * F + q * 32) = o;
+      if (NT) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(orow + (long)X * F + q * 32));
+      else *reinterpret_cast<f32x4*>(orow + (long)X * F + q * 32) = o;
     }
     if (l == 0) drow[X] = d;
   }
@@ -561,14 +534,16 @@ extern "C" int creste_bev_splat_mode_f32(const float* xyz, const float* feats, i
     const int kpt = (P + BUILD_THREADS - 1) / BUILD_THREADS;
     static_assert(BUILD_MAX_CELLS <= 16384, "the packed {rank, cell} word keeps 14 bits for the cell");
     if (P <= 65536 && kpt <= 16)
-      splat_build_reg_kernel<16><<<dim3(Q, B), BUILD_THREADS, smem, s>>>(w.key, coords, P, GH, GW, rpb, w.offset, w.recu);
+      splat_build_reg_kernel<16><<<dim3(Q, B), BUILD_THREADS, smem, s>>>(w.key, coords, P, GH, GW, rpb, w.rank, w.offset);
     else if (P <= 65536 && kpt <= 32)
-      splat_build_reg_kernel<32><<<dim3(Q, B), BUILD_THREADS, smem, s>>>(w.key, coords, P, GH, GW, rpb, w.offset, w.recu);
+      splat_build_reg_kernel<32><<<dim3(Q, B), BUILD_THREADS, smem, s>>>(w.key, coords, P, GH, GW, rpb, w.rank, w.offset);
     else if (P <= 65536 && kpt <= 48)
-      splat_build_reg_kernel<48><<<dim3(Q, B), BUILD_THREADS, smem, s>>>(w.key, coords, P, GH, GW, rpb, w.offset, w.recu);
+      splat_build_reg_kernel<48><<<dim3(Q, B), BUILD_THREADS, smem, s>>>(w.key, coords, P, GH, GW, rpb, w.rank, w.offset);
     else
-      splat_build_kernel<<<dim3(Q, B), BUILD_THREADS, smem, s>>>(w.key, coords, P, GH, GW, rpb, w.rank, w.offset, w.recu);
+      splat_build_kernel<<<dim3(Q, B), BUILD_THREADS, smem, s>>>(w.key, coords, P, GH, GW, rpb, w.rank, w.offset);
     CRESTE_CHECK_LAUNCH("splat_build");
+    splat_fill_rec_kernel<<<g1, 256, 0, s>>>(w.key, w.rank, w.offset, coords, w.recu, BP, P, E);
+    CRESTE_CHECK_LAUNCH("splat_fill_rec");
   }
   splat_sort_rec_kernel<<<dim3((E + SORT_CELLS - 1) / SORT_CELLS, B), 256, 0, s>>>(w.offset, w.recu, w.rec, P, E);
   CRESTE_CHECK_LAUNCH("splat_sort_rec");
@@ -578,24 +553,17 @@ extern "C" int creste_bev_splat_mode_f32(const float* xyz, const float* feats, i
     const int rows = B * GH;
     const size_t smem = 2 * (size_t)(GW + 2) * sizeof(int);
     CRESTE_REQUIRE(smem <= 64 * 1024, "bev_splat: grid width %d too large for the offset staging", GW);
-    static const int rif = getenv("CRESTE_SPLAT_ROWS") ? atoi(getenv("CRESTE_SPLAT_ROWS")) : 4;     // tuning knob
-#define CRESTE_SPLAT_G8(NQ, M, R) \
-  splat_gather8_kernel<NQ, M, R><<<rows, 256, smem, s>>>(feats, feats_cs, w.rec, w.offset, B, P, GH, GW, min_weight, bev, dens)
-#define CRESTE_SPLAT_G8R(NQ, M)                                                                         \
-    do {                                                                                                \
-      if (rif == 2) CRESTE_SPLAT_G8(NQ, M, 2); else if (rif == 3) CRESTE_SPLAT_G8(NQ, M, 3); else if (rif == 6) CRESTE_SPLAT_G8(NQ, M, 6); \
-      else if (rif == 8) CRESTE_SPLAT_G8(NQ, M, 8); else CRESTE_SPLAT_G8(NQ, M, 4);                     \
-    } while (0)
-#define CRESTE_SPLAT_G8M(NQ)                                                                            \
-    do {                                                                                                \
-      if (mode == CRESTE_SPLAT_MEAN) CRESTE_SPLAT_G8R(NQ, 0);                                           \
-      else if (mode == CRESTE_SPLAT_SUM) CRESTE_SPLAT_G8R(NQ, 1);                                       \
-      else CRESTE_SPLAT_G8R(NQ, 2);                                                                     \
+    // 4 entries in flight per lane group (2 / 3 / 6 / 8 measured within 10 % of each other, 4 best on the frustum);
+    // nontemporal stores for the 403 MB output: the map is not re-read by this kernel and keeping it out of the L2
+    // leaves the cache to the feature rows (4 re-reads each) -- 201 -> 176 us on the whole call
+#define CRESTE_SPLAT_G8M(NQ)                                                                                              \
+    do {                                                                                                                  \
+      if (mode == CRESTE_SPLAT_MEAN) splat_gather8_kernel<NQ, 0, 4, true><<<rows, 256, smem, s>>>(feats, feats_cs, w.rec, w.offset, B, P, GH, GW, min_weight, bev, dens); \
+      else if (mode == CRESTE_SPLAT_SUM) splat_gather8_kernel<NQ, 1, 4, true><<<rows, 256, smem, s>>>(feats, feats_cs, w.rec, w.offset, B, P, GH, GW, min_weight, bev, dens); \
+      else splat_gather8_kernel<NQ, 2, 4, true><<<rows, 256, smem, s>>>(feats, feats_cs, w.rec, w.offset, B, P, GH, GW, min_weight, bev, dens); \
     } while (0)
     if (F == 32) CRESTE_SPLAT_G8M(1); else if (F == 64) CRESTE_SPLAT_G8M(2); else if (F == 96) CRESTE_SPLAT_G8M(3); else CRESTE_SPLAT_G8M(4);
 #undef CRESTE_SPLAT_G8M
-#undef CRESTE_SPLAT_G8R
-#undef CRESTE_SPLAT_G8
     CRESTE_CHECK_LAUNCH("splat_gather8");
     return CRESTE_OK;
   }
