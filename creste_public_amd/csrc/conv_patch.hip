@@ -20,6 +20,10 @@
 // octets but always cover 16 row indices distinct mod 16) are conflict-free for any tap shift.
 #include "common.h"
 
+// (nontemporal output stores were measured here and LOSE: f16x3 unchanged, bf16x6 -4 %, bf16 -18 % -- the next layer finds
+// part of the map in the 256 MB Infinity Cache, which streaming stores bypass; plain stores it is)
+#define CRESTE_OUT_STORE(ptr, v) (*(ptr) = (v))
+
 namespace creste {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -122,7 +126,7 @@ __device__ __forceinline__ void patch_epilogue(const f32x16 (&acc)[2][TN], const
             v[j] = act_apply(v[j], p.act) * rmask;
             vmax = fmaxf(vmax, fabsf(v[j]));
           }
-          *reinterpret_cast<f32x4*>(p.out + m * p.out_cs + p.out_co + n) = v;
+          CRESTE_OUT_STORE(reinterpret_cast<f32x4*>(p.out + m * p.out_cs + p.out_co + n), v);
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -186,7 +190,7 @@ __device__ __forceinline__ void patch_epilogue_lds(const f32x16 (&acc)[2][TN], c
             v[j] = act_apply(v[j], p.act) * rmask;
             vmax = fmaxf(vmax, fabsf(v[j]));
           }
-          *reinterpret_cast<f32x4*>(p.out + m * p.out_cs + p.out_co + n) = v;
+          CRESTE_OUT_STORE(reinterpret_cast<f32x4*>(p.out + m * p.out_cs + p.out_co + n), v);
         }
       }
       __syncthreads();
