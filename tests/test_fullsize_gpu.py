@@ -17,7 +17,7 @@ import torch
 import creste_public_amd
 from creste_public_amd import MaxEntIRL, synth
 from creste_public_amd.config import maxent_irl_cfg
-from test_model_gpu import _rms, _stage, calibrate_bn
+from test_model_gpu import _rms, _stage, assert_within_fp32_noise_floor, calibrate_bn
 
 pytestmark = pytest.mark.gpu
 
@@ -100,14 +100,6 @@ def test_fullsize_stages_on_identical_inputs(hip_full, oracle_full):
                                    rtol=1e-4, atol=1e-4)
 
 
-def _quantile(err, q):
-    """q-quantile of |err| over a strided subsample (kthvalue handles what torch.quantile cannot)."""
-    x = err.abs().flatten()
-    if x.numel() > 2_000_000:
-        x = x[::max(1, x.numel() // 2_000_000)]
-    return float(torch.kthvalue(x, max(1, int(q * x.numel()))).values)
-
-
 def test_fullsize_end_to_end_within_fp32_noise_floor(hip_full, oracle_full):
     """Every float output against the float64 oracle, judged by the fp32 CPU oracle's own distance to it.
     Encoder-side keys (smooth in the inputs): rms and 99.9th percentile of |error| within 4x.  Keys behind the splat are
@@ -120,22 +112,7 @@ def test_fullsize_end_to_end_within_fp32_noise_floor(hip_full, oracle_full):
     move them) plus a loose rms bound (16x)."""
     mode, _, got = hip_full
     _, ref, ref64, _, _ = oracle_full
-    n = 0
-    smooth = ("depth_preds_logits", "depth_preds_metric", "depth_preds_feats", "dino_pe_feats")
-    for k, t in ref64.items():
-        if k.startswith("_") or not torch.is_tensor(t) or not t.is_floating_point():
-            continue
-        g, r, t = got[k].detach().double().cpu(), ref[k].detach().double(), t.detach().double()
-        e_hip, e_cpu = _rms(g - t), _rms(r - t)
-        floor = 1e-7 * max(_rms(t), 1.0)
-        for q in ((0.999,) if k in smooth else (0.5, 0.9)):
-            q_hip, q_cpu = _quantile(g - t, q), _quantile(r - t, q)
-            assert q_hip <= 4.0 * q_cpu + 10 * floor, \
-                f"{mode}:{k}: {q}-quantile |hip-f64| {q_hip:.3e} vs the fp32 reference's own {q_cpu:.3e}"
-        factor = 4.0 if k in smooth else 16.0
-        assert e_hip <= factor * e_cpu + floor, \
-            f"{mode}:{k}: |hip-f64| rms {e_hip:.3e} vs the fp32 reference's own noise {e_cpu:.3e}"
-        n += 1
+    n = assert_within_fp32_noise_floor(got, ref, ref64, f"{mode}:")
     assert n >= 14
     flips = (got["bev_coords"].cpu().floor() != ref["bev_coords"].floor()).any(dim=-1).float().mean().item()
     assert flips < 2e-2, f"{mode}: end-to-end voxel-index mismatch rate {flips:.2e}"
