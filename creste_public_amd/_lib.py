@@ -108,6 +108,8 @@ SIGNATURES = {
     "creste_scatter_rows_f32": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp]),
     "creste_bev_splat_bwd_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp, _i, _vp,
                                       _vp, _vp]),
+    "creste_bev_splat_mode_bwd_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _i, _vp, _i, _vp,
+                                           _vp, _vp]),
     "creste_depth_expectation_bwd_f32": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "creste_zero_insert_nhwc_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "creste_pixel_geometry_bwd_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp,

@@ -1243,9 +1243,15 @@ __global__ __launch_bounds__(256) void splat_cell_grad_kernel(const float* __res
   }
 }
 
+// MODE 0 'mean' (bev = sum / max(D, min_w)), 1 'sum', 2 'max' (bev = max(0, max over taps and points of w*f): the
+// cotangent of a cell/channel goes to the entries that ATTAIN a positive maximum -- recomputed with the forward's own
+// arithmetic, w*f == bev bit for bit; exact ties and a maximum of 0 are measure-zero cases whose sub-gradient the
+// reference leaves to torch_scatter's argmax / torch.maximum's tie rule).
+template <int MODE>
 __global__ __launch_bounds__(256) void splat_point_grad_kernel(
     const float* __restrict__ coords, const float* __restrict__ feats, int feats_cs, const float* __restrict__ g_bev,
-    const float* __restrict__ dens, const float* __restrict__ gD, float* __restrict__ g_feats, int gf_cs,
+    const float* __restrict__ bev, const float* __restrict__ dens, const float* __restrict__ gD,
+    float* __restrict__ g_feats, int gf_cs,
     float* __restrict__ g_xyz, long BP, int P, int F, int GH, int GW, float vox_x, float vox_y, float min_w) {
   const int sub = threadIdx.x & 31;
   const long half = (blockIdx.x * 256L + threadIdx.x) >> 5, nhalf = ((long)gridDim.x * 256) >> 5;
@@ -1266,17 +1272,24 @@ __global__ __launch_bounds__(256) void splat_point_grad_kernel(
         const int xd = t >> 1, yd = t & 1;           // reference tap order (0,0),(0,1),(1,0),(1,1)
         const int xi = X0 + xd, yi = Y0 + yd;
         if ((unsigned)xi >= (unsigned)GW || (unsigned)yi >= (unsigned)GH) continue;
-        const float wx = xd ? rX : 1.f - rX, wy = yd ? rY : 1.f - rY;
+        const float wx = xd ? rX : __fsub_rn(1.f, rX), wy = yd ? rY : __fsub_rn(1.f, rY);
+        const float w = __fmul_rn(wx, wy);
         const long cell = (b * GH + yi) * GW + xi;
-        const float inv = 1.f / fmaxf(dens[cell], min_w);
+        const float inv = MODE == 0 ? 1.f / fmaxf(dens[cell], min_w) : 1.f;
         float dot = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int c = sub + 32 * j;
           if (c < F) {
             const float g = g_bev[cell * F + c];
-            gf[j] += wx * wy * g * inv;
-            dot += g * feats[p * feats_cs + c];
+            const float f = feats[p * feats_cs + c];
+            if (MODE == 2) {
+              const float v = __fmul_rn(w, f);
+              if (v > 0.f && v == bev[cell * F + c]) { gf[j] += w * g; dot += g * f; }
+            } else {
+              gf[j] += w * g * inv;
+              dot += g * f;
+            }
           }
         }
 #pragma unroll
@@ -1297,6 +1310,10 @@ __global__ __launch_bounds__(256) void splat_point_grad_kernel(
       g_xyz[p * 3 + 2] = 0.f;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void splat_dens_grad_kernel(const float* __restrict__ g_dens, float* __restrict__ gD, long ncell) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < ncell; i += (long)gridDim.x * 256) gD[i] = g_dens ? g_dens[i] : 0.f;
 }
 
 // depth = sum_k softmax(logits)_k * bins_k / 1000  ->  g_logits_k (+)= g_depth * p_k * (bins_k/1000 - depth)
@@ -1329,21 +1346,34 @@ __global__ __launch_bounds__(256) void depth_expectation_bwd_kernel(const float*
 
 }  // namespace creste
 
+extern "C" int creste_bev_splat_mode_bwd_f32(const float* coords, const float* feats, int feats_cs, const float* g_bev,
+                                             const float* g_dens, const float* bev, const float* dens, int B, int P, int F,
+                                             int GH, int GW, float vox_x, float vox_y, float min_weight, int mode,
+                                             float* g_feats, int gf_cs, float* g_xyz, float* cell_work, void* stream) {
+  CRESTE_REQUIRE(coords && feats && g_bev && bev && dens && g_feats && cell_work, "bev_splat_bwd: null pointer");
+  CRESTE_REQUIRE(B > 0 && P > 0 && F > 0 && F <= 256 && GH > 0 && GW > 0 && vox_x > 0.f && vox_y > 0.f,
+                 "bev_splat_bwd: bad dims (F <= 256)");
+  CRESTE_REQUIRE(mode >= 0 && mode <= 2, "bev_splat_bwd: unknown scatter mode %d", mode);
+  hipStream_t s = (hipStream_t)stream;
+  const long ncell = (long)B * GH * GW, BP = (long)B * P;
+  if (mode == 0) splat_cell_grad_kernel<<<grid1d(ncell * 32), 256, 0, s>>>(g_bev, bev, dens, g_dens, cell_work, ncell, F, min_weight);
+  else splat_dens_grad_kernel<<<grid1d(ncell), 256, 0, s>>>(g_dens, cell_work, ncell);
+  CRESTE_CHECK_LAUNCH("splat_cell_grad");
+#define CRESTE_SPLAT_BWD(M)                                                                                              \
+  splat_point_grad_kernel<M><<<grid1d(BP * 32), 256, 0, s>>>(coords, feats, feats_cs, g_bev, bev, dens, cell_work, g_feats, \
+                                                            gf_cs, g_xyz, BP, P, F, GH, GW, vox_x, vox_y, min_weight)
+  if (mode == 0) CRESTE_SPLAT_BWD(0); else if (mode == 1) CRESTE_SPLAT_BWD(1); else CRESTE_SPLAT_BWD(2);
+#undef CRESTE_SPLAT_BWD
+  CRESTE_CHECK_LAUNCH("splat_point_grad");
+  return CRESTE_OK;
+}
+
 extern "C" int creste_bev_splat_bwd_f32(const float* coords, const float* feats, int feats_cs, const float* g_bev,
                                         const float* g_dens, const float* bev, const float* dens, int B, int P, int F,
                                         int GH, int GW, float vox_x, float vox_y, float min_weight, float* g_feats,
                                         int gf_cs, float* g_xyz, float* cell_work, void* stream) {
-  CRESTE_REQUIRE(coords && feats && g_bev && bev && dens && g_feats && cell_work, "bev_splat_bwd: null pointer");
-  CRESTE_REQUIRE(B > 0 && P > 0 && F > 0 && F <= 256 && GH > 0 && GW > 0 && vox_x > 0.f && vox_y > 0.f,
-                 "bev_splat_bwd: bad dims (F <= 256)");
-  hipStream_t s = (hipStream_t)stream;
-  const long ncell = (long)B * GH * GW, BP = (long)B * P;
-  splat_cell_grad_kernel<<<grid1d(ncell * 32), 256, 0, s>>>(g_bev, bev, dens, g_dens, cell_work, ncell, F, min_weight);
-  CRESTE_CHECK_LAUNCH("splat_cell_grad");
-  splat_point_grad_kernel<<<grid1d(BP * 32), 256, 0, s>>>(coords, feats, feats_cs, g_bev, dens, cell_work, g_feats, gf_cs,
-                                                         g_xyz, BP, P, F, GH, GW, vox_x, vox_y, min_weight);
-  CRESTE_CHECK_LAUNCH("splat_point_grad");
-  return CRESTE_OK;
+  return creste_bev_splat_mode_bwd_f32(coords, feats, feats_cs, g_bev, g_dens, bev, dens, B, P, F, GH, GW, vox_x, vox_y,
+                                       min_weight, 0, g_feats, gf_cs, g_xyz, cell_work, stream);
 }
 
 extern "C" int creste_depth_expectation_bwd_f32(const float* logits, int cs, int64_t P, int C, const float* bin_values,

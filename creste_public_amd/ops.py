@@ -450,8 +450,8 @@ def bev_splat(xyz, feats: Act, off_xy, vox_xy, GH, GW, min_weight=1.0, scatter_m
     return coords, bev, dens
 
 
-def bev_splat_bwd(coords, feats: Act, g_bev: Act, g_dens, bev: Act, dens, vox_xy, min_weight=1.0):
-    """cotangents of (bev, dens) -> (g_feats Act viewed as [B,P,F], g_xyz [B,P,3]); see creste_bev_splat_bwd_f32."""
+def bev_splat_bwd(coords, feats: Act, g_bev: Act, g_dens, bev: Act, dens, vox_xy, min_weight=1.0, scatter_mode="mean"):
+    """cotangents of (bev, dens) -> (g_feats Act viewed as [B,P,F], g_xyz [B,P,3]); see creste_bev_splat_mode_bwd_f32."""
     lib = _lib.load()
     B, P, _ = coords.shape
     F, GH, GW = feats.C, bev.H, bev.W
@@ -460,11 +460,11 @@ def bev_splat_bwd(coords, feats: Act, g_bev: Act, g_dens, bev: Act, dens, vox_xy
     g_feats = Act.empty(feats.N, feats.H, feats.W, F, dev)
     g_xyz = torch.empty((B, P, 3), dtype=torch.float32, device=dev)
     work = torch.empty(B * GH * GW, dtype=torch.float32, device=dev)
-    _lib.check(lib.creste_bev_splat_bwd_f32(_chk(coords).data_ptr(), feats.ptr, feats.cs, g_bev.ptr,
-                                            _chk(g_dens).data_ptr() if g_dens is not None else None, bev.ptr,
-                                            _chk(dens).data_ptr(), B, P, F, GH, GW, float(vox_xy[0]), float(vox_xy[1]),
-                                            float(min_weight), g_feats.ptr, g_feats.cs, g_xyz.data_ptr(),
-                                            work.data_ptr(), _stream()), "bev_splat_bwd")
+    _lib.check(lib.creste_bev_splat_mode_bwd_f32(_chk(coords).data_ptr(), feats.ptr, feats.cs, g_bev.ptr,
+                                                 _chk(g_dens).data_ptr() if g_dens is not None else None, bev.ptr,
+                                                 _chk(dens).data_ptr(), B, P, F, GH, GW, float(vox_xy[0]), float(vox_xy[1]),
+                                                 float(min_weight), SPLAT_MODES[scatter_mode], g_feats.ptr, g_feats.cs,
+                                                 g_xyz.data_ptr(), work.data_ptr(), _stream()), "bev_splat_bwd")
     return g_feats, g_xyz
 
 

@@ -411,6 +411,13 @@ int creste_bev_splat_bwd_f32(const float* coords, const float* feats, int feats_
                              const float* g_dens, const float* bev, const float* dens, int B, int P, int F, int GH,
                              int GW, float vox_x, float vox_y, float min_weight, float* g_feats, int gf_cs,
                              float* g_xyz, float* cell_work, void* stream);
+/* The same for every scatter mode of creste_bev_splat_mode_f32 (CRESTE_SPLAT_MEAN / _SUM / _MAX; splat_projection.py:
+ * 334-352): 'max' routes a cell/channel cotangent to the entries that attain a positive maximum (w*f == bev, the
+ * forward's own arithmetic); exact ties are a measure-zero case the reference leaves to torch_scatter's argmax. */
+int creste_bev_splat_mode_bwd_f32(const float* coords, const float* feats, int feats_cs, const float* g_bev,
+                                  const float* g_dens, const float* bev, const float* dens, int B, int P, int F, int GH,
+                                  int GW, float vox_x, float vox_y, float min_weight, int mode, float* g_feats, int gf_cs,
+                                  float* g_xyz, float* cell_work, void* stream);
 /* Backward of creste_depth_expectation_f32: g_logits (+)= g_depth * softmax * (bin/1000 - depth). */
 int creste_depth_expectation_bwd_f32(const float* logits, int cs, int64_t P, int C, const float* bin_values,
                                      const float* g_depth, float* g_logits, int g_cs, int accumulate, void* stream);

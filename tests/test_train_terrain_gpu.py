@@ -295,3 +295,57 @@ def test_device_label_ops_match_the_reference_loops():
     gref = torch.zeros(B * H * W, Z, device="cuda")
     gref[cell.long()] = w
     assert torch.equal(pred.grad, gref.view(B, H, W, Z).permute(0, 3, 1, 2))
+
+
+@pytest.mark.parametrize("mode", ["sum", "max"])
+def test_splat_backward_sum_and_max_modes(mode):
+    """scatter_mode 'sum' / 'max' of Camera2MapMulti.splat_soft (reference splat_projection.py:334-344): forward +
+    backward of the HIP op against float64 autograd of a torch restatement ('max' = torch_scatter's scatter-max per tap
+    folded with torch.maximum against the zero volume).  Features are strictly positive so that no maximum ties with
+    the zero initial volume -- the sub-gradient of exact ties is implementation-defined in the reference too."""
+    from creste_public_amd import ops
+    B, P, F, G = 2, 300, 16, 12
+    g = torch.Generator().manual_seed(9)
+    X = torch.rand(B, P, generator=g) * (G + 1) - 1.0
+    Y = torch.rand(B, P, generator=g) * (G + 1) - 1.0
+    xyz = torch.zeros(B, P, 3)
+    xyz[..., 1] = -(X * 0.1 - 0.6)          # mx = -y + off_x ; X = mx / vox
+    xyz[..., 0] = -(Y * 0.1 - 0.6)
+    feats = torch.rand(B, P, F, generator=g) + 0.1
+    off, vox = (0.6, 0.6), (0.1, 0.1)
+    fa = ops.Act(feats.view(B, 1, P, F).cuda().contiguous(), F)
+    coords, bev, dens = ops.bev_splat(xyz.cuda(), fa, off, vox, G, G, 1.0, mode)
+    wb = torch.randn(B, G, G, F, generator=g)
+    wd = torch.randn(B, G, G, generator=g) * 0.1
+    g_feats, g_xyz = ops.bev_splat_bwd(coords, fa, ops.Act(wb.cuda().contiguous(), F), wd.cuda().contiguous(), bev, dens, vox,
+                                       1.0, scatter_mode=mode)
+    torch.cuda.synchronize()
+
+    # float64 restatement with autograd
+    xy = coords.cpu().double().requires_grad_(True)
+    f64 = feats.double().requires_grad_(True)
+    X0, Y0 = xy[..., 0].floor(), xy[..., 1].floor()
+    rX, rY = xy[..., 0] - X0, xy[..., 1] - Y0
+    vol = torch.zeros(B, G * G, F, dtype=torch.float64)
+    den = torch.zeros(B, G * G, dtype=torch.float64)
+    for xd in (0, 1):
+        for yd in (0, 1):
+            w = (rX if xd else 1 - rX) * (rY if yd else 1 - rY)
+            xi, yi = X0.long() + xd, Y0.long() + yd
+            ok = (xi >= 0) & (xi < G) & (yi >= 0) & (yi < G)
+            idx = (yi * G + xi).clamp(0, G * G - 1)
+            wv = w * ok
+            den = den.scatter_add(1, idx, wv)
+            src = wv.unsqueeze(-1) * f64
+            ie = idx.unsqueeze(-1).expand(-1, -1, F)
+            if mode == "sum":
+                vol = vol.scatter_add(1, ie, src)
+            else:
+                tap = torch.zeros(B, G * G, F, dtype=torch.float64).scatter_reduce(1, ie, src, reduce="amax", include_self=True)
+                vol = torch.maximum(tap, vol)
+    ((vol.view(B, G, G, F) * wb.double()).sum() + (den.view(B, G, G) * wd.double()).sum()).backward()
+    assert _rel(bev.nchw().permute(0, 2, 3, 1).cpu(), vol.view(B, G, G, F).detach()) < 1e-6
+    assert _rel(g_feats.buf.view(B, P, F).cpu(), f64.grad) < 1e-5
+    # d/dcoords -> d/dxyz: X = (-y + off)/vox, Y = (-x + off)/vox
+    gx_ref = torch.stack([-xy.grad[..., 1] / vox[1], -xy.grad[..., 0] / vox[0], torch.zeros(B, P, dtype=torch.float64)], dim=-1)
+    assert _p95(g_xyz.cpu(), gx_ref) < 1e-4
