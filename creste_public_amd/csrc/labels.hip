@@ -36,54 +36,60 @@ __global__ __launch_bounds__(256) void label_mark_kernel(const int64_t* __restri
   for (long i = blockIdx.x * 256L + threadIdx.x; i < HW; i += (long)gridDim.x * 256) table[(long)b * L + gt[(long)b * HW + i]] = 1;
 }
 
-// one workgroup: per sample, rank of every present label among the present labels of that sample (ascending), then the
-// reference's running offset: new = rank + offset, offset += number of present non-ignore labels.  table -> new label
-__global__ __launch_bounds__(1024) void label_rank_kernel(int* __restrict__ table, int B, int L, int ignore, int* __restrict__ nclass) {
+// one workgroup per sample: rank of every present label among the sample's present labels (ascending) -> table (absent
+// labels and the ignore label: -1), and the sample's count of present non-ignore labels / its largest rank
+__global__ __launch_bounds__(1024) void label_rank_kernel(int* __restrict__ table, int L, int ignore, int* __restrict__ nonign,
+                                                          int* __restrict__ toprank) {
   __shared__ int s_w[16];
   __shared__ int s_carry, s_nonign, s_top;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  int offset = 0, mytop = -1;
-  if (t == 0) s_top = -1;
-  for (int b = 0; b < B; ++b) {
-    if (t == 0) { s_carry = 0; s_nonign = 0; }
-    __syncthreads();
-    int* tb = table + (long)b * L;
-    for (int base = 0; base < L; base += 1024) {
-      const int l = base + t;
-      const int v = l < L ? tb[l] : 0;
-      int inc = v;
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t == 0) { s_carry = 0; s_nonign = 0; s_top = -1; }
+  __syncthreads();
+  int* tb = table + (long)b * L;
+  int mytop = -1, mine = 0;
+  for (int base = 0; base < L; base += 1024) {
+    const int l = base + t;
+    const int v = l < L ? tb[l] : 0;
+    int inc = v;
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d); if (lane >= d) inc += up; }
-      if (lane == 63) s_w[w] = inc;
-      __syncthreads();
-      int pre = s_carry;
-      for (int k = 0; k < w; ++k) pre += s_w[k];
-      if (l < L) {
-        int nl = ignore;
-        if (v && l != ignore) {
-          nl = pre + inc - v + offset;                 // index in the sample's sorted unique list + running offset
-          mytop = max(mytop, nl);
-          atomicAdd(&s_nonign, 1);
-        }
-        tb[l] = nl;
-      }
-      __syncthreads();
-      if (t == 1023) s_carry = pre + inc;
-      __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inc, d); if (lane >= d) inc += up; }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int pre = s_carry;
+    for (int k = 0; k < w; ++k) pre += s_w[k];
+    if (l < L) {
+      int r = -1;
+      if (v && l != ignore) { r = pre + inc - v; mytop = max(mytop, r); ++mine; }   // index in the sorted unique list
+      tb[l] = r;
     }
-    offset += s_nonign;
+    __syncthreads();
+    if (t == 1023) s_carry = pre + inc;
     __syncthreads();
   }
+  atomicAdd(&s_nonign, mine);
   atomicMax(&s_top, mytop);
   __syncthreads();
-  if (t == 0) *nclass = max(s_top, ignore) + 1;
+  if (t == 0) { nonign[b] = s_nonign; toprank[b] = s_top; }
 }
 
-__global__ __launch_bounds__(256) void label_map_kernel(const int64_t* __restrict__ gt, long HW, int L, const int* __restrict__ table,
-                                                        int64_t* __restrict__ out) {
+// new label = rank + running offset (offset of sample b = present non-ignore labels of the samples before it:
+// utils.py:66-76); the ignore label stays.  Thread 0 of block (0,0) also publishes the class count.
+__global__ __launch_bounds__(256) void label_map_kernel(const int64_t* __restrict__ gt, long HW, int L, int B, int ignore,
+                                                        const int* __restrict__ table, const int* __restrict__ nonign,
+                                                        const int* __restrict__ toprank, int64_t* __restrict__ out,
+                                                        int* __restrict__ nclass) {
   const int b = blockIdx.y;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < HW; i += (long)gridDim.x * 256)
-    out[(long)b * HW + i] = table[(long)b * L + gt[(long)b * HW + i]];
+  int off = 0;
+  for (int k = 0; k < b; ++k) off += nonign[k];
+  if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
+    int top = ignore, o = 0;
+    for (int k = 0; k < B; ++k) { if (toprank[k] >= 0) top = max(top, toprank[k] + o); o += nonign[k]; }
+    *nclass = top + 1;
+  }
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
+    const int r = table[(long)b * L + gt[(long)b * HW + i]];
+    out[(long)b * HW + i] = r < 0 ? ignore : r + off;
+  }
 }
 
 // ---- stable grouping of the valid cells by class
@@ -219,10 +225,12 @@ extern "C" int creste_remap_labels_i64(const int64_t* gt, int B, int64_t HW, int
   CRESTE_REQUIRE(gt && table && out && nclass && B > 0 && HW > 0 && L > 0, "remap_labels: bad args");
   CRESTE_REQUIRE(ignore_idx >= 0 && ignore_idx < L, "remap_labels: ignore index %d outside [0, %d)", ignore_idx, L);
   hipStream_t s = (hipStream_t)stream;
-  CRESTE_HIP(hipMemsetAsync(table, 0, (size_t)B * L * sizeof(int), s));
+  CRESTE_HIP(hipMemsetAsync(table, 0, ((size_t)B * L + 2 * (size_t)B) * sizeof(int), s));
+  int* nonign = table + (size_t)B * L;
+  int* toprank = nonign + B;
   label_mark_kernel<<<dim3(lgrid(HW, 256), B), 256, 0, s>>>(gt, HW, L, table);
-  label_rank_kernel<<<1, 1024, 0, s>>>(table, B, L, ignore_idx, nclass);
-  label_map_kernel<<<dim3(lgrid(HW, 256), B), 256, 0, s>>>(gt, HW, L, table, out);
+  label_rank_kernel<<<B, 1024, 0, s>>>(table, L, ignore_idx, nonign, toprank);
+  label_map_kernel<<<dim3(lgrid(HW, 256), B), 256, 0, s>>>(gt, HW, L, B, ignore_idx, table, nonign, toprank, out, nclass);
   CRESTE_CHECK_LAUNCH("remap_labels");
   return CRESTE_OK;
 }

@@ -33,7 +33,7 @@ def remap_labels_in_batch(gt: torch.Tensor, ignore_idx: int = 0):
     if lo < 0:
         raise HipLibraryError(f"remap_labels_in_batch: negative label {lo}")
     L = max(hi, ignore_idx) + 1
-    table = torch.empty(B * L, dtype=torch.int32, device=g.device)
+    table = torch.empty(B * (L + 2), dtype=torch.int32, device=g.device)
     out = torch.empty_like(g)
     nclass = torch.empty(1, dtype=torch.int32, device=g.device)
     _lib.check(_lib.load().creste_remap_labels_i64(g.data_ptr(), B, HW, int(ignore_idx), L, table.data_ptr(), out.data_ptr(),

@@ -383,7 +383,7 @@ int creste_smooth_l1_loss_f32(int kind, const float* pred, int cs, const float* 
  * creste/utils/loss_utils.py:203-286).
  *   label_minmax : out2 = (min, max) of n int64 labels (sizes the presence table).
  *   remap_labels : gt [B,HW] int64 in [0,L) -> out: per sample, label -> (index in that sample's sorted unique labels)
- *                  + running offset (offset += present non-ignore labels), ignore_idx kept; table: B*L ints of work;
+ *                  + running offset (offset += present non-ignore labels), ignore_idx kept; table: B*(L+2) ints of work;
  *                  *nclass (device int) = largest new label + 1.
  *   group_by_class: the cells with label in [0,K), != ignore_idx and fov != 0 (fov may be NULL), grouped by class in
  *                  ascending class order, row-major order inside a class: counts [K], offsets [K+1], class_list [n]
