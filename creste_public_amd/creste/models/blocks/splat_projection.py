@@ -114,10 +114,16 @@ class Camera2MapMulti(nn.Module):
         assert len(x) >= 3, "Input must contain depth, features and camera projection matrix."
         depth, feats, p2p = x[:3]
         require_hip(depth, "Camera2MapMulti")
-        if self.training and len(x) == 4:
-            raise NotImplementedError("movability-masked multiview splat is a training-only branch")
         B, N, F, H, W = feats.shape
         assert N % self.NC == 0, f"Number of frames must be divisible by {self.NC}"
+        if self.training:
+            # BatchNorm on batch statistics, autograd-connected; with the immovable-object mask as 4th input the keys
+            # take the `_mv` suffix and the mask multiplies the range mask (reference :214-219)
+            from ....train_terrain import splat_forward_train
+            mv, sfx = (x[3].reshape(B * N, H, W), "_mv") if len(x) == 4 else (None, "")
+            bev, dens, coords = splat_forward_train(self, depth.reshape(B * N, H, W), feats.reshape(B * N, F, H, W),
+                                                    p2p.reshape(B * N, 4, 4), mv, "_train_engine" + sfx)
+            return {f"bev_features{sfx}": bev, f"bev_densities{sfx}": dens, f"bev_coords{sfx}": coords}
         fbuf = self.fusion_buffer(B * N, H, W, F, feats.device)
         ops.nchw_to_nhwc(feats.reshape(B * N, F, H, W).contiguous().float(), out=fbuf.slice(0, F))
         r = self.forward_act(depth.reshape(B * N, H, W).contiguous().float(), fbuf,

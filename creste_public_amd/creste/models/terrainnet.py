@@ -46,9 +46,9 @@ class TerrainNet(nn.Module):
         self.use_temporal = _cfg_get(model_cfg, "use_temporal", False)
         self.use_movability = _cfg_get(model_cfg, "use_movability", False)
         self.load_setting = _cfg_get(model_cfg, "load_setting", "strict")
-        if self.use_temporal or self.use_movability:
-            raise NotImplementedError("temporal ConvGRU / movability double-splat are disabled in the "
-                                      "shipped configs and out of this tier's scope")
+        if self.use_temporal:
+            raise NotImplementedError("the temporal ConvGRU is disabled in the shipped configs and out of this "
+                                      "tier's scope")
         self.bev_classifer_cfg = _cfg_get(model_cfg, "bev_classifier", None)
         self.bev_semantic_head_cfg = _cfg_get(model_cfg, "bev_semantic_head", None)
         if self.bev_semantic_head_cfg is not None:
@@ -158,5 +158,6 @@ class TerrainNet(nn.Module):
         require_hip(rgbd, "TerrainNet")
         if self.training:
             from ...train_terrain import terrainnet_forward_train
-            return terrainnet_forward_train(self, rgbd, p2p)
+            mv = x[2] if self.use_movability and len(x) > 2 else None     # immovable mask [B,N,Hs,Ws] (:317-320)
+            return terrainnet_forward_train(self, rgbd, p2p, mv)
         return self.pack_outputs(self.forward_act(rgbd, p2p), rgbd.shape[0])

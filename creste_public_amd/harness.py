@@ -249,7 +249,7 @@ class SSCTrainer(DistillTrainer):
             self.arena.begin()                            # .grad of the non-encoder parameters = views of one buffer
         total, logs = 0.0, {}
         for task, data in batch.items():
-            outputs = self.model((data["image"], data["p2p"]))
+            outputs = self.model((data["image"], data["p2p"], data.get("immovable_depth_label", None)))
             eng = getattr(getattr(self.model, "depthcomp", None), "_train_engine", None)
             if eng is not None and self._engine_owned:    # encoder gradients: flat arena, comm overlapped in its backward
                 eng.arena, eng.bucket_bytes = True, self.bucket_bytes

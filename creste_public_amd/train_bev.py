@@ -151,6 +151,7 @@ class BevHeadFn(torch.autograd.Function):
     def forward(ctx, eng, bev, *params):
         eng.gen += 1
         ctx.eng, ctx.gen = eng, eng.gen
+        ctx.set_materialize_grads(False)          # a head no loss consumes costs no backward work
         outs = eng.forward(as_act(bev))
         return tuple(t.nchw() for pair in outs for t in pair)
 
@@ -168,10 +169,12 @@ class BevHeadFn(torch.autograd.Function):
         return (None, g_in.nchw() if g_in is not None else None, *(grads.get(id(p)) for p in eng.params()))
 
 
-def bev_heads_forward_train(net, bev: torch.Tensor) -> list:
-    """InpaintingResNet18MultiHead in training mode: [B,F,GH,GW] -> [(preds, features)] per head (autograd-aware)."""
-    eng = getattr(net, "_train_engine", None)
+def bev_heads_forward_train(net, bev: torch.Tensor, slot: str = "_train_engine") -> list:
+    """InpaintingResNet18MultiHead in training mode: [B,F,GH,GW] -> [(preds, features)] per head (autograd-aware).
+    `slot`: attribute holding the engine -- a second pass before the first one's backward (`_mv`) needs its own."""
+    eng = getattr(net, slot, None)
     if eng is None:
-        eng = net._train_engine = BevHeadTrainEngine(net)
+        eng = BevHeadTrainEngine(net)
+        setattr(net, slot, eng)
     flat = BevHeadFn.apply(eng, bev, *eng.params())
     return [(flat[2 * i], flat[2 * i + 1]) for i in range(len(eng.heads))]

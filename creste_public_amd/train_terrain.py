@@ -36,7 +36,9 @@ class SplatTrainEngine:
         z = self.m.z_proj
         return [z[0].weight, z[0].bias, z[2].weight, z[2].bias] + self.fusion.params()
 
-    def forward(self, depth: torch.Tensor, feats: Act, p2p: torch.Tensor):
+    def forward(self, depth: torch.Tensor, feats: Act, p2p: torch.Tensor, mv_mask: torch.Tensor = None):
+        """mv_mask [B*Hs*Ws] (or None): the immovable-object mask of the reference's `_mv` pass, multiplied into the
+        range mask (splat_projection.py:214-219)."""
         m = self.m
         if m.NC != 1 or m.scatter_mode != "mean" or m.mode != "bilinear":
             raise NotImplementedError("HIP splat: single camera, bilinear, mean (the shipped config)")
@@ -47,6 +49,8 @@ class SplatTrainEngine:
         xyz, mask = ops.pixel_geometry(depth, p2p, g["bounds"], g["w1"], g["b1"], g["w2"], g["b2"], fbuf.slice(F, m.z_dim))
         fused = self.fusion.fwd(Act(fbuf.buf, fbuf.cs, 0))
         self.mask = mask.view(-1, 1)
+        if mv_mask is not None:
+            self.mask = self.mask * mv_mask.reshape(-1, 1).to(self.mask.dtype)
         masked = tpoint(2, fused, gate=self.mask, hw=1)                          # per-pixel range mask
         gh, gw = g["grid"]
         coords, bev, dens = ops.bev_splat(xyz, masked, g["off"], g["vox"], gh, gw, m.min_weight)
@@ -99,11 +103,13 @@ class SplatTrainEngine:
 
 class SplatFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, depth, feats, p2p, *params):
+    def forward(ctx, eng, depth, feats, p2p, mv_mask, *params):
         eng.gen += 1
         ctx.eng, ctx.gen = eng, eng.gen
+        ctx.set_materialize_grads(False)
         bev, dens, coords = eng.forward(depth.detach().float().contiguous(), as_act(feats),
-                                        p2p.detach().float().contiguous())
+                                        p2p.detach().float().contiguous(),
+                                        mv_mask.detach().float().contiguous() if mv_mask is not None else None)
         ctx.mark_non_differentiable(coords)
         return bev.nchw(), dens.unsqueeze(1), coords
 
@@ -120,24 +126,45 @@ class SplatFn(torch.autograd.Function):
         gd = g_dens.detach().float().reshape(eng.saved["dens"].shape).contiguous() if g_dens is not None else None
         grads = {}
         g_depth, g_feats = eng.backward(gb, gd, grads)
-        return (None, g_depth, g_feats.nchw(), None, *(grads.get(id(p)) for p in eng.params()))
+        return (None, g_depth, g_feats.nchw(), None, None, *(grads.get(id(p)) for p in eng.params()))
 
 
-def terrainnet_forward_train(model, rgbd: torch.Tensor, p2p: torch.Tensor) -> dict:
-    """TerrainNet.forward in training mode -> the reference's output dict, every float output autograd-connected."""
+def splat_forward_train(cam2map, depth, feats, p2p, mv_mask=None, slot="_train_engine"):
+    """Camera2MapMulti in training mode (BatchNorm on batch statistics) as ONE autograd node; `slot` names the engine
+    instance -- a second forward whose backward is still pending (the `_mv` pass) needs its own saved state."""
+    eng = getattr(cam2map, slot, None)
+    if eng is None:
+        eng = SplatTrainEngine(cam2map)
+        setattr(cam2map, slot, eng)
+    return SplatFn.apply(eng, depth, feats, p2p, mv_mask, *eng.params())
+
+
+def terrainnet_forward_train(model, rgbd: torch.Tensor, p2p: torch.Tensor, mv_mask: torch.Tensor = None) -> dict:
+    """TerrainNet.forward in training mode -> the reference's output dict, every float output autograd-connected.
+    `use_movability` (terrainnet.py:310-344): the anchor splat, then a second splat with the immovable-object mask
+    (`bev_*_mv`) and a second pass of the BEV heads on it -- whose un-suffixed `inpainting_sam_dynamic_*` /
+    `elevation_*` entries REPLACE the first pass's (only the `inpainting_sam` prefix takes the suffix,
+    inpainting.py:41-44)."""
     if not rgbd.is_cuda:
         raise HipLibraryError("TerrainNet training runs on the HIP kernels only (got a CPU tensor)")
     B, N, Cc, H, W = rgbd.shape
     if N != 1 or model.views != 1:
         raise NotImplementedError("HIP pipeline: one view per sample (views=1, the shipped config)")
     out = backbone_forward_train(model.depthcomp, rgbd)
-    eng = getattr(model.cam2map, "_train_engine", None)
-    if eng is None:
-        eng = model.cam2map._train_engine = SplatTrainEngine(model.cam2map)
-    bev, dens, coords = SplatFn.apply(eng, out["depth_preds_metric"], out["depth_preds_feats"],
-                                      p2p.reshape(B * N, 4, 4), *eng.params())
+    p2p_ = p2p.reshape(B * N, 4, 4)
+    bev, dens, coords = splat_forward_train(model.cam2map, out["depth_preds_metric"], out["depth_preds_feats"], p2p_)
     out.update({"bev_features": bev, "bev_densities": dens, "bev_coords": coords})
+    bev_mv = None
+    if model.use_movability and mv_mask is not None:
+        bev_mv, dens_mv, coords_mv = splat_forward_train(model.cam2map, out["depth_preds_metric"],
+                                                         out["depth_preds_feats"], p2p_, mv_mask, "_train_engine_mv")
+        out.update({"bev_features_mv": bev_mv, "bev_densities_mv": dens_mv, "bev_coords_mv": coords_mv})
     if model.bevclassifier is not None:
         heads = bev_heads_forward_train(model.bevclassifier, bev)
         out.update(model.bevclassifier._wrap([dict(preds=p, features=f) for p, f in heads]))
+        if model.use_movability:
+            if bev_mv is None:
+                raise KeyError("bev_features_mv: use_movability needs the immovable mask as third input")
+            heads = bev_heads_forward_train(model.bevclassifier, bev_mv, slot="_train_engine_mv")
+            out.update(model.bevclassifier._wrap([dict(preds=p, features=f) for p, f in heads], "_mv"))
     return out

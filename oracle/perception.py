@@ -4,8 +4,9 @@ RGB-D encoder -> depth bins -> metric depth -> camera->BEV bilinear splat -> BEV
 Follows /root/reference/creste/models/{vision_encoder.py:11-49, depth.py:17-158,
 distillation.py:19-207, terrainnet.py:24-350}, /root/reference/creste/models/blocks/
 splat_projection.py:12-354 and /root/reference/creste/utils/depth_utils.py:300-313.
-Only the configuration the shipped YAMLs select is restated (single view, no temporal layer,
-no multiview distillation, scatter_mode 'mean'); anything else raises NotImplementedError.
+Restated: the configuration the shipped YAMLs select (single view, no temporal layer, no multiview
+distillation, scatter_mode 'mean') plus the scatter modes 'sum' / 'max' and the training-only `use_movability` double
+splat (terrainnet.py:310-344); anything else raises NotImplementedError.
 """
 import torch
 import torch.nn.functional as F
@@ -182,6 +183,10 @@ class Camera2MapMulti(nn.Module):
     def forward(self, x):
         depth, feats, p2p = x[:3]
         xyz, mask, f = self.fuse(depth, feats, p2p)
+        suffix = ""
+        if self.training and len(x) == 4:                 # immovable-object mask [B,N,H,W] (:214-219)
+            mask = mask * x[3].unsqueeze(2)
+            suffix = "_mv"
         f = f * mask
         B, N, Fd, H, W = f.shape
         assert N % self.NC == 0
@@ -192,9 +197,9 @@ class Camera2MapMulti(nn.Module):
         xy = self.to_voxel_coords(pts)
         vol, dens, taps = self.splat_mean(xy, fl, self.grid_size[:2])
         gh, gw = int(self.grid_size[0]), int(self.grid_size[1])
-        return {"bev_features": vol.view(B * NS, Fd, gh, gw),
-                "bev_densities": dens.view(B * NS, gh, gw, 1).permute(0, 3, 1, 2),
-                "bev_coords": xy,
+        return {f"bev_features{suffix}": vol.view(B * NS, Fd, gh, gw),
+                f"bev_densities{suffix}": dens.view(B * NS, gh, gw, 1).permute(0, 3, 1, 2),
+                f"bev_coords{suffix}": xy,
                 "_tap_indices": taps}  # oracle-only extra: int64 [B,4,P] linear idx per tap
 
 
@@ -204,8 +209,9 @@ class TerrainNet(nn.Module):
 
     def __init__(self, cfg):
         super().__init__()
-        if _get(cfg, "use_temporal", False) or _get(cfg, "use_movability", False):
-            raise NotImplementedError("temporal / movability branches are out of scope")
+        if _get(cfg, "use_temporal", False):
+            raise NotImplementedError("the temporal ConvGRU branch is out of scope")
+        self.use_movability = _get(cfg, "use_movability", False)
         name = _get(cfg["vision_backbone"], "class_name", None) or "DistillationBackbone"
         if name != "DistillationBackbone":
             raise NotImplementedError(f"Vision backbone {name} not implemented")
@@ -229,6 +235,23 @@ class TerrainNet(nn.Module):
         N = self.views
         depth = out["depth_preds_metric"].view(B, N, Hs, Ws)
         feats = out[self.splat_key].view(B, N, Z, Hs, Ws)
+        if self.training and self.use_movability:
+            # anchor view, then every view with the immovable mask (:310-322); the second head pass overwrites the
+            # un-suffixed `inpainting_sam_dynamic_*` / `elevation_*` entries -- only the `inpainting_sam` prefix takes
+            # the suffix (inpainting.py:41-44, terrainnet.py:342-344)
+            sp = self.cam2map([depth[:, 0:1], feats[:, 0:1], p2p[:, 0:1]])
+            sp.pop("_tap_indices")
+            out.update(sp)
+            if len(x) > 2 and x[2] is not None:
+                self.cam2map.NC = N
+                sp = self.cam2map([depth, feats, p2p, x[2]])
+                self.cam2map.NC = 1
+                sp.pop("_tap_indices")
+                out.update(sp)
+            if self.bevclassifier is not None:
+                out.update(self.bevclassifier(out))
+                out.update(self.bevclassifier(out, key_suffix="_mv"))
+            return out
         sp = self.cam2map([depth, feats, p2p])
         if not keep_taps:
             sp.pop("_tap_indices")

@@ -43,6 +43,15 @@ class Golden:
         return self.z.files
 
 
+def analytic_cotangent(shape, phase):
+    """the fixed [B,C,H,W] cotangent tests/golden/make_golden.py used for its gradient fixtures (rebuilt, not stored)"""
+    import numpy as np
+    import torch
+    B, C, H, W = shape
+    b, c, y, x = np.meshgrid(np.arange(B), np.arange(C), np.arange(H), np.arange(W), indexing="ij")
+    return torch.from_numpy(np.sin(0.37 * c + 0.11 * y + 0.05 * x + 1.3 * b + phase).astype(np.float32))
+
+
 @pytest.fixture(scope="session")
 def golden():
     cache = {}

@@ -168,6 +168,48 @@ def gen_splat_modes():
             bev_features_abs_sum=bf.abs().sum(), num_cams=torch.tensor(nc), **sd_arrays(m))
 
 
+def analytic_cotangent(shape, phase):
+    """a fixed smooth [B,C,H,W] cotangent (float64 sine pattern rounded to fp32) -- cheap to rebuild in the tests"""
+    B, C, H, W = shape
+    b, c, y, x = np.meshgrid(np.arange(B), np.arange(C), np.arange(H), np.arange(W), indexing="ij")
+    return torch.from_numpy(np.sin(0.37 * c + 0.11 * y + 0.05 * x + 1.3 * b + phase).astype(np.float32))
+
+
+def gen_splat_mv():
+    """Camera2MapMulti in TRAINING mode with the immovable-object mask as 4th input (splat_projection.py:214-219:
+    `_mv` keys, mask multiplied into the range mask, BatchNorm on batch statistics) + the gradients of a fixed linear
+    functional of the `_mv` features w.r.t. depth and features."""
+    from creste.models.blocks.splat_projection import Camera2MapMulti
+    from creste_public_amd.config import terrainnet_cfg
+    cfgd = dict(terrainnet_cfg().to_dict()["camera_projector"]); cfgd["num_cams"] = 1
+    g = torch.Generator().manual_seed(777)
+    torch.manual_seed(11)
+    m = Camera2MapMulti(wrap(cfgd), mode="bilinear")
+    randomise_bn(m, g)
+    sd0 = sd_arrays(m)
+    sd0 = {k: v.clone() for k, v in sd0.items()}
+    m.train()
+    B, hs, ws = 2, 14, 20
+    depth = (torch.rand(B, 1, hs, ws, generator=g) * 14.0 + 0.3).requires_grad_(True)
+    with torch.no_grad():
+        depth[:, :, :1, :3] = 30.0
+    feats = torch.randn(B, 1, 256, hs, ws, generator=g).requires_grad_(True)
+    p2p = make_p2p(B, hs, ws)
+    p2p[:, :, :3, 3] += torch.randn(B, 1, 3, generator=g) * 0.05
+    mv = (torch.rand(B, 1, hs, ws, generator=g) > 0.3).float()
+    out = m([depth, feats, p2p, mv])
+    assert set(out) == {"bev_features_mv", "bev_densities_mv", "bev_coords_mv"}
+    bf, dens = out["bev_features_mv"], out["bev_densities_mv"]
+    R, Rd = analytic_cotangent(bf.shape, 0.0), analytic_cotangent(dens.shape, 1.0)     # not stored: tests rebuild them
+    ((bf * R).sum() + (dens * Rd).sum()).backward()
+    touched = (dens[:, 0] != 0) | (bf != 0).any(dim=1)
+    after = {"after/" + k: v for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+    npz("splat_mv.npz", depth=depth, feats=feats, p2p=p2p, mv_mask=mv, bev_coords=out["bev_coords_mv"],
+        bev_densities=dens, touched_idx=touched.nonzero(), touched_feats=bf.permute(0, 2, 3, 1)[touched],
+        bev_features_abs_sum=bf.abs().sum(), g_depth=depth.grad, g_feats=feats.grad,
+        g_fuse_w=m.vision_fusion.convs[0].weight.grad, g_z0_w=m.z_proj[0].weight.grad, **sd0, **after)
+
+
 def gen_vin_svf_loss():
     import creste.models.blocks.vin as vin_mod
     from creste.models.blocks.vin import VIN
@@ -459,6 +501,7 @@ if __name__ == "__main__":
         pass
     gen_splat()
     gen_splat_modes()
+    gen_splat_mv()
     gen_vin_svf_loss()
     gen_blocks_and_utils()
     gen_distill_losses()

@@ -95,6 +95,35 @@ def test_splat_max_mode_and_multi_camera_semantics(golden):
     torch.testing.assert_close(b["bev_densities"][0], a["bev_densities"].sum(0), rtol=1e-5, atol=1e-6)
 
 
+def test_movability_masked_splat_matches_reference(golden):
+    """training-mode Camera2MapMulti with the immovable mask as 4th input (splat_projection.py:214-219): `_mv` keys,
+    forward values, BatchNorm running statistics and the gradients w.r.t. depth / features / parameters."""
+    from conftest import analytic_cotangent
+    g = golden("splat_mv.npz")
+    m = op.Camera2MapMulti(terrainnet_cfg()["camera_projector"])
+    m.load_state_dict(g.sd(), strict=True)
+    m.train()
+    depth, feats = g.t("depth").requires_grad_(True), g.t("feats").requires_grad_(True)
+    out = m([depth, feats, g.t("p2p"), g.t("mv_mask")])
+    out.pop("_tap_indices")
+    assert set(out) == {"bev_features_mv", "bev_densities_mv", "bev_coords_mv"}
+    bf, dens = out["bev_features_mv"], out["bev_densities_mv"]
+    assert torch.equal(out["bev_coords_mv"], g.t("bev_coords"))
+    torch.testing.assert_close(dens, g.t("bev_densities"), rtol=0, atol=1e-6)
+    idx = g.t("touched_idx")
+    torch.testing.assert_close(bf.permute(0, 2, 3, 1)[idx[:, 0], idx[:, 1], idx[:, 2]], g.t("touched_feats"),
+                               rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(bf.abs().sum(), g.t("bev_features_abs_sum"), rtol=1e-5, atol=0)
+    ((bf * analytic_cotangent(bf.shape, 0.0)).sum() + (dens * analytic_cotangent(dens.shape, 1.0)).sum()).backward()
+    torch.testing.assert_close(depth.grad, g.t("g_depth"), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(feats.grad, g.t("g_feats"), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(m.vision_fusion.convs[0].weight.grad, g.t("g_fuse_w"), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(m.z_proj[0].weight.grad, g.t("g_z0_w"), rtol=1e-4, atol=1e-5)
+    for k in ("running_mean", "running_var"):
+        torch.testing.assert_close(getattr(m.vision_fusion.convs[1], k), g.t(f"after/vision_fusion.convs.1.{k}"),
+                                   rtol=1e-5, atol=1e-6)
+
+
 def test_splat_invariants(golden):
     g = golden("splat_small.npz")
     m = _splat_module(golden)

@@ -48,7 +48,7 @@ def test_splat_stage_training():
 
     eng = SplatTrainEngine(m)
     dg, fg = depth.cuda().requires_grad_(True), feats.cuda().requires_grad_(True)
-    bev, dens, coords = SplatFn.apply(eng, dg, fg, p2p.view(B, 4, 4).cuda(), *eng.params())
+    bev, dens, coords = SplatFn.apply(eng, dg, fg, p2p.view(B, 4, 4).cuda(), None, *eng.params())
     ((bev * wb.cuda()).sum() + (dens * wd.cuda()).sum()).backward()
     torch.cuda.synchronize()
     assert _rel(coords, out_r["bev_coords"]) < 1e-5
@@ -80,7 +80,38 @@ def _ssc_objective(out, depth_label, fimg, ws):
     return loss
 
 
-def test_terrainnet_training_step():
+def test_movability_masked_splat_matches_reference_golden(golden):
+    """Camera2MapMulti.train() with the immovable mask as 4th input against the REFERENCE's own run
+    (tests/golden/splat_mv.npz): `_mv` keys, values, BatchNorm running statistics, gradients."""
+    from conftest import analytic_cotangent
+    from creste_public_amd.creste.models.blocks.splat_projection import Camera2MapMulti
+    g = golden("splat_mv.npz")
+    m = Camera2MapMulti(terrainnet_cfg()["camera_projector"])
+    m.load_state_dict(g.sd(), strict=True)
+    m = m.cuda().train()
+    depth, feats = g.t("depth").cuda().requires_grad_(True), g.t("feats").cuda().requires_grad_(True)
+    out = m([depth, feats, g.t("p2p").cuda(), g.t("mv_mask").cuda()])
+    assert set(out) == {"bev_features_mv", "bev_densities_mv", "bev_coords_mv"}
+    bf, dens = out["bev_features_mv"], out["bev_densities_mv"]
+    assert torch.equal(out["bev_coords_mv"].cpu(), g.t("bev_coords"))
+    torch.testing.assert_close(dens.cpu(), g.t("bev_densities"), rtol=0, atol=1e-6)
+    idx = g.t("touched_idx")
+    torch.testing.assert_close(bf.permute(0, 2, 3, 1).cpu()[idx[:, 0], idx[:, 1], idx[:, 2]], g.t("touched_feats"),
+                               rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(bf.abs().sum().cpu(), g.t("bev_features_abs_sum"), rtol=1e-5, atol=0)
+    ((bf * analytic_cotangent(bf.shape, 0.0).cuda()).sum() + (dens * analytic_cotangent(dens.shape, 1.0).cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    assert _rel(depth.grad, g.t("g_depth")) < 1e-3 and _p95(depth.grad, g.t("g_depth")) < 1e-3
+    assert _rel(feats.grad, g.t("g_feats")) < 1e-4
+    assert _rel(m.vision_fusion.convs[0].weight.grad, g.t("g_fuse_w")) < 1e-3
+    assert _rel(m.z_proj[0].weight.grad, g.t("g_z0_w")) < 1e-3
+    for k in ("running_mean", "running_var"):
+        torch.testing.assert_close(getattr(m.vision_fusion.convs[1], k).cpu(), g.t(f"after/vision_fusion.convs.1.{k}"),
+                                   rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("movability", [False, True])
+def test_terrainnet_training_step(movability):
     import oracle.blocks as ob
     from oracle.perception import TerrainNet as OracleNet
     from creste_public_amd import train_backbone as TB
@@ -88,6 +119,8 @@ def test_terrainnet_training_step():
     H, W, B = 64, 96, 2
     torch.manual_seed(31)
     cfg = terrainnet_cfg((H, W))
+    if movability:          # terrainnet.py:310-344: anchor splat + mask splat, two passes of the BEV heads
+        cfg["use_movability"] = True
     ob.DROP_CONNECT, TB.DROP_CONNECT = 0.0, 0.0
     try:
         ref = OracleNet(cfg)
@@ -103,11 +136,13 @@ def test_terrainnet_training_step():
         depth_label = torch.rand(B, 1, Hs, Ws, generator=g) * 30000.0 - 2000.0
         fimg = torch.randn(B, 1, 128, Hs, Ws, generator=g)
         keys = ["inpainting_sam_preds", "inpainting_sam_dynamic_preds", "elevation_preds"]
-        out_r = ref((rgbd.double(), p2p.double()))
+        mv = (torch.rand(B, 1, Hs, Ws, generator=g) > 0.25).float()
+        extra_r, extra = ((mv.double(),), (mv.cuda(),)) if movability else ((), ())
+        out_r = ref((rgbd.double(), p2p.double()) + extra_r)
         ws = {k: torch.randn(out_r[k].shape, generator=g) for k in keys}
         loss_r = _ssc_objective(out_r, depth_label.double(), fimg.double(), {k: v.double() for k, v in ws.items()})
         loss_r.backward()
-        out = model((rgbd.cuda(), p2p.cuda()))
+        out = model((rgbd.cuda(), p2p.cuda()) + extra)
         loss = _ssc_objective(out, depth_label.cuda(), fimg.cuda(), {k: v.cuda() for k, v in ws.items()})
         loss.backward()
         torch.cuda.synchronize()
@@ -116,8 +151,15 @@ def test_terrainnet_training_step():
     assert set(out.keys()) == set(out_r.keys())
     for k in ("depth_preds_logits", "depth_preds_metric", "dino_pe_feats"):
         assert _rel(out[k], out_r[k]) < 2e-4, k
-    for k in ("bev_features", "bev_densities") + tuple(keys):
+    more = ("bev_features_mv", "bev_densities_mv", "inpainting_sam_mv_preds") if movability else ()
+    assert all(k in out for k in more)
+    for k in ("bev_features", "bev_densities") + tuple(keys) + more:
         assert _p95(out[k], out_r[k]) < 2e-3, (k, _p95(out[k], out_r[k]))
+    if movability:          # both passes updated the BatchNorm running statistics, in the reference's order
+        for name in ("bevclassifier.bn1", "cam2map.vision_fusion.convs.1"):
+            a, b = model.get_submodule(name), ref.get_submodule(name)
+            assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 2, name
+            assert _rel(a.running_var, b.running_var) < 1e-3 and _rel(a.running_mean, b.running_mean) < 1e-3, name
     assert abs(float(loss) - float(loss_r)) < 2e-3 * abs(float(loss_r))
     ref_p = dict(ref.named_parameters())
     unused = ("_conv_head", "trunk._bn1", "_fc")
