@@ -42,6 +42,10 @@ class _PadConv2d(nn.Conv2d):
         self.static_pad = pad
 
 
+# expand 1x1 + depthwise conv of the thin-input MBConv blocks as one kernel (csrc/mbconv.hip); off = the two-kernel path
+FUSE_MBCONV = True
+
+
 class MBConvBlock(nn.Module):
     def __init__(self, k, s, e, cin, cout, pad):
         super().__init__()
@@ -74,7 +78,18 @@ class MBConvBlock(nn.Module):
             return (r.weight.detach().reshape(r.out_channels, -1).contiguous(), r.bias.detach().contiguous(),
                     x.weight.detach().reshape(x.out_channels, -1).contiguous(), x.bias.detach().contiguous())
 
+        def expand_pack():                     # [Cin][Cexp] BN-folded weights + bias of the fused expand + depthwise kernel
+            ex, b0 = self._expand_conv, self._bn0
+            if b0.training:
+                raise NotImplementedError("training-mode BatchNorm is not on the HIP path")
+            sc = b0.weight.detach() / torch.sqrt(b0.running_var + b0.eps)
+            w = (ex.weight.detach().reshape(self.mid, self.cin) * sc.view(-1, 1)).t().contiguous()
+            return w.float(), (b0.bias.detach() - b0.running_mean * sc).float().contiguous()
+
         return dict(
+            expand_fused=Cached(lambda: [self._expand_conv.weight, self._bn0.weight, self._bn0.bias,
+                                         self._bn0.running_mean, self._bn0.running_var], expand_pack)
+            if self.has_expand else None,
             expand=ConvUnit(self._expand_conv, self._bn0, ACT_SWISH) if self.has_expand else None,
             dw=Cached(lambda: [dw.weight, b1.weight, b1.bias, b1.running_mean, b1.running_var], dw_pack),
             se=Cached(lambda: [self._se_reduce.weight, self._se_reduce.bias, self._se_expand.weight,
@@ -85,10 +100,16 @@ class MBConvBlock(nn.Module):
         if self._plan is None:
             self._plan = self._build()
         p = self._plan
-        h = p["expand"](x) if p["expand"] is not None else x
         w, b = p["dw"].get()
-        h, gate = ops.dwconv2d_se(h, w, b, self.k, self.s, self._depthwise_conv.static_pad, ACT_SWISH,
-                                  *p["se"].get())
+        pad = self._depthwise_conv.static_pad
+        Ho, Wo = (x.H + pad[0] + pad[1] - self.k) // self.s + 1, (x.W + pad[2] + pad[3] - self.k) // self.s + 1
+        if FUSE_MBCONV and p["expand"] is not None and ops.mbconv_fusable(x, self.mid, self.k, self.s, Ho, Wo):
+            # thin-input blocks: the 6x expanded tensor stays in LDS between the expand and the depthwise conv
+            we, be = p["expand_fused"].get()
+            h, gate = ops.mbconv_expand_dw_se(x, we, be, w, b, self.k, self.s, pad, *p["se"].get())
+        else:
+            h = p["expand"](x) if p["expand"] is not None else x
+            h, gate = ops.dwconv2d_se(h, w, b, self.k, self.s, pad, ACT_SWISH, *p["se"].get())
         res = x if (self.s == 1 and self.cin == self.cout) else None   # id_skip (drop-connect is train-only)
         return p["project"](h, res=res, a_scale=gate)
 

@@ -1,0 +1,246 @@
+// MBConv front half in ONE pass: expand 1x1 conv (+ folded BN + swish) -> depthwise KxK / stride S conv (+ folded BN +
+// swish) -> squeeze-excite partial channel sums, for the early EfficientNet blocks whose expanded tensor is the largest
+// HBM object of the encoder (16 -> 96 channels at 304x608x16 = 1.1 GB written by the expand conv and read back by the
+// depthwise conv; reference call site creste/models/blocks/effnet.py:83 -> efficientnet_pytorch MBConvBlock.forward).
+// The expanded activations never reach HBM.
+//
+// One workgroup (256 threads) owns a strip of TW output columns x a band of output rows x ALL expanded channels and
+// walks down the band one output row at a time:
+//   ring  : the last K expanded rows (IW = (TW-1)*S + K pixels x Cexp channels) in LDS -- each expanded value is
+//           computed once per strip (horizontal halo (K-S)/(TW*S), vertical halo K-S rows per band)
+//   phase 1  S new input rows (K at the top of the band) are staged in LDS 
+//   phase 2  expand: thread = (pixel slice, channel quad); the quad's Cin x 4 weights live in registers, the pixel's
+//            input vector is a broadcast ds_read_b128 per 4 input channels; EXACT fp32 FMAs in channel order
+//            (Cin <= 40: this is VALU work, ~1/20 of the time the tensor's HBM round trip costs), pixels outside the
+//            image are stored as zeros (the depthwise conv pads the EXPANDED map)
+//   phase 3  depthwise: thread = (output column slice, channel quad), taps read from the ring, same accumulation order
+//            as dwconv_se_kernel (bias, then ky-major / kx-minor) -> output row, SE sums, running |max|
+#include "common.h"
+
+namespace creste {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MbArgs {
+  const float* x; const float* we; const float* be; const float* wd; const float* bd;
+  float* out; float* partial; float* amax;
+  int H, W, x_cs, Cexp, Ho, Wo, pad_t, pad_l, rows_per_band, nbands, nstrips;
+};
+
+// swish on the hardware transcendentals: v * rcp(1 + exp2(-v * log2 e)) -- v_exp_f32 and v_rcp_f32 are 1-ulp
+// instructions; expf + an IEEE division cost ~25 VALU instructions per value, and this kernel is VALU-bound (the two
+// activations were 2/3 of its instruction count).  Relative error <= ~1e-6 for |v| <= 10.
+__device__ __forceinline__ f32x4 swish4(f32x4 v) {
+  f32x4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    r[j] = v[j] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v[j] * -1.44269504088896341f));
+  return r;
+}
+
+template <int K, int S, int CIN, int TW, int MINB>
+__global__ __launch_bounds__(256, MINB) void mbconv_expand_dw_kernel(const MbArgs a) {
+  constexpr int IW = (TW - 1) * S + K;
+  constexpr int CQ = CIN / 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Cexp = a.Cexp, NQ = Cexp >> 2, PP = 256 / NQ;
+  float* const xrow = smem;                               // [K][IW][CIN]
+  float* const ring = xrow + K * IW * CIN;                // [K][IW][Cexp]
+  float* const red = ring + K * IW * Cexp;                // [PP][Cexp]
+  const int tid = threadIdx.x;
+  const int q = tid % NQ, ps = tid / NQ;
+  const bool active = ps < PP;
+  const int n = blockIdx.y;
+  const int chunk = xcd_remap(blockIdx.x, a.nstrips * a.nbands);
+  const int strip = chunk % a.nstrips, band = chunk / a.nstrips;
+  const int ox0 = strip * TW;
+  const int oy0 = band * a.rows_per_band, oy1 = min(a.Ho, oy0 + a.rows_per_band);
+  const int ix0 = ox0 * S - a.pad_l;                      // image column of ring / xrow pixel 0
+  const int iy_base = oy0 * S - a.pad_t;                  // image row of ring row 0 (may be negative)
+
+  f32x4 wq[CIN], dwq[K * K];
+  f32x4 bq = {0.f, 0.f, 0.f, 0.f}, dbq = bq;
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < CIN; ++k) wq[k] = *reinterpret_cast<const f32x4*>(a.we + (size_t)k * Cexp + 4 * q);
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) dwq[t] = *reinterpret_cast<const f32x4*>(a.wd + (size_t)t * Cexp + 4 * q);
+    bq = *reinterpret_cast<const f32x4*>(a.be + 4 * q);
+    dbq = *reinterpret_cast<const f32x4*>(a.bd + 4 * q);
+  }
+  f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
+  float vmax = 0.f;
+  int next_r = 0;                                         // ring rows [0, next_r) (relative to iy_base) are computed
+  for (int oy = oy0; oy < oy1; ++oy) {
+    const int need = (oy - oy0) * S + K;                  // rows [0, need) must be present
+    const int nr = need - next_r;                         // K on the band's first row, S afterwards
+    // phase 1: stage the nr new input rows (zeros outside the image).  (Prefetching them one output row ahead through
+    // registers was measured and LOSES: +8..44 VGPRs drop the 16-channel kernel from 3 to 2 waves per SIMD, 442 -> 481 us
+    // -- the kernel is VALU-bound, co-resident workgroups already cover the load latency.)
+    for (int e = tid; e < nr * IW * CQ; e += 256) {
+      const int kq = e % CQ, px = (e / CQ) % IW, r = e / (CQ * IW);
+      const int iy = iy_base + next_r + r, ix = ix0 + px;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+        v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.x_cs + 4 * kq);
+      *reinterpret_cast<f32x4*>(xrow + (size_t)e * 4) = v;                  // [r][px][kq] == e
+    }
+    __syncthreads();
+    // expand the new rows into the ring
+    if (active) {
+      for (int p = ps; p < nr * IW; p += PP) {
+        const int r = p / IW, px = p - r * IW;
+        const int rr = next_r + r, iy = iy_base + rr, ix = ix0 + px;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+          acc = bq;
+          const float* xp = xrow + (r * IW + px) * CIN;
+#pragma unroll
+          for (int kq = 0; kq < CQ; ++kq) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + 4 * kq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += wq[4 * kq + j] * xv[j];
+          }
+          acc = swish4(acc);
+        }
+        *reinterpret_cast<f32x4*>(ring + ((rr % K) * IW + px) * Cexp + 4 * q) = acc;
+      }
+    }
+    next_r = need;
+    __syncthreads();
+    // depthwise taps of output row oy
+    if (active) {
+      const int r0 = (oy - oy0) * S;
+      for (int ox = ps; ox < TW; ox += PP) {
+        if (ox0 + ox >= a.Wo) break;
+        f32x4 acc = dbq;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          const float* rp = ring + (((r0 + ky) % K) * IW + ox * S) * Cexp + 4 * q;
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) acc += *reinterpret_cast<const f32x4*>(rp + kx * Cexp) * dwq[ky * K + kx];
+        }
+        acc = swish4(acc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vmax = fmaxf(vmax, fabsf(acc[j]));
+        ssum += acc;
+        *reinterpret_cast<f32x4*>(a.out + ((size_t)(n * a.Ho + oy) * a.Wo + ox0 + ox) * Cexp + 4 * q) = acc;
+      }
+    }
+    // (no barrier here: the next row's staging only touches xrow, which this row's expand phase finished reading
+    //  before the barrier above; its ring writes come after the barrier that follows the staging)
+  }
+  __syncthreads();
+  // squeeze-excite partial sums of this workgroup: fixed-order sum over the pixel slices
+  if (active) *reinterpret_cast<f32x4*>(red + ps * Cexp + 4 * q) = ssum;
+  __syncthreads();
+  if (active && ps == 0) {
+    f32x4 tot = ssum;
+    for (int k = 1; k < PP; ++k) tot += *reinterpret_cast<const f32x4*>(red + k * Cexp + 4 * q);
+    *reinterpret_cast<f32x4*>(a.partial + ((size_t)n * a.nstrips * a.nbands + chunk) * Cexp + 4 * q) = tot;
+  }
+  if (a.amax) {
+    __syncthreads();
+    block_amax_update(vmax, a.amax, red);
+  }
+}
+
+struct MbPlan { int TW, nstrips, nbands, rows_per_band; size_t smem; };
+
+static bool mb_plan(int K, int S, int Cin, int Cexp, int N, int Ho, int Wo, MbPlan* p) {
+  if (!((K == 3 || K == 5) && (S == 1 || S == 2))) return false;
+  if (!(Cin == 16 || Cin == 24 || Cin == 40) || Cexp % 4 || Cexp < 4 || Cexp > 256) return false;
+  // strip width: smallest (horizontal halo factor) x (1.15 if the K-row ring leaves room for only one workgroup per CU)
+  const int cand[3] = {32, 16, 8};
+  int tw = 0;
+  size_t smem = 0;
+  float best = 1e30f;
+  for (int c = 0; c < 3; ++c) {
+    if (cand[c] == 32 && S == 2) continue;                 // instantiated: TW 32 for S = 1, TW 16 / 8 for both
+    const int iw = (cand[c] - 1) * S + K;
+    const size_t b = ((size_t)K * iw * (Cin + Cexp) + (size_t)(256 / (Cexp / 4)) * Cexp) * sizeof(float);
+    if (b > 160u * 1024) continue;
+    const float cost = (float)iw / (float)(cand[c] * S) * (b <= 80u * 1024 ? 1.f : 1.15f);
+    if (cost < best) { best = cost; tw = cand[c]; smem = b; }
+  }
+  if (!tw) return false;
+  p->TW = tw; p->smem = smem;
+  p->nstrips = (Wo + tw - 1) / tw;
+  int bands = (2048 + p->nstrips * N - 1) / (p->nstrips * N);
+  if (bands < 1) bands = 1;
+  int rows = (Ho + bands - 1) / bands;
+  const int min_rows = (K - S) * 3 / S > 1 ? (K - S) * 3 / S : 1;      // keep the vertical halo <= ~1/3 of a band
+  if (rows < min_rows) rows = min_rows;
+  p->rows_per_band = rows;
+  p->nbands = (Ho + rows - 1) / rows;
+  return true;
+}
+
+}  // namespace creste
+
+using namespace creste;
+
+extern "C" int creste_mbconv_partial_count(int N, int Ho, int Wo, int Cin, int Cexp, int K, int stride) {
+  MbPlan p;
+  if (N <= 0 || Ho <= 0 || Wo <= 0 || !mb_plan(K, stride, Cin, Cexp, N, Ho, Wo, &p)) return -1;
+  return p.nstrips * p.nbands;
+}
+
+template <int K, int S, int CIN, int TW>
+static int launch_mb(const MbArgs& a, int N, const MbPlan& p, hipStream_t s) {
+  static std::atomic<uint64_t> devs1{0}, devs2{0};
+  const dim3 grid(p.nstrips * p.nbands, N);
+  // K = 5 with 40 input channels holds 260 weight registers per thread: one workgroup per CU whatever the LDS use
+  // (the two-per-CU register budget would spill 256 B per lane)
+  constexpr bool kHeavy = K == 5 && CIN == 40;
+  if (!kHeavy && p.smem <= 80 * 1024) {
+    constexpr int kMinB = kHeavy ? 1 : 2;                  // (keeps the spilling variant out of the binary)
+    if (p.smem > 64 * 1024) CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(mbconv_expand_dw_kernel<K, S, CIN, TW, kMinB>), (int)p.smem, devs2));
+    mbconv_expand_dw_kernel<K, S, CIN, TW, kMinB><<<grid, 256, p.smem, s>>>(a);
+  } else {
+    if (p.smem > 64 * 1024) CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(mbconv_expand_dw_kernel<K, S, CIN, TW, 1>), (int)p.smem, devs1));
+    mbconv_expand_dw_kernel<K, S, CIN, TW, 1><<<grid, 256, p.smem, s>>>(a);
+  }
+  CRESTE_CHECK_LAUNCH("mbconv_expand_dw");
+  return CRESTE_OK;
+}
+
+template <int K, int S, int CIN>
+static int launch_mb_tw(const MbArgs& a, int N, const MbPlan& p, hipStream_t s) {
+  if constexpr (S == 1) {
+    if (p.TW == 32) return launch_mb<K, S, CIN, 32>(a, N, p, s);
+  }
+  if (p.TW == 16) return launch_mb<K, S, CIN, 16>(a, N, p, s);
+  return launch_mb<K, S, CIN, 8>(a, N, p, s);
+}
+
+template <int CIN>
+static int launch_mb_ks(const MbArgs& a, int N, int K, int S, const MbPlan& p, hipStream_t s) {
+  if (K == 3 && S == 1) return launch_mb_tw<3, 1, CIN>(a, N, p, s);
+  if (K == 3) return launch_mb_tw<3, 2, CIN>(a, N, p, s);
+  if (S == 1) return launch_mb_tw<5, 1, CIN>(a, N, p, s);
+  return launch_mb_tw<5, 2, CIN>(a, N, p, s);
+}
+
+extern "C" int creste_mbconv_expand_dw_f32(const float* x, int N, int H, int W, int Cin, int x_cs, const float* w_expand,
+                                           const float* b_expand, const float* w_dw, const float* b_dw, float* out,
+                                           float* partial, float* out_amax, int Cexp, int Ho, int Wo, int K, int stride,
+                                           int pad_t, int pad_l, void* stream) {
+  CRESTE_REQUIRE(x && w_expand && b_expand && w_dw && b_dw && out && partial, "mbconv_expand_dw: null pointer");
+  CRESTE_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && N < 65536, "mbconv_expand_dw: bad dims");
+  CRESTE_REQUIRE(x_cs % 4 == 0 && x_cs >= Cin && (reinterpret_cast<uintptr_t>(x) & 15) == 0,
+                 "mbconv_expand_dw: input slice must be 16-byte aligned with a channel stride that is a multiple of 4");
+  CRESTE_REQUIRE(pad_t >= 0 && pad_l >= 0 && pad_t < K && pad_l < K, "mbconv_expand_dw: bad padding");
+  MbPlan p;
+  CRESTE_REQUIRE(mb_plan(K, stride, Cin, Cexp, N, Ho, Wo, &p),
+                 "mbconv_expand_dw: not built for K=%d stride=%d Cin=%d Cexp=%d (K 3|5, stride 1|2, Cin 16|24|40, Cexp <= 256)",
+                 K, stride, Cin, Cexp);
+  CRESTE_REQUIRE((long)(Ho - 1) * stride - pad_t + K - 1 < H + K && (long)(Wo - 1) * stride - pad_l + K - 1 < W + K,
+                 "mbconv_expand_dw: output extent exceeds the padded input");
+  MbArgs a{x, w_expand, b_expand, w_dw, b_dw, out, partial, out_amax, H, W, x_cs, Cexp, Ho, Wo, pad_t, pad_l,
+           p.rows_per_band, p.nbands, p.nstrips};
+  hipStream_t s = (hipStream_t)stream;
+  if (Cin == 16) return launch_mb_ks<16>(a, N, K, stride, p, s);
+  if (Cin == 24) return launch_mb_ks<24>(a, N, K, stride, p, s);
+  return launch_mb_ks<40>(a, N, K, stride, p, s);
+}

@@ -594,6 +594,17 @@ extern "C" int creste_se_gate_f32(const float* x, float* partial, const float* w
   return CRESTE_OK;
 }
 
+extern "C" int creste_se_gate_partial_f32(const float* partial, int nchunk, const float* w1, const float* b1,
+                                          const float* w2, const float* b2, float* gate, int N, int HW, int C, int Cse,
+                                          void* stream) {
+  CRESTE_REQUIRE(partial && w1 && b1 && w2 && b2 && gate, "se_gate_partial: null pointer");
+  CRESTE_REQUIRE(C % 4 == 0 && C > 0 && Cse > 0 && N > 0 && HW > 0 && nchunk > 0, "se_gate_partial: bad dims");
+  se_gate_kernel<<<N, SEG_T, (size_t)(C + Cse + (C < SEG_T ? (SEG_T / C) * C : C)) * sizeof(float), (hipStream_t)stream>>>(
+      partial, w1, b1, w2, b2, gate, HW, C, Cse, nchunk);
+  CRESTE_CHECK_LAUNCH("se_gate");
+  return CRESTE_OK;
+}
+
 extern "C" int creste_upsample_concat_nhwc_f32(const float* x1, int N, int H1, int W1, int C1, int x1_cs,
                                                const float* skip, int C2, int skip_cs, float* out,
                                                int Ho, int Wo, int out_cs, int out_co, float rh,

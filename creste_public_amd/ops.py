@@ -291,6 +291,40 @@ def dwconv2d_se(x: Act, w_taps, bias, K, stride, pad, act, se_w1, se_b1, se_w2, 
     return out, gate
 
 
+def mbconv_fusable(x: Act, Cexp: int, K: int, stride: int, Ho: int, Wo: int) -> bool:
+    """is the fused expand + depthwise kernel built for this MBConv block AND a win?  Measured at batch 16 of 608x1216
+    (scripts/mbconv_micro.py, whole block, f16x3): 16->96 k3/s2 950 -> 544 us, 24->144 k3/s1 712 -> 534, 24->144 k5/s2
+    511 -> 370; 40->240 k5/s1 355 -> 595 and k3/s2 168 -> 184 LOSE (the exact-fp32 expand is VALU work that grows with
+    Cin while the HBM round trip it saves shrinks with the map) -- so: up to 24 input channels."""
+    return x.C <= 24 and _lib.load().creste_mbconv_partial_count(x.N, Ho, Wo, x.C, Cexp, K, stride) > 0
+
+
+def mbconv_expand_dw_se(x: Act, w_expand, b_expand, w_taps, b_dw, K, stride, pad, se_w1, se_b1, se_w2, se_b2):
+    """MBConv front half in one pass: expand 1x1 + BN + swish -> depthwise KxK + BN + swish -> squeeze-excite gate; the
+    expanded tensor stays in LDS (csrc/mbconv.hip).  w_expand [Cin][Cexp], w_taps [K*K][Cexp] (BN-folded)."""
+    lib = _lib.load()
+    Cexp = w_expand.shape[1]
+    Ho = (x.H + pad[0] + pad[1] - K) // stride + 1
+    Wo = (x.W + pad[2] + pad[3] - K) // stride + 1
+    dev = x.buf.device
+    nchunk = lib.creste_mbconv_partial_count(x.N, Ho, Wo, x.C, Cexp, K, stride)
+    if nchunk <= 0:
+        raise HipLibraryError(f"mbconv_expand_dw is not built for Cin={x.C} Cexp={Cexp} K={K} stride={stride}")
+    out = Act.empty(x.N, Ho, Wo, Cexp, dev)
+    partial = torch.empty((x.N, nchunk, Cexp), dtype=torch.float32, device=dev)
+    gate = torch.empty((x.N, Cexp), dtype=torch.float32, device=dev)
+    if TRACK_AMAX:
+        out.amax = _AmaxPool.slot(dev)
+    _lib.check(lib.creste_mbconv_expand_dw_f32(
+        x.ptr, x.N, x.H, x.W, x.C, x.cs, _chk(w_expand).data_ptr(), _chk(b_expand).data_ptr(), _chk(w_taps).data_ptr(),
+        _chk(b_dw).data_ptr(), out.ptr, partial.data_ptr(), out.amax.data_ptr() if TRACK_AMAX else None, Cexp, Ho, Wo,
+        K, stride, pad[0], pad[2], _stream()), "mbconv_expand_dw")
+    _lib.check(lib.creste_se_gate_partial_f32(partial.data_ptr(), nchunk, _chk(se_w1).data_ptr(), _chk(se_b1).data_ptr(),
+                                              _chk(se_w2).data_ptr(), _chk(se_b2).data_ptr(), gate.data_ptr(), x.N,
+                                              Ho * Wo, Cexp, se_w1.shape[0], _stream()), "se_gate_partial")
+    return out, gate
+
+
 def se_gate(x: Act, w1, b1, w2, b2) -> torch.Tensor:
     lib = _lib.load()
     assert x.co == 0 and x.cs == x.C

@@ -137,6 +137,24 @@ int creste_dwconv_se_nhwc_f32(const float* in, const float* w, const float* bias
 int creste_se_gate_f32(const float* x, float* partial, const float* w1, const float* b1,
                        const float* w2, const float* b2, float* gate, int N, int HW, int C, int Cse,
                        void* stream);
+/* the gate from `nchunk` partial-sum rows per image that another kernel left in `partial` ([N][nchunk][C]) */
+int creste_se_gate_partial_f32(const float* partial, int nchunk, const float* w1, const float* b1, const float* w2,
+                               const float* b2, float* gate, int N, int HW, int C, int Cse, void* stream);
+
+/* MBConv front half in one pass (csrc/mbconv.hip): out = swish(dw_KxK/stride(swish(x * w_expand + b_expand)) + b_dw)
+ * -- the expand 1x1 conv, its folded BatchNorm + swish, the depthwise conv (zero padding of the EXPANDED map: pad_t /
+ * pad_l, bottom / right implied by Ho, Wo), its folded BatchNorm + swish, and the squeeze-excite partial channel sums of
+ * the output; the expanded tensor never reaches HBM.  Replaces, for the early EfficientNet-B0 blocks, the
+ * `_expand_conv -> _bn0 -> swish -> _depthwise_conv -> _bn1 -> swish` chain of efficientnet_pytorch 0.7.1
+ * MBConvBlock.forward (reference call site creste/models/blocks/effnet.py:83).  Exact fp32 FMAs in every precision
+ * mode.  x: NHWC slice (channel stride x_cs); w_expand [Cin][Cexp], w_dw [K*K][Cexp] (both BN-folded), out dense
+ * [N,Ho,Wo,Cexp]; partial: [N][creste_mbconv_partial_count(..)][Cexp] -> creste_se_gate_partial_f32.
+ * Built for K 3|5, stride 1|2, Cin 16|24|40, Cexp <= 256 (multiple of 4); anything else is CRESTE_ERR_ARG. */
+int creste_mbconv_partial_count(int N, int Ho, int Wo, int Cin, int Cexp, int K, int stride);   /* < 0: not built */
+int creste_mbconv_expand_dw_f32(const float* x, int N, int H, int W, int Cin, int x_cs, const float* w_expand,
+                                const float* b_expand, const float* w_dw, const float* b_dw, float* out,
+                                float* partial, float* out_amax, int Cexp, int Ho, int Wo, int K, int stride,
+                                int pad_t, int pad_l, void* stream);
 
 /* out[..., 0:C2] = skip ; out[..., C2:C2+C1] = bilinear_upsample(x1) (align_corners=False, PyTorch
  * source-index rule src = rs*(dst+0.5)-0.5 clamped at 0).  reference effnet.py:25-28

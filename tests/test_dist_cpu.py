@@ -176,7 +176,7 @@ class _StandInTerrainNet(torch.nn.Module):
         self.elev = torch.nn.Conv2d(8, 2, 1)
 
     def forward(self, x):
-        image, _ = x
+        image = x[0]                      # (image, p2p, immovable mask | None), as train_ssc.py:103 passes it
         h = torch.relu(self.enc(image[:, 0]))
         return {"inpainting_sam_preds": self.sam(h), "inpainting_sam_dynamic_preds": self.dyn(h),
                 "elevation_preds": self.elev(h)}

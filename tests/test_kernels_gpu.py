@@ -267,6 +267,53 @@ def test_dwconv_se_fused(ops, Cc, K, s, pad):
     torch.testing.assert_close(gate.cpu().double(), gate_ref, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("Cin,K,s,pad,HW", [(16, 3, 2, (0, 1, 0, 1), (45, 71)), (24, 3, 1, (1, 1, 1, 1), (37, 50)),
+                                            (24, 5, 2, (1, 2, 1, 2), (40, 33)), (40, 5, 1, (2, 2, 2, 2), (23, 19)),
+                                            (40, 3, 2, (0, 1, 0, 1), (30, 41)), (16, 5, 1, (2, 2, 2, 2), (9, 7))])
+def test_mbconv_expand_depthwise_fused(ops, Cin, K, s, pad, HW):
+    """expand 1x1 + swish -> depthwise KxK + swish -> squeeze-excite gate in one pass (csrc/mbconv.hip) against float64
+    torch: ragged strips / bands (sizes that are no multiple of the tile), an input SLICE of a wider buffer, the
+    zero padding of the EXPANDED map (bias + swish must not leak into the border), the running |max|."""
+    g = torch.Generator().manual_seed(Cin * 100 + K * 10 + s)
+    N, (H, W), Cexp, Cse = 3, HW, 6 * Cin, max(1, Cin // 4)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    we, be = torch.randn(Cexp, Cin, generator=g) / Cin ** 0.5, torch.randn(Cexp, generator=g) + 0.5
+    wd, bd = torch.randn(Cexp, 1, K, K, generator=g) / K, torch.randn(Cexp, generator=g)
+    w1, b1 = torch.randn(Cse, Cexp, generator=g) / Cexp ** 0.5, torch.randn(Cse, generator=g)
+    w2, b2 = torch.randn(Cexp, Cse, generator=g) / Cse ** 0.5, torch.randn(Cexp, generator=g)
+    e = F.conv2d(x.double(), we.double().view(Cexp, Cin, 1, 1), be.double())
+    e = e * torch.sigmoid(e)
+    y = F.conv2d(F.pad(e, (pad[2], pad[3], pad[0], pad[1])), wd.double(), bd.double(), stride=s, groups=Cexp)
+    y = y * torch.sigmoid(y)
+    h = y.mean(dim=(2, 3)) @ w1.double().t() + b1.double()
+    gate_ref = torch.sigmoid((h * torch.sigmoid(h)) @ w2.double().t() + b2.double())
+    wide = torch.randn(N, H, W, Cin + 8, generator=g)                      # the block's input is a channel slice
+    wide[..., 4:4 + Cin] = x.permute(0, 2, 3, 1)
+    xa = ops.Act(dev(wide), Cin, 4)
+    old = ops.TRACK_AMAX
+    ops.TRACK_AMAX = True
+    try:
+        out, gate = ops.mbconv_expand_dw_se(xa, dev(we.t().contiguous()), dev(be), dev(wd.view(Cexp, K * K).t().contiguous()),
+                                            dev(bd), K, s, pad, dev(w1), dev(b1), dev(w2), dev(b2))
+    finally:
+        ops.TRACK_AMAX = old
+    torch.testing.assert_close(from_act(out).double(), y, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(gate.cpu().double(), gate_ref, rtol=1e-5, atol=2e-6)
+    assert abs(float(out.amax) - float(y.abs().max())) <= 1e-5 * float(y.abs().max())
+
+
+def test_mbconv_fused_rejects_what_it_is_not_built_for(ops):
+    lib = ops._lib.load()
+    assert lib.creste_mbconv_partial_count(2, 10, 10, 32, 192, 3, 1) < 0          # 32 input channels
+    assert lib.creste_mbconv_partial_count(2, 10, 10, 16, 96, 7, 1) < 0           # 7x7
+    assert lib.creste_mbconv_partial_count(2, 10, 10, 40, 480, 3, 1) < 0          # more than 256 expanded channels
+    x = ops.Act(torch.zeros(1, 8, 8, 32, device="cuda"), 32, 0)
+    w = torch.zeros(32, 192, device="cuda")
+    with pytest.raises(ops.HipLibraryError):
+        ops.mbconv_expand_dw_se(x, w, w[0], torch.zeros(9, 192, device="cuda"), w[0], 3, 1, (1, 1, 1, 1), w[:8], w[0, :8],
+                                w[:, :8].contiguous(), w[0])
+
+
 @pytest.mark.parametrize("Cc,Cse,HW", [(32, 8, (40, 52)), (96, 4, (64, 70)), (1152, 48, (5, 7))])
 def test_se_gate(ops, Cc, Cse, HW):
     g = torch.Generator().manual_seed(Cc)
