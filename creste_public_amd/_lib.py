@@ -50,6 +50,8 @@ SIGNATURES = {
     "creste_se_gate_f32": (_i, [_vp] * 7 + [_i] * 4 + [_vp]),
     "creste_se_gate_partial_f32": (_i, [_vp, _i] + [_vp] * 5 + [_i] * 4 + [_vp]),
     "creste_mbconv_partial_count": (_i, [_i] * 7),
+    "creste_stem_dw_partial_count": (_i, [_i] * 4),
+    "creste_stem_dw_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "creste_mbconv_expand_dw_f32": (_i, [_vp, _i, _i, _i, _i, _i] + [_vp] * 7 + [_i] * 7 + [_vp]),
     "creste_upsample_concat_nhwc_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i,
                                               _f, _f, _vp, _vp]),

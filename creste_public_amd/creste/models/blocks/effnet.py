@@ -110,8 +110,14 @@ class MBConvBlock(nn.Module):
         else:
             h = p["expand"](x) if p["expand"] is not None else x
             h, gate = ops.dwconv2d_se(h, w, b, self.k, self.s, pad, ACT_SWISH, *p["se"].get())
+        return self.project_act(x, h, gate)
+
+    def project_act(self, x: Act, h: Act, gate) -> Act:
+        """SE-gated project conv + BN (+ identity skip) on the depthwise output h."""
+        if self._plan is None:
+            self._plan = self._build()
         res = x if (self.s == 1 and self.cin == self.cout) else None   # id_skip (drop-connect is train-only)
-        return p["project"](h, res=res, a_scale=gate)
+        return self._plan["project"](h, res=res, a_scale=gate)
 
 
 class EfficientNetB0Trunk(nn.Module):
@@ -133,13 +139,38 @@ class EfficientNetB0Trunk(nn.Module):
         self._fc = nn.Linear(1280, 1000)
         self._stem = None
 
+    def _stem_pack(self):
+        """[(ky*3+kx)*4+ci][32] BN-folded stem weights + bias of the fused stem + depthwise kernel"""
+        cv, b0 = self._conv_stem, self._bn0
+        if b0.training:
+            raise NotImplementedError("training-mode BatchNorm is not on the HIP path")
+        sc = b0.weight.detach() / torch.sqrt(b0.running_var + b0.eps)
+        w = (cv.weight.detach() * sc.view(-1, 1, 1, 1)).permute(2, 3, 1, 0).reshape(-1, cv.out_channels).contiguous()
+        return w.float(), (b0.bias.detach() - b0.running_mean * sc).float().contiguous()
+
     def extract_endpoints_act(self, x: Act):
         if self._stem is None:
             self._stem = ConvUnit(self._conv_stem, self._bn0, ACT_SWISH, pad=self._conv_stem.static_pad)
-        x = self._stem(x)
+            self._stem_fused = Cached(lambda: [self._conv_stem.weight, self._bn0.weight, self._bn0.bias,
+                                               self._bn0.running_mean, self._bn0.running_var], self._stem_pack)
+        b0, pad = self._blocks[0], self._conv_stem.static_pad
+        H1, W1 = (x.H + pad[0] + pad[1] - 3) // 2 + 1, (x.W + pad[2] + pad[3] - 3) // 2 + 1
+        skip0 = (FUSE_MBCONV and not b0.has_expand and b0.k == 3 and b0.s == 1 and self._conv_stem.in_channels == 4
+                 and ops.stem_dw_fusable(x, 32, H1, W1))
+        if skip0:
+            # stem conv -> block 0's depthwise conv in one kernel: the 32-channel stem output stays in LDS
+            if b0._plan is None:
+                b0._plan = b0._build()
+            ws, bs = self._stem_fused.get()
+            wd, bd = b0._plan["dw"].get()
+            h, gate = ops.stem_dw_se(x, ws, bs, pad, wd, bd, b0._depthwise_conv.static_pad, *b0._plan["se"].get())
+            x = b0.project_act(None, h, gate)
+        else:
+            x = self._stem(x)
         eps, prev, n = {}, x, len(self._blocks)
         for i, blk in enumerate(self._blocks):
-            x = blk.forward_act(x)
+            if not (skip0 and i == 0):
+                x = blk.forward_act(x)
             if prev.H > x.H:
                 eps[f"reduction_{len(eps) + 1}"] = prev
             elif i == n - 1:

@@ -176,6 +176,155 @@ static bool mb_plan(int K, int S, int Cin, int Cexp, int N, int Ho, int Wo, MbPl
   return true;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Encoder stem + first MBConv block's depthwise half in one pass: 3x3 / stride 2 conv of the 4-channel RGB-D image
+// (+ folded BN + swish; EfficientNet `_conv_stem`, `_bn0`; reference effnet.py:41-44,83) -> depthwise 3x3 / stride 1
+// (+ folded BN + swish; block 0 has no expand conv) -> squeeze-excite sums.  Same strip / band / row-ring structure as
+// above with the stem conv as the producer of the ring rows: the 32-channel stem output (378 MB at batch 16) never
+// reaches HBM, and the stem leaves the fp32-MFMA implicit-GEMM kernel, where its 4-channel input filled 4 of 16
+// K-lanes (0.42 ms for 6.8 GFLOP).  Exact fp32 FMAs, taps in (ky, kx, ci) order.
+struct StemArgs {
+  const float* x; const float* ws; const float* bs; const float* wd; const float* bd;
+  float* out; float* partial; float* amax;
+  int H, W, C1, H1, W1, pad_t, pad_l, dpad_t, dpad_l, rows_per_band, nbands, nstrips;
+};
+
+template <int TW>
+__global__ __launch_bounds__(256, 2) void stem_dw_kernel(const StemArgs a) {
+  constexpr int K = 3, IW = TW + K - 1, XW = 2 * IW + 1;   // ring row / staged input row, in pixels
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int C1 = a.C1, NQ = C1 >> 2, PP = 256 / NQ;
+  float* const xin = smem;                                 // [2 * K + 1][XW][4]
+  float* const ring = xin + (2 * K + 1) * XW * 4;          // [K][IW][C1]
+  float* const red = ring + K * IW * C1;                   // [PP][C1]
+  const int tid = threadIdx.x;
+  const int q = tid % NQ, ps = tid / NQ;
+  const bool active = ps < PP;
+  const int n = blockIdx.y;
+  const int chunk = xcd_remap(blockIdx.x, a.nstrips * a.nbands);
+  const int strip = chunk % a.nstrips, band = chunk / a.nstrips;
+  const int ox0 = strip * TW;
+  const int oy0 = band * a.rows_per_band, oy1 = min(a.H1, oy0 + a.rows_per_band);
+  const int x1_0 = ox0 - a.dpad_l, y1_base = oy0 - a.dpad_t;       // stem column of ring pixel 0 / stem row of ring row 0
+  const int ix_0 = 2 * x1_0 - a.pad_l;                             // image column of staged pixel 0
+
+  f32x4 wsq[36], dwq[9];
+  f32x4 bq = {0.f, 0.f, 0.f, 0.f}, dbq = bq;
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < 36; ++t) wsq[t] = *reinterpret_cast<const f32x4*>(a.ws + (size_t)t * C1 + 4 * q);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dwq[t] = *reinterpret_cast<const f32x4*>(a.wd + (size_t)t * C1 + 4 * q);
+    bq = *reinterpret_cast<const f32x4*>(a.bs + 4 * q);
+    dbq = *reinterpret_cast<const f32x4*>(a.bd + 4 * q);
+  }
+  f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
+  float vmax = 0.f;
+  constexpr int NPRE = (3 * XW + 255) / 256;
+  f32x4 pre[NPRE];
+  int next_r = 0;
+  for (int oy = oy0; oy < oy1; ++oy) {
+    const int need = (oy - oy0) + K;
+    const int nr = need - next_r;                          // new stem rows: K at the top of the band, then 1
+    const int iy_0 = 2 * (y1_base + next_r) - a.pad_t;     // image row of staged row 0
+    if (oy == oy0) {                                       // top of the band: 2K+1 image rows, staged directly
+      for (int e = tid; e < (2 * nr + 1) * XW; e += 256) {
+        const int r = e / XW, px = e - r * XW;
+        const int iy = iy_0 + r, ix = ix_0 + px;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+          v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(n * a.H + iy) * a.W + ix) * 4);
+        *reinterpret_cast<f32x4*>(xin + (size_t)e * 4) = v;
+      }
+    } else {                                               // afterwards: the 3 rows prefetched during the previous row
+#pragma unroll
+      for (int j = 0; j < NPRE; ++j)
+        if (tid + 256 * j < 3 * XW) *reinterpret_cast<f32x4*>(xin + (size_t)(tid + 256 * j) * 4) = pre[j];
+    }
+    __syncthreads();
+    if (oy + 1 < oy1) {                                    // next row's image rows: in flight during both phases below
+      const int iy_n = 2 * (y1_base + need) - a.pad_t;
+#pragma unroll
+      for (int j = 0; j < NPRE; ++j) {
+        const int e = tid + 256 * j, r = e / XW, px = e - r * XW;
+        const int iy = iy_n + r, ix = ix_0 + px;
+        const bool ok = e < 3 * XW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? a.x + ((size_t)(n * a.H + iy) * a.W + ix) * 4 : a.x);
+        pre[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    if (active) {
+      for (int p = ps; p < nr * IW; p += PP) {
+        const int r = p / IW, px = p - r * IW;
+        const int rr = next_r + r, y1 = y1_base + rr, x1 = x1_0 + px;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)y1 < (unsigned)a.H1 && (unsigned)x1 < (unsigned)a.W1) {
+          acc = bq;
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const f32x4 xv = *reinterpret_cast<const f32x4*>(xin + ((2 * r + ky) * XW + 2 * px + kx) * 4);
+#pragma unroll
+              for (int ci = 0; ci < 4; ++ci) acc += wsq[(ky * 3 + kx) * 4 + ci] * xv[ci];
+            }
+          acc = swish4(acc);
+        }
+        *reinterpret_cast<f32x4*>(ring + ((rr % K) * IW + px) * C1 + 4 * q) = acc;
+      }
+    }
+    next_r = need;
+    __syncthreads();
+    if (active) {
+      const int r0 = oy - oy0;
+      for (int ox = ps; ox < TW; ox += PP) {
+        if (ox0 + ox >= a.W1) break;
+        f32x4 acc = dbq;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          const float* rp = ring + (((r0 + ky) % K) * IW + ox) * C1 + 4 * q;
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) acc += *reinterpret_cast<const f32x4*>(rp + kx * C1) * dwq[ky * K + kx];
+        }
+        acc = swish4(acc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vmax = fmaxf(vmax, fabsf(acc[j]));
+        ssum += acc;
+        *reinterpret_cast<f32x4*>(a.out + ((size_t)(n * a.H1 + oy) * a.W1 + ox0 + ox) * C1 + 4 * q) = acc;
+      }
+    }
+  }
+  __syncthreads();
+  if (active) *reinterpret_cast<f32x4*>(red + ps * C1 + 4 * q) = ssum;
+  __syncthreads();
+  if (active && ps == 0) {
+    f32x4 tot = ssum;
+    for (int k = 1; k < PP; ++k) tot += *reinterpret_cast<const f32x4*>(red + k * C1 + 4 * q);
+    *reinterpret_cast<f32x4*>(a.partial + ((size_t)n * a.nstrips * a.nbands + chunk) * C1 + 4 * q) = tot;
+  }
+  if (a.amax) {
+    __syncthreads();
+    block_amax_update(vmax, a.amax, red);
+  }
+}
+
+constexpr int STEM_TW = 62;                                // ring rows of 64 pixels: two full rounds of 32 pixel slices
+
+static bool stem_plan(int N, int H1, int W1, int C1, MbPlan* p) {
+  if (C1 % 4 || C1 < 4 || C1 > 64 || 256 % (C1 / 4)) return false;
+  constexpr int IW = STEM_TW + 2, XW = 2 * IW + 1;
+  p->TW = STEM_TW;
+  p->smem = ((size_t)7 * XW * 4 + (size_t)3 * IW * C1 + (size_t)(256 / (C1 / 4)) * C1) * sizeof(float);
+  p->nstrips = (W1 + STEM_TW - 1) / STEM_TW;
+  int bands = (2048 + p->nstrips * N - 1) / (p->nstrips * N);
+  int rows = (H1 + bands - 1) / bands;
+  if (rows < 6) rows = 6;
+  p->rows_per_band = rows;
+  p->nbands = (H1 + rows - 1) / rows;
+  return true;
+}
+
 }  // namespace creste
 
 using namespace creste;
@@ -243,4 +392,28 @@ extern "C" int creste_mbconv_expand_dw_f32(const float* x, int N, int H, int W, 
   if (Cin == 16) return launch_mb_ks<16>(a, N, K, stride, p, s);
   if (Cin == 24) return launch_mb_ks<24>(a, N, K, stride, p, s);
   return launch_mb_ks<40>(a, N, K, stride, p, s);
+}
+
+extern "C" int creste_stem_dw_partial_count(int N, int H1, int W1, int C1) {
+  MbPlan p;
+  if (N <= 0 || H1 <= 0 || W1 <= 0 || !stem_plan(N, H1, W1, C1, &p)) return -1;
+  return p.nstrips * p.nbands;
+}
+
+extern "C" int creste_stem_dw_f32(const float* x, int N, int H, int W, const float* w_stem, const float* b_stem, int pad_t,
+                                  int pad_l, const float* w_dw, const float* b_dw, int dpad_t, int dpad_l, float* out,
+                                  float* partial, float* out_amax, int C1, int H1, int W1, void* stream) {
+  CRESTE_REQUIRE(x && w_stem && b_stem && w_dw && b_dw && out && partial, "stem_dw: null pointer");
+  CRESTE_REQUIRE(N > 0 && N < 65536 && H > 0 && W > 0 && H1 > 0 && W1 > 0, "stem_dw: bad dims");
+  CRESTE_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "stem_dw: the 4-channel NHWC image must be 16-byte aligned");
+  CRESTE_REQUIRE(pad_t >= 0 && pad_t < 3 && pad_l >= 0 && pad_l < 3 && dpad_t >= 0 && dpad_t < 3 && dpad_l >= 0 && dpad_l < 3,
+                 "stem_dw: bad padding");
+  CRESTE_REQUIRE(2L * (H1 - 1) - pad_t < H && 2L * (W1 - 1) - pad_l < W, "stem_dw: stem output extent exceeds the image");
+  MbPlan p;
+  CRESTE_REQUIRE(stem_plan(N, H1, W1, C1, &p), "stem_dw: %d stem channels not built (multiple of 4 dividing 1024, <= 64)", C1);
+  StemArgs a{x, w_stem, b_stem, w_dw, b_dw, out, partial, out_amax, H, W, C1, H1, W1, pad_t, pad_l, dpad_t, dpad_l,
+             p.rows_per_band, p.nbands, p.nstrips};
+  stem_dw_kernel<STEM_TW><<<dim3(p.nstrips * p.nbands, N), 256, p.smem, (hipStream_t)stream>>>(a);
+  CRESTE_CHECK_LAUNCH("stem_dw");
+  return CRESTE_OK;
 }

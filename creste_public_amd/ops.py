@@ -325,6 +325,37 @@ def mbconv_expand_dw_se(x: Act, w_expand, b_expand, w_taps, b_dw, K, stride, pad
     return out, gate
 
 
+def stem_dw_fusable(x: Act, C1: int, H1: int, W1: int) -> bool:
+    return x.C == 4 and x.cs == 4 and x.co == 0 and _lib.load().creste_stem_dw_partial_count(x.N, H1, W1, C1) > 0
+
+
+def stem_dw_se(x: Act, w_stem, b_stem, pad, w_taps, b_dw, dpad, se_w1, se_b1, se_w2, se_b2):
+    """encoder stem (3x3/2 conv of the 4-channel image + BN + swish) -> block 0's depthwise 3x3 + BN + swish -> SE gate
+    in one pass (csrc/mbconv.hip); w_stem [36][C1] in (ky, kx, ci) order, w_taps [9][C1]."""
+    lib = _lib.load()
+    C1 = w_stem.shape[1]
+    H1 = (x.H + pad[0] + pad[1] - 3) // 2 + 1
+    W1 = (x.W + pad[2] + pad[3] - 3) // 2 + 1
+    assert (H1 + dpad[0] + dpad[1] - 3 + 1, W1 + dpad[2] + dpad[3] - 3 + 1) == (H1, W1), "depthwise conv must keep the size"
+    dev = x.buf.device
+    nchunk = lib.creste_stem_dw_partial_count(x.N, H1, W1, C1)
+    if nchunk <= 0 or x.C != 4 or x.cs != 4 or x.co != 0:
+        raise HipLibraryError("stem_dw is built for a dense 4-channel NHWC image")
+    out = Act.empty(x.N, H1, W1, C1, dev)
+    partial = torch.empty((x.N, nchunk, C1), dtype=torch.float32, device=dev)
+    gate = torch.empty((x.N, C1), dtype=torch.float32, device=dev)
+    if TRACK_AMAX:
+        out.amax = _AmaxPool.slot(dev)
+    _lib.check(lib.creste_stem_dw_f32(x.ptr, x.N, x.H, x.W, _chk(w_stem).data_ptr(), _chk(b_stem).data_ptr(), pad[0], pad[2],
+                                      _chk(w_taps).data_ptr(), _chk(b_dw).data_ptr(), dpad[0], dpad[2], out.ptr,
+                                      partial.data_ptr(), out.amax.data_ptr() if TRACK_AMAX else None, C1, H1, W1,
+                                      _stream()), "stem_dw")
+    _lib.check(lib.creste_se_gate_partial_f32(partial.data_ptr(), nchunk, _chk(se_w1).data_ptr(), _chk(se_b1).data_ptr(),
+                                              _chk(se_w2).data_ptr(), _chk(se_b2).data_ptr(), gate.data_ptr(), x.N,
+                                              H1 * W1, C1, se_w1.shape[0], _stream()), "se_gate_partial")
+    return out, gate
+
+
 def se_gate(x: Act, w1, b1, w2, b2) -> torch.Tensor:
     lib = _lib.load()
     assert x.co == 0 and x.cs == x.C

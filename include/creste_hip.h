@@ -150,6 +150,15 @@ int creste_se_gate_partial_f32(const float* partial, int nchunk, const float* w1
  * mode.  x: NHWC slice (channel stride x_cs); w_expand [Cin][Cexp], w_dw [K*K][Cexp] (both BN-folded), out dense
  * [N,Ho,Wo,Cexp]; partial: [N][creste_mbconv_partial_count(..)][Cexp] -> creste_se_gate_partial_f32.
  * Built for K 3|5, stride 1|2, Cin 16|24|40, Cexp <= 256 (multiple of 4); anything else is CRESTE_ERR_ARG. */
+/* Encoder stem + the depthwise half of the first MBConv block in one pass: out = swish(dw3x3(swish(conv3x3/2(x) +
+ * b_stem)) + b_dw) for the 4-channel NHWC RGB-D image x [N,H,W,4] (`_conv_stem`/`_bn0` then block 0's
+ * `_depthwise_conv`/`_bn1`, reference effnet.py:41-44,83); w_stem [(ky*3+kx)*4+ci][C1], w_dw [9][C1] (BN-folded);
+ * pad_t/pad_l: the stem's static 'same' padding, dpad_*: the depthwise conv's; out dense [N,H1,W1,C1]; partial:
+ * [N][creste_stem_dw_partial_count(..)][C1] -> creste_se_gate_partial_f32. */
+int creste_stem_dw_partial_count(int N, int H1, int W1, int C1);   /* < 0: not built */
+int creste_stem_dw_f32(const float* x, int N, int H, int W, const float* w_stem, const float* b_stem, int pad_t,
+                       int pad_l, const float* w_dw, const float* b_dw, int dpad_t, int dpad_l, float* out,
+                       float* partial, float* out_amax, int C1, int H1, int W1, void* stream);
 int creste_mbconv_partial_count(int N, int Ho, int Wo, int Cin, int Cexp, int K, int stride);   /* < 0: not built */
 int creste_mbconv_expand_dw_f32(const float* x, int N, int H, int W, int Cin, int x_cs, const float* w_expand,
                                 const float* b_expand, const float* w_dw, const float* b_dw, float* out,

@@ -48,3 +48,19 @@ for (k, s, cin, cout, H, W) in BLOCKS:
     d = (outs[True] - outs[False]).abs().max().item(); sc = outs[False].abs().max().item()
     print(f"k{k} s{s} {cin}->{6*cin}->{cout} @{H}x{W}: max|fused - split| = {d:.3e} (max|out| {sc:.3e})")
 print(f"{prec}: front halves of the five blocks: split {tot[0]:.3f} ms, fused {tot[1]:.3f} ms")
+# stem + block 0 (fused stem / depthwise kernel vs conv kernel + depthwise kernel)
+from creste_public_amd.creste.models.blocks.effnet import EfficientNetB0Trunk
+trunk = EfficientNetB0Trunk(4, (608, 1216)).to(dev).eval()
+for m in trunk.modules():
+    if isinstance(m, torch.nn.BatchNorm2d):
+        m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+img = ops.nchw_to_nhwc(torch.rand(B, 4, 608, 1216, device=dev))
+img.amax = img.buf.abs().max().reshape(1).clone()
+trunk._blocks = trunk._blocks[:1]
+res = {}
+with torch.no_grad():
+    for fused in (False, True):
+        E.FUSE_MBCONV = fused
+        res[fused] = list(trunk.extract_endpoints_act(img).values())[-1].buf.clone()
+        print(f"stem + block 0 {'fused' if fused else 'split'}: {timeit(lambda: trunk.extract_endpoints_act(img)) * 1e3:7.1f} us")
+print(f"max|fused - split| = {(res[True] - res[False]).abs().max().item():.3e} (max|out| {res[False].abs().max().item():.3e})")

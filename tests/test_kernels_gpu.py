@@ -302,6 +302,32 @@ def test_mbconv_expand_depthwise_fused(ops, Cin, K, s, pad, HW):
     assert abs(float(out.amax) - float(y.abs().max())) <= 1e-5 * float(y.abs().max())
 
 
+@pytest.mark.parametrize("HW,pad", [((64, 130), (0, 1, 0, 1)), ((45, 37), (1, 1, 1, 1)), ((17, 9), (0, 1, 1, 1))])
+def test_stem_depthwise_fused(ops, HW, pad):
+    """3x3/2 stem conv of the RGB-D image + swish -> depthwise 3x3 + swish -> SE gate in one pass (csrc/mbconv.hip)
+    against float64 torch, on sizes that are no multiple of the strip / band tiling, with asymmetric 'same' padding."""
+    g = torch.Generator().manual_seed(HW[0])
+    N, (H, W), C1, Cse = 3, HW, 32, 8
+    x = torch.randn(N, 4, H, W, generator=g)
+    ws, bs = torch.randn(C1, 4, 3, 3, generator=g) / 6, torch.randn(C1, generator=g) * 0.5
+    wd, bd = torch.randn(C1, 1, 3, 3, generator=g) / 3, torch.randn(C1, generator=g)
+    w1, b1 = torch.randn(Cse, C1, generator=g) / C1 ** 0.5, torch.randn(Cse, generator=g)
+    w2, b2 = torch.randn(C1, Cse, generator=g) / Cse ** 0.5, torch.randn(C1, generator=g)
+    e = F.conv2d(F.pad(x.double(), (pad[2], pad[3], pad[0], pad[1])), ws.double(), bs.double(), stride=2)
+    e = e * torch.sigmoid(e)
+    y = F.conv2d(e, wd.double(), bd.double(), padding=1, groups=C1)
+    y = y * torch.sigmoid(y)
+    h = y.mean(dim=(2, 3)) @ w1.double().t() + b1.double()
+    gate_ref = torch.sigmoid((h * torch.sigmoid(h)) @ w2.double().t() + b2.double())
+    xa = to_act(ops, x)
+    assert xa.cs == 4
+    out, gate = ops.stem_dw_se(xa, dev(ws.permute(2, 3, 1, 0).reshape(36, C1)), dev(bs), pad,
+                               dev(wd.view(C1, 9).t().contiguous()), dev(bd), (1, 1, 1, 1), dev(w1), dev(b1), dev(w2), dev(b2))
+    assert (out.H, out.W) == tuple(y.shape[-2:])
+    torch.testing.assert_close(from_act(out).double(), y, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(gate.cpu().double(), gate_ref, rtol=1e-5, atol=2e-6)
+
+
 def test_mbconv_fused_rejects_what_it_is_not_built_for(ops):
     lib = ops._lib.load()
     assert lib.creste_mbconv_partial_count(2, 10, 10, 32, 192, 3, 1) < 0          # 32 input channels
