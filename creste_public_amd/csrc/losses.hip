@@ -35,6 +35,10 @@ __device__ __forceinline__ float mpc_dot(const float (&r)[D], const float* __res
   return s;
 }
 
+// exp on the hardware transcendental (v_exp_f32, 1 ulp; the scaled argument adds <= |x| * 6e-8): the library expf is
+// ~15 VALU instructions and every pair of the N x M sweep pays one
+__device__ __forceinline__ float mpc_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
 // stats[i] = (max, sumexp, count, possum)
 template <int D>
 __global__ __launch_bounds__(256) void mpc_rows_kernel(const float* __restrict__ f, const float* __restrict__ a,
@@ -64,8 +68,8 @@ __global__ __launch_bounds__(256) void mpc_rows_kernel(const float* __restrict__
       const int j = j0 + jj;
       if (j == i + self_off) continue;
       const float z = mpc_dot<D>(r, tile[jj]) * inv_t;
-      if (z > mx) { se = se * expf(mx - z) + 1.f; mx = z; }
-      else se += expf(z - mx);
+      if (z > mx) { se = se * mpc_exp(mx - z) + 1.f; mx = z; }
+      else se += mpc_exp(z - mx);
       if (tlab[jj] == li) { cnt += 1.f; ps += z; }
     }
   }
@@ -80,8 +84,8 @@ __global__ void mpc_merge_kernel(const float4* __restrict__ part, int N, int nsp
   for (int k = 0; k < nsplit; ++k) {
     const float4 p = part[(size_t)k * N + i];
     if (p.y > 0.f) {
-      if (p.x > mx) { se = se * expf(mx - p.x) + p.y; mx = p.x; }
-      else se += p.y * expf(p.x - mx);
+      if (p.x > mx) { se = se * mpc_exp(mx - p.x) + p.y; mx = p.x; }
+      else se += p.y * mpc_exp(p.x - mx);
     }
     cnt += p.z; ps += p.w;
   }
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256) void mpc_grad_kernel(const float* __restrict__
       if (s.z <= 0.f) continue;                                   // a row without positives contributes nothing
       const float z = mpc_dot<D>(r, tile[kk]) * inv_t;
       const float w = ROWS ? wi : trw[kk] * gscale;
-      float gij = expf(z - s.x) * s.y;
+      float gij = mpc_exp(z - s.x) * s.y;
       if (tlab[kk] == lt) gij -= s.w;
       gij *= w * inv_t;
 #pragma unroll
@@ -193,6 +197,15 @@ __global__ void mpc_sum_splits_kernel(const float* __restrict__ part, long n, in
 
 }  // namespace creste
 
+namespace creste {     // csrc/supcon_mfma.hip: the same sweeps on the matrix cores (D = 16, 32, 64)
+bool mpc_mfma_supported(int D);
+int64_t mpc_mfma_workspace_bytes(int N, int M, int D);
+int mpc_mfma_rows(const float* f, const float* a, const int64_t* lab_f, const int64_t* lab_a, const float* rw, int N, int M,
+                  int D, int self_off, float inv_t, float4* part, int ns, int per_split, void* work, hipStream_t s);
+int mpc_mfma_grad(bool rows, const float4* stats, const float* rw, int N, int M, int D, int self_off, float inv_t,
+                  float gscale, float* gpart, int ns, int per_split, void* work, hipStream_t s);
+}  // namespace creste
+
 using namespace creste;
 
 static inline int mpc_splits(int rows) {
@@ -201,11 +214,16 @@ static inline int mpc_splits(int rows) {
   return n < 1 ? 1 : (n > 16 ? 16 : n);
 }
 
-// workspace: stats [N] | split stats [16][N] | loss partials [4096] | split gradients [16][max(N,M)][D]
-extern "C" int64_t creste_multipos_con_workspace_bytes(int N, int M, int D) {
-  if (N <= 0 || M <= 0 || D <= 0) return -1;
+// workspace: stats [N] | split stats [16][N] | loss partials [4096] | split gradients [16][max(N,M)][D] | the packed
+// fp16 operands of the matrix-core path (D = 16, 32, 64)
+static inline int64_t mpc_base_bytes(int N, int M, int D) {
   const int64_t big = N > M ? N : M;
   return (int64_t)N * 16 * 17 + 4096 * 4 + 16 * big * D * 4;
+}
+
+extern "C" int64_t creste_multipos_con_workspace_bytes(int N, int M, int D) {
+  if (N <= 0 || M <= 0 || D <= 0) return -1;
+  return mpc_base_bytes(N, M, D) + (mpc_mfma_supported(D) ? mpc_mfma_workspace_bytes(N, M, D) : 0);
 }
 
 #define CRESTE_MPC_DISPATCH(D_, CALL)            \
@@ -227,10 +245,16 @@ extern "C" int creste_multipos_con_forward_f32(const float* feats, const float* 
   float* partial = (float*)((char*)work + (size_t)N * 16 * 17);
   const int nb = (N + 255) / 256, ns = mpc_splits(N);
   const int per = ((M + ns - 1) / ns + MPC_TILE - 1) / MPC_TILE * MPC_TILE;
+  if (mpc_mfma_supported(D)) {
+    const int rc = mpc_mfma_rows(feats, all_feats, labels, all_labels, row_weights, N, M, D, self_offset, 1.f / temperature,
+                                 part, ns, per, (char*)work + mpc_base_bytes(N, M, D), s);
+    if (rc != CRESTE_OK) return rc;
+  } else {
 #define CALL(DD) mpc_rows_kernel<DD><<<dim3(nb, ns), 256, 0, s>>>(feats, all_feats, labels, all_labels, N, M, self_offset, 1.f / temperature, part, per)
-  CRESTE_MPC_DISPATCH(D, CALL)
+    CRESTE_MPC_DISPATCH(D, CALL)
 #undef CALL
-  CRESTE_CHECK_LAUNCH("mpc_rows");
+    CRESTE_CHECK_LAUNCH("mpc_rows");
+  }
   mpc_merge_kernel<<<nb, 256, 0, s>>>(part, N, ns, stats);
   const int lb = nb < 1024 ? nb : 1024;
   mpc_loss_kernel<<<lb, 256, 0, s>>>(stats, row_weights, N, partial);
@@ -252,6 +276,17 @@ extern "C" int creste_multipos_con_backward_f32(const float* feats, const float*
   const int ns_r = mpc_splits(N), ns_c = mpc_splits(M);
   const int per_r = ((M + ns_r - 1) / ns_r + MPC_TILE - 1) / MPC_TILE * MPC_TILE;
   const int per_c = ((N + ns_c - 1) / ns_c + MPC_TILE - 1) / MPC_TILE * MPC_TILE;
+  if (mpc_mfma_supported(D)) {      // (forward packed the operands into the same workspace)
+    void* mw = (char*)work + mpc_base_bytes(N, M, D);
+    int rc = mpc_mfma_grad(true, stats, row_weights, N, M, D, self_offset, 1.f / temperature, gs, gpart, ns_r, per_r, mw, s);
+    if (rc != CRESTE_OK) return rc;
+    mpc_sum_splits_kernel<<<1024, 256, 0, s>>>(gpart, (long)N * D, ns_r, g_feats);
+    rc = mpc_mfma_grad(false, stats, row_weights, N, M, D, self_offset, 1.f / temperature, gs, gpart, ns_c, per_c, mw, s);
+    if (rc != CRESTE_OK) return rc;
+    mpc_sum_splits_kernel<<<1024, 256, 0, s>>>(gpart, (long)M * D, ns_c, g_all);
+    CRESTE_CHECK_LAUNCH("mpc_grad");
+    return CRESTE_OK;
+  }
 #define CALL(DD)                                                                                                          \
   mpc_grad_kernel<DD, true><<<dim3((N + 255) / 256, ns_r), 256, 0, s>>>(feats, all_feats, labels, all_labels, stats,    \
                                                                          row_weights, N, M, self_offset, 1.f / temperature, gs, gpart, per_r); \

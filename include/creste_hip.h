@@ -468,7 +468,9 @@ int creste_pixel_geometry_bwd_f32(const float* depth, const float* p2p, int B, i
  * column of row i's own sample).
  * forward: *loss = mean_i w_i * (logsumexp_{j != self} z_ij - mean_{j in P_i} z_ij), rows without positives count 0;
  * backward (same workspace, after forward): g_feats [N][D], g_all [M][D] = grad_scale * d loss / d (feats, all_feats).
- * D in {8,16,32,64}; work: creste_multipos_con_workspace_bytes(N, M, D). */
+ * D in {8,16,32,64}; D = 16 / 32 / 64 run on the matrix cores (csrc/supcon_mfma.hip: fp16 hi+lo operands rescaled by
+ * exact powers of two from a device |max|, fp32 accumulation -- any finite feature magnitude).
+ * work: creste_multipos_con_workspace_bytes(N, M, D). */
 int64_t creste_multipos_con_workspace_bytes(int N, int M, int D);
 int creste_multipos_con_forward_f32(const float* feats, const float* all_feats, const int64_t* labels,
                                     const int64_t* all_labels, const float* row_weights, int N, int M, int D,

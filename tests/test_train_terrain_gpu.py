@@ -261,6 +261,41 @@ def test_fused_multipos_contrastive_loss(N, D, ncls, weights):
     assert abs(float(l2h) - float(l2r)) < 2e-6 * abs(float(l2r))
 
 
+@pytest.mark.parametrize("N,M,off,D", [(200, 523, 200, 16), (333, 1000, 500, 32), (97, 97, 0, 64), (64, 4096, 1024, 32)])
+def test_multipos_contrastive_kernels_with_gathered_columns(N, M, off, D):
+    """the data-parallel shape of the loss: N local rows against M >= N gathered columns, the local rows sitting at
+    `off` in the gathered list (self pairs excluded there), row weights -- forward and both gradients against float64
+    tensor code (definition: supcon_loss.py:56-115); D = 16 / 32 / 64 run on the matrix cores (csrc/supcon_mfma.hip)."""
+    from creste_public_amd.loss_ops import MultiPosConFn
+    g = torch.Generator().manual_seed(N + M)
+    T = 0.07
+    a = torch.nn.functional.normalize(torch.randn(M, D, generator=g), dim=1)
+    la = torch.randint(0, 7, (M,), generator=g)
+    la[off] = 99                                                # local row 0: no positives
+    w = torch.rand(N, generator=g) + 0.25
+    ar = a.double().requires_grad_(True)
+    fr = ar[off:off + N]
+    z = fr @ ar.t() / T
+    eye = torch.zeros(N, M, dtype=torch.bool)
+    eye[torch.arange(N), torch.arange(N) + off] = True
+    pos = (la[off:off + N, None] == la[None, :]) & ~eye
+    lse = torch.logsumexp(z.masked_fill(eye, float("-inf")), dim=1)
+    cnt = pos.sum(1)
+    per = torch.where(cnt > 0, lse - (z * pos).sum(1) / cnt.clamp(min=1), torch.zeros_like(lse))
+    loss_r = (per * w.double()).mean()
+    loss_r.backward()
+    fg = a[off:off + N].clone().cuda().requires_grad_(True)
+    ag = a.clone().cuda().requires_grad_(True)
+    loss = MultiPosConFn.apply(fg, ag, la[off:off + N].cuda(), la.cuda(), w.cuda(), off, T)
+    (2.5 * loss).backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_r)) < 3e-6 * abs(float(loss_r))
+    gt = ar.grad.clone()                                         # float64 autograd put both roles into one tensor
+    got = ag.grad.cpu().double()
+    got[off:off + N] += fg.grad.cpu().double()
+    assert _rel(got, 2.5 * gt) < 3e-5, _rel(got, 2.5 * gt)
+
+
 def test_ssc_losses_on_gpu_match_reference_golden(tmp_path):
     """the SSC objective as the GPU runs it (fused contrastive + depth-CE/MSE kernels where they apply) against the
     reference's own LossManager outputs."""
