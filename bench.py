@@ -354,6 +354,24 @@ def irl_extras(model_infer, device, steps=3):
     return out
 
 
+def latency_extras(model, device, iters=30):
+    """single-frame latency of the same forward (the deployed robot runs batch 1: scripts/runtime in the reference)"""
+    from creste_public_amd import synth
+    rgbd, p2p = synth.make_frames(1, IMG_H, IMG_W, seed=7)
+    rgbd, p2p = rgbd.to(device), p2p.to(device)
+    with torch.no_grad():
+        for _ in range(3):
+            model((rgbd, p2p))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            model((rgbd, p2p))
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    return {"batch": 1, "ms_per_frame": round(ms, 3), "frames_per_s": round(1e3 / ms, 1),
+            "note": "eager launches through the C ABI, inputs resident in HBM; not the headline workload"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -499,6 +517,7 @@ def main():
                                   "; ".join(f"{k} = {v}" for k, v in DTYPE.items()))
             line["fp32_equivalent_frames_per_s"] = {k: line["modes_frames_per_s"][k] for k in ("f32", "bf16x6")}
         if args.gpus == 1 and not args.no_irl:
+            line["latency"] = latency_extras(model, device)
             line["irl"] = irl_extras(model, device)
             line["distill"] = distill_extras(device)
             line["ssc"] = ssc_extras(device)

@@ -9,7 +9,7 @@ prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 creste_public_amd.set_precision(prec)
 dev = torch.device("cuda")
 model = bench.build_model(dev)
-B, H, W = 16, bench.IMG_H, bench.IMG_W
+B, H, W = (int(sys.argv[2]) if len(sys.argv) > 2 else 16), bench.IMG_H, bench.IMG_W
 gen = torch.Generator().manual_seed(1337)
 rgbd = torch.zeros(B, 1, 4, H, W, device=dev); rgbd[:, 0, :3] = torch.rand(B, 3, H, W, generator=gen).to(dev)
 scan = synth.lidar_scan(B, gen).to(dev); l2c = synth.lidar2camrect(B, H, W).to(dev); p2p = synth.make_p2p(B, H, W).to(dev)
