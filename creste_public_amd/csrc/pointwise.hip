@@ -291,6 +291,187 @@ __global__ __launch_bounds__(256) void upsample_concat_kernel(
   if (amax) block_amax_update(vmax, amax, scratch);
 }
 
+// Exact 2x variant (every Up block of the encoder and the heads' second upsample): a thread owns one channel quad of
+// one LOW-resolution pixel and writes the 2 x 2 output pixels it maps to -- the 3 x 3 source neighbourhood is loaded
+// once (9 quad loads per 4 outputs instead of 16; the generic kernel runs at 2.7 TB/s on vector-memory ISSUE, not on
+// bytes).  Each output is formed with the same taps, the same weights and the same expression as the generic kernel
+// (PyTorch's source-index rule, clamped at the borders), so the results are bit-identical.
+__global__ __launch_bounds__(256) void upsample2x_concat_kernel(
+    const float* __restrict__ x1, int H1, int W1, int C1, int x1_cs, const float* __restrict__ skip, int C2,
+    int skip_cs, float* __restrict__ out, int out_cs, int out_co, float* __restrict__ amax) {
+  __shared__ float scratch[4];
+  const int cq = (C1 + C2) >> 2, c2q = C2 >> 2;
+  const int n = blockIdx.y / H1, y = blockIdx.y - n * H1;
+  const int Ho = 2 * H1, Wo = 2 * W1;
+  const int qpp = cq < 256 ? cq : 256, xpp = 256 / qpp;
+  float vmax = 0.f;
+  // vertical taps of output rows 2y and 2y + 1 (align_corners = False, scale 0.5): src = 0.5 * (dst + 0.5) - 0.5
+  float wyb[2];
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy) {
+    float sy = 0.5f * ((float)(2 * y + dy) + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+    wyb[dy] = sy - (float)(int)sy;
+  }
+  for (int q0 = 0; q0 < cq; q0 += qpp) {
+    const int q = q0 + (int)threadIdx.x % qpp, xs = (int)threadIdx.x / qpp;
+    if (q >= cq || xs >= xpp) continue;
+    float* o0 = out + ((long)(n * Ho + 2 * y) * Wo) * out_cs + out_co + q * 4;
+    float* o1 = o0 + (long)Wo * out_cs;
+    if (q < c2q) {                                          // skip connection: a 2 x 2 copy
+      const float* s0 = skip + ((long)(n * Ho + 2 * y) * Wo) * skip_cs + q * 4;
+      const float* s1 = s0 + (long)Wo * skip_cs;
+      for (int x = blockIdx.x * xpp + xs; x < W1; x += gridDim.x * xpp) {
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const f32x4 a = ld4(s0 + (long)(2 * x + dx) * skip_cs), b = ld4(s1 + (long)(2 * x + dx) * skip_cs);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) vmax = fmaxf(vmax, fmaxf(fabsf(a[j]), fabsf(b[j])));
+          st4(o0 + (long)(2 * x + dx) * out_cs, a);
+          st4(o1 + (long)(2 * x + dx) * out_cs, b);
+        }
+      }
+      continue;
+    }
+    const int c = (q - c2q) * 4;
+    // rows y-1 (clamped), y, y+1 (clamped)
+    const float* rm = x1 + ((long)n * H1 + (y > 0 ? y - 1 : 0)) * W1 * x1_cs + c;
+    const float* r0 = x1 + ((long)n * H1 + y) * W1 * x1_cs + c;
+    const float* rp = x1 + ((long)n * H1 + (y < H1 - 1 ? y + 1 : y)) * W1 * x1_cs + c;
+    for (int x = blockIdx.x * xpp + xs; x < W1; x += gridDim.x * xpp) {
+      const int xm = x > 0 ? x - 1 : 0, xp = x < W1 - 1 ? x + 1 : x;
+      f32x4 v[3][3];
+      v[0][0] = ld4(rm + (long)xm * x1_cs); v[0][1] = ld4(rm + (long)x * x1_cs); v[0][2] = ld4(rm + (long)xp * x1_cs);
+      v[1][0] = ld4(r0 + (long)xm * x1_cs); v[1][1] = ld4(r0 + (long)x * x1_cs); v[1][2] = ld4(r0 + (long)xp * x1_cs);
+      v[2][0] = ld4(rp + (long)xm * x1_cs); v[2][1] = ld4(rp + (long)x * x1_cs); v[2][2] = ld4(rp + (long)xp * x1_cs);
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        // output row 2y + dy takes neighbourhood rows (dy, dy + 1) and output column 2x + dx columns (dx, dx + 1): in
+        // the interior those ARE PyTorch's (y0, y1) / (x0, x1); at a border the clamped duplicate holds the same data
+        // as the tap it stands in for, or its weight is exactly 0
+        const float wy1 = wyb[dy], wy0 = 1.f - wy1;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          float sx = 0.5f * ((float)(2 * x + dx) + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
+          const float lx = sx - (float)(int)sx, hx = 1.f - lx;
+          const f32x4 r = wy0 * (hx * v[dy][dx] + lx * v[dy][dx + 1]) + wy1 * (hx * v[dy + 1][dx] + lx * v[dy + 1][dx + 1]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) vmax = fmaxf(vmax, fabsf(r[j]));
+          st4((dy ? o1 : o0) + (long)(2 * x + dx) * out_cs, r);
+        }
+      }
+    }
+  }
+  if (amax) block_amax_update(vmax, amax, scratch);
+}
+
+// Exact 2x, wide maps: the same arithmetic with the low-resolution rows in an LDS ring.  The register kernel above
+// loads every source quad nine times (once per 3 x 3 neighbourhood that contains it): 2.25 bytes read per byte
+// written -- measured, its stores alone take 186 us of the 321 us on the heads' 256-channel map, the loads the rest.
+// Here a workgroup owns a strip of TW source columns and walks down a band of source rows; each source row is
+// fetched ONCE per strip (+2 halo columns) into a four-slot ring -- the fetch of row y + 2 is in flight while the two
+// output rows of source row y are formed from slots (y-1, y, y+1) -- one barrier per source row.
+#ifndef UPS_RING_LDS
+#define UPS_RING_LDS (52 * 1024)   // three workgroups per CU: measured best (26 KB: 310 us, 52: 271, 80: 292 on the heads' map)
+#endif
+template <int TW>
+__global__ __launch_bounds__(256) void upsample2x_ring_kernel(
+    const float* __restrict__ x1, int H1, int W1, int C1, int x1_cs, const float* __restrict__ skip, int C2,
+    int skip_cs, float* __restrict__ out, int out_cs, int out_co, float* __restrict__ amax, int rows_per_band,
+    int nstrips) {
+  constexpr int IW = TW + 2;
+  extern __shared__ __attribute__((aligned(16))) float ring[];            // [4][IW][C1]
+  __shared__ float scratch[4];
+  const int c1q = C1 >> 2, c2q = C2 >> 2, cq = c1q + c2q;
+  const int n = blockIdx.y, strip = blockIdx.x % nstrips, band = blockIdx.x / nstrips;
+  const int xs0 = strip * TW, y0 = band * rows_per_band, y1 = min(H1, y0 + rows_per_band);
+  const int Ho = 2 * H1, Wo = 2 * W1;
+  const int tid = threadIdx.x;
+  const int nld = IW * c1q;                                               // quads of one staged row
+  constexpr int NPRE = 6;                                                 // staged quads per thread (host: nld <= 6 * 256)
+  f32x4 pre[NPRE];
+  auto fetch = [&](int row) __attribute__((always_inline)) {              // source row `row` (clamped columns) -> registers
+    const float* rp = x1 + ((long)n * H1 + row) * W1 * x1_cs;
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+      const int e = tid + 256 * j;
+      const int px = e / c1q, q = e - px * c1q;
+      int xc = xs0 - 1 + px; xc = xc < 0 ? 0 : (xc > W1 - 1 ? W1 - 1 : xc);
+      pre[j] = ld4(rp + (long)xc * x1_cs + 4 * (e < nld ? q : 0));
+    }
+  };
+  auto commit = [&](int row) __attribute__((always_inline)) {
+    float* dst = ring + (size_t)(row & 3) * IW * C1;
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+      const int e = tid + 256 * j;
+      if (e < nld) st4(dst + (size_t)e * 4, pre[j]);                       // [px][q] == e
+    }
+  };
+  // prologue: rows y0-1 (clamped), y0, y0+1 (clamped)
+  const int rfirst = y0 > 0 ? y0 - 1 : 0, rlast = min(H1 - 1, y0 + 1);
+  for (int r = rfirst; r <= rlast; ++r) { fetch(r); commit(r); }
+  __syncthreads();
+  float vmax = 0.f;
+  for (int y = y0; y < y1; ++y) {
+    const bool more = y + 2 <= H1 - 1 && y + 1 < y1;                      // the next source row needs row y + 2
+    if (more) fetch(y + 2);
+    const int ym = y > 0 ? y - 1 : 0, yp = y < H1 - 1 ? y + 1 : y;
+    const float* rows[3] = {ring + (size_t)(ym & 3) * IW * C1, ring + (size_t)(y & 3) * IW * C1,
+                            ring + (size_t)(yp & 3) * IW * C1};
+    float wyb[2];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      float sy = 0.5f * ((float)(2 * y + dy) + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+      wyb[dy] = sy - (float)(int)sy;
+    }
+    float* o0 = out + ((long)(n * Ho + 2 * y) * Wo) * out_cs + out_co;
+    float* o1 = o0 + (long)Wo * out_cs;
+    for (int e = tid; e < TW * cq; e += 256) {
+      const int xl = e / cq, q = e - xl * cq, x = xs0 + xl;
+      if (x >= W1) break;
+      if (q < c2q) {                                                       // skip connection: a 2 x 2 copy
+        const float* s0 = skip + ((long)(n * Ho + 2 * y) * Wo) * skip_cs + q * 4;
+        const float* s1 = s0 + (long)Wo * skip_cs;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const f32x4 a = ld4(s0 + (long)(2 * x + dx) * skip_cs), b = ld4(s1 + (long)(2 * x + dx) * skip_cs);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) vmax = fmaxf(vmax, fmaxf(fabsf(a[j]), fabsf(b[j])));
+          st4(o0 + (long)(2 * x + dx) * out_cs + q * 4, a);
+          st4(o1 + (long)(2 * x + dx) * out_cs + q * 4, b);
+        }
+        continue;
+      }
+      // staged pixel index of source column x is xl + 1; its clamped neighbours: at the map's borders the duplicate
+      const int pm = x > 0 ? xl : xl + 1, pp = x < W1 - 1 ? xl + 2 : xl + 1;
+      const int c = (q - c2q) * 4;
+      f32x4 v[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        v[i][0] = ld4(rows[i] + pm * C1 + c);
+        v[i][1] = ld4(rows[i] + (xl + 1) * C1 + c);
+        v[i][2] = ld4(rows[i] + pp * C1 + c);
+      }
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        const float wy1 = wyb[dy], wy0 = 1.f - wy1;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          float sx = 0.5f * ((float)(2 * x + dx) + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
+          const float lx = sx - (float)(int)sx, hx = 1.f - lx;
+          const f32x4 r = wy0 * (hx * v[dy][dx] + lx * v[dy][dx + 1]) + wy1 * (hx * v[dy + 1][dx] + lx * v[dy + 1][dx + 1]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) vmax = fmaxf(vmax, fabsf(r[j]));
+          st4((dy ? o1 : o0) + (long)(2 * x + dx) * out_cs + q * 4, r);
+        }
+      }
+    }
+    if (more) commit(y + 2);
+    __syncthreads();
+  }
+  if (amax) block_amax_update(vmax, amax, scratch);
+}
+
 // ------------------------------------------------------------------------------ max-pool DSxDS/DS
 // DS = 2: nn.MaxPool2d(2, 2) / F.max_pool2d(x, ds, ds) of the reward head (vin.py:104-106); DS = 1: the degenerate
 // pool of reward_cfg.ds == 1 (a row/column crop into the output slice).
@@ -616,6 +797,43 @@ extern "C" int creste_upsample_concat_nhwc_f32(const float* x1, int N, int H1, i
   CRESTE_REQUIRE(out_cs >= out_co + C1 + C2, "upsample_concat: output slice exceeds out_cs");
   CRESTE_REQUIRE((long)N * Ho < 65536 * 32768L && (long)Wo * ((C1 + C2) / 4) < (1L << 30), "upsample_concat: extent too large");
   const int cq_all = (C1 + C2) / 4, qpp = cq_all < 256 ? cq_all : 256, xpp = 256 / qpp;
+  if (Ho == 2 * H1 && Wo == 2 * W1 && rh == 0.5f && rw == 0.5f && H1 > 1 && W1 > 1) {
+    // wide maps: source rows staged once per strip in an LDS ring (four slots of (TW + 2) x C1 floats, three
+    // workgroups per CU); the strip is the widest that fits, and a staged row must fit the kernel's 6 register quads per thread
+    int tw = 0;
+    for (int c = 32; c >= 4 && !tw; c >>= 1)
+      if (4L * (c + 2) * C1 * 4 <= UPS_RING_LDS && (long)(c + 2) * (C1 / 4) <= 6 * 256) tw = c;
+    if (tw && (long)N * H1 * W1 >= 16384) {
+      const int nstrips = (W1 + tw - 1) / tw;
+      int bands = (2048 + nstrips * N - 1) / (nstrips * N);
+      int rows = (H1 + bands - 1) / bands;
+      if (rows < 4) rows = 4;
+      bands = (H1 + rows - 1) / rows;
+      const size_t smem = 4UL * (tw + 2) * C1 * 4;
+      const dim3 grid(nstrips * bands, N);
+      hipStream_t st = (hipStream_t)stream;
+      static std::atomic<uint64_t> devs32{0}, devs16{0}, devs8{0}, devs4{0};
+#define CRESTE_UPS_RING(TW_, DEVS)                                                                                       \
+  do {                                                                                                                   \
+    if (smem > 64 * 1024) CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(upsample2x_ring_kernel<TW_>), (int)smem, DEVS)); \
+    upsample2x_ring_kernel<TW_><<<grid, 256, smem, st>>>(x1, H1, W1, C1, x1_cs, skip, C2, skip_cs, out, out_cs, out_co, \
+                                                        out_amax, rows, nstrips);                                        \
+  } while (0)
+      if (tw == 32) CRESTE_UPS_RING(32, devs32);
+      else if (tw == 16) CRESTE_UPS_RING(16, devs16);
+      else if (tw == 8) CRESTE_UPS_RING(8, devs8);
+      else CRESTE_UPS_RING(4, devs4);
+#undef CRESTE_UPS_RING
+      CRESTE_CHECK_LAUNCH("upsample2x_ring");
+      return CRESTE_OK;
+    }
+    int bx2 = (W1 + 2 * xpp - 1) / (2 * xpp);                     // ~2 source columns (4 output columns) per thread
+    if (bx2 < 1) bx2 = 1;
+    upsample2x_concat_kernel<<<dim3(bx2, N * H1), 256, 0, (hipStream_t)stream>>>(x1, H1, W1, C1, x1_cs, skip, C2, skip_cs,
+                                                                               out, out_cs, out_co, out_amax);
+    CRESTE_CHECK_LAUNCH("upsample2x_concat");
+    return CRESTE_OK;
+  }
   const int passes = (cq_all + qpp - 1) / qpp;                    // quad passes per workgroup (1 unless C > 1024)
   int bx = (Wo + 2 * xpp - 1) / (2 * xpp);                        // ~2 columns per thread and pass
   if (bx < 1) bx = 1;

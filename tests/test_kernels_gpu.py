@@ -370,6 +370,26 @@ def test_upsample_concat(ops, sf):
     torch.testing.assert_close(from_act(out), ref, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("N,C1,C2,H1,W1", [(2, 40, 8, 96, 100), (1, 472, 24, 40, 410), (3, 8, 0, 5, 7), (1, 256, 0, 130, 128)])
+def test_upsample2x_concat_ring_and_register_kernels(ops, N, C1, C2, H1, W1):
+    """exact 2x: the LDS-ring kernel (wide maps; ragged strips and bands, clamped borders) and the register kernel
+    (small maps) against torch, plus the running |max|"""
+    g = torch.Generator().manual_seed(H1 * W1)
+    x1 = torch.randn(N, C1, H1, W1, generator=g)
+    up = F.interpolate(x1, scale_factor=2, mode="bilinear", align_corners=False)
+    skip = torch.randn(N, C2, 2 * H1, 2 * W1, generator=g) * 3 if C2 else None
+    ref = torch.cat([skip, up], dim=1) if C2 else up
+    old = ops.TRACK_AMAX
+    ops.TRACK_AMAX = True
+    try:
+        out = ops.upsample_concat(to_act(ops, x1), to_act(ops, skip) if C2 else None, 2 * H1, 2 * W1, 0.5, 0.5)
+    finally:
+        ops.TRACK_AMAX = old
+    torch.testing.assert_close(from_act(out), ref, rtol=1e-6, atol=1e-6)
+    if out.amax is not None:
+        assert float(out.amax) >= float(ref.abs().max()) * (1 - 1e-6)
+
+
 def test_maxpool_affine_resize(ops):
     g = torch.Generator().manual_seed(4)
     x = torch.randn(2, 40, 16, 24, generator=g)
