@@ -47,6 +47,8 @@ SIGNATURES = {
     "creste_dwconv2d_nhwc_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
     "creste_se_partial_count": (_i, [_i, _i]),
     "creste_dwconv_se_nhwc_f32": (_i, [_vp] * 6 + [_i] * 11 + [_vp]),
+    "creste_dwconv_se_tile_partial_count": (_i, [_i] * 5),
+    "creste_dwconv_se_tile_f32": (_i, [_vp] * 6 + [_i] * 10 + [_vp]),
     "creste_se_gate_f32": (_i, [_vp] * 7 + [_i] * 4 + [_vp]),
     "creste_se_gate_partial_f32": (_i, [_vp, _i] + [_vp] * 5 + [_i] * 4 + [_vp]),
     "creste_mbconv_partial_count": (_i, [_i] * 7),

@@ -27,6 +27,11 @@ struct MbArgs {
   int H, W, x_cs, Cexp, Ho, Wo, pad_t, pad_l, rows_per_band, nbands, nstrips;
 };
 
+// fused multiply-adds, written out: the library is built with -ffp-contract=off (the geometry kernels rely on it), and
+// these kernels are VALU-bound -- a * b + c as two instructions doubled their arithmetic
+__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x4 fma4(f32x4 a, float b, f32x4 c) { return __builtin_elementwise_fma(a, f32x4{b, b, b, b}, c); }
+
 // swish on the hardware transcendentals: v * rcp(1 + exp2(-v * log2 e)) -- v_exp_f32 and v_rcp_f32 are 1-ulp
 // instructions; expf + an IEEE division cost ~25 VALU instructions per value, and this kernel is VALU-bound (the two
 // activations were 2/3 of its instruction count).  Relative error <= ~1e-6 for |v| <= 10.
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(256, MINB) void mbconv_expand_dw_kernel(const MbArg
           for (int kq = 0; kq < CQ; ++kq) {
             const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + 4 * kq);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc += wq[4 * kq + j] * xv[j];
+            for (int j = 0; j < 4; ++j) acc = fma4(wq[4 * kq + j], xv[j], acc);
           }
           acc = swish4(acc);
         }
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(256, MINB) void mbconv_expand_dw_kernel(const MbArg
         for (int ky = 0; ky < K; ++ky) {
           const float* rp = ring + (((r0 + ky) % K) * IW + ox * S) * Cexp + 4 * q;
 #pragma unroll
-          for (int kx = 0; kx < K; ++kx) acc += *reinterpret_cast<const f32x4*>(rp + kx * Cexp) * dwq[ky * K + kx];
+          for (int kx = 0; kx < K; ++kx) acc = fma4(*reinterpret_cast<const f32x4*>(rp + kx * Cexp), dwq[ky * K + kx], acc);
         }
         acc = swish4(acc);
 #pragma unroll
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void stem_dw_kernel(const StemArgs a) {
             for (int kx = 0; kx < 3; ++kx) {
               const f32x4 xv = *reinterpret_cast<const f32x4*>(xin + ((2 * r + ky) * XW + 2 * px + kx) * 4);
 #pragma unroll
-              for (int ci = 0; ci < 4; ++ci) acc += wsq[(ky * 3 + kx) * 4 + ci] * xv[ci];
+              for (int ci = 0; ci < 4; ++ci) acc = fma4(wsq[(ky * 3 + kx) * 4 + ci], xv[ci], acc);
             }
           acc = swish4(acc);
         }
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void stem_dw_kernel(const StemArgs a) {
         for (int ky = 0; ky < K; ++ky) {
           const float* rp = ring + (((r0 + ky) % K) * IW + ox) * C1 + 4 * q;
 #pragma unroll
-          for (int kx = 0; kx < K; ++kx) acc += *reinterpret_cast<const f32x4*>(rp + kx * C1) * dwq[ky * K + kx];
+          for (int kx = 0; kx < K; ++kx) acc = fma4(*reinterpret_cast<const f32x4*>(rp + kx * C1), dwq[ky * K + kx], acc);
         }
         acc = swish4(acc);
 #pragma unroll
@@ -302,6 +307,86 @@ __global__ __launch_bounds__(256, 2) void stem_dw_kernel(const StemArgs a) {
     f32x4 tot = ssum;
     for (int k = 1; k < PP; ++k) tot += *reinterpret_cast<const f32x4*>(red + k * C1 + 4 * q);
     *reinterpret_cast<f32x4*>(a.partial + ((size_t)n * a.nstrips * a.nbands + chunk) * C1 + 4 * q) = tot;
+  }
+  if (a.amax) {
+    __syncthreads();
+    block_amax_update(vmax, a.amax, red);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Depthwise KxK / stride S conv + folded BN + swish + squeeze-excite sums of the DEEP MBConv blocks (240 .. 1152 channels
+// on 76x152 .. 19x38 maps; reference call site effnet.py:83) from an LDS tile: a workgroup owns TH x TW output pixels of
+// a group of 8 channel quads, stages the (TH-1)*S+K x (TW-1)*S+K input pixels of those 32 channels once (7-8
+// independent quad loads per thread, issued back to back; ONE barrier), then every thread forms four output quads from
+// LDS with its quad's K*K weights in registers.  The register-blocked dwconv_se_kernel re-reads each input quad 2.5 .. 10
+// times through L1 / L2 and keeps only 2-3 waves per SIMD in flight (100 weight registers at K = 5): it runs these
+// layers at 0.7 .. 1.5 TB/s, latency-bound.  (A row-ring variant of this kernel was built and measured: with <= 1
+// output per thread per barrier it is barrier-bound and loses.)
+struct DwArgs {
+  const float* x; const float* wd; const float* bd;
+  float* out; float* partial; float* amax;
+  int H, W, C, Ho, Wo, pad_t, pad_l, tiles_x, tiles_y, ngroups;
+};
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void dwconv_tile_kernel(const DwArgs a) {
+  constexpr int TH = S == 1 ? 8 : 4, TW = S == 1 ? 16 : 8;               // output tile
+  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K, NPX = IH * IW;
+  constexpr int NQ = 8, CG = 4 * NQ, PP = 256 / NQ;                      // 8 channel quads x 32 pixel slices
+  __shared__ __attribute__((aligned(16))) float tile[NPX * CG];
+  __shared__ __attribute__((aligned(16))) float red[PP * CG];
+  const int C = a.C, tid = threadIdx.x, q = tid % NQ, ps = tid / NQ;
+  const int n = blockIdx.y;
+  int id = blockIdx.x;
+  const int grp = id % a.ngroups; id /= a.ngroups;
+  const int chunk = id, tx = id % a.tiles_x, ty = id / a.tiles_x;
+  const int c0 = grp * CG;
+  const bool cok = c0 + 4 * q < C;                                        // the last group may be partial
+  const int oy0 = ty * TH, ox0 = tx * TW, iy0 = oy0 * S - a.pad_t, ix0 = ox0 * S - a.pad_l;
+  for (int e = tid; e < NPX * NQ; e += 256) {
+    const int px = e / NQ, qq = e - px * NQ;
+    const int py = px / IW, pxx = px - py * IW;
+    const int iy = iy0 + py, ix = ix0 + pxx;
+    const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && c0 + 4 * qq < C;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? a.x + ((size_t)(n * a.H + iy) * a.W + ix) * C + c0 + 4 * qq : a.x);
+    *reinterpret_cast<f32x4*>(tile + (size_t)e * 4) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 dwq[K * K], dbq = {0.f, 0.f, 0.f, 0.f};
+  if (cok) {
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) dwq[t] = *reinterpret_cast<const f32x4*>(a.wd + (size_t)t * C + c0 + 4 * q);
+    dbq = *reinterpret_cast<const f32x4*>(a.bd + c0 + 4 * q);
+  }
+  __syncthreads();
+  f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
+  float vmax = 0.f;
+  if (cok) {
+#pragma unroll
+    for (int j = 0; j < TH * TW / PP; ++j) {
+      const int o = ps + PP * j, oyl = o / TW, oxl = o - oyl * TW;
+      const int oy = oy0 + oyl, ox = ox0 + oxl;
+      if (oy >= a.Ho || ox >= a.Wo) continue;
+      f32x4 acc = dbq;
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const float* rp = tile + ((oyl * S + ky) * IW + oxl * S) * CG + 4 * q;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) acc = fma4(*reinterpret_cast<const f32x4*>(rp + kx * CG), dwq[ky * K + kx], acc);
+      }
+      acc = swish4(acc);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vmax = fmaxf(vmax, fabsf(acc[i]));
+      ssum += acc;
+      *reinterpret_cast<f32x4*>(a.out + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * C + c0 + 4 * q) = acc;
+    }
+  }
+  *reinterpret_cast<f32x4*>(red + ps * CG + 4 * q) = ssum;
+  __syncthreads();
+  if (ps == 0 && cok) {
+    f32x4 tot = ssum;
+    for (int k = 1; k < PP; ++k) tot += *reinterpret_cast<const f32x4*>(red + k * CG + 4 * q);
+    *reinterpret_cast<f32x4*>(a.partial + ((size_t)n * a.tiles_x * a.tiles_y + chunk) * C + c0 + 4 * q) = tot;
   }
   if (a.amax) {
     __syncthreads();
@@ -415,5 +500,39 @@ extern "C" int creste_stem_dw_f32(const float* x, int N, int H, int W, const flo
              p.rows_per_band, p.nbands, p.nstrips};
   stem_dw_kernel<STEM_TW><<<dim3(p.nstrips * p.nbands, N), 256, p.smem, (hipStream_t)stream>>>(a);
   CRESTE_CHECK_LAUNCH("stem_dw");
+  return CRESTE_OK;
+}
+
+static bool dw_tile_dims(int K, int S, int C, int Ho, int Wo, int* tx, int* ty) {
+  if (!((K == 3 || K == 5) && (S == 1 || S == 2)) || C % 4 || C < 4 || Ho <= 0 || Wo <= 0) return false;
+  const int th = S == 1 ? 8 : 4, tw = S == 1 ? 16 : 8;
+  *tx = (Wo + tw - 1) / tw; *ty = (Ho + th - 1) / th;
+  return true;
+}
+
+extern "C" int creste_dwconv_se_tile_partial_count(int Ho, int Wo, int C, int K, int stride) {
+  int tx, ty;
+  return dw_tile_dims(K, stride, C, Ho, Wo, &tx, &ty) ? tx * ty : -1;
+}
+
+extern "C" int creste_dwconv_se_tile_f32(const float* in, const float* w, const float* bias, float* out, float* partial,
+                                         float* out_amax, int N, int H, int W, int C, int Ho, int Wo, int K, int stride,
+                                         int pad_t, int pad_l, void* stream) {
+  CRESTE_REQUIRE(in && w && bias && out && partial, "dwconv_se_tile: null pointer");
+  CRESTE_REQUIRE(N > 0 && N < 65536 && H > 0 && W > 0, "dwconv_se_tile: bad dims");
+  CRESTE_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15) == 0 && pad_t >= 0 && pad_l >= 0 && pad_t < K && pad_l < K,
+                 "dwconv_se_tile: input must be 16-byte aligned, padding below the kernel size");
+  int tx, ty;
+  CRESTE_REQUIRE(dw_tile_dims(K, stride, C, Ho, Wo, &tx, &ty), "dwconv_se_tile: not built for C=%d K=%d stride=%d", C, K, stride);
+  const int ngroups = (C / 4 + 7) / 8;
+  CRESTE_REQUIRE((long)tx * ty * ngroups < (1L << 31), "dwconv_se_tile: grid too large");
+  DwArgs a{in, w, bias, out, partial, out_amax, H, W, C, Ho, Wo, pad_t, pad_l, tx, ty, ngroups};
+  const dim3 grid((unsigned)(tx * ty * ngroups), N);
+  hipStream_t s = (hipStream_t)stream;
+  if (K == 3 && stride == 1) dwconv_tile_kernel<3, 1><<<grid, 256, 0, s>>>(a);
+  else if (K == 3) dwconv_tile_kernel<3, 2><<<grid, 256, 0, s>>>(a);
+  else if (stride == 1) dwconv_tile_kernel<5, 1><<<grid, 256, 0, s>>>(a);
+  else dwconv_tile_kernel<5, 2><<<grid, 256, 0, s>>>(a);
+  CRESTE_CHECK_LAUNCH("dwconv_se_tile");
   return CRESTE_OK;
 }

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void se_partial_kernel(const float* __restrict
 // (bias, then ky-major / kx-minor taps), so results are bit-identical to the one-output-per-thread form.
 // Chunks are remapped so that one XCD's L2 sees a contiguous band of rows (vertical halo reuse).
 template <int K, int S>
-__global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict__ in,
+__global__ __launch_bounds__(512) void dwconv_se_kernel(const float* __restrict__ in,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ bias,
                                                         float* __restrict__ out, float* __restrict__ partial,
@@ -120,16 +120,19 @@ __global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict_
   constexpr int XG = 4, NI = (XG - 1) * S + K;
   const int n = blockIdx.y, chunk = xcd_remap(blockIdx.x, nchunk);
   const int cq = C >> 2;
-  const int slices = 256 / cq > 0 ? 256 / cq : 1;
+  // blockDim.x = cq * slices for cq <= 512 (every thread owns one channel quad of one pixel slice: no idle lanes at 168 or
+  // 288 quads, where 256-thread workgroups left 34 % / 44 % of their threads without work), else 256 threads looping
+  const int nt = blockDim.x;
+  const int slices = nt / cq > 0 ? nt / cq : 1;
   const int gw = (Wo + XG - 1) / XG;                 // groups per output row
   const int G = Ho * gw;
   const int per = (G + nchunk - 1) / nchunk;
   const int g0 = chunk * per, g1 = min(G, g0 + per);
   const long HWo = (long)Ho * Wo;
   float vmax = 0.f;
-  for (int q0 = 0; q0 < cq; q0 += 256) {
-    const int tq = (cq >= 256) ? q0 + threadIdx.x : threadIdx.x % cq;
-    const int sl = (cq >= 256) ? 0 : threadIdx.x / cq;
+  for (int q0 = 0; q0 < cq; q0 += nt) {
+    const int tq = (cq >= nt) ? q0 + threadIdx.x : threadIdx.x % cq;
+    const int sl = (cq >= nt) ? 0 : threadIdx.x / cq;
     const bool active = tq < cq && sl < slices;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (active) {
@@ -965,12 +968,15 @@ extern "C" int creste_dwconv_se_nhwc_f32(const float* in, const float* w, const 
                  "dwconv_se: kernel size %d / stride %d not built (3 or 5; 1 or 2)", K, stride);
   const int nchunk = creste_se_partial_count(Ho * Wo, C);
   const int cq = C / 4;
-  const int slices = 256 / cq > 0 ? 256 / cq : 1;
+  // a whole number of pixel slices of cq threads, rounded up to whole waves (the spare lanes idle, but take part in the
+  // wave reductions)
+  const int nt = cq <= 512 ? (cq * (512 / cq) + 63) / 64 * 64 : 256;
+  const int slices = nt / cq > 0 ? nt / cq : 1;
   const size_t smem = (size_t)slices * C * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(nchunk, N);
 #define CRESTE_DWSE(KK, SS) \
-  dwconv_se_kernel<KK, SS><<<grid, 256, smem, s>>>(in, w, bias, out, partial, out_amax, H, W, C, Ho, Wo, pad_t, pad_l, act, nchunk)
+  dwconv_se_kernel<KK, SS><<<grid, nt, smem, s>>>(in, w, bias, out, partial, out_amax, H, W, C, Ho, Wo, pad_t, pad_l, act, nchunk)
   if (K == 3 && stride == 1) CRESTE_DWSE(3, 1);
   else if (K == 3) CRESTE_DWSE(3, 2);
   else if (stride == 1) CRESTE_DWSE(5, 1);

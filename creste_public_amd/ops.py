@@ -269,6 +269,9 @@ def dwconv2d(x: Act, w_taps: torch.Tensor, bias: torch.Tensor, K, stride, pad, a
     return out
 
 
+DW_TILE, DW_TILE_MIN_C = True, 16       # policy of dwconv2d_se: LDS-tile kernel for channel counts >= DW_TILE_MIN_C
+
+
 def dwconv2d_se(x: Act, w_taps, bias, K, stride, pad, act, se_w1, se_b1, se_w2, se_b2):
     """depthwise conv + activation and the squeeze-excite gate of its output (one read of the tensor)."""
     lib = _lib.load()
@@ -277,10 +280,24 @@ def dwconv2d_se(x: Act, w_taps, bias, K, stride, pad, act, se_w1, se_b1, se_w2, 
     Wo = (x.W + pad[2] + pad[3] - K) // stride + 1
     dev = x.buf.device
     out = Act.empty(x.N, Ho, Wo, x.C, dev)
-    partial = torch.empty((x.N, lib.creste_se_partial_count(Ho * Wo, x.C), x.C), dtype=torch.float32, device=dev)
     gate = torch.empty((x.N, x.C), dtype=torch.float32, device=dev)
     if TRACK_AMAX:
         out.amax = _AmaxPool.slot(dev)
+    # measured at batch 16 (scripts/dwconv_micro.py): the tile kernel wins at stride 1 (1152 ch k5 19x38: 140 -> 83 us, 672 ch k5
+    # 38x76: 182 -> 106, 240 ch k5 76x152: 217 -> 183) and at k5 / stride 2 (76 -> 70); k3 / stride 2 stays register-blocked
+    use_tile = DW_TILE and act == ACT_SWISH and x.C >= DW_TILE_MIN_C and (stride == 1 or K == 5)
+    ntile = lib.creste_dwconv_se_tile_partial_count(Ho, Wo, x.C, K, stride) if use_tile else -1
+    if ntile > 0:          # many channels on a small map: the LDS-tile kernel (csrc/mbconv.hip)
+        partial = torch.empty((x.N, ntile, x.C), dtype=torch.float32, device=dev)
+        _lib.check(lib.creste_dwconv_se_tile_f32(x.ptr, _chk(w_taps).data_ptr(), _chk(bias).data_ptr(), out.ptr,
+                                                 partial.data_ptr(), out.amax.data_ptr() if TRACK_AMAX else None,
+                                                 x.N, x.H, x.W, x.C, Ho, Wo, K, stride, pad[0], pad[2], _stream()),
+                   "dwconv_se_tile")
+        _lib.check(lib.creste_se_gate_partial_f32(partial.data_ptr(), ntile, _chk(se_w1).data_ptr(), _chk(se_b1).data_ptr(),
+                                                  _chk(se_w2).data_ptr(), _chk(se_b2).data_ptr(), gate.data_ptr(), x.N,
+                                                  Ho * Wo, x.C, se_w1.shape[0], _stream()), "se_gate_partial")
+        return out, gate
+    partial = torch.empty((x.N, lib.creste_se_partial_count(Ho * Wo, x.C), x.C), dtype=torch.float32, device=dev)
     _lib.check(lib.creste_dwconv_se_nhwc_f32(x.ptr, _chk(w_taps).data_ptr(), _chk(bias).data_ptr(), out.ptr,
                                              partial.data_ptr(), out.amax.data_ptr() if TRACK_AMAX else None,
                                              x.N, x.H, x.W, x.C, Ho, Wo, K, stride, pad[0], pad[2], act,

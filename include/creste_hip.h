@@ -134,6 +134,12 @@ int creste_se_partial_count(int HW, int C);   /* partial-sum rows per image for 
 int creste_dwconv_se_nhwc_f32(const float* in, const float* w, const float* bias, float* out,
                               float* partial, float* out_amax, int N, int H, int W, int C, int Ho, int Wo,
                               int K, int stride, int pad_t, int pad_l, int act, void* stream);
+/* The same operator (swish only) from an LDS tile (csrc/mbconv.hip) -- the deep MBConv blocks' many-channel / small-map
+ * shapes; partial is [N][creste_dwconv_se_tile_partial_count(..)][C] -> creste_se_gate_partial_f32. */
+int creste_dwconv_se_tile_partial_count(int Ho, int Wo, int C, int K, int stride);   /* < 0: not built */
+int creste_dwconv_se_tile_f32(const float* in, const float* w, const float* bias, float* out, float* partial,
+                              float* out_amax, int N, int H, int W, int C, int Ho, int Wo, int K, int stride,
+                              int pad_t, int pad_l, void* stream);
 int creste_se_gate_f32(const float* x, float* partial, const float* w1, const float* b1,
                        const float* w2, const float* b2, float* gate, int N, int HW, int C, int Cse,
                        void* stream);

@@ -246,7 +246,8 @@ def test_dwconv(ops, K, s, pad):
     torch.testing.assert_close(from_act(out), ref, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("Cc,K,s,pad", [(96, 3, 2, (0, 1, 0, 1)), (240, 5, 1, (2, 2, 2, 2)), (1152, 3, 1, (1, 1, 1, 1))])
+@pytest.mark.parametrize("Cc,K,s,pad", [(96, 3, 2, (0, 1, 0, 1)), (240, 5, 1, (2, 2, 2, 2)), (1152, 3, 1, (1, 1, 1, 1)),
+                                        (672, 5, 2, (1, 2, 1, 2)), (40, 5, 1, (2, 2, 2, 2)), (168, 3, 1, (1, 1, 1, 1))])
 def test_dwconv_se_fused(ops, Cc, K, s, pad):
     g = torch.Generator().manual_seed(Cc + K)
     N, H, W, Cse = 2, 45, 31, 12
