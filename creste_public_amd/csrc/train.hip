@@ -118,6 +118,17 @@ struct MomArgs {
   int C, nk;
 };
 
+// pivot of the one-pass variance (MODE 4): the mean of 16 pixels spread over the tensor.  sum (x - s) and sum (x - s)^2 in
+// ONE read give var = E[(x-s)^2] - E[x-s]^2 without the cancellation of the raw-moment form as long as s lies within a
+// few standard deviations of the mean (the two-pass form read the tensor twice: ~6 % of a distillation step)
+__device__ __forceinline__ float bn_pivot(const float* __restrict__ x, int x_cs, long P, int c) {
+  const long step = P >= 16 ? P / 16 : 1;
+  const int n = P >= 16 ? 16 : (int)P;
+  float s = 0.f;
+  for (int k = 0; k < n; ++k) s += x[(long)k * step * x_cs + c];
+  return s / (float)n;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void moments_kernel(const MomArgs a) {
   extern __shared__ float sm[];   // [nk][rows][Ct]
@@ -128,8 +139,8 @@ __global__ __launch_bounds__(256) void moments_kernel(const MomArgs a) {
   const bool active = row < rows;
   float s[MOM_MAXK] = {0.f, 0.f, 0.f, 0.f, 0.f};
   if (active) {
-    const float mu = (MODE >= 1) ? a.mean[c] : 0.f;
-    const float is = (MODE >= 2) ? a.invstd[c] : 0.f;
+    const float mu = (MODE == 4) ? bn_pivot(a.x, a.x_cs, a.P, c) : (MODE >= 1) ? a.mean[c] : 0.f;
+    const float is = (MODE == 2 || MODE == 3) ? a.invstd[c] : 0.f;
     const float md = (MODE == 3 && a.G) ? a.mdot[c] : 0.f;
     const float cc = (MODE == 3 && a.G) ? a.cc[c] : 0.f;
 #pragma unroll 4
@@ -137,6 +148,7 @@ __global__ __launch_bounds__(256) void moments_kernel(const MomArgs a) {
       const float xv = a.x[p * a.x_cs + c];
       if (MODE == 0) s[0] += xv;
       if (MODE == 1) { const float d = xv - mu; s[0] += d * d; }
+      if (MODE == 4) { const float d = xv - mu; s[0] += d; s[1] += d * d; }
       if (MODE == 2) {
         const float xh = (xv - mu) * is, xd = a.xd[p * a.xd_cs + c];
         s[0] += xd; s[1] += xh * xd;
@@ -178,8 +190,10 @@ __global__ __launch_bounds__(256) void moments4_kernel(const MomArgs a) {
   const mq4 z = {0.f, 0.f, 0.f, 0.f};
   mq4 s[MOM_MAXK] = {z, z, z, z, z};
   if (active) {
-    const mq4 mu = (MODE >= 1) ? ld(a.mean + c) : z;
-    const mq4 is = (MODE >= 2) ? ld(a.invstd + c) : z;
+    mq4 mu = (MODE >= 1 && MODE != 4) ? ld(a.mean + c) : z;
+    if (MODE == 4)
+      for (int j = 0; j < 4; ++j) mu[j] = bn_pivot(a.x, a.x_cs, a.P, c + j);
+    const mq4 is = (MODE == 2 || MODE == 3) ? ld(a.invstd + c) : z;
     const mq4 md = (MODE == 3 && a.G) ? ld(a.mdot + c) : z;
     const mq4 cc = (MODE == 3 && a.G) ? ld(a.cc + c) : z;
 #pragma unroll 2
@@ -187,6 +201,7 @@ __global__ __launch_bounds__(256) void moments4_kernel(const MomArgs a) {
       const mq4 xv = ld(a.x + p * a.x_cs + c);
       if (MODE == 0) s[0] += xv;
       if (MODE == 1) { const mq4 d = xv - mu; s[0] += d * d; }
+      if (MODE == 4) { const mq4 d = xv - mu; s[0] += d; s[1] += d * d; }
       if (MODE == 2) {
         const mq4 xh = (xv - mu) * is, xd = ld(a.xd + p * a.xd_cs + c);
         s[0] += xd; s[1] += xh * xd;
@@ -235,6 +250,31 @@ __global__ void bn_finish_stats_kernel(const float* __restrict__ mean, const flo
   invstd[c] = 1.f / sqrtf(var[c] + eps);
   if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
   if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (var[c] * unbias);
+}
+
+// MODE 4 partials [blocks][2][C] -> mean, biased variance, 1/sqrt(var + eps) and the running statistics: one wave per channel
+// (fixed summation order), replacing two finalize launches and bn_finish_stats_kernel
+__global__ __launch_bounds__(64) void bn_stats_finish_kernel(const float* __restrict__ partial, const float* __restrict__ x,
+                                                             int x_cs, long P, int nblocks, int C, float* __restrict__ mean,
+                                                             float* __restrict__ var, float* __restrict__ invstd,
+                                                             float* running_mean, float* running_var, float eps,
+                                                             float momentum, float unbias) {
+  const int c = blockIdx.x;
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = threadIdx.x; b < nblocks; b += 64) {
+    s1 += partial[((size_t)b * 2 + 0) * C + c];
+    s2 += partial[((size_t)b * 2 + 1) * C + c];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  if (threadIdx.x == 0) {
+    const float inv_p = 1.f / (float)P, m1 = s1 * inv_p, m2 = s2 * inv_p;
+    const float mu = bn_pivot(x, x_cs, P, c) + m1;
+    const float v = fmaxf(m2 - m1 * m1, 0.f);
+    mean[c] = mu; var[c] = v; invstd[c] = 1.f / sqrtf(v + eps);
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (v * unbias);
+  }
 }
 
 // ------------------------------------------------------------------------------------ elementwise
@@ -589,7 +629,9 @@ extern "C" int creste_conv_flip_weight_f32(const float* w, float* wt, int Cout, 
   return CRESTE_OK;
 }
 
-static int run_moments(int mode, MomArgs a, float* out, float* partial, hipStream_t s) {
+// mode 4 (one-pass shifted moments): `out` is unused, *nblocks_out receives the number of partial rows for
+// bn_stats_finish_kernel
+static int run_moments(int mode, MomArgs a, float* out, float* partial, hipStream_t s, int* nblocks_out = nullptr) {
   CRESTE_REQUIRE(a.C > 0 && a.P > 0, "bn moments: bad dims");
   a.partial = partial;
   auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
@@ -604,8 +646,10 @@ static int run_moments(int mode, MomArgs a, float* out, float* partial, hipStrea
     if (mode == 0) moments4_kernel<0><<<grid4, 256, smem4, s>>>(a);
     else if (mode == 1) moments4_kernel<1><<<grid4, 256, smem4, s>>>(a);
     else if (mode == 2) moments4_kernel<2><<<grid4, 256, smem4, s>>>(a);
+    else if (mode == 4) moments4_kernel<4><<<grid4, 256, smem4, s>>>(a);
     else moments4_kernel<3><<<grid4, 256, smem4, s>>>(a);
     CRESTE_CHECK_LAUNCH("bn_moments4");
+    if (mode == 4) { *nblocks_out = blocks4; return CRESTE_OK; }
     moments_finalize_kernel<<<a.nk * a.C, 64, 0, s>>>(partial, out, blocks4, a.nk, a.C, 1.f / (float)a.P);
     CRESTE_CHECK_LAUNCH("bn_moments_finalize");
     return CRESTE_OK;
@@ -618,8 +662,10 @@ static int run_moments(int mode, MomArgs a, float* out, float* partial, hipStrea
   if (mode == 0) moments_kernel<0><<<grid, 256, smem, s>>>(a);
   else if (mode == 1) moments_kernel<1><<<grid, 256, smem, s>>>(a);
   else if (mode == 2) moments_kernel<2><<<grid, 256, smem, s>>>(a);
+  else if (mode == 4) moments_kernel<4><<<grid, 256, smem, s>>>(a);
   else moments_kernel<3><<<grid, 256, smem, s>>>(a);
   CRESTE_CHECK_LAUNCH("bn_moments");
+  if (mode == 4) { *nblocks_out = blocks; return CRESTE_OK; }
   moments_finalize_kernel<<<a.nk * a.C, 64, 0, s>>>(partial, out, blocks, a.nk, a.C, 1.f / (float)a.P);
   CRESTE_CHECK_LAUNCH("bn_moments_finalize");
   return CRESTE_OK;
@@ -634,15 +680,13 @@ extern "C" int creste_bn_train_forward_f32(const float* x, int x_cs, int64_t P, 
   CRESTE_REQUIRE(x && mean && invstd && var_scratch && y && work && P > 1, "bn_train_forward: bad args");
   hipStream_t s = (hipStream_t)stream;
   MomArgs a = {};
-  a.x = x; a.x_cs = x_cs; a.P = P; a.C = C; a.nk = 1;
-  int rc = run_moments(0, a, mean, (float*)work, s);
+  a.x = x; a.x_cs = x_cs; a.P = P; a.C = C; a.nk = 2;
+  int nblocks = 0;
+  const int rc = run_moments(4, a, nullptr, (float*)work, s, &nblocks);       // one read: sum (x - pivot), sum (x - pivot)^2
   if (rc) return rc;
-  a.mean = mean;
-  rc = run_moments(1, a, var_scratch, (float*)work, s);
-  if (rc) return rc;
-  bn_finish_stats_kernel<<<(C + 255) / 256, 256, 0, s>>>(mean, var_scratch, invstd, running_mean, running_var, C, eps,
-                                                        momentum, (float)P / (float)(P - 1));
-  CRESTE_CHECK_LAUNCH("bn_finish_stats");
+  bn_stats_finish_kernel<<<C, 64, 0, s>>>((const float*)work, x, x_cs, P, nblocks, C, mean, var_scratch, invstd,
+                                         running_mean, running_var, eps, momentum, (float)P / (float)(P - 1));
+  CRESTE_CHECK_LAUNCH("bn_stats_finish");
   EwArgs e = {};
   e.x = x; e.x_cs = x_cs; e.gamma = gamma; e.beta = beta; e.mean = mean; e.invstd = invstd;
   e.o0 = y; e.o0_cs = y_cs; e.P = P; e.C = C; e.relu = relu; e.amax = out_amax;

@@ -189,6 +189,35 @@ def test_batchnorm_train_forward_tangent_backward(C, relu):
     assert int(bn.num_batches_tracked) == 1
 
 
+def test_batchnorm_one_pass_statistics_on_hard_data():
+    """the training-mode statistics are ONE read of the tensor (pivot-shifted moments, csrc/train.hip): channels with a
+    mean far larger than their spread, a constant channel, a channel whose first pixel is an outlier, a big tensor"""
+    from creste_public_amd import train_ops as T
+    g = torch.Generator().manual_seed(0)
+    N, C, H, W = 4, 8, 96, 130
+    x = torch.randn(N, C, H, W, generator=g)
+    x[:, 0] = x[:, 0] * 1e-2 + 100.0                          # mean / std = 1e4
+    x[:, 1] = 3.25                                            # zero variance
+    x[:, 2] = x[:, 2] * 0.1 - 7.0
+    x[0, 2, 0, 0] = 500.0                                     # the first pixel (a pivot sample) is an outlier
+    x[:, 3] *= 1e-3
+    x[:, 4] = x[:, 4] * 50.0 + 1e3
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+    op = T.BNT(bn, False)
+    y = op.fwd(T.as_act(x.cuda())).nchw().cpu().double()
+    xd = x.double()
+    mu = xd.mean(dim=(0, 2, 3), keepdim=True)
+    var = ((xd - mu) ** 2).mean(dim=(0, 2, 3), keepdim=True)
+    ref = (xd - mu) / torch.sqrt(var + bn.eps)
+    # tolerance: fp32 input resolution relative to the channel's spread (channel 0: 100 * 2^-24 / 0.01 = 6e-4)
+    err = (y - ref).abs().amax(dim=(0, 2, 3))
+    lim = torch.tensor([3e-3, 1e-6, 2e-3, 1e-4, 1e-3, 1e-4, 1e-4, 1e-4], dtype=torch.float64)
+    assert (err <= lim).all(), err
+    n = N * H * W
+    torch.testing.assert_close(bn.running_mean.cpu().double(), 0.1 * mu.view(-1), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn.running_var.cpu().double(), 0.9 + 0.1 * var.view(-1) * n / (n - 1), rtol=2e-4, atol=1e-7)
+
+
 def test_pool_and_upsample_transposes():
     from creste_public_amd import train_ops as T
     g = torch.Generator().manual_seed(3)
