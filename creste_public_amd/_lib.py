@@ -49,6 +49,7 @@ SIGNATURES = {
     "creste_dwconv_se_nhwc_f32": (_i, [_vp] * 6 + [_i] * 11 + [_vp]),
     "creste_dwconv_se_tile_partial_count": (_i, [_i] * 5),
     "creste_dwconv_se_tile_f32": (_i, [_vp] * 6 + [_i] * 10 + [_vp]),
+    "creste_dwconv_tile_f32": (_i, [_vp] * 4 + [_i] * 11 + [_vp]),
     "creste_se_gate_f32": (_i, [_vp] * 7 + [_i] * 4 + [_vp]),
     "creste_se_gate_partial_f32": (_i, [_vp, _i] + [_vp] * 5 + [_i] * 4 + [_vp]),
     "creste_mbconv_partial_count": (_i, [_i] * 7),

@@ -329,7 +329,7 @@ struct DwArgs {
   int H, W, C, Ho, Wo, pad_t, pad_l, tiles_x, tiles_y, ngroups;
 };
 
-template <int K, int S>
+template <int K, int S, bool SWISH>
 __global__ __launch_bounds__(256) void dwconv_tile_kernel(const DwArgs a) {
   constexpr int TH = S == 1 ? 8 : 4, TW = S == 1 ? 16 : 8;               // output tile
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K, NPX = IH * IW;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const DwArgs a) {
   if (cok) {
 #pragma unroll
     for (int t = 0; t < K * K; ++t) dwq[t] = *reinterpret_cast<const f32x4*>(a.wd + (size_t)t * C + c0 + 4 * q);
-    dbq = *reinterpret_cast<const f32x4*>(a.bd + c0 + 4 * q);
+    if (a.bd) dbq = *reinterpret_cast<const f32x4*>(a.bd + c0 + 4 * q);
   }
   __syncthreads();
   f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
@@ -374,16 +374,17 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(const DwArgs a) {
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) acc = fma4(*reinterpret_cast<const f32x4*>(rp + kx * CG), dwq[ky * K + kx], acc);
       }
-      acc = swish4(acc);
+      if (SWISH) acc = swish4(acc);
 #pragma unroll
       for (int i = 0; i < 4; ++i) vmax = fmaxf(vmax, fabsf(acc[i]));
       ssum += acc;
       *reinterpret_cast<f32x4*>(a.out + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * C + c0 + 4 * q) = acc;
     }
   }
+  if (!a.partial && !a.amax) return;                                       // plain depthwise conv (training path)
   *reinterpret_cast<f32x4*>(red + ps * CG + 4 * q) = ssum;
   __syncthreads();
-  if (ps == 0 && cok) {
+  if (a.partial && ps == 0 && cok) {
     f32x4 tot = ssum;
     for (int k = 1; k < PP; ++k) tot += *reinterpret_cast<const f32x4*>(red + k * CG + 4 * q);
     *reinterpret_cast<f32x4*>(a.partial + ((size_t)n * a.tiles_x * a.tiles_y + chunk) * C + c0 + 4 * q) = tot;
@@ -515,24 +516,43 @@ extern "C" int creste_dwconv_se_tile_partial_count(int Ho, int Wo, int C, int K,
   return dw_tile_dims(K, stride, C, Ho, Wo, &tx, &ty) ? tx * ty : -1;
 }
 
+template <bool SWISH>
+static int launch_dw_tile(const DwArgs& a, int N, int K, int stride, hipStream_t s) {
+  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.ngroups), N);
+  if (K == 3 && stride == 1) dwconv_tile_kernel<3, 1, SWISH><<<grid, 256, 0, s>>>(a);
+  else if (K == 3) dwconv_tile_kernel<3, 2, SWISH><<<grid, 256, 0, s>>>(a);
+  else if (stride == 1) dwconv_tile_kernel<5, 1, SWISH><<<grid, 256, 0, s>>>(a);
+  else dwconv_tile_kernel<5, 2, SWISH><<<grid, 256, 0, s>>>(a);
+  CRESTE_CHECK_LAUNCH("dwconv_tile");
+  return CRESTE_OK;
+}
+
+static int run_dw_tile(const float* in, const float* w, const float* bias, float* out, float* partial, float* out_amax,
+                       int N, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad_t, int pad_l, bool swish,
+                       void* stream) {
+  CRESTE_REQUIRE(in && w && out, "dwconv_tile: null pointer");
+  CRESTE_REQUIRE(N > 0 && N < 65536 && H > 0 && W > 0, "dwconv_tile: bad dims");
+  CRESTE_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15) == 0 && pad_t >= 0 && pad_l >= 0 && pad_t < K && pad_l < K,
+                 "dwconv_tile: input must be 16-byte aligned, padding below the kernel size");
+  int tx, ty;
+  CRESTE_REQUIRE(dw_tile_dims(K, stride, C, Ho, Wo, &tx, &ty), "dwconv_tile: not built for C=%d K=%d stride=%d", C, K, stride);
+  const int ngroups = (C / 4 + 7) / 8;
+  CRESTE_REQUIRE((long)tx * ty * ngroups < (1L << 31), "dwconv_tile: grid too large");
+  DwArgs a{in, w, bias, out, partial, out_amax, H, W, C, Ho, Wo, pad_t, pad_l, tx, ty, ngroups};
+  return swish ? launch_dw_tile<true>(a, N, K, stride, (hipStream_t)stream)
+               : launch_dw_tile<false>(a, N, K, stride, (hipStream_t)stream);
+}
+
 extern "C" int creste_dwconv_se_tile_f32(const float* in, const float* w, const float* bias, float* out, float* partial,
                                          float* out_amax, int N, int H, int W, int C, int Ho, int Wo, int K, int stride,
                                          int pad_t, int pad_l, void* stream) {
-  CRESTE_REQUIRE(in && w && bias && out && partial, "dwconv_se_tile: null pointer");
-  CRESTE_REQUIRE(N > 0 && N < 65536 && H > 0 && W > 0, "dwconv_se_tile: bad dims");
-  CRESTE_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15) == 0 && pad_t >= 0 && pad_l >= 0 && pad_t < K && pad_l < K,
-                 "dwconv_se_tile: input must be 16-byte aligned, padding below the kernel size");
-  int tx, ty;
-  CRESTE_REQUIRE(dw_tile_dims(K, stride, C, Ho, Wo, &tx, &ty), "dwconv_se_tile: not built for C=%d K=%d stride=%d", C, K, stride);
-  const int ngroups = (C / 4 + 7) / 8;
-  CRESTE_REQUIRE((long)tx * ty * ngroups < (1L << 31), "dwconv_se_tile: grid too large");
-  DwArgs a{in, w, bias, out, partial, out_amax, H, W, C, Ho, Wo, pad_t, pad_l, tx, ty, ngroups};
-  const dim3 grid((unsigned)(tx * ty * ngroups), N);
-  hipStream_t s = (hipStream_t)stream;
-  if (K == 3 && stride == 1) dwconv_tile_kernel<3, 1><<<grid, 256, 0, s>>>(a);
-  else if (K == 3) dwconv_tile_kernel<3, 2><<<grid, 256, 0, s>>>(a);
-  else if (stride == 1) dwconv_tile_kernel<5, 1><<<grid, 256, 0, s>>>(a);
-  else dwconv_tile_kernel<5, 2><<<grid, 256, 0, s>>>(a);
-  CRESTE_CHECK_LAUNCH("dwconv_se_tile");
-  return CRESTE_OK;
+  CRESTE_REQUIRE(bias && partial, "dwconv_se_tile: null pointer");
+  return run_dw_tile(in, w, bias, out, partial, out_amax, N, H, W, C, Ho, Wo, K, stride, pad_t, pad_l, true, stream);
+}
+
+extern "C" int creste_dwconv_tile_f32(const float* in, const float* w, const float* bias, float* out, int N, int H, int W,
+                                      int C, int Ho, int Wo, int K, int stride, int pad_t, int pad_l, int act, void* stream) {
+  CRESTE_REQUIRE(act == CRESTE_ACT_NONE || act == CRESTE_ACT_SWISH, "dwconv_tile: activation %d not built (none, swish)", act);
+  return run_dw_tile(in, w, bias, out, nullptr, nullptr, N, H, W, C, Ho, Wo, K, stride, pad_t, pad_l, act == CRESTE_ACT_SWISH,
+                     stream);
 }

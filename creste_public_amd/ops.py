@@ -256,6 +256,9 @@ def conv2d(x: Act | None, pc: PackedConv, out: Act | None = None, res: Act | Non
     return out
 
 
+DW_TILE, DW_TILE_MIN_C = True, 16       # policy of dwconv2d / dwconv2d_se: LDS-tile kernel for channel counts >= DW_TILE_MIN_C
+
+
 def dwconv2d(x: Act, w_taps: torch.Tensor, bias: torch.Tensor, K, stride, pad, act) -> Act:
     """w_taps [K*K, C]; pad = (pad_t, pad_b, pad_l, pad_r)."""
     lib = _lib.load()
@@ -263,13 +266,18 @@ def dwconv2d(x: Act, w_taps: torch.Tensor, bias: torch.Tensor, K, stride, pad, a
     Ho = (x.H + pad[0] + pad[1] - K) // stride + 1
     Wo = (x.W + pad[2] + pad[3] - K) // stride + 1
     out = Act.empty(x.N, Ho, Wo, x.C, x.buf.device)
+    if DW_TILE and act in (ACT_NONE, ACT_SWISH) and x.C >= DW_TILE_MIN_C and (stride == 1 or K == 5) \
+            and lib.creste_dwconv_se_tile_partial_count(Ho, Wo, x.C, K, stride) > 0:
+        _lib.check(lib.creste_dwconv_tile_f32(x.ptr, _chk(w_taps).data_ptr(), _chk(bias).data_ptr() if bias is not None else None,
+                                              out.ptr, x.N, x.H, x.W, x.C, Ho, Wo, K, stride, pad[0], pad[2], act, _stream()),
+                   "dwconv_tile")
+        return out
+    if bias is None:
+        bias = torch.zeros(x.C, dtype=torch.float32, device=x.buf.device)
     _lib.check(lib.creste_dwconv2d_nhwc_f32(x.ptr, _chk(w_taps).data_ptr(), _chk(bias).data_ptr(),
                                             out.ptr, x.N, x.H, x.W, x.C, Ho, Wo, K, stride, pad[0],
                                             pad[2], act, _stream()), "dwconv2d")
     return out
-
-
-DW_TILE, DW_TILE_MIN_C = True, 16       # policy of dwconv2d_se: LDS-tile kernel for channel counts >= DW_TILE_MIN_C
 
 
 def dwconv2d_se(x: Act, w_taps, bias, K, stride, pad, act, se_w1, se_b1, se_w2, se_b2):

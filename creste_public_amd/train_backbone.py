@@ -200,6 +200,7 @@ class DwConvT:
         if key != self._key:
             Cn = w.shape[0]
             self._w = w.detach()[:, 0].reshape(Cn, -1).t().contiguous()          # [K*K, C] tap-major
+            self._wflip = self._w.flip(0).contiguous()                           # taps of the stride-1 input gradient
             self._zero = torch.zeros(Cn, dtype=torch.float32, device=w.device)
             self._key = key
         return self._w
@@ -224,6 +225,13 @@ class DwConvT:
             dst.copy_(gt.t().reshape(w.shape))                                  # layout change back to [C,1,K,K]
         if not need_input:
             return None
+        if self.s == 1 and ops.DW_TILE and Cn >= ops.DW_TILE_MIN_C and gy.cs == gy.C and gy.co == 0 \
+                and (gy.H, gy.W) == (x.H, x.W):
+            # stride 1: the input gradient is the depthwise conv of gy with the flipped taps and pad' = K - 1 - pad
+            self._taps()
+            k1 = self.K - 1
+            return ops.dwconv2d(gy, self._wflip, None, self.K, 1, (k1 - self.pad[0], k1 - self.pad[1], k1 - self.pad[2],
+                                                                    k1 - self.pad[3]), ops.ACT_NONE)
         gx = _new(x)
         _lib.check(lib.creste_dwconv_dgrad_f32(gy.ptr, self._taps().data_ptr(), gx.ptr, x.N, x.H, x.W, Cn, gy.H, gy.W,
                                                self.K, self.s, self.pad[0], self.pad[2], _stream()), "dwconv_dgrad")

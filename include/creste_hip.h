@@ -140,6 +140,10 @@ int creste_dwconv_se_tile_partial_count(int Ho, int Wo, int C, int K, int stride
 int creste_dwconv_se_tile_f32(const float* in, const float* w, const float* bias, float* out, float* partial,
                               float* out_amax, int N, int H, int W, int C, int Ho, int Wo, int K, int stride,
                               int pad_t, int pad_l, void* stream);
+/* plain depthwise conv (+ bias, may be NULL) (+ swish) on the same LDS-tile kernel: the training path's forward and,
+ * with the taps flipped and pad' = K-1-pad, its stride-1 input gradient */
+int creste_dwconv_tile_f32(const float* in, const float* w, const float* bias, float* out, int N, int H, int W, int C,
+                           int Ho, int Wo, int K, int stride, int pad_t, int pad_l, int act, void* stream);
 int creste_se_gate_f32(const float* x, float* partial, const float* w1, const float* b1,
                        const float* w2, const float* b2, float* gate, int N, int HW, int C, int Cse,
                        void* stream);
