@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const float* __restri
         if (tx < 0 || tx % stride) continue;
         const int ox = tx / stride;
         if (ox >= Wo) continue;
-        acc += ld4(gy + (((long)n * Ho + oy) * Wo + ox) * C + c) * ld4(w + (ky * K + kx) * C + c);
+        acc = __builtin_elementwise_fma(ld4(gy + (((long)n * Ho + oy) * Wo + ox) * C + c), ld4(w + (ky * K + kx) * C + c), acc);
       }
     }
     st4(gx + i * 4, acc);
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
 #pragma unroll
         for (int ky = 0; ky < K; ++ky)
 #pragma unroll
-          for (int kx = 0; kx < K; ++kx) s[ky * K + kx] += g * win[ky][kx];
+          for (int kx = 0; kx < K; ++kx) s[ky * K + kx] = __builtin_fmaf(g, win[ky][kx], s[ky * K + kx]);   // (the library is built with -ffp-contract=off)
         fresh = false;
         if (++ox == Wo) { ox = 0; fresh = true; if (++oy == Ho) { oy = 0; ++n; } }
       }
