@@ -89,6 +89,7 @@ struct PatchArgs {
   int act;
   int nchunk;
   int tiles_x, tiles_y, tiles_n;
+  int gate_hw;               // > 0: pixels were re-tiled as one flat image; a_scale row = linear pixel / gate_hw
 };
 
 // Epilogue.  The MFMAs are issued with the WEIGHT fragment as the first operand, so D = W * X^T: in the
@@ -279,16 +280,30 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
     const bool ok = a_gpix[r] >= 0 && ch < p.Cin;
     return *reinterpret_cast<const f32x4*>(ok ? p.in + (size_t)a_gpix[r] * p.in_cs + ch : p.in);
   };
-  auto load_gate = [&](int c) __attribute__((always_inline)) -> f32x4 {
-    const int ch = c * PT_CK + cq * 4;
-    return *reinterpret_cast<const f32x4*>(p.a_scale + (size_t)img * p.Cin + (ch < p.Cin ? ch : 0));
+  // squeeze-excite gate of the chunk being staged: one row of a_scale per IMAGE -- the workgroup's image, or (flat
+  // re-tiling of a 1x1 conv, gate_hw > 0) the image of each staged pixel
+  f32x4 gate[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) gate[r] = f32x4{1.f, 1.f, 1.f, 1.f};
+  auto load_gate = [&](int c) __attribute__((always_inline)) {
+    const int ch = c * PT_CK + cq * 4, chc = ch < p.Cin ? ch : 0;
+    if (p.gate_hw > 0) {
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) {
+        const int im = a_gpix[r] >= 0 ? a_gpix[r] / p.gate_hw : 0;
+        gate[r] = *reinterpret_cast<const f32x4*>(p.a_scale + (size_t)im * p.Cin + chc);
+      }
+    } else {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(p.a_scale + (size_t)img * p.Cin + chc);
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) gate[r] = g;
+    }
   };
-  f32x4 gate = {1.f, 1.f, 1.f, 1.f};                        // squeeze-excite gate of the chunk being staged
   auto store_a = [&](int r, int c, f32x4 v, char* buf) __attribute__((always_inline)) {
     if (r * 128 + (tid >> 2) >= NPIX) return;
     char* dst = buf + a_lofs0 + r * (128 * 16);
     const bool ok = a_gpix[r] >= 0 && c * PT_CK + cq * 4 < p.Cin;
-    if (p.a_scale) v *= gate;
+    if (p.a_scale) v *= gate[r];
     if (F16) v *= a_mul;
     if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 rem = v;
@@ -309,7 +324,7 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // ---- prologue: chunk 0 of A, weight tile (0,0)
-  if (p.a_scale) gate = load_gate(0);
+  if (p.a_scale) load_gate(0);
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) store_a(r, 0, load_a(r, 0), abase);
   dma_b(0);
@@ -330,7 +345,7 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
 #pragma unroll
       for (int r = 0; r < ROUNDS; ++r)
         if ((r < T ? r : T - 1) == t && more_a) ra[r] = load_a(r, c + 1);
-      if (t == 0 && more_a && p.a_scale) gate = load_gate(c + 1);
+      if (t == 0 && more_a && p.a_scale) load_gate(c + 1);
 
       // ---- MFMAs of (chunk c, tap t)
       const int ky = t / K, kx = t % K;
@@ -894,7 +909,22 @@ int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
   a.nchunk = (d->Cin + PT_CK - 1) / PT_CK;
   a.tiles_x = (d->Wo + PT_TW - 1) / PT_TW;
   a.tiles_y = (d->Ho + PT_TH - 1) / PT_TH;
-  const int bn = 64 * patch_tn(d->Cout, d->prec, d->Cin, d->KH, (long)a.tiles_x * a.tiles_y * d->N);
+  a.gate_hw = 0;
+  // A stride-1 1x1 conv has no halo: when the 8 x 32 pixel tiles pad the map by more than 12 % (19 x 38: 24 x 64 =
+  // 2.1x the pixels, 38 x 76: 1.33x), its N*H*W pixels are re-tiled as ONE image of width 32 -- every tile is 256
+  // consecutive pixels of the NHWC buffer, every linear pixel index (input, output, residual, row mask) is unchanged;
+  // only the per-image squeeze-excite gate needs the pixel's image (gate_hw).  Same box, A/B: 192->1152 @19x38 x16 152 -> 88 us,
+  // 1152->192 86 -> 65, 112->672 @38x76 155 -> 142; batch-16 step 46.62 -> 46.16 ms
+  if (d->KH == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && !d->up_src && d->Ho == d->H && d->Wo == d->W) {
+    const long hw = (long)d->H * d->W, P = hw * d->N;
+    const long padded = (long)a.tiles_x * a.tiles_y * PT_TH * PT_TW;
+    if (P % PT_TW == 0 && padded * 100 > hw * 112 && P / PT_TW < (1L << 30) && hw < (1L << 30)) {
+      a.gate_hw = d->a_scale ? (int)hw : 0;
+      a.N = 1; a.W = a.Wo = PT_TW; a.H = a.Ho = (int)(P / PT_TW);
+      a.tiles_x = 1; a.tiles_y = (a.Ho + PT_TH - 1) / PT_TH;
+    }
+  }
+  const int bn = 64 * patch_tn(d->Cout, d->prec, d->Cin, d->KH, (long)a.tiles_x * a.tiles_y * a.N);
   a.tiles_n = (d->Cout + bn - 1) / bn;
   const int split = patch_split(d->prec);
   const int K = d->KH;

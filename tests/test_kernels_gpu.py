@@ -231,6 +231,37 @@ def test_conv_slices_gate_and_rowmask(ops):
     assert (full[..., :20] == -7).all() and (full[..., 36:] == -7).all()
 
 
+@pytest.mark.parametrize("prec,tol", [("bf16x6", 1e-5), ("f16x3", 1e-5)])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,gated", [(4, 19, 40, 1152, 192, True), (16, 19, 38, 192, 1152, False),
+                                                  (8, 38, 76, 112, 72, True), (2, 19, 38, 64, 64, True)])
+def test_conv1x1_flat_retiling(ops, prec, tol, N, H, W, Cin, Cout, gated):
+    """1x1 convs on maps that the 8 x 32 pixel tiles cover badly are re-tiled as one flat image of width 32 (when
+    N*H*W is a multiple of 32; the last case is not and keeps the 2-D tiles): squeeze-excite gate per image (tiles that
+    straddle two images), residual, bias, running |max|"""
+    g = torch.Generator().manual_seed(N * H + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g)
+    gate = torch.rand(N, Cin, generator=g) + 0.25 if gated else None
+    res = torch.randn(N, Cout, H, W, generator=g)
+    xin = x.double() * (gate.double().view(N, Cin, 1, 1) if gated else 1.0)
+    ref = F.conv2d(xin, w.double(), b.double()) + res.double()
+    xa = to_act(ops, x)
+    xa.amax = dev(x.abs().max().reshape(1))
+    pc = ops.pack_conv(dev(w), dev(b), None, 1, 0, 0, {"bf16x6": ops.PREC_BF16X6, "f16x3": ops.PREC_F16X3}[prec])
+    old = ops.TRACK_AMAX
+    ops.TRACK_AMAX = True
+    try:
+        out = ops.conv2d(xa, pc, res=to_act(ops, res), a_scale=dev(gate) if gated else None)
+    finally:
+        ops.TRACK_AMAX = old
+    got = from_act(out).double()
+    rel = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    assert rel < tol, f"{prec}: relative rms error {rel:.2e}"
+    assert float((got - ref).abs().max()) < 50 * tol * float(ref.abs().max())
+    assert float(out.amax) >= float(ref.abs().max()) * (1 - 1e-5)
+
+
 @pytest.mark.parametrize("K,s,pad", [(3, 1, (1, 1, 1, 1)), (3, 2, (0, 1, 0, 1)), (5, 2, (1, 2, 1, 2)),
                                      (5, 1, (2, 2, 2, 2))])
 def test_dwconv(ops, K, s, pad):
