@@ -845,7 +845,10 @@ static inline int patch_tn(int cout, int prec, int cin, int K, long px_tiles) {
   const int max_tn = cout > 128 ? (prec == CRESTE_PREC_F16X3 ? 4 : 2) : (cout > 64 ? 2 : 1);
   int tn = max_tn;
   if (K == 1 && cin < 256 && tn == 4) tn = 2;            // write-bound expand convs: 256-wide tiles only add latency
-  while (tn > 1 && px_tiles * ((cout + 64 * tn - 1) / (64 * tn)) < 400) tn >>= 1;   // < ~1.5 workgroups per CU
+  // 1x1 convs are latency chains of a few chunk steps per workgroup: they want MORE, lighter workgroups than the 3x3
+  // kernels (same box, A/B: 192->1152 @19x38 x16 88 -> 55 us, 112->672 @38x76 140 -> 83; batch-16 step 44.65 -> 44.12 ms)
+  const long thr = K == 1 && cin < 256 ? 1600 : (K == 1 ? 800 : 400);
+  while (tn > 1 && px_tiles * ((cout + 64 * tn - 1) / (64 * tn)) < thr) tn >>= 1;   // < ~1.5 workgroups per CU
   return tn;
 }
 constexpr int PATCH_UNIT_PAD = 4;     // packed units are padded to a multiple of the widest tile
