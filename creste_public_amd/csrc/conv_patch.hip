@@ -200,7 +200,9 @@ __device__ __forceinline__ void patch_epilogue_lds(const f32x16 (&acc)[2][TN], c
   if (p.out_amax) block_amax_update(vmax, p.out_amax, scratch);
 }
 
-template <int K, int SPLIT, int TN, bool F16>
+// FG: the squeeze-excite gate row is looked up per staged PIXEL (flat re-tiling of a gated 1x1 conv, gate_hw > 0) -- its
+// own instantiation: the per-round gate registers pushed the common 128-register kernels into scratch
+template <int K, int SPLIT, int TN, bool F16, bool FG = false>
 __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) void conv_patch_kernel(const PatchArgs p) {
   typedef typename Piece<F16>::V8 V8;
   typedef typename Piece<F16>::V4 V4;
@@ -280,30 +282,29 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
     const bool ok = a_gpix[r] >= 0 && ch < p.Cin;
     return *reinterpret_cast<const f32x4*>(ok ? p.in + (size_t)a_gpix[r] * p.in_cs + ch : p.in);
   };
-  // squeeze-excite gate of the chunk being staged: one row of a_scale per IMAGE -- the workgroup's image, or (flat
-  // re-tiling of a 1x1 conv, gate_hw > 0) the image of each staged pixel
-  f32x4 gate[ROUNDS];
+  // squeeze-excite gate of the chunk being staged: one row of a_scale per IMAGE -- the workgroup's image, or (FG) the
+  // image of each staged pixel
+  constexpr int NG = FG ? ROUNDS : 1;
+  f32x4 gate[NG];
 #pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) gate[r] = f32x4{1.f, 1.f, 1.f, 1.f};
+  for (int r = 0; r < NG; ++r) gate[r] = f32x4{1.f, 1.f, 1.f, 1.f};
   auto load_gate = [&](int c) __attribute__((always_inline)) {
     const int ch = c * PT_CK + cq * 4, chc = ch < p.Cin ? ch : 0;
-    if (p.gate_hw > 0) {
+    if constexpr (FG) {
 #pragma unroll
       for (int r = 0; r < ROUNDS; ++r) {
         const int im = a_gpix[r] >= 0 ? a_gpix[r] / p.gate_hw : 0;
         gate[r] = *reinterpret_cast<const f32x4*>(p.a_scale + (size_t)im * p.Cin + chc);
       }
     } else {
-      const f32x4 g = *reinterpret_cast<const f32x4*>(p.a_scale + (size_t)img * p.Cin + chc);
-#pragma unroll
-      for (int r = 0; r < ROUNDS; ++r) gate[r] = g;
+      gate[0] = *reinterpret_cast<const f32x4*>(p.a_scale + (size_t)img * p.Cin + chc);
     }
   };
   auto store_a = [&](int r, int c, f32x4 v, char* buf) __attribute__((always_inline)) {
     if (r * 128 + (tid >> 2) >= NPIX) return;
     char* dst = buf + a_lofs0 + r * (128 * 16);
     const bool ok = a_gpix[r] >= 0 && c * PT_CK + cq * 4 < p.Cin;
-    if (p.a_scale) v *= gate[r];
+    if (p.a_scale) v *= gate[FG ? r : 0];
     if (F16) v *= a_mul;
     if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 rem = v;
@@ -846,7 +847,8 @@ static inline int patch_tn(int cout, int prec, int cin, int K, long px_tiles) {
   int tn = max_tn;
   if (K == 1 && cin < 256 && tn == 4) tn = 2;            // write-bound expand convs: 256-wide tiles only add latency
   // 1x1 convs are latency chains of a few chunk steps per workgroup: they want MORE, lighter workgroups than the 3x3
-  // kernels (same box, A/B: 192->1152 @19x38 x16 88 -> 55 us, 112->672 @38x76 140 -> 83; batch-16 step 44.65 -> 44.12 ms)
+  // kernels (same box, A/B in isolation: 192->1152 @19x38 x16 88 -> 55 us, 112->672 @38x76 140 -> 83; in the network the
+  // two changes together are worth ~0.1 ms of the 43.5 ms step)
   const long thr = K == 1 && cin < 256 ? 1600 : (K == 1 ? 800 : 400);
   while (tn > 1 && px_tiles * ((cout + 64 * tn - 1) / (64 * tn)) < thr) tn >>= 1;   // < ~1.5 workgroups per CU
   return tn;
@@ -860,10 +862,15 @@ template <int K, int SPLIT, int TN, bool F16>
 static int launch_patch(const PatchArgs& a, hipStream_t s) {
   constexpr int PH = PT_TH + K - 1, PW = PT_TW + K - 1, NPIXP = (PH * PW + 15) / 16 * 16;
   constexpr int smem = 2 * (SPLIT * 2 * NPIXP * 16) + 2 * (SPLIT * 2 * 64 * TN * 16);
-  static std::atomic<uint64_t> attr_devs{0};
-  if (smem > 64 * 1024) CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(conv_patch_kernel<K, SPLIT, TN, F16>), smem, attr_devs));
+  static std::atomic<uint64_t> attr_devs{0}, attr_devs_fg{0};
   const int nblk = a.tiles_n * a.tiles_x * a.tiles_y * a.N;
-  conv_patch_kernel<K, SPLIT, TN, F16><<<nblk, 512, smem, s>>>(a);
+  if (K == 1 && a.gate_hw > 0) {
+    if (smem > 64 * 1024) CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(conv_patch_kernel<K, SPLIT, TN, F16, true>), smem, attr_devs_fg));
+    conv_patch_kernel<K, SPLIT, TN, F16, true><<<nblk, 512, smem, s>>>(a);
+  } else {
+    if (smem > 64 * 1024) CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(conv_patch_kernel<K, SPLIT, TN, F16>), smem, attr_devs));
+    conv_patch_kernel<K, SPLIT, TN, F16><<<nblk, 512, smem, s>>>(a);
+  }
   CRESTE_CHECK_LAUNCH("conv_patch");
   return CRESTE_OK;
 }
@@ -916,8 +923,8 @@ int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
   // A stride-1 1x1 conv has no halo: when the 8 x 32 pixel tiles pad the map by more than 12 % (19 x 38: 24 x 64 =
   // 2.1x the pixels, 38 x 76: 1.33x), its N*H*W pixels are re-tiled as ONE image of width 32 -- every tile is 256
   // consecutive pixels of the NHWC buffer, every linear pixel index (input, output, residual, row mask) is unchanged;
-  // only the per-image squeeze-excite gate needs the pixel's image (gate_hw).  Same box, A/B: 192->1152 @19x38 x16 152 -> 88 us,
-  // 1152->192 86 -> 65, 112->672 @38x76 155 -> 142; batch-16 step 46.62 -> 46.16 ms
+  // only the per-image squeeze-excite gate needs the pixel's image (gate_hw).  Same box, A/B in isolation: 192->1152 @19x38 x16
+  // 152 -> 88 us, 1152->192 86 -> 65, 112->672 @38x76 155 -> 142
   if (d->KH == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && !d->up_src && d->Ho == d->H && d->Wo == d->W) {
     const long hw = (long)d->H * d->W, P = hw * d->N;
     const long padded = (long)a.tiles_x * a.tiles_y * PT_TH * PT_TW;
