@@ -48,10 +48,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
         op = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
         objs.append(op)
         if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_m):
-            cmd = [hipcc, *FLAGS, "-x", "hip", "-c", sp, "-o", op]
+            cmd = [hipcc, *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-x", "hip", "-c", sp, "-o", op]
             if verbose:
                 print("[creste build]", " ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
+            r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+            remarks = [ln for ln in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" in ln]
+            other = [ln for ln in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in ln]
+            if r.returncode or any("warning:" in ln or "error:" in ln for ln in other):   # (else: the remarks' source context)
+                print("\n".join(other), file=sys.stderr, flush=True)
+            if r.returncode:
+                raise subprocess.CalledProcessError(r.returncode, cmd)
+            with open(op + ".usage.txt", "w") as f:        # registers / scratch / occupancy of every kernel: resource_usage()
+                f.write("\n".join(remarks) + "\n")
             rebuilt = True
     if rebuilt or not os.path.exists(LIB):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]
@@ -59,6 +67,31 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print("[creste build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
     return LIB
+
+
+def resource_usage() -> dict:
+    """{mangled kernel name: {"vgprs", "agprs", "scratch", "occupancy", "lds", "source"}} of the last build (from the
+    compiler's kernel-resource-usage remarks; tests/test_abi.py keeps the hot kernels out of scratch with it)."""
+    import re
+    out = {}
+    for src in SOURCES:
+        path = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o.usage.txt")
+        if not os.path.exists(path):
+            continue
+        cur = None
+        for ln in open(path):
+            m = re.search(r"Function Name: (\S+)", ln)
+            if m:
+                cur = out.setdefault(m.group(1), {"source": src})
+                continue
+            if cur is None:
+                continue
+            for key, pat in (("vgprs", r"VGPRs: (\d+)"), ("agprs", r"AGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                             ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)"), ("lds", r"LDS Size \[bytes/block\]: (\d+)")):
+                m = re.search(pat, ln)
+                if m:
+                    cur[key] = int(m.group(1))
+    return out
 
 
 if __name__ == "__main__":

@@ -96,3 +96,27 @@ def test_plan_dispatch_table_is_current_and_loader_rejects_garbage(tmp_path):
     assert b"not a creste plan" in lib.creste_last_error()
     assert lib.creste_hip_model_load(b"/nonexistent.plan", 0, ctypes.byref(h)) != 0
     assert lib.creste_hip_model_num_outputs(None) == -1
+
+
+def test_hot_kernels_stay_out_of_scratch():
+    """register spills are silent and expensive (a per-round gate array once pushed the common 1x1 conv kernel into 132
+    bytes of scratch per lane: +1 ms per batch-16 step): the compiler's resource remarks of the last build are kept next
+    to the objects (creste_public_amd/build.py) and every kernel must be spill-free unless it is on this short list."""
+    from creste_public_amd import build
+    build.build(verbose=False)
+    usage = build.resource_usage()
+    assert len(usage) > 200, "kernel-resource-usage remarks missing: rebuild with `python -m creste_public_amd.build --force`"
+    allowed = {                                    # mangled-name fragment -> bytes per lane tolerated
+        "conv_patch3_kernelILi2ELi2ELb1ELb0E": 64,    # f16x3 3x3, 128-channel tiles at 128 registers (2 workgroups per CU)
+        "conv_patch3_kernelILi2ELi2ELb0ELb0E": 48,    # bf16x3 twin
+        "conv_patch_kernelILi1ELi2ELi2ELb1ELb0E": 16,
+        "conv_patch_kernelILi1ELi2ELi2ELb1ELb1E": 160,  # gated flat 1x1 at 128-channel tiles: not reached by the network
+        "conv_patch_row_kernelILi7E": 48,
+        "Lb0ELb1EEEvNS_9PatchArgsE": 400,             # fused-upsample loader variants (hipnn.FUSE_UPSAMPLE = False)
+    }
+    bad = []
+    for name, u in usage.items():
+        lim = max([v for k, v in allowed.items() if k in name] or [0])
+        if u.get("scratch", 0) > lim:
+            bad.append((name, u["scratch"], lim))
+    assert not bad, bad
