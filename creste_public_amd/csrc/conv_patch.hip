@@ -402,8 +402,10 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
 //      LDS so two 8-wave workgroups share a CU and cover each other's barriers.
 // UP = the loader also forms the bilinear-upsample half of a concat input (separate instantiation: its
 // address arithmetic costs ~40 VGPRs, which the plain kernels at 128 VGPRs/lane cannot spare).
+// (the f16x3 128-channel tile takes the 256-register budget too: at 128 registers it spilled 52 bytes per lane -- same
+// box, batch-16 step 42.80 -> 42.62 ms)
 template <int SPLIT, int TN, bool F16, bool UP>
-__global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) void conv_patch3_kernel(const PatchArgs p) {
+__global__ __launch_bounds__(512, (SPLIT * TN >= 6 || (F16 && !UP && TN == 2)) ? 2 : PATCH_WAVES_PER_SIMD) void conv_patch3_kernel(const PatchArgs p) {
   typedef typename Piece<F16>::V8 V8;
   typedef typename Piece<F16>::V4 V4;
   constexpr int K = 3;
