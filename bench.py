@@ -174,7 +174,21 @@ def cpu_baseline(batches=(1, 16), runs=5, budget_s=210.0):
             "by_batch": {str(k): v for k, v in per.items()}, "blas": blas}
 
 
-def distill_extras(device, steps=3, B=8):
+def _median_step_ms(fn, steps):
+    """median wall time of `steps` synchronised calls (a single hiccup -- another tenant of the box, a stalled copy --
+    tripled a 3-step mean once: the side measurements report the median)"""
+    ts, last = [], None
+    for _ in range(steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        last = fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2], last
+
+
+def distill_extras(device, steps=5, B=8):
     """BASELINE configs[3], per-GPU part: one stage-1 distillation training step (train_pefree.py) -- training-mode
     forward, CrossEntropyDepth + SmoothL1Depth + MSELoss, backward to all 25.5 M encoder parameters into the flat
     all-reduce arena, Adam -- batch 8 of 1216x608 on the HIP training kernels."""
@@ -193,11 +207,7 @@ def distill_extras(device, steps=3, B=8):
              "fimg_label": torch.randn(B, 1, 128, IMG_H // 4, IMG_W // 4, generator=g).to(device)}
     tr = harness.DistillTrainer(model, LossManager(cfg), cfg)
     tr.training_step(batch); tr.training_step(batch); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        logs = tr.training_step(batch)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
+    ms, logs = _median_step_ms(lambda: tr.training_step(batch), steps)
     n = sum(p.numel() for p in model.parameters() if p.grad is not None)
     del tr, model, batch
     torch.cuda.empty_cache()
@@ -206,7 +216,7 @@ def distill_extras(device, steps=3, B=8):
                               f"{n} parameters with gradients, Adam; loss {float(logs['train/loss']):.3f}"}
 
 
-def ssc_extras(device, steps=3, B=8):
+def ssc_extras(device, steps=5, B=8):
     """BASELINE configs[3], second stage: one BEV-SSC training step (train_ssc.py) -- TerrainNet in training mode
     (encoder + depth-guided splat + ResNet-18 BEV heads), the six SSC losses, backward through the splat into
     features and depth, Adam -- batch 8 of 1216x608 -> 256x256 BEV on the HIP training kernels."""
@@ -231,11 +241,7 @@ def ssc_extras(device, steps=3, B=8):
     batch = {"joint": {k: v.to(device) for k, v in data.items()}}
     tr = harness.SSCTrainer(model, LossManager(cfg).to(device), cfg)
     tr.training_step(batch); tr.training_step(batch); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        logs = tr.training_step(batch)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
+    ms, logs = _median_step_ms(lambda: tr.training_step(batch), steps)
     n = sum(p.numel() for p in model.parameters() if p.grad is not None)
     del tr, model, batch
     torch.cuda.empty_cache()
@@ -259,7 +265,7 @@ IRL_VARIANTS = {
 }
 
 
-def irl_step_bench(model_infer, device, variant, steps=3):
+def irl_step_bench(model_infer, device, variant, steps=5):
     """One IRL training step (reference train_traversability.py:66-105): frozen HIP backbone forward, reward net
     (train mode, hipGraph-replayed HIP kernels), value iteration + expected SVF, MaxEntIRLLoss with counterfactual
     mixing (alpha 0.5) and gradient penalty, backward incl. the second-order term, Adam."""
@@ -309,11 +315,7 @@ def irl_step_bench(model_infer, device, variant, steps=3):
             return loss.detach(), out
 
         step(); step(); torch.cuda.synchronize()              # eager step, then the capturing step
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss, out = step()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / steps * 1e3
+        ms, (loss, out) = _median_step_ms(step, steps)
         sweeps = int(model.traversability_head.last_sweeps.item())
         occ = float((out["bev_densities"] > 0).float().mean())
         res = {"train_step_ms": round(ms, 2), "batch": B, "bev_grid": [GH, GW], "mdp_grid": list(v["map_size"]),
@@ -341,7 +343,7 @@ def vi_kernel_bench(device, B, Hg, Wg):
     return {"ms": round(ms, 3), "sweeps": n, "algorithmic_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 3)}
 
 
-def irl_extras(model_infer, device, steps=3):
+def irl_extras(model_infer, device, steps=5):
     """The second half of BASELINE.json's metric: IRL train-step time, at the reference config, at BASELINE configs[2]
     (256x256 MDP grid) and at configs[4]'s per-GPU shape (512x512 BEV, bf16 encoder, counterfactual IRL)."""
     out = {"config": "frames 1216x608; frozen HIP backbone + reward net training kernels + VI + SVF (T=50) + CF-IRL loss "
