@@ -83,6 +83,13 @@ def pointwise2(op: int, a: Act, b: Act | None, out: Act | None = None) -> Act:
     return out
 
 
+# True: in the f16x3 operand mode (fp32 operands as fp16 hi+lo, product error <= 2^-21) the reward network's convs -- forward,
+# tangent, both input gradients and the weight gradients -- run on the f16 matrix cores like the backbone's (parity tests
+# pass).  Off by default: measured, the IRL step does not get faster (reference config 31.2 -> 31.9 ms, 256x256 MDP grid
+# 56.9 -> 56.1 ms: the reward network is launch- and BatchNorm-bound, not MFMA-bound), so it keeps exact fp32 products.
+REWARD_FOLLOWS_F16X3 = False
+
+
 class ConvT:
     """stride-1 'same' conv without bias: y = W * x."""
 
@@ -98,17 +105,24 @@ class ConvT:
     def params(self):
         return [self.conv.weight]
 
+    def _prec(self, cin):
+        from . import hipnn
+        if REWARD_FOLLOWS_F16X3 and hipnn._precision == ops.PREC_F16X3:
+            return ops.conv_precision(ops.PREC_F16X3, self.K, 1, cin)
+        return ops.PREC_F32
+
     def _packed(self):
         w = self.conv.weight
-        key = (w.data_ptr(), w._version, ops.CACHE_EPOCH)
+        Cout, Cin = w.shape[:2]
+        pf, pb = self._prec(Cin), self._prec((Cout + 3) // 4 * 4)
+        key = (w.data_ptr(), w._version, ops.CACHE_EPOCH, pf, pb)
         if key != self._key:
-            Cout, Cin = w.shape[:2]
-            self._fw = ops.pack_conv(w, None, None, 1, self.K // 2, ops.ACT_NONE, ops.PREC_F32)
+            self._fw = ops.pack_conv(w, None, None, 1, self.K // 2, ops.ACT_NONE, pf)
             cpad = (Cout + 3) // 4 * 4
             wt = torch.empty((Cin, cpad, self.K, self.K), dtype=torch.float32, device=w.device)
             _lib.check(_lib_().creste_conv_flip_weight_f32(w.detach().contiguous().data_ptr(), wt.data_ptr(), Cout,
                                                            Cin, self.K, cpad, _stream()), "conv_flip_weight")
-            self._bw = ops.pack_conv(wt, None, None, 1, self.K // 2, ops.ACT_NONE, ops.PREC_F32)
+            self._bw = ops.pack_conv(wt, None, None, 1, self.K // 2, ops.ACT_NONE, pb)
             self._key = key
         return self._fw, self._bw
 
@@ -133,6 +147,15 @@ class ConvT:
         Cout, Cin = w.shape[:2]
         lib = _lib_()
         _, acc = grad_slot(grads, w)
+        if (self._prec(Cin) == ops.PREC_F16X3 and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 8 and Cout >= 8
+                and x.cs % 4 == 0 and gy.cs % 4 == 0 and x.co % 4 == 0 and gy.co % 4 == 0):
+            work = torch.empty(lib.creste_conv_wgrad_strided_workspace_bytes(x.N, x.H, x.W, Cin, Cout, self.K),
+                               dtype=torch.uint8, device=w.device)
+            _lib.check(lib.creste_conv_wgrad_f16x3(x.ptr, x.cs, gy.ptr, gy.cs, grads[id(w)].data_ptr(),
+                                                   ops.absmax(x).data_ptr(), ops.absmax(gy).data_ptr(), x.N, x.H, x.W,
+                                                   x.H, x.W, Cin, Cout, self.K, 1, self.K // 2, self.K // 2, int(acc),
+                                                   work.data_ptr(), _stream()), "conv_wgrad_f16x3")
+            return
         work = torch.empty(lib.creste_conv_wgrad_workspace_bytes(x.N, x.H, x.W, Cin, Cout, self.K),
                            dtype=torch.uint8, device=w.device)
         _lib.check(lib.creste_conv_wgrad_f32(x.ptr, x.cs, gy.ptr, gy.cs, grads[id(w)].data_ptr(), x.N, x.H, x.W, Cin,
@@ -472,9 +495,11 @@ class _Phases:
         if ent == "warm":
             static_in = [t.detach().clone() for t in ins]
             torch.cuda.synchronize()
+            ops.reset_amax_pool()                # |max| slots taken inside the graph are zero-filled BY the graph ...
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 outs = fn(*static_in)
+            ops.reset_amax_pool()                # ... and nobody outside it shares their block
             ent = self.graphs[key] = (g, static_in, outs)
         g, static_in, outs = ent
         for st, t in zip(static_in, ins):
