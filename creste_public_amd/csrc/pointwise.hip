@@ -677,6 +677,51 @@ __global__ __launch_bounds__(256) void pixel_geometry_kernel(
   }
 }
 
+// The shipped z-MLP (1 -> 64 -> 32) with one LANE per pixel: the pixel's 64 hidden units and 32 outputs live in its own
+// registers, every weight is a wave-uniform SCALAR operand (the compiler's s_load from the kernel-argument pointers), so the
+// 2048 multiply-adds per pixel need no LDS and no shuffles -- the lane-per-output form above is bound by 64 shuffles per
+// output (220 us per batch of 16; this form: ~70).  Same operations in the same order (geometry fma chain; s = b2[j], then
+// h = 0..63): bit-identical.
+__global__ __launch_bounds__(256) void pixel_geometry_px_kernel(
+    const float* __restrict__ depth, const float* __restrict__ p2p, int B, int Hs, int Ws,
+    const float* __restrict__ bounds, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ xyz, float* __restrict__ mask,
+    float* __restrict__ zfeat, int z_cs, int z_co) {
+  const unsigned P32 = (unsigned)Hs * (unsigned)Ws, total = (unsigned)B * P32;
+  const unsigned g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= total) return;
+  const float d = depth[g];
+  const int b = (int)(g / P32);
+  const unsigned p = g - (unsigned)b * P32;
+  const int v = (int)(p / (unsigned)Ws), u = (int)(p - (unsigned)v * (unsigned)Ws);
+  const float c0 = (float)u * d, c1 = (float)v * d;
+  const float* M = p2p + (long)b * 16;
+  float q[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    q[k] = __fmaf_rn(M[k * 4 + 3], 1.0f, __fmaf_rn(M[k * 4 + 2], d, __fmaf_rn(M[k * 4 + 1], c1, __fmul_rn(M[k * 4 + 0], c0))));
+  xyz[(long)g * 3 + 0] = q[0]; xyz[(long)g * 3 + 1] = q[1]; xyz[(long)g * 3 + 2] = q[2];
+  const bool ok = q[0] >= bounds[0] && q[1] >= bounds[1] && q[2] >= bounds[2] &&
+                  q[0] < bounds[3] && q[1] < bounds[4] && q[2] < bounds[5];
+  mask[g] = ok ? 1.f : 0.f;
+  float hv[64];
+#pragma unroll
+  for (int h = 0; h < 64; ++h) hv[h] = fmaxf(__fmaf_rn(w1[h], q[2], b1[h]), 0.f);
+  float* zo = zfeat + (long)g * z_cs + z_co;
+#pragma unroll
+  for (int j4 = 0; j4 < 32; j4 += 4) {
+    f32x4 o;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      float sacc = b2[j4 + jj];
+#pragma unroll
+      for (int h = 0; h < 64; ++h) sacc = __fmaf_rn(w2[(j4 + jj) * 64 + h], hv[h], sacc);
+      o[jj] = fmaxf(sacc, 0.f);
+    }
+    st4(zo + j4, o);
+  }
+}
+
 // ------------------------------------------------------------------------------ channel affine + act
 // y = act(x * scale[c] + shift[c])  (an eval-mode BatchNorm that follows a ReLU and therefore cannot be
 // folded into the preceding conv: MultiScaleFCN trunk, reference conv.py:118-128)
@@ -934,6 +979,12 @@ extern "C" int creste_pixel_geometry_f32(const float* depth, const float* p2p, i
   CRESTE_REQUIRE(zdim > 0 && zdim <= 256 && 256 % zdim == 0 && zhid > 0, "pixel_geometry: zdim must divide 256");
   CRESTE_REQUIRE((long)B * Hs * Ws < (1L << 31), "pixel_geometry: B*Hs*Ws overflows int32");
   const long total = (long)B * Hs * Ws;
+  if (zhid == 64 && zdim == 32 && z_cs % 4 == 0 && z_co % 4 == 0 && (reinterpret_cast<uintptr_t>(zfeat) & 15) == 0) {
+    pixel_geometry_px_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        depth, p2p, B, Hs, Ws, bounds6, w1, b1, w2, b2, xyz, mask, zfeat, z_cs, z_co);
+    CRESTE_CHECK_LAUNCH("pixel_geometry_px");
+    return CRESTE_OK;
+  }
   const int per = 256 / zdim;
   const size_t smem = (size_t)(2 * zhid + zdim * zhid + zdim) * sizeof(float);
   pixel_geometry_kernel<<<grid_for(total, per, 256 * 16), 256, smem, (hipStream_t)stream>>>(
