@@ -307,7 +307,15 @@ class PlanModel:
                     stride=tuple(stride[:nd.value]))
 
     def __call__(self, inputs, stream=None) -> dict:
-        """inputs: CUDA fp32 tensors with the plan's shapes -> dict name -> torch tensor COPIED out of the arena."""
+        """inputs: CUDA fp32 tensors with the plan's shapes -> dict name -> HOST torch tensor copied out of the arena
+        (every output, synchronously: a convenience for tests -- a deployment calls `run` and reads the outputs it needs
+        in place, `self.outputs[i]["ptr"]`)."""
+        self.run(inputs, stream)
+        torch.cuda.current_stream().synchronize()
+        return {d["name"]: self._fetch(d) for d in self.outputs}
+
+    def run(self, inputs, stream=None) -> None:
+        """enqueue one inference on `stream` (default: torch's current stream); the outputs stay in the plan's arena"""
         C = self._C
         from . import _lib
         arr = (C.c_void_p * len(self.inputs))()
@@ -320,8 +328,7 @@ class PlanModel:
             arr[i] = t.data_ptr()
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
         _lib.check(self._lib.creste_hip_model_infer(self._h, arr, len(self.inputs), s), "model_infer")
-        torch.cuda.current_stream().synchronize()
-        return {d["name"]: self._fetch(d) for d in self.outputs}
+        self._keep = keep                       # the staged inputs must outlive the asynchronous copy into the arena
 
     def _fetch(self, d):
         """copy an output out of the arena through the library's own d2h helper (no torch view of foreign memory)."""
