@@ -120,3 +120,34 @@ def test_expected_svf_mass_bounds_full_grid():
     assert float(svf.min()) >= 0.0 and float(tot.max()) <= T + 1e-3 and float(tot.min()) > 1.0   # mass only leaves the grid
     assert states.shape == (Bn, T, 2) and int(states.min()) >= 0 and int(states[..., 0].max()) < Hh
     assert float(grid.sum(dim=(1, 2)).max()) <= T + 1e-3
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_fused_and_unfused_trunk_paths_agree_at_full_size(prec):
+    """the fused kernels of the encoder trunk (stem + block 0, MBConv front halves, LDS-tile depthwise convs, flat 1x1
+    re-tiling) against the kernel-per-op path on the same weights at 608x1216: every endpoint within fp32 round-off of
+    the other (the fused paths use exact fp32 FMAs and 1-ulp hardware exp / rcp in their activations)"""
+    import creste_public_amd
+    from creste_public_amd import ops, synth
+    from creste_public_amd.creste.models.blocks import effnet as E
+    torch.manual_seed(3)
+    creste_public_amd.set_precision(prec)
+    try:
+        trunk = E.EfficientNetB0Trunk(4, (608, 1216))
+        synth.randomize_bn(trunk, seed=5)
+        trunk = trunk.cuda().eval()
+        x = ops.nchw_to_nhwc(torch.rand(2, 4, 608, 1216, device="cuda"))
+        x.amax = x.buf.abs().max().reshape(1)
+        outs = {}
+        with torch.no_grad():
+            for fused in (True, False):
+                E.FUSE_MBCONV, ops.DW_TILE = fused, fused
+                outs[fused] = {k: v.buf.clone() for k, v in trunk.extract_endpoints_act(x).items()}
+    finally:
+        E.FUSE_MBCONV, ops.DW_TILE = True, True
+        creste_public_amd.set_precision("f32")
+    assert set(outs[True]) == set(outs[False]) and len(outs[True]) == 5
+    for k, a in outs[True].items():
+        b = outs[False][k]
+        rel = float((a - b).double().pow(2).mean().sqrt() / b.double().pow(2).mean().sqrt())
+        assert rel < (3e-6 if prec == "f32" else 2e-5), (k, rel)
