@@ -1028,7 +1028,7 @@ extern "C" int creste_conv_wgrad_f16x3(const float* x, int x_cs, const float* gy
     const int nbands = (H + W3_KS - 1) / W3_KS;
     const long base = (long)N * nbands;                            // chunks before column segmentation
     const long tiles3 = (long)tiles_co * tiles_ci * 3;
-    long nseg = (1024 + tiles3 * base - 1) / (tiles3 * base);      // ~1024 workgroups in flight
+    long nseg = (512 + tiles3 * base - 1) / (tiles3 * base);       // >= 512 workgroups (A/B on one box: 1024 -> 512: SSC step 125.5 -> 124.4 ms; fewer partial sets to reduce)
     const long seg_cap = cap / base > 0 ? cap / base : 1;          // the workspace holds `cap` partial sets
     nseg = nseg < 1 ? 1 : (nseg > seg_cap ? seg_cap : nseg);
     if (nseg > W) nseg = W;
