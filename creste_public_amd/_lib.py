@@ -86,6 +86,8 @@ SIGNATURES = {
     "creste_bn_train_tangent_f32": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "creste_bn_train_backward_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp,
                                           _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "creste_bn_relu_train_backward_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                               _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "creste_pointwise2_f32": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
     "creste_maxpool2_idx_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "creste_maxpool2_route_f32": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

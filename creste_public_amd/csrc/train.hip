@@ -113,6 +113,7 @@ struct MomArgs {
   const float *x, *xd, *gy, *G;
   int x_cs, xd_cs, gy_cs, G_cs;
   const float *mean, *invstd, *mdot, *cc;
+  const float *mgamma, *mbeta;   // MODE 3, both non-null: the cotangents pass the mask of the fused ReLU, gamma * xh + beta > 0
   float* partial;      // [blocks][nk][C]
   long P;
   int C, nk;
@@ -155,9 +156,10 @@ __global__ __launch_bounds__(256) void moments_kernel(const MomArgs a) {
       }
       if (MODE == 3) {
         const float xh = (xv - mu) * is;
-        if (a.gy) { const float g = a.gy[p * a.gy_cs + c]; s[0] += g; s[1] += g * xh; }
+        const bool on = !a.mbeta || a.mgamma[c] * xh + a.mbeta[c] > 0.f;
+        if (a.gy) { const float g = on ? a.gy[p * a.gy_cs + c] : 0.f; s[0] += g; s[1] += g * xh; }
         if (a.G) {
-          const float g = a.G[p * a.G_cs + c];
+          const float g = on ? a.G[p * a.G_cs + c] : 0.f;
           const float t = (a.xd[p * a.xd_cs + c] - md) - xh * cc;
           s[2] += g; s[3] += g * xh; s[4] += g * t;
         }
@@ -208,9 +210,14 @@ __global__ __launch_bounds__(256) void moments4_kernel(const MomArgs a) {
       }
       if (MODE == 3) {
         const mq4 xh = (xv - mu) * is;
-        if (a.gy) { const mq4 g = ld(a.gy + p * a.gy_cs + c); s[0] += g; s[1] += g * xh; }
+        mq4 on = {1.f, 1.f, 1.f, 1.f};
+        if (a.mbeta) {                                    // the forward's y = gamma * xh + beta, same expression: same sign
+          const mq4 yv = ld(a.mgamma + c) * xh + ld(a.mbeta + c);
+          for (int j = 0; j < 4; ++j) on[j] = yv[j] > 0.f ? 1.f : 0.f;
+        }
+        if (a.gy) { const mq4 g = ld(a.gy + p * a.gy_cs + c) * on; s[0] += g; s[1] += g * xh; }
         if (a.G) {
-          const mq4 g = ld(a.G + p * a.G_cs + c);
+          const mq4 g = ld(a.G + p * a.G_cs + c) * on;
           const mq4 t = (ld(a.xd + p * a.xd_cs + c) - md) - xh * cc;
           s[2] += g; s[3] += g * xh; s[4] += g * t;
         }
@@ -314,11 +321,12 @@ __global__ __launch_bounds__(256) void bn_elementwise_kernel(const EwArgs a) {
       a.o0[p * a.o0_cs + c] = g * is * t;
     } else {
       float gx = 0.f;
-      if (a.gy) gx = g * is * (a.gy[p * a.gy_cs + c] - a.mom_b[c] - xh * a.mom_b[a.C + c]);
+      const bool on = !a.beta || g * xh + a.beta[c] > 0.f;         // MODE 2 with beta: the cotangents pass the fused ReLU's mask
+      if (a.gy) gx = g * is * ((on ? a.gy[p * a.gy_cs + c] : 0.f) - a.mom_b[c] - xh * a.mom_b[a.C + c]);
       if (a.G) {
         const float cc = a.mom_t[a.C + c];
         const float t = (a.xd[p * a.xd_cs + c] - a.mom_t[c]) - xh * cc;
-        const float pg = a.G[p * a.G_cs + c] - a.mom_b[2 * a.C + c] - xh * a.mom_b[3 * a.C + c];   // P(G)
+        const float pg = (on ? a.G[p * a.G_cs + c] : 0.f) - a.mom_b[2 * a.C + c] - xh * a.mom_b[3 * a.C + c];   // P(G)
         gx -= g * is * is * (a.mom_b[4 * a.C + c] * xh + cc * pg + a.mom_b[3 * a.C + c] * t);
         a.o1[p * a.o1_cs + c] = g * is * pg;
       }
@@ -358,11 +366,16 @@ __global__ __launch_bounds__(256) void bn_elementwise4_kernel(const EwArgs a) {
       st4e(a.o0 + (long)p * a.o0_cs + c, g * is * t);
     } else {
       ew4 gx = splat4(0.f);
-      if (a.gy) gx = g * is * (ld4e(a.gy + (long)p * a.gy_cs + c) - ld4e(a.mom_b + c) - xh * ld4e(a.mom_b + a.C + c));
+      ew4 on = splat4(1.f);
+      if (a.beta) {                                        // MODE 2 with beta: the cotangents pass the fused ReLU's mask
+        const ew4 yv = g * xh + ld4e(a.beta + c);
+        on = ew4{yv[0] > 0.f ? 1.f : 0.f, yv[1] > 0.f ? 1.f : 0.f, yv[2] > 0.f ? 1.f : 0.f, yv[3] > 0.f ? 1.f : 0.f};
+      }
+      if (a.gy) gx = g * is * (ld4e(a.gy + (long)p * a.gy_cs + c) * on - ld4e(a.mom_b + c) - xh * ld4e(a.mom_b + a.C + c));
       if (a.G) {
         const ew4 cc = ld4e(a.mom_t + a.C + c);
         const ew4 t = (ld4e(a.xd + (long)p * a.xd_cs + c) - ld4e(a.mom_t + c)) - xh * cc;
-        const ew4 pg = ld4e(a.G + (long)p * a.G_cs + c) - ld4e(a.mom_b + 2 * a.C + c) - xh * ld4e(a.mom_b + 3 * a.C + c);
+        const ew4 pg = ld4e(a.G + (long)p * a.G_cs + c) * on - ld4e(a.mom_b + 2 * a.C + c) - xh * ld4e(a.mom_b + 3 * a.C + c);
         gx -= g * is * is * (ld4e(a.mom_b + 4 * a.C + c) * xh + cc * pg + ld4e(a.mom_b + 3 * a.C + c) * t);
         st4e(a.o1 + (long)p * a.o1_cs + c, g * is * pg);
       }
@@ -637,6 +650,7 @@ static int run_moments(int mode, MomArgs a, float* out, float* partial, hipStrea
   auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   auto cs = [](const void* p, int st) { return !p || st % 4 == 0; };
   if (a.C % 4 == 0 && al(a.x) && al(a.xd) && al(a.gy) && al(a.G) && al(a.mean) && al(a.invstd) && al(a.mdot) && al(a.cc) &&
+      al(a.mgamma) && al(a.mbeta) &&
       cs(a.x, a.x_cs) && cs(a.xd, a.xd_cs) && cs(a.gy, a.gy_cs) && cs(a.G, a.G_cs)) {
     const int ctq = a.C >= 256 ? 64 : a.C / 4, rows4 = 256 / ctq;
     const long per4 = (a.P + rows4 - 1) / rows4;
@@ -714,7 +728,7 @@ extern "C" int creste_bn_train_tangent_f32(const float* x, int x_cs, const float
   return CRESTE_OK;
 }
 
-extern "C" int creste_bn_train_backward_f32(const float* x, int x_cs, const float* xd, int xd_cs, const float* gy,
+static int bn_train_backward_impl(const float* relu_beta, const float* x, int x_cs, const float* xd, int xd_cs, const float* gy,
                                             int gy_cs, const float* gyd, int gyd_cs, int64_t P, int C,
                                             const float* gamma, const float* mean, const float* invstd,
                                             const float* mom_t, float* mom_b, float* gx, int gx_cs, float* gxd,
@@ -722,16 +736,18 @@ extern "C" int creste_bn_train_backward_f32(const float* x, int x_cs, const floa
                                             float* gx_amax, void* work, void* stream) {
   CRESTE_REQUIRE(x && mean && invstd && mom_b && gx && work && (gy || gyd), "bn_train_backward: null pointer");
   CRESTE_REQUIRE(!gyd || (xd && mom_t && gxd), "bn_train_backward: the tangent cotangent needs xd, mom_t and gxd");
+  CRESTE_REQUIRE(!relu_beta || gamma, "bn_relu_train_backward: gamma is needed to recompute the ReLU mask");
   hipStream_t s = (hipStream_t)stream;
   MomArgs a = {};
   a.x = x; a.x_cs = x_cs; a.xd = xd; a.xd_cs = xd_cs; a.gy = gy; a.gy_cs = gy_cs; a.G = gyd; a.G_cs = gyd_cs;
   a.P = P; a.C = C; a.nk = 5; a.mean = mean; a.invstd = invstd;
   if (gyd) { a.mdot = mom_t; a.cc = mom_t + C; }
+  if (relu_beta) { a.mgamma = gamma; a.mbeta = relu_beta; }
   const int rc = run_moments(3, a, mom_b, (float*)work, s);
   if (rc) return rc;
   EwArgs e = {};
   e.x = x; e.x_cs = x_cs; e.xd = xd; e.xd_cs = xd_cs; e.gy = gy; e.gy_cs = gy_cs; e.G = gyd; e.G_cs = gyd_cs;
-  e.gamma = gamma; e.mean = mean; e.invstd = invstd; e.mom_t = mom_t; e.mom_b = mom_b;
+  e.gamma = gamma; e.beta = relu_beta; e.mean = mean; e.invstd = invstd; e.mom_t = mom_t; e.mom_b = mom_b;
   e.o0 = gx; e.o0_cs = gx_cs; e.o1 = gxd; e.o1_cs = gxd_cs; e.P = P; e.C = C; e.amax = gx_amax;
   if (ew_vec_ok(e)) bn_elementwise4_kernel<2><<<grid1d(P * C / 4, 1024), 256, 0, s>>>(e);
   else bn_elementwise_kernel<2><<<grid1d(P * C), 256, 0, s>>>(e);
@@ -742,6 +758,30 @@ extern "C" int creste_bn_train_backward_f32(const float* x, int x_cs, const floa
     CRESTE_CHECK_LAUNCH("bn_param_grad");
   }
   return CRESTE_OK;
+}
+
+extern "C" int creste_bn_train_backward_f32(const float* x, int x_cs, const float* xd, int xd_cs, const float* gy,
+                                            int gy_cs, const float* gyd, int gyd_cs, int64_t P, int C,
+                                            const float* gamma, const float* mean, const float* invstd,
+                                            const float* mom_t, float* mom_b, float* gx, int gx_cs, float* gxd,
+                                            int gxd_cs, float* g_gamma, float* g_beta, int accumulate,
+                                            float* gx_amax, void* work, void* stream) {
+  return bn_train_backward_impl(nullptr, x, x_cs, xd, xd_cs, gy, gy_cs, gyd, gyd_cs, P, C, gamma, mean, invstd, mom_t, mom_b,
+                                gx, gx_cs, gxd, gxd_cs, g_gamma, g_beta, accumulate, gx_amax, work, stream);
+}
+
+// BatchNorm + ReLU backward in one: the cotangents are masked with the ReLU's own mask, recomputed from x with the
+// forward's expression (gamma * xh + beta > 0: same operations, same sign) -- no separate pass that reads y and gy and
+// writes the masked cotangent (3 of the 8 tensor passes of a BatchNorm + ReLU backward)
+extern "C" int creste_bn_relu_train_backward_f32(const float* x, int x_cs, const float* xd, int xd_cs, const float* gy,
+                                                 int gy_cs, const float* gyd, int gyd_cs, int64_t P, int C,
+                                                 const float* gamma, const float* beta, const float* mean,
+                                                 const float* invstd, const float* mom_t, float* mom_b, float* gx,
+                                                 int gx_cs, float* gxd, int gxd_cs, float* g_gamma, float* g_beta,
+                                                 int accumulate, float* gx_amax, void* work, void* stream) {
+  CRESTE_REQUIRE(beta, "bn_relu_train_backward: null beta");
+  return bn_train_backward_impl(beta, x, x_cs, xd, xd_cs, gy, gy_cs, gyd, gyd_cs, P, C, gamma, mean, invstd, mom_t, mom_b,
+                                gx, gx_cs, gxd, gxd_cs, g_gamma, g_beta, accumulate, gx_amax, work, stream);
 }
 
 extern "C" int creste_pointwise2_f32(int op, const float* a, int a_cs, const float* b, int b_cs, float* o, int o_cs,

@@ -221,9 +221,6 @@ class BNT:
     def bwd(self, gy, gyd, grads, need_input=True):
         bn = self.bn
         dev = self.x.buf.device
-        if self.relu:                                  # through the ReLU mask first
-            gy = pointwise2(1, self.y, gy) if gy is not None else None
-            gyd = pointwise2(1, self.y, gyd) if gyd is not None else None
         ref = gy if gy is not None else gyd
         gx = _new(ref)
         gx.amax = _amax_slot(dev)
@@ -235,11 +232,15 @@ class BNT:
             gg, acc = grad_slot(grads, bn.weight)
             gb, _ = grad_slot(grads, bn.bias)
         has_t = gyd is not None
-        _lib.check(_lib_().creste_bn_train_backward_f32(
+        # with the fused ReLU the kernels mask the cotangents themselves (the mask is recomputed from x with the forward's
+        # expression): no separate pass over y and gy
+        fn = _lib_().creste_bn_relu_train_backward_f32 if self.relu else _lib_().creste_bn_train_backward_f32
+        extra = (bn.bias.data_ptr(),) if self.relu else ()
+        _lib.check(fn(
             self.x.ptr, self.x.cs, self.xd.ptr if has_t else None, self.xd.cs if has_t else 0,
             gy.ptr if gy is not None else None, gy.cs if gy is not None else 0,
             gyd.ptr if has_t else None, gyd.cs if has_t else 0, _px(self.x), bn.num_features,
-            bn.weight.data_ptr(), self.mean.data_ptr(), self.invstd.data_ptr(),
+            bn.weight.data_ptr(), *extra, self.mean.data_ptr(), self.invstd.data_ptr(),
             self.mom_t.data_ptr() if has_t else None, mom_b.data_ptr(), gx.ptr, gx.cs,
             gxd.ptr if has_t else None, gxd.cs if has_t else 0,
             gg.data_ptr() if gg is not None else None, gb.data_ptr() if gb is not None else None, acc,

@@ -331,6 +331,13 @@ int creste_bn_train_backward_f32(const float* x, int x_cs, const float* xd, int 
                                  const float* mean, const float* invstd, const float* mom_t, float* mom_b,
                                  float* gx, int gx_cs, float* gxd, int gxd_cs, float* g_gamma, float* g_beta,
                                  int accumulate, float* gx_amax, void* work, void* stream);
+/* BatchNorm + fused ReLU backward: as above, with the cotangents masked by the ReLU's mask -- recomputed from x with
+ * the forward's own expression (gamma * xh + beta > 0), so no separate mask pass reads y / writes a masked cotangent. */
+int creste_bn_relu_train_backward_f32(const float* x, int x_cs, const float* xd, int xd_cs, const float* gy, int gy_cs,
+                                 const float* gyd, int gyd_cs, int64_t P, int C, const float* gamma, const float* beta,
+                                 const float* mean, const float* invstd, const float* mom_t, float* mom_b,
+                                 float* gx, int gx_cs, float* gxd, int gxd_cs, float* g_gamma, float* g_beta,
+                                 int accumulate, float* gx_amax, void* work, void* stream);
 
 /* op 0: o = max(a, 0) | op 1: o = a > 0 ? b : 0 (ReLU backward / tangent with a = the ReLU output) |
  * op 2: o = a + b.  [P][C] with pixel strides. */
