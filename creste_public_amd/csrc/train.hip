@@ -86,6 +86,254 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __
   }
 }
 
+// ---------------------------------------------------------------------------- row-walk wgrad (K = 3, 5)
+// The per-tap kernel above reads both operands K*K times (one workgroup per tap): at 5x5 on a 256x256 grid that is
+// 11 GB of L2 traffic per call and the matrix cores wait on it.  Here a workgroup walks a band of rows of one
+// 64-pixel column segment with the last K rows of x (plus the K-1 halo columns) in an LDS ring and the current gy row
+// beside it: every element is fetched once, and all K*K taps are formed from the ring.  A wave owns one
+// 16(co) x 16(ci) tile for NTAP taps (v_mfma_f32_16x16x4_f32: 4 pixels per issue; 40 channels pad to 48, not 64).
+// LDS pixel strides are = 16 mod 32 floats, so the four 16-lane pixel groups of an operand read hit distinct banks.
+constexpr int WR_TW = 64;   // pixels per column segment
+constexpr int WR_XI = 3;    // float4 prefetch registers per thread: x row
+constexpr int WR_GI = 2;    //                                      gy row
+
+struct WrArgs {
+  const float* x;
+  const float* gy;
+  float* partial;
+  int x_cs, gy_cs, N, H, W, Cin, Cout;
+  int cpx, cpy;          // LDS pixel strides (floats)
+  int tci, pairs;        // ci tiles, (co, ci) tile pairs
+  int nseg, nband, band_rows;
+};
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// CPX > 0: NTAP == K*K and the x stride is the compile-time CPX, so every tap is an immediate offset from one of K row
+// pointers (25 hoisted per-tap addresses would not fit beside 100 accumulator registers).
+template <int K, int NTAP, int MAXT, int CPX>
+__global__ __launch_bounds__(MAXT) void wgrad_rows_kernel(const WrArgs a) {
+  constexpr int PAD = K / 2, XW = WR_TW + K - 1, KK = K * K;
+  static_assert(CPX == 0 || NTAP == KK, "immediate tap offsets need the whole kernel in one wave");
+  extern __shared__ __attribute__((aligned(16))) float wr_lds[];
+  float* xs = wr_lds;                               // [K][XW][cpx]
+  float* gs = wr_lds + K * XW * a.cpx;              // [TW][cpy]
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int b = blockIdx.x;
+  const int seg = b % a.nseg; b /= a.nseg;
+  const int band = b % a.nband;
+  const int n = b / a.nband;
+  const int x0 = seg * WR_TW;
+  const int y0 = band * a.band_rows, y1 = min(a.H, y0 + a.band_rows);
+  const int cq_x = a.Cin >> 2, cq_g = a.Cout >> 2;
+  const int n_xi = XW * cq_x, n_gi = WR_TW * cq_g;
+  const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs;
+  const float* gn = a.gy + (size_t)n * a.H * a.W * a.gy_cs;
+
+  f32x4v px[WR_XI], pg[WR_GI];
+  auto fetch_x = [&](int iy) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < WR_XI; ++i) {
+      const int it = tid + i * nt;
+      f32x4v v = {0.f, 0.f, 0.f, 0.f};
+      if (it < n_xi) {
+        const int j = it / cq_x, c = (it - j * cq_x) * 4;
+        const int ix = x0 - PAD + j;
+        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+          v = *reinterpret_cast<const f32x4v*>(xn + ((size_t)iy * a.W + ix) * a.x_cs + c);
+      }
+      px[i] = v;
+    }
+  };
+  auto store_x = [&](int iy) __attribute__((always_inline)) {
+    float* dst = xs + ((iy + K) % K) * XW * a.cpx;
+#pragma unroll
+    for (int i = 0; i < WR_XI; ++i) {
+      const int it = tid + i * nt;
+      if (it < n_xi) {
+        const int j = it / cq_x, c = (it - j * cq_x) * 4;
+        *reinterpret_cast<f32x4v*>(dst + j * a.cpx + c) = px[i];
+      }
+    }
+  };
+  auto fetch_g = [&](int y) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < WR_GI; ++i) {
+      const int it = tid + i * nt;
+      f32x4v v = {0.f, 0.f, 0.f, 0.f};
+      if (it < n_gi) {
+        const int j = it / cq_g, c = (it - j * cq_g) * 4;
+        if (y < y1 && x0 + j < a.W) v = *reinterpret_cast<const f32x4v*>(gn + ((size_t)y * a.W + x0 + j) * a.gy_cs + c);
+      }
+      pg[i] = v;
+    }
+  };
+  auto store_g = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < WR_GI; ++i) {
+      const int it = tid + i * nt;
+      if (it < n_gi) {
+        const int j = it / cq_g, c = (it - j * cq_g) * 4;
+        *reinterpret_cast<f32x4v*>(gs + j * a.cpy + c) = pg[i];
+      }
+    }
+  };
+
+  // this wave's tile and taps
+  const int pair = wave % a.pairs, tap0 = (wave / a.pairs) * NTAP;
+  const int co0 = (pair / a.tci) * 16, ci0 = (pair % a.tci) * 16;
+  const int lr = lane & 15, lj = lane >> 4;
+  const int a_off = lj * a.cpy + min(co0 + lr, a.Cout - 1);      // clamped lanes feed rows / columns nobody stores
+  const int b_off = lj * a.cpx + min(ci0 + lr, a.Cin - 1);
+  f32x4v acc[NTAP];
+#pragma unroll
+  for (int i = 0; i < NTAP; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  for (int iy = y0 - PAD; iy < y0 + PAD; ++iy) {     // rows y0-PAD .. y0+PAD-1 of the ring
+    fetch_x(iy);
+    store_x(iy);
+  }
+  fetch_x(y0 + PAD);
+  fetch_g(y0);
+  for (int y = y0; y < y1; ++y) {
+    store_x(y + PAD);
+    store_g();
+    __syncthreads();
+    fetch_x(y + 1 + PAD);
+    fetch_g(y + 1);
+    if constexpr (CPX > 0) {
+      const float* xr[K];
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) xr[ky] = xs + b_off + ((y + ky - PAD + K) % K) * (XW * CPX);
+#pragma unroll 2
+      for (int q = 0; q < WR_TW; q += 4) {
+        const float av = gs[a_off + q * a.cpy];
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx)
+            acc[ky * K + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xr[ky][(q + kx) * CPX], acc[ky * K + kx], 0, 0, 0);
+      }
+    } else {
+      int off[NTAP];
+#pragma unroll
+      for (int i = 0; i < NTAP; ++i) {
+        const int tap = tap0 + i;
+        const int ky = tap / K, kx = tap - ky * K;
+        off[i] = __builtin_amdgcn_readfirstlane((((y + ky - PAD + K) % K) * XW + kx) * a.cpx);
+      }
+#pragma unroll 2
+      for (int q = 0; q < WR_TW; q += 4) {
+        const float av = gs[a_off + q * a.cpy];
+        const float* xb = xs + b_off + q * a.cpx;
+#pragma unroll
+        for (int i = 0; i < NTAP; ++i)
+          if (tap0 + i < KK) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xb[off[i]], acc[i], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // D layout of the 16x16x4 MFMA: col (ci) = lane & 15, row (co) = 4 * (lane >> 4) + r
+  float* out = a.partial + (size_t)blockIdx.x * KK * a.Cout * a.Cin;
+  const int ci = ci0 + lr;
+#pragma unroll
+  for (int i = 0; i < NTAP; ++i) {
+    const int tap = tap0 + i;
+    if (tap < KK && ci < a.Cin) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + 4 * lj + r;
+        if (co < a.Cout) out[((size_t)tap * a.Cout + co) * a.Cin + ci] = acc[i][r];
+      }
+    }
+  }
+}
+
+struct WrPlan {
+  bool ok;
+  int ntap, nw, tci, pairs, cpx, cpy, nseg, nband, band_rows, nwg;
+  size_t smem;
+};
+
+static inline int wr_stride(int c) {   // smallest stride >= c that is 16 mod 32 floats
+  int s = (c + 15) / 16 * 16;
+  return (s % 32 == 16) ? s : s + 16;
+}
+
+static WrPlan wr_plan(const float* x, int x_cs, const float* gy, int gy_cs, int N, int H, int W, int Cin, int Cout, int K) {
+  WrPlan p{};
+  if ((K != 3 && K != 5) || Cin % 4 || Cout % 4 || x_cs % 4 || gy_cs % 4 || Cin < 8 || Cout < 8) return p;
+  if (x && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15)) return p;
+  const int tco = (Cout + 15) / 16;
+  p.tci = (Cin + 15) / 16;
+  p.pairs = tco * p.tci;
+  if (p.pairs > 16) return p;
+  // fewest waves per workgroup first (whole kernel per wave): small workgroups share a CU, so one's row hand-over
+  // (barriers, LDS stores) overlaps another's matrix phase
+  static const int opts5[] = {25, 13, 7}, opts3[] = {9, 5, 3};
+  const int* opts = K == 5 ? opts5 : opts3;
+  const int XW = WR_TW + K - 1;
+  p.cpx = wr_stride(Cin);
+  p.cpy = wr_stride(Cout);
+  p.ntap = 0;
+  for (int i = 0; i < 3; ++i) {
+    const int ts = (K * K + opts[i] - 1) / opts[i];
+    const int cap = opts[i] >= 13 ? 12 : 16;          // 52 / 100 accumulator registers: 768 threads at most
+    const int nt = p.pairs * ts * 64;
+    if (p.pairs * ts > cap || XW * (Cin / 4) > WR_XI * nt || WR_TW * (Cout / 4) > WR_GI * nt) continue;
+    if (opts[i] == K * K && p.cpx != 48 && p.cpx != 80) continue;   // whole-kernel waves are built for these strides
+    p.ntap = opts[i];
+    p.nw = p.pairs * ts;
+    break;
+  }
+  if (!p.ntap) return p;
+  p.smem = ((size_t)K * XW * p.cpx + (size_t)WR_TW * p.cpy) * 4;
+  if (p.smem > 160 * 1024) return p;
+  p.nseg = (W + WR_TW - 1) / WR_TW;
+  int per_cu = (int)((160 * 1024) / p.smem);
+  per_cu = per_cu < 16 / p.nw ? per_cu : 16 / p.nw;
+  per_cu = per_cu < 1 ? 1 : per_cu;
+  int nb = 256 * per_cu / (N * p.nseg);
+  nb = nb < 1 ? 1 : (nb > H ? H : nb);
+  p.band_rows = (H + nb - 1) / nb;
+  p.nband = (H + p.band_rows - 1) / p.band_rows;
+  p.nwg = N * p.nseg * p.nband;
+  p.ok = true;
+  return p;
+}
+
+// the same sum for many partial sets (row-walk wgrad: one per workgroup): 64 elements x 4 chunk groups per block, the
+// four group sums added in a fixed order
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ partial, float* __restrict__ gw,
+                                                            int nchunk, int Cout, int Cin, int KK, int accumulate) {
+  __shared__ float red[4][64];
+  const int total = Cout * Cin * KK;
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + e;
+  const int per = (nchunk + 3) / 4;
+  const int c0 = g * per, c1 = min(nchunk, c0 + per);
+  float s0 = 0.f, s1 = 0.f;
+  if (j < total) {
+    int c = c0;
+    for (; c + 1 < c1; c += 2) {
+      s0 += partial[(size_t)c * total + j];
+      s1 += partial[(size_t)(c + 1) * total + j];
+    }
+    if (c < c1) s0 += partial[(size_t)c * total + j];
+  }
+  red[g][e] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && j < total) {
+    const float s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    const int ci = j % Cin, co = (j / Cin) % Cout, tap = j / (Cin * Cout);
+    const int i = (co * Cin + ci) * KK + tap;
+    gw[i] = accumulate ? gw[i] + s : s;
+  }
+}
+
 // OIHW -> dgrad weight: w'[ci][co][K-1-ky][K-1-kx] = w[co][ci][ky][kx] (a stride-1 conv's input gradient is
 // the conv of gy with the flipped, channel-transposed kernel, pad K-1-pad); Cout padded with zero input
 // channels up to cout_pad (the conv engine wants Cin % 4 == 0).
@@ -607,7 +855,10 @@ using namespace creste;
 
 extern "C" int64_t creste_conv_wgrad_workspace_bytes(int N, int H, int W, int Cin, int Cout, int K) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || K <= 0) return -1;
-  return (int64_t)wgrad_chunks((long)N * H * W, K) * K * K * Cout * Cin * 4;
+  const int64_t per_tap = (int64_t)wgrad_chunks((long)N * H * W, K) * K * K * Cout * Cin * 4;
+  const WrPlan p = wr_plan(nullptr, 0, nullptr, 0, N, H, W, Cin, Cout, K);     // strides / alignment decide at run time
+  const int64_t rows = p.ok ? (int64_t)p.nwg * K * K * Cout * Cin * 4 : 0;
+  return per_tap > rows ? per_tap : rows;
 }
 
 extern "C" int creste_conv_wgrad_f32(const float* x, int x_cs, const float* gy, int gy_cs, float* gw, int N, int H,
@@ -619,11 +870,37 @@ extern "C" int creste_conv_wgrad_f32(const float* x, int x_cs, const float* gy, 
   CRESTE_REQUIRE(K * K <= 65535, "conv_wgrad: kernel too large");
   const long M = (long)N * H * W;
   CRESTE_REQUIRE(M < (1L << 31), "conv_wgrad: N*H*W overflows int32");
+  hipStream_t s = (hipStream_t)stream;
+  const WrPlan wp = wr_plan(x, x_cs, gy, gy_cs, N, H, W, Cin, Cout, K);
+  if (wp.ok) {
+    static std::atomic<uint64_t> devs[8];
+    WrArgs a{x, gy, (float*)work, x_cs, gy_cs, N, H, W, Cin, Cout, wp.cpx, wp.cpy, wp.tci, wp.pairs, wp.nseg, wp.nband,
+             wp.band_rows};
+#define CRESTE_WR(K_, NTAP_, MAXT_, CPX_, SLOT_)                                                                        \
+  {                                                                                                                    \
+    CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wgrad_rows_kernel<K_, NTAP_, MAXT_, CPX_>), 160 * 1024,   \
+                               devs[SLOT_]));                                                                          \
+    wgrad_rows_kernel<K_, NTAP_, MAXT_, CPX_><<<wp.nwg, wp.nw * 64, wp.smem, s>>>(a);                                  \
+  }
+    if (K == 5 && wp.ntap == 25 && wp.cpx == 48) CRESTE_WR(5, 25, 768, 48, 0)
+    else if (K == 5 && wp.ntap == 25) CRESTE_WR(5, 25, 768, 80, 1)
+    else if (K == 5 && wp.ntap == 13) CRESTE_WR(5, 13, 768, 0, 2)
+    else if (K == 5) CRESTE_WR(5, 7, 1024, 0, 3)
+    else if (wp.ntap == 9 && wp.cpx == 48) CRESTE_WR(3, 9, 1024, 48, 4)
+    else if (wp.ntap == 9) CRESTE_WR(3, 9, 1024, 80, 5)
+    else if (wp.ntap == 5) CRESTE_WR(3, 5, 1024, 0, 6)
+    else CRESTE_WR(3, 3, 1024, 0, 7)
+#undef CRESTE_WR
+    CRESTE_CHECK_LAUNCH("wgrad_rows");
+    wgrad_reduce4_kernel<<<(Cout * Cin * K * K + 63) / 64, 256, 0, s>>>((const float*)work, gw, wp.nwg, Cout, Cin, K * K,
+                                                                        accumulate);
+    CRESTE_CHECK_LAUNCH("wgrad_reduce");
+    return CRESTE_OK;
+  }
   int nchunk = wgrad_chunks(M, K);
   long chunk_px = (M + nchunk - 1) / nchunk;
   chunk_px = (chunk_px + WG_PIX - 1) / WG_PIX * WG_PIX;
   nchunk = (int)((M + chunk_px - 1) / chunk_px);
-  hipStream_t s = (hipStream_t)stream;
   wgrad_partial_kernel<<<dim3(nchunk, K * K), 256, 0, s>>>(x, x_cs, gy, gy_cs, (float*)work, N, H, W, Cin, Cout, K,
                                                           pad, (int)chunk_px);
   CRESTE_CHECK_LAUNCH("wgrad_partial");
