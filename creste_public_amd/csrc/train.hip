@@ -72,20 +72,6 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(const float* __restr
   }
 }
 
-// gw[co][ci][ky][kx] (torch OIHW) = (accumulate ? gw : 0) + sum_chunk partial[chunk][tap][co][ci]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw, int nchunk,
-                                    int Cout, int Cin, int KK, int accumulate) {
-  const int total = Cout * Cin * KK;
-  // threads follow the partial layout [tap][co][ci] (coalesced reads of every chunk); one scattered write each
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
-    const int ci = j % Cin, co = (j / Cin) % Cout, tap = j / (Cin * Cout);
-    float s = 0.f;
-    for (int c = 0; c < nchunk; ++c) s += partial[(size_t)c * total + j];
-    const int i = (co * Cin + ci) * KK + tap;
-    gw[i] = accumulate ? gw[i] + s : s;
-  }
-}
-
 // ---------------------------------------------------------------------------- row-walk wgrad (K = 3, 5)
 // The per-tap kernel above reads both operands K*K times (one workgroup per tap): at 5x5 on a 256x256 grid that is
 // 11 GB of L2 traffic per call and the matrix cores wait on it.  Here a workgroup walks a band of rows of one
@@ -95,6 +81,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __
 // LDS pixel strides are = 16 mod 32 floats, so the four 16-lane pixel groups of an operand read hit distinct banks.
 constexpr int WR_TW = 64;   // pixels per column segment
 constexpr int WR_XI = 3;    // float4 prefetch registers per thread: x row
+constexpr int WR_XI1 = 4;   //   1x1 convs (two-wave workgroups)
 constexpr int WR_GI = 2;    //                                      gy row
 
 struct WrArgs {
@@ -114,7 +101,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int K, int NTAP, int MAXT, int CPX>
 __global__ __launch_bounds__(MAXT) void wgrad_rows_kernel(const WrArgs a) {
   constexpr int PAD = K / 2, XW = WR_TW + K - 1, KK = K * K;
-  static_assert(CPX == 0 || NTAP == KK, "immediate tap offsets need the whole kernel in one wave");
+  static_assert(CPX == 0 || (NTAP == KK && K > 1), "immediate tap offsets need the whole kernel in one wave");
   extern __shared__ __attribute__((aligned(16))) float wr_lds[];
   float* xs = wr_lds;                               // [K][XW][cpx]
   float* gs = wr_lds + K * XW * a.cpx;              // [TW][cpy]
@@ -132,10 +119,11 @@ __global__ __launch_bounds__(MAXT) void wgrad_rows_kernel(const WrArgs a) {
   const float* xn = a.x + (size_t)n * a.H * a.W * a.x_cs;
   const float* gn = a.gy + (size_t)n * a.H * a.W * a.gy_cs;
 
-  f32x4v px[WR_XI], pg[WR_GI];
+  constexpr int XI = K == 1 ? WR_XI1 : WR_XI;
+  f32x4v px[XI], pg[WR_GI];
   auto fetch_x = [&](int iy) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < WR_XI; ++i) {
+    for (int i = 0; i < XI; ++i) {
       const int it = tid + i * nt;
       f32x4v v = {0.f, 0.f, 0.f, 0.f};
       if (it < n_xi) {
@@ -150,7 +138,7 @@ __global__ __launch_bounds__(MAXT) void wgrad_rows_kernel(const WrArgs a) {
   auto store_x = [&](int iy) __attribute__((always_inline)) {
     float* dst = xs + ((iy + K) % K) * XW * a.cpx;
 #pragma unroll
-    for (int i = 0; i < WR_XI; ++i) {
+    for (int i = 0; i < XI; ++i) {
       const int it = tid + i * nt;
       if (it < n_xi) {
         const int j = it / cq_x, c = (it - j * cq_x) * 4;
@@ -265,7 +253,7 @@ static inline int wr_stride(int c) {   // smallest stride >= c that is 16 mod 32
 
 static WrPlan wr_plan(const float* x, int x_cs, const float* gy, int gy_cs, int N, int H, int W, int Cin, int Cout, int K) {
   WrPlan p{};
-  if ((K != 3 && K != 5) || Cin % 4 || Cout % 4 || x_cs % 4 || gy_cs % 4 || Cin < 8 || Cout < 8) return p;
+  if ((K != 1 && K != 3 && K != 5) || Cin % 4 || Cout % 4 || x_cs % 4 || gy_cs % 4 || Cin < 8 || Cout < 8) return p;
   if (x && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15)) return p;
   const int tco = (Cout + 15) / 16;
   p.tci = (Cin + 15) / 16;
@@ -273,8 +261,9 @@ static WrPlan wr_plan(const float* x, int x_cs, const float* gy, int gy_cs, int 
   if (p.pairs > 16) return p;
   // fewest waves per workgroup first (whole kernel per wave): small workgroups share a CU, so one's row hand-over
   // (barriers, LDS stores) overlaps another's matrix phase
-  static const int opts5[] = {25, 13, 7}, opts3[] = {9, 5, 3};
-  const int* opts = K == 5 ? opts5 : opts3;
+  static const int opts5[] = {25, 13, 7}, opts3[] = {9, 5, 3}, opts1[] = {1, 1, 1};
+  const int* opts = K == 5 ? opts5 : (K == 3 ? opts3 : opts1);
+  const int xi = K == 1 ? WR_XI1 : WR_XI;
   const int XW = WR_TW + K - 1;
   p.cpx = wr_stride(Cin);
   p.cpy = wr_stride(Cout);
@@ -283,8 +272,8 @@ static WrPlan wr_plan(const float* x, int x_cs, const float* gy, int gy_cs, int 
     const int ts = (K * K + opts[i] - 1) / opts[i];
     const int cap = opts[i] >= 13 ? 12 : 16;          // 52 / 100 accumulator registers: 768 threads at most
     const int nt = p.pairs * ts * 64;
-    if (p.pairs * ts > cap || XW * (Cin / 4) > WR_XI * nt || WR_TW * (Cout / 4) > WR_GI * nt) continue;
-    if (opts[i] == K * K && p.cpx != 48 && p.cpx != 80) continue;   // whole-kernel waves are built for these strides
+    if (p.pairs * ts > cap || XW * (Cin / 4) > xi * nt || WR_TW * (Cout / 4) > WR_GI * nt) continue;
+    if (K > 1 && opts[i] == K * K && p.cpx != 48 && p.cpx != 80) continue;   // whole-kernel waves are built for these strides
     p.ntap = opts[i];
     p.nw = p.pairs * ts;
     break;
@@ -305,8 +294,9 @@ static WrPlan wr_plan(const float* x, int x_cs, const float* gy, int gy_cs, int 
   return p;
 }
 
-// the same sum for many partial sets (row-walk wgrad: one per workgroup): 64 elements x 4 chunk groups per block, the
-// four group sums added in a fixed order
+// gw[co][ci][ky][kx] (torch OIHW) = (accumulate ? gw : 0) + sum_chunk partial[chunk][tap][co][ci]
+// threads follow the partial layout [tap][co][ci] (coalesced reads of every chunk); 64 elements x 4 chunk groups per
+// block (a 1x1 conv has ~1000 elements and 512 partial sets), the four group sums added in a fixed order
 __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ partial, float* __restrict__ gw,
                                                             int nchunk, int Cout, int Cin, int KK, int accumulate) {
   __shared__ float red[4][64];
@@ -873,7 +863,7 @@ extern "C" int creste_conv_wgrad_f32(const float* x, int x_cs, const float* gy, 
   hipStream_t s = (hipStream_t)stream;
   const WrPlan wp = wr_plan(x, x_cs, gy, gy_cs, N, H, W, Cin, Cout, K);
   if (wp.ok) {
-    static std::atomic<uint64_t> devs[8];
+    static std::atomic<uint64_t> devs[9];
     WrArgs a{x, gy, (float*)work, x_cs, gy_cs, N, H, W, Cin, Cout, wp.cpx, wp.cpy, wp.tci, wp.pairs, wp.nseg, wp.nband,
              wp.band_rows};
 #define CRESTE_WR(K_, NTAP_, MAXT_, CPX_, SLOT_)                                                                        \
@@ -889,7 +879,8 @@ extern "C" int creste_conv_wgrad_f32(const float* x, int x_cs, const float* gy, 
     else if (wp.ntap == 9 && wp.cpx == 48) CRESTE_WR(3, 9, 1024, 48, 4)
     else if (wp.ntap == 9) CRESTE_WR(3, 9, 1024, 80, 5)
     else if (wp.ntap == 5) CRESTE_WR(3, 5, 1024, 0, 6)
-    else CRESTE_WR(3, 3, 1024, 0, 7)
+    else if (K == 3) CRESTE_WR(3, 3, 1024, 0, 7)
+    else CRESTE_WR(1, 1, 1024, 0, 8)
 #undef CRESTE_WR
     CRESTE_CHECK_LAUNCH("wgrad_rows");
     wgrad_reduce4_kernel<<<(Cout * Cin * K * K + 63) / 64, 256, 0, s>>>((const float*)work, gw, wp.nwg, Cout, Cin, K * K,
@@ -904,8 +895,8 @@ extern "C" int creste_conv_wgrad_f32(const float* x, int x_cs, const float* gy, 
   wgrad_partial_kernel<<<dim3(nchunk, K * K), 256, 0, s>>>(x, x_cs, gy, gy_cs, (float*)work, N, H, W, Cin, Cout, K,
                                                           pad, (int)chunk_px);
   CRESTE_CHECK_LAUNCH("wgrad_partial");
-  wgrad_reduce_kernel<<<grid1d((long)Cout * Cin * K * K, 256), 256, 0, s>>>((const float*)work, gw, nchunk, Cout, Cin,
-                                                                           K * K, accumulate);
+  wgrad_reduce4_kernel<<<(Cout * Cin * K * K + 63) / 64, 256, 0, s>>>((const float*)work, gw, nchunk, Cout, Cin, K * K,
+                                                                      accumulate);
   CRESTE_CHECK_LAUNCH("wgrad_reduce");
   return CRESTE_OK;
 }

@@ -462,13 +462,30 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16_col3_kernel(
   }
 }
 
-__global__ void wgrad_strided_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw, int nchunk,
-                                            int Cout, int Cin, int KK, int accumulate) {
+// 64 elements x 4 chunk groups per block (two running sums per thread), the group sums added in a fixed order: a thread
+// of the one-element-per-thread form walked all nchunk partial sets serially
+__global__ __launch_bounds__(256) void wgrad_strided_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw,
+                                                                   int nchunk, int Cout, int Cin, int KK, int accumulate) {
+  __shared__ float red[4][64];
   const int total = Cout * Cin * KK;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + e;
+  const int per = (nchunk + 3) / 4;
+  const int c0 = g * per, c1 = min(nchunk, c0 + per);
+  float s0 = 0.f, s1 = 0.f;
+  if (j < total) {
+    int c = c0;
+    for (; c + 1 < c1; c += 2) {
+      s0 += partial[(size_t)c * total + j];
+      s1 += partial[(size_t)(c + 1) * total + j];
+    }
+    if (c < c1) s0 += partial[(size_t)c * total + j];
+  }
+  red[g][e] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && j < total) {
+    const float s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
     const int ci = j % Cin, co = (j / Cin) % Cout, tap = j / (Cin * Cout);
-    float s = 0.f;
-    for (int c = 0; c < nchunk; ++c) s += partial[(size_t)c * total + j];
     const int i = (co * Cin + ci) * KK + tap;
     gw[i] = accumulate ? gw[i] + s : s;
   }
@@ -992,7 +1009,7 @@ extern "C" int creste_conv_wgrad_strided_f32(const float* x, int x_cs, const flo
                                                                     Cin, Cout, K, stride, pad_t, pad_l, (int)chunk_px);
     CRESTE_CHECK_LAUNCH("wgrad_strided_partial");
   }
-  wgrad_strided_reduce_kernel<<<grid1d((long)Cout * Cin * K * K, 1024), 256, 0, s>>>((const float*)work, gw, nchunk,
+  wgrad_strided_reduce_kernel<<<(unsigned)(((long)Cout * Cin * K * K + 63) / 64), 256, 0, s>>>((const float*)work, gw, nchunk,
                                                                                     Cout, Cin, K * K, accumulate);
   CRESTE_CHECK_LAUNCH("wgrad_strided_reduce");
   return CRESTE_OK;
@@ -1041,7 +1058,7 @@ extern "C" int creste_conv_wgrad_f16x3(const float* x, int x_cs, const float* gy
                                                                              N, H, W, Cin, Cout, pad_t, pad_l, nbands,
                                                                              (int)nseg, seg_w, tiles_co, tiles_ci);
       CRESTE_CHECK_LAUNCH("wgrad_f16_col3");
-      wgrad_strided_reduce_kernel<<<grid1d((long)Cout * Cin * 9, 1024), 256, 0, s>>>((const float*)work, gw, nchunk3, Cout,
+      wgrad_strided_reduce_kernel<<<(unsigned)(((long)Cout * Cin * 9 + 63) / 64), 256, 0, s>>>((const float*)work, gw, nchunk3, Cout,
                                                                                  Cin, 9, accumulate);
       CRESTE_CHECK_LAUNCH("wgrad_strided_reduce");
       return CRESTE_OK;
@@ -1051,7 +1068,7 @@ extern "C" int creste_conv_wgrad_f16x3(const float* x, int x_cs, const float* gy
       x, x_cs, gy, gy_cs, (float*)work, x_amax, gy_amax, N, H, W, Ho, Wo, Cin, Cout, K, stride, pad_t, pad_l,
       (int)chunk_px, tiles_co, tiles_ci);
   CRESTE_CHECK_LAUNCH("wgrad_f16");
-  wgrad_strided_reduce_kernel<<<grid1d((long)Cout * Cin * K * K, 1024), 256, 0, s>>>((const float*)work, gw, nchunk,
+  wgrad_strided_reduce_kernel<<<(unsigned)(((long)Cout * Cin * K * K + 63) / 64), 256, 0, s>>>((const float*)work, gw, nchunk,
                                                                                     Cout, Cin, K * K, accumulate);
   CRESTE_CHECK_LAUNCH("wgrad_strided_reduce");
   return CRESTE_OK;

@@ -7,7 +7,8 @@ s = torch.cuda.current_stream().cuda_stream
 torch.manual_seed(0)
 for (Cin, Cout, K, H, W, N) in [(40, 64, 5, 256, 256, 8), (64, 32, 3, 256, 256, 8), (32, 32, 3, 256, 256, 8),
                                  (32, 32, 3, 128, 128, 8), (40, 64, 5, 128, 256, 8), (40, 64, 5, 64, 128, 8),
-                                 (64, 32, 3, 64, 128, 8)]:
+                                 (64, 32, 3, 64, 128, 8), (32, 32, 1, 256, 256, 8), (32, 16, 1, 256, 256, 8), (48, 1, 1, 256, 256, 8),
+                                 (32, 32, 1, 64, 64, 8)]:
     x = torch.randn(N, H, W, Cin, device="cuda"); gy = torch.randn(N, H, W, Cout, device="cuda")
     gw = torch.empty(Cout, Cin, K, K, device="cuda")
     work = torch.empty(lib.creste_conv_wgrad_workspace_bytes(N, H, W, Cin, Cout, K), dtype=torch.uint8, device="cuda")
