@@ -88,6 +88,8 @@ SIGNATURES = {
                                           _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "creste_bn_relu_train_backward_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                                _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "creste_bn_act_train_backward_f32": (_i, [_i, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i,
+                                              _vp, _vp, _vp]),
     "creste_pointwise2_f32": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
     "creste_maxpool2_idx_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "creste_maxpool2_route_f32": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

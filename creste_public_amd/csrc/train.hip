@@ -351,11 +351,22 @@ struct MomArgs {
   const float *x, *xd, *gy, *G;
   int x_cs, xd_cs, gy_cs, G_cs;
   const float *mean, *invstd, *mdot, *cc;
-  const float *mgamma, *mbeta;   // MODE 3, both non-null: the cotangents pass the mask of the fused ReLU, gamma * xh + beta > 0
+  const float *mgamma, *mbeta;   // MODE 3, both non-null: the cotangents pass the derivative of the fused activation at
+                                 // z = gamma * xh + beta (mact 1: ReLU mask z > 0; mact 2: swish'(z))
+  int mact;
   float* partial;      // [blocks][nk][C]
   long P;
   int C, nk;
 };
+
+// derivative of the activation fused behind the BatchNorm, at the forward's own z (same expression: same bits)
+__device__ __forceinline__ float bn_act_grad(int act, float z) {
+  if (act == 2) {
+    const float sg = 1.f / (1.f + expf(-z));
+    return sg + z * sg * (1.f - sg);
+  }
+  return z > 0.f ? 1.f : 0.f;
+}
 
 // pivot of the one-pass variance (MODE 4): the mean of 16 pixels spread over the tensor.  sum (x - s) and sum (x - s)^2 in
 // ONE read give var = E[(x-s)^2] - E[x-s]^2 without the cancellation of the raw-moment form as long as s lies within a
@@ -394,10 +405,10 @@ __global__ __launch_bounds__(256) void moments_kernel(const MomArgs a) {
       }
       if (MODE == 3) {
         const float xh = (xv - mu) * is;
-        const bool on = !a.mbeta || a.mgamma[c] * xh + a.mbeta[c] > 0.f;
-        if (a.gy) { const float g = on ? a.gy[p * a.gy_cs + c] : 0.f; s[0] += g; s[1] += g * xh; }
+        const float on = a.mbeta ? bn_act_grad(a.mact, a.mgamma[c] * xh + a.mbeta[c]) : 1.f;
+        if (a.gy) { const float g = a.gy[p * a.gy_cs + c] * on; s[0] += g; s[1] += g * xh; }
         if (a.G) {
-          const float g = on ? a.G[p * a.G_cs + c] : 0.f;
+          const float g = a.G[p * a.G_cs + c] * on;
           const float t = (a.xd[p * a.xd_cs + c] - md) - xh * cc;
           s[2] += g; s[3] += g * xh; s[4] += g * t;
         }
@@ -451,7 +462,7 @@ __global__ __launch_bounds__(256) void moments4_kernel(const MomArgs a) {
         mq4 on = {1.f, 1.f, 1.f, 1.f};
         if (a.mbeta) {                                    // the forward's y = gamma * xh + beta, same expression: same sign
           const mq4 yv = ld(a.mgamma + c) * xh + ld(a.mbeta + c);
-          for (int j = 0; j < 4; ++j) on[j] = yv[j] > 0.f ? 1.f : 0.f;
+          for (int j = 0; j < 4; ++j) on[j] = bn_act_grad(a.mact, yv[j]);
         }
         if (a.gy) { const mq4 g = ld(a.gy + p * a.gy_cs + c) * on; s[0] += g; s[1] += g * xh; }
         if (a.G) {
@@ -533,10 +544,10 @@ struct EwArgs {
   float* amax;            // optional running max|o0| (MODE 0 and 2), see block_amax_update
   int o0_cs, o1_cs;
   long P;
-  int C, relu;
+  int C, act;             // MODE 0: activation on the output (0 none, 1 ReLU, 2 swish); MODE 2 with beta: its derivative
 };
 
-//   MODE 0  bn forward      o0 = gamma*xh + beta (relu optional)
+//   MODE 0  bn forward      o0 = act(gamma*xh + beta)
 //   MODE 1  bn tangent      o0 = gamma*invstd*((xd - m(xd)) - xh*c)
 //   MODE 2  bn backward     o0 = gx, o1 = gxd (joint; G may be null -> plain first-order backward)
 template <int MODE>
@@ -551,7 +562,8 @@ __global__ __launch_bounds__(256) void bn_elementwise_kernel(const EwArgs a) {
     const float xh = (a.x[p * a.x_cs + c] - a.mean[c]) * is;
     if (MODE == 0) {
       float y = g * xh + (a.beta ? a.beta[c] : 0.f);
-      if (a.relu) y = fmaxf(y, 0.f);
+      if (a.act == 1) y = fmaxf(y, 0.f);
+      else if (a.act == 2) y = y / (1.f + expf(-y));
       vmax = fmaxf(vmax, fabsf(y));
       a.o0[p * a.o0_cs + c] = y;
     } else if (MODE == 1) {
@@ -559,12 +571,12 @@ __global__ __launch_bounds__(256) void bn_elementwise_kernel(const EwArgs a) {
       a.o0[p * a.o0_cs + c] = g * is * t;
     } else {
       float gx = 0.f;
-      const bool on = !a.beta || g * xh + a.beta[c] > 0.f;         // MODE 2 with beta: the cotangents pass the fused ReLU's mask
-      if (a.gy) gx = g * is * ((on ? a.gy[p * a.gy_cs + c] : 0.f) - a.mom_b[c] - xh * a.mom_b[a.C + c]);
+      const float on = a.beta ? bn_act_grad(a.act, g * xh + a.beta[c]) : 1.f;   // MODE 2 with beta: fused activation
+      if (a.gy) gx = g * is * (a.gy[p * a.gy_cs + c] * on - a.mom_b[c] - xh * a.mom_b[a.C + c]);
       if (a.G) {
         const float cc = a.mom_t[a.C + c];
         const float t = (a.xd[p * a.xd_cs + c] - a.mom_t[c]) - xh * cc;
-        const float pg = (on ? a.G[p * a.G_cs + c] : 0.f) - a.mom_b[2 * a.C + c] - xh * a.mom_b[3 * a.C + c];   // P(G)
+        const float pg = a.G[p * a.G_cs + c] * on - a.mom_b[2 * a.C + c] - xh * a.mom_b[3 * a.C + c];   // P(G)
         gx -= g * is * is * (a.mom_b[4 * a.C + c] * xh + cc * pg + a.mom_b[3 * a.C + c] * t);
         a.o1[p * a.o1_cs + c] = g * is * pg;
       }
@@ -596,7 +608,11 @@ __global__ __launch_bounds__(256) void bn_elementwise4_kernel(const EwArgs a) {
     const ew4 xh = (ld4e(a.x + (long)p * a.x_cs + c) - ld4e(a.mean + c)) * is;
     if (MODE == 0) {
       ew4 y = g * xh + (a.beta ? ld4e(a.beta + c) : splat4(0.f));
-      if (a.relu) y = relu4(y);
+      if (a.act == 1) y = relu4(y);
+      else if (a.act == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = y[j] / (1.f + expf(-y[j]));
+      }
       vmax = fmaxf(vmax, amax4(y));
       st4e(a.o0 + (long)p * a.o0_cs + c, y);
     } else if (MODE == 1) {
@@ -607,7 +623,7 @@ __global__ __launch_bounds__(256) void bn_elementwise4_kernel(const EwArgs a) {
       ew4 on = splat4(1.f);
       if (a.beta) {                                        // MODE 2 with beta: the cotangents pass the fused ReLU's mask
         const ew4 yv = g * xh + ld4e(a.beta + c);
-        on = ew4{yv[0] > 0.f ? 1.f : 0.f, yv[1] > 0.f ? 1.f : 0.f, yv[2] > 0.f ? 1.f : 0.f, yv[3] > 0.f ? 1.f : 0.f};
+        on = ew4{bn_act_grad(a.act, yv[0]), bn_act_grad(a.act, yv[1]), bn_act_grad(a.act, yv[2]), bn_act_grad(a.act, yv[3])};
       }
       if (a.gy) gx = g * is * (ld4e(a.gy + (long)p * a.gy_cs + c) * on - ld4e(a.mom_b + c) - xh * ld4e(a.mom_b + a.C + c));
       if (a.G) {
@@ -971,7 +987,7 @@ extern "C" int creste_bn_train_forward_f32(const float* x, int x_cs, int64_t P, 
   CRESTE_CHECK_LAUNCH("bn_stats_finish");
   EwArgs e = {};
   e.x = x; e.x_cs = x_cs; e.gamma = gamma; e.beta = beta; e.mean = mean; e.invstd = invstd;
-  e.o0 = y; e.o0_cs = y_cs; e.P = P; e.C = C; e.relu = relu; e.amax = out_amax;
+  e.o0 = y; e.o0_cs = y_cs; e.P = P; e.C = C; e.act = relu; e.amax = out_amax;
   if (ew_vec_ok(e)) bn_elementwise4_kernel<0><<<grid1d(P * C / 4, 1024), 256, 0, s>>>(e);
   else bn_elementwise_kernel<0><<<grid1d(P * C), 256, 0, s>>>(e);
   CRESTE_CHECK_LAUNCH("bn_forward");
@@ -996,7 +1012,7 @@ extern "C" int creste_bn_train_tangent_f32(const float* x, int x_cs, const float
   return CRESTE_OK;
 }
 
-static int bn_train_backward_impl(const float* relu_beta, const float* x, int x_cs, const float* xd, int xd_cs, const float* gy,
+static int bn_train_backward_impl(int act, const float* relu_beta, const float* x, int x_cs, const float* xd, int xd_cs, const float* gy,
                                             int gy_cs, const float* gyd, int gyd_cs, int64_t P, int C,
                                             const float* gamma, const float* mean, const float* invstd,
                                             const float* mom_t, float* mom_b, float* gx, int gx_cs, float* gxd,
@@ -1004,18 +1020,19 @@ static int bn_train_backward_impl(const float* relu_beta, const float* x, int x_
                                             float* gx_amax, void* work, void* stream) {
   CRESTE_REQUIRE(x && mean && invstd && mom_b && gx && work && (gy || gyd), "bn_train_backward: null pointer");
   CRESTE_REQUIRE(!gyd || (xd && mom_t && gxd), "bn_train_backward: the tangent cotangent needs xd, mom_t and gxd");
-  CRESTE_REQUIRE(!relu_beta || gamma, "bn_relu_train_backward: gamma is needed to recompute the ReLU mask");
+  CRESTE_REQUIRE(!relu_beta || gamma, "bn_act_train_backward: gamma is needed to recompute the activation's input");
+  CRESTE_REQUIRE(act != 2 || !gyd, "bn_act_train_backward: the swish form is first order only");
   hipStream_t s = (hipStream_t)stream;
   MomArgs a = {};
   a.x = x; a.x_cs = x_cs; a.xd = xd; a.xd_cs = xd_cs; a.gy = gy; a.gy_cs = gy_cs; a.G = gyd; a.G_cs = gyd_cs;
   a.P = P; a.C = C; a.nk = 5; a.mean = mean; a.invstd = invstd;
   if (gyd) { a.mdot = mom_t; a.cc = mom_t + C; }
-  if (relu_beta) { a.mgamma = gamma; a.mbeta = relu_beta; }
+  if (relu_beta) { a.mgamma = gamma; a.mbeta = relu_beta; a.mact = act; }
   const int rc = run_moments(3, a, mom_b, (float*)work, s);
   if (rc) return rc;
   EwArgs e = {};
   e.x = x; e.x_cs = x_cs; e.xd = xd; e.xd_cs = xd_cs; e.gy = gy; e.gy_cs = gy_cs; e.G = gyd; e.G_cs = gyd_cs;
-  e.gamma = gamma; e.beta = relu_beta; e.mean = mean; e.invstd = invstd; e.mom_t = mom_t; e.mom_b = mom_b;
+  e.gamma = gamma; e.beta = relu_beta; e.act = act; e.mean = mean; e.invstd = invstd; e.mom_t = mom_t; e.mom_b = mom_b;
   e.o0 = gx; e.o0_cs = gx_cs; e.o1 = gxd; e.o1_cs = gxd_cs; e.P = P; e.C = C; e.amax = gx_amax;
   if (ew_vec_ok(e)) bn_elementwise4_kernel<2><<<grid1d(P * C / 4, 1024), 256, 0, s>>>(e);
   else bn_elementwise_kernel<2><<<grid1d(P * C), 256, 0, s>>>(e);
@@ -1034,7 +1051,7 @@ extern "C" int creste_bn_train_backward_f32(const float* x, int x_cs, const floa
                                             const float* mom_t, float* mom_b, float* gx, int gx_cs, float* gxd,
                                             int gxd_cs, float* g_gamma, float* g_beta, int accumulate,
                                             float* gx_amax, void* work, void* stream) {
-  return bn_train_backward_impl(nullptr, x, x_cs, xd, xd_cs, gy, gy_cs, gyd, gyd_cs, P, C, gamma, mean, invstd, mom_t, mom_b,
+  return bn_train_backward_impl(0, nullptr, x, x_cs, xd, xd_cs, gy, gy_cs, gyd, gyd_cs, P, C, gamma, mean, invstd, mom_t, mom_b,
                                 gx, gx_cs, gxd, gxd_cs, g_gamma, g_beta, accumulate, gx_amax, work, stream);
 }
 
@@ -1048,8 +1065,21 @@ extern "C" int creste_bn_relu_train_backward_f32(const float* x, int x_cs, const
                                                  int gx_cs, float* gxd, int gxd_cs, float* g_gamma, float* g_beta,
                                                  int accumulate, float* gx_amax, void* work, void* stream) {
   CRESTE_REQUIRE(beta, "bn_relu_train_backward: null beta");
-  return bn_train_backward_impl(beta, x, x_cs, xd, xd_cs, gy, gy_cs, gyd, gyd_cs, P, C, gamma, mean, invstd, mom_t, mom_b,
+  return bn_train_backward_impl(1, beta, x, x_cs, xd, xd_cs, gy, gy_cs, gyd, gyd_cs, P, C, gamma, mean, invstd, mom_t, mom_b,
                                 gx, gx_cs, gxd, gxd_cs, g_gamma, g_beta, accumulate, gx_amax, work, stream);
+}
+
+// the same for any activation fused behind the BatchNorm (act 1: ReLU, 2: swish = z * sigmoid(z), first order only):
+// the cotangents are multiplied by act'(z) with z = gamma * xh + beta recomputed from x -- the unfused swish kept z AND y
+// in memory and spent two more passes (forward z -> y, backward (z, gy) -> gz)
+extern "C" int creste_bn_act_train_backward_f32(int act, const float* x, int x_cs, const float* gy, int gy_cs, int64_t P,
+                                                int C, const float* gamma, const float* beta, const float* mean,
+                                                const float* invstd, float* mom_b, float* gx, int gx_cs, float* g_gamma,
+                                                float* g_beta, int accumulate, float* gx_amax, void* work, void* stream) {
+  CRESTE_REQUIRE(act == 1 || act == 2, "bn_act_train_backward: act must be 1 (ReLU) or 2 (swish)");
+  CRESTE_REQUIRE(beta && gy, "bn_act_train_backward: null beta / gy");
+  return bn_train_backward_impl(act, beta, x, x_cs, nullptr, 0, gy, gy_cs, nullptr, 0, P, C, gamma, mean, invstd, nullptr,
+                                mom_b, gx, gx_cs, nullptr, 0, g_gamma, g_beta, accumulate, gx_amax, work, stream);
 }
 
 extern "C" int creste_pointwise2_f32(int op, const float* a, int a_cs, const float* b, int b_cs, float* o, int o_cs,

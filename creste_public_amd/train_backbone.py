@@ -155,6 +155,15 @@ class ConvG:
         return ops.conv2d(gz, bw)
 
 
+# BatchNorm -> swish pairs as ONE forward and ONE backward op (the activation inside the BatchNorm kernels, its derivative
+# recomputed from x in the backward): z is never stored and two streaming passes per pair go away
+FUSE_BN_SWISH = True
+
+
+def _swish():
+    return [] if FUSE_BN_SWISH else [SwishT()]
+
+
 class SwishT:
     def params(self):
         return []
@@ -170,8 +179,8 @@ class SwishT:
 class BN:
     """training-mode BatchNorm (train_ops.BNT) with a forward/backward-only interface."""
 
-    def __init__(self, bn: nn.BatchNorm2d, relu=False):
-        self.op = BNT(bn, relu)
+    def __init__(self, bn: nn.BatchNorm2d, relu=False, swish=False):
+        self.op = BNT(bn, 2 if swish else relu)
 
     def params(self):
         return self.op.params()
@@ -312,8 +321,8 @@ class MBConvT:
     def __init__(self, blk, rate: float):
         body = []
         if blk.has_expand:
-            body += [ConvG(blk._expand_conv, pad=(0, 0, 0, 0)), BN(blk._bn0), SwishT()]
-        body += [DwConvT(blk._depthwise_conv), BN(blk._bn1), SwishT(), SET(blk._se_reduce, blk._se_expand),
+            body += [ConvG(blk._expand_conv, pad=(0, 0, 0, 0)), BN(blk._bn0, swish=FUSE_BN_SWISH), *_swish()]
+        body += [DwConvT(blk._depthwise_conv), BN(blk._bn1, swish=FUSE_BN_SWISH), *_swish(), SET(blk._se_reduce, blk._se_expand),
                  ConvG(blk._project_conv, pad=(0, 0, 0, 0)), BN(blk._bn2)]
         self.body = Seq(body)
         self.skip = blk.s == 1 and blk.cin == blk.cout
@@ -402,7 +411,7 @@ class BackboneTrainEngine:
         if eff.apply_final_batch_norm:
             raise NotImplementedError("apply_final_batch_norm")
         tr = eff.trunk
-        self.stem = Seq([ConvG(tr._conv_stem), BN(tr._bn0), SwishT()])
+        self.stem = Seq([ConvG(tr._conv_stem), BN(tr._bn0, swish=FUSE_BN_SWISH), *_swish()])
         n = len(tr._blocks)
         self.blocks = [MBConvT(b, DROP_CONNECT * float(i) / n) for i, b in enumerate(tr._blocks)]
         self.ups = [UpBlockT(getattr(eff, f"up{i}")) for i in range(1, eff.n_ups + 1)]

@@ -179,7 +179,9 @@ class BNT:
     def __init__(self, bn: nn.BatchNorm2d, relu: bool):
         if not isinstance(bn, nn.BatchNorm2d) or bn.momentum is None or not bn.affine or not bn.track_running_stats:
             raise NotImplementedError("HIP training path: affine BatchNorm2d with momentum and running stats only")
-        self.bn, self.relu = bn, relu
+        # relu: False / True, or the activation code of creste_bn_train_forward_f32 (2 = swish, first order only)
+        self.bn, self.act = bn, int(relu)
+        self.relu = self.act == 1
 
     def params(self):
         return [self.bn.weight, self.bn.bias]
@@ -199,13 +201,15 @@ class BNT:
         _lib.check(_lib_().creste_bn_train_forward_f32(
             x.ptr, x.cs, _px(x), Cn, bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), float(bn.momentum),
             bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.mean.data_ptr(), self.invstd.data_ptr(),
-            var.data_ptr(), y.ptr, y.cs, int(self.relu), y.amax.data_ptr() if y.amax is not None else None,
+            var.data_ptr(), y.ptr, y.cs, self.act, y.amax.data_ptr() if y.amax is not None else None,
             self._work(dev).data_ptr(), _stream()), "bn_train_forward")
         bn.num_batches_tracked += 1
         self.y = y
         return y
 
     def tan(self, xd: Act, out=None) -> Act:
+        if self.act == 2:
+            raise NotImplementedError("BatchNorm + swish is built for first-order training (the backbone) only")
         bn, dev = self.bn, xd.buf.device
         self.xd = xd
         self.mom_t = torch.empty((2, bn.num_features), device=dev)
@@ -232,6 +236,16 @@ class BNT:
             gg, acc = grad_slot(grads, bn.weight)
             gb, _ = grad_slot(grads, bn.bias)
         has_t = gyd is not None
+        if self.act == 2:                      # BatchNorm + swish: act'(z) from the recomputed z, no stored z
+            if has_t:
+                raise NotImplementedError("BatchNorm + swish is built for first-order training (the backbone) only")
+            _lib.check(_lib_().creste_bn_act_train_backward_f32(
+                2, self.x.ptr, self.x.cs, gy.ptr, gy.cs, _px(self.x), bn.num_features, bn.weight.data_ptr(),
+                bn.bias.data_ptr(), self.mean.data_ptr(), self.invstd.data_ptr(), mom_b.data_ptr(), gx.ptr, gx.cs,
+                gg.data_ptr() if gg is not None else None, gb.data_ptr() if gb is not None else None, acc,
+                gx.amax.data_ptr() if gx.amax is not None else None, self._work(dev).data_ptr(), _stream()),
+                "bn_act_train_backward")
+            return gx, None
         # with the fused ReLU the kernels mask the cotangents themselves (the mask is recomputed from x with the forward's
         # expression): no separate pass over y and gy
         fn = _lib_().creste_bn_relu_train_backward_f32 if self.relu else _lib_().creste_bn_train_backward_f32

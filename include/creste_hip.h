@@ -321,8 +321,8 @@ int creste_conv_flip_weight_f32(const float* w, float* wt, int Cout, int Cin, in
 int64_t creste_bn_workspace_bytes(int C);
 int creste_bn_train_forward_f32(const float* x, int x_cs, int64_t P, int C, const float* gamma, const float* beta,
                                 float eps, float momentum, float* running_mean, float* running_var, float* mean,
-                                float* invstd, float* var_scratch, float* y, int y_cs, int relu, float* out_amax,
-                                void* work, void* stream);
+                                float* invstd, float* var_scratch, float* y, int y_cs, int relu /* 0 none, 1 ReLU, 2 swish */,
+                                float* out_amax, void* work, void* stream);
 int creste_bn_train_tangent_f32(const float* x, int x_cs, const float* xd, int xd_cs, int64_t P, int C,
                                 const float* gamma, const float* mean, const float* invstd, float* mom_t,
                                 float* yd, int yd_cs, void* work, void* stream);
@@ -338,6 +338,14 @@ int creste_bn_relu_train_backward_f32(const float* x, int x_cs, const float* xd,
                                  const float* mean, const float* invstd, const float* mom_t, float* mom_b,
                                  float* gx, int gx_cs, float* gxd, int gxd_cs, float* g_gamma, float* g_beta,
                                  int accumulate, float* gx_amax, void* work, void* stream);
+/* First-order backward of BatchNorm + a fused activation (act 1: ReLU, 2: swish = z * sigmoid(z); the forward is
+ * creste_bn_train_forward_f32 with relu = act): gy is multiplied by act'(z), z = gamma * xh + beta recomputed from x.
+ * Replaces efficientnet_pytorch's BatchNorm2d -> MemoryEfficientSwish pairs in training mode (reference call site
+ * creste/models/blocks/effnet.py:83) without keeping z in memory. */
+int creste_bn_act_train_backward_f32(int act, const float* x, int x_cs, const float* gy, int gy_cs, int64_t P, int C,
+                                     const float* gamma, const float* beta, const float* mean, const float* invstd,
+                                     float* mom_b, float* gx, int gx_cs, float* g_gamma, float* g_beta, int accumulate,
+                                     float* gx_amax, void* work, void* stream);
 
 /* op 0: o = max(a, 0) | op 1: o = a > 0 ? b : 0 (ReLU backward / tangent with a = the ReLU output) |
  * op 2: o = a + b.  [P][C] with pixel strides. */

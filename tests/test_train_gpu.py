@@ -194,6 +194,37 @@ def test_batchnorm_train_forward_tangent_backward(C, relu):
     assert int(bn.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("C", [3, 16, 144])
+def test_batchnorm_swish_forward_backward(C):
+    """BatchNorm + swish as one op (activation inside the BatchNorm kernels, swish'(z) recomputed from x in the backward):
+    the backbone's BatchNorm2d -> MemoryEfficientSwish pairs, against float64 autograd"""
+    from creste_public_amd import train_ops as T
+    g = torch.Generator().manual_seed(100 + C)
+    N, H, W = 2, 11, 13
+    x = torch.randn(N, C, H, W, generator=g) * 1.5 - 0.3
+    gy = torch.randn(N, C, H, W, generator=g)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 2.0); bn.bias.normal_(0, 0.5)
+    ref = copy.deepcopy(bn).double().train()
+    xr = x.double().requires_grad_(True)
+    z = ref(xr)
+    y = z * torch.sigmoid(z)
+    y.backward(gy.double())
+    bn = bn.cuda().train()
+    op = T.BNT(bn, 2)
+    ya = op.fwd(T.as_act(x.cuda()))
+    torch.testing.assert_close(ya.nchw().cpu().double(), y.detach(), rtol=1e-4, atol=1e-5)
+    grads = {}
+    gx, gxd = op.bwd(T.as_act(gy.cuda()), None, grads)
+    assert gxd is None
+    torch.testing.assert_close(gx.nchw().cpu().double(), xr.grad, rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(grads[id(bn.weight)].cpu().double(), ref.weight.grad, rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(grads[id(bn.bias)].cpu().double(), ref.bias.grad, rtol=2e-4, atol=2e-4)
+    with pytest.raises(NotImplementedError):
+        op.tan(T.as_act(x.cuda()))
+
+
 def test_batchnorm_one_pass_statistics_on_hard_data():
     """the training-mode statistics are ONE read of the tensor (pivot-shifted moments, csrc/train.hip): channels with a
     mean far larger than their spread, a constant channel, a channel whose first pixel is an outlier, a big tensor"""
