@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void wgrad_f16_kernel(
 // neighbouring column image in LDS: the gy column and ONE new x column per step serve all three taps (a ring of four
 // x-column images; the per-tap kernel above streams every operand 9 x tiles times through L2: 55 GB for the
 // 496 -> 496 layer), every fragment stays an aligned ds_read_b128, and both loader halves do the same amount of
-// conversion work.  36 MFMAs per wave and step (two waves per SIMD), one barrier per column.
+// conversion work.  36 MFMAs and 20 operand reads per wave and step (two waves per SIMD), one barrier per column.
 constexpr int W3_KS = 32, W3_NOCT = W3_KS / 8, W3_OCT = 128 * 16, W3_PLANE = W3_NOCT * W3_OCT, W3_IMG = 2 * W3_PLANE;
 constexpr int W3_SMEM = 2 * W3_IMG + 4 * W3_IMG;           // gy column double buffer + ring of four x columns
 // channel row r of an octet image sits at 16-byte slot r ^ ((r >> 4) & 3): the loader's rows 4q + c (fixed c) and the
@@ -337,7 +337,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16_col3_kernel(
   char* const Bimg = smem + 2 * W3_IMG;                      // [4][W3_IMG], slot = (source column + 1) & 3
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;                  // 8 waves: 4 (co strips of 32) x 2 (ci halves of 64)
+  // 8 waves: 2 (co halves of 64) x 4 (ci strips of 32).  A wave's gy fragments (2 sub-strips) serve all three taps and
+  // each x fragment serves both sub-strips: 20 ds_read_b128 per 36 MFMAs (the 4 x 2 split read 28 -- 229 KB per
+  // workgroup and step, 78 % of what the LDS delivers in the time the MFMAs take)
+  const int wm = wave & 1, wn = wave >> 1;
   int id = xcd_remap(blockIdx.x, gridDim.x);
   const int kyi = id % 3; id /= 3;
   const int tci = id % tiles_ci; id /= tiles_ci;
@@ -425,22 +428,24 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16_col3_kernel(
     const char* A = Aimg + ((col - xs) & 1) * W3_IMG;
 #pragma unroll
     for (int ks = 0; ks < W3_KS / 16; ++ks) {
-      h8 a[2];
+      h8 a[2][2];
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-        a[pl] = *reinterpret_cast<const h8*>(A + pl * W3_PLANE + (ks * 2 + lh) * W3_OCT + w3_swz(wm * 32 + li) * 16);
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          a[i][pl] = *reinterpret_cast<const h8*>(A + pl * W3_PLANE + (ks * 2 + lh) * W3_OCT + w3_swz(wm * 64 + i * 32 + li) * 16);
 #pragma unroll
       for (int kxi = 0; kxi < 3; ++kxi) {
         const char* B = bslot(col - pad_l + kxi);
+        h8 b[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          h8 b[2];
+        for (int pl = 0; pl < 2; ++pl)
+          b[pl] = *reinterpret_cast<const h8*>(B + pl * W3_PLANE + (ks * 2 + lh) * W3_OCT + w3_swz(wn * 32 + li) * 16);
 #pragma unroll
-          for (int pl = 0; pl < 2; ++pl)
-            b[pl] = *reinterpret_cast<const h8*>(B + pl * W3_PLANE + (ks * 2 + lh) * W3_OCT + w3_swz(wn * 64 + j * 32 + li) * 16);
-          c[kxi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], c[kxi][j], 0, 0, 0);
-          c[kxi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], c[kxi][j], 0, 0, 0);
-          c[kxi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], c[kxi][j], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+          c[kxi][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[0], c[kxi][i], 0, 0, 0);
+          c[kxi][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[1], c[kxi][i], 0, 0, 0);
+          c[kxi][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[0], c[kxi][i], 0, 0, 0);
         }
       }
     }
@@ -450,13 +455,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16_col3_kernel(
 #pragma unroll
   for (int kxi = 0; kxi < 3; ++kxi) {
     float* out = partial + ((size_t)chunk * 9 + kyi * 3 + kxi) * Cout * Cin;
+    const int colc = ci0 + wn * 32 + li;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int colc = ci0 + wn * 64 + j * 32 + li;
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < Cout && colc < Cin) out[(size_t)row * Cin + colc] = c[kxi][j][r] * sc;
+        const int row = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < Cout && colc < Cin) out[(size_t)row * Cin + colc] = c[kxi][i][r] * sc;
       }
     }
   }
