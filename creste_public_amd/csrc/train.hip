@@ -324,6 +324,39 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restr
   }
 }
 
+// 1x1 convs with at most four output channels (the reward head, 48 -> 1): a streaming reduction, not a matrix product --
+// thread = (pixel lane, input-channel quad), float4 loads of x, the pixel lanes of a block summed through LDS in a fixed
+// order; partial[block][co][ci] goes to wgrad_reduce4_kernel like every other partial set
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(const float* __restrict__ x, int x_cs, const float* __restrict__ gy,
+                                                         int gy_cs, float* __restrict__ partial, long P, int Cin, int Cout) {
+  __shared__ f32x4v red[256];
+  const int cq = Cin >> 2, pl_n = 256 / cq;
+  const int q = threadIdx.x % cq, pl = threadIdx.x / cq;
+  const bool active = pl < pl_n;
+  f32x4v acc[4];
+#pragma unroll
+  for (int co = 0; co < 4; ++co) acc[co] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  if (active) {
+#pragma unroll 2
+    for (long p = (long)blockIdx.x * pl_n + pl; p < P; p += (long)gridDim.x * pl_n) {
+      const f32x4v xv = *reinterpret_cast<const f32x4v*>(x + p * x_cs + q * 4);
+#pragma unroll
+      for (int co = 0; co < 4; ++co)
+        if (co < Cout) acc[co] += xv * gy[p * gy_cs + co];
+    }
+  }
+  for (int co = 0; co < Cout; ++co) {
+    __syncthreads();
+    red[threadIdx.x] = acc[co];
+    __syncthreads();
+    if ((int)threadIdx.x < cq) {
+      f32x4v t = {0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < pl_n; ++r) t += red[r * cq + threadIdx.x];
+      *reinterpret_cast<f32x4v*>(partial + ((size_t)blockIdx.x * Cout + co) * Cin + threadIdx.x * 4) = t;
+    }
+  }
+}
+
 // OIHW -> dgrad weight: w'[ci][co][K-1-ky][K-1-kx] = w[co][ci][ky][kx] (a stride-1 conv's input gradient is
 // the conv of gy with the flipped, channel-transposed kernel, pad K-1-pad); Cout padded with zero input
 // channels up to cout_pad (the conv engine wants Cin % 4 == 0).
@@ -901,6 +934,14 @@ extern "C" int creste_conv_wgrad_f32(const float* x, int x_cs, const float* gy, 
     CRESTE_CHECK_LAUNCH("wgrad_rows");
     wgrad_reduce4_kernel<<<(Cout * Cin * K * K + 63) / 64, 256, 0, s>>>((const float*)work, gw, wp.nwg, Cout, Cin, K * K,
                                                                         accumulate);
+    CRESTE_CHECK_LAUNCH("wgrad_reduce");
+    return CRESTE_OK;
+  }
+  if (K == 1 && Cout <= 4 && Cin % 4 == 0 && Cin <= 1024 && x_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const int nb = wgrad_chunks(M, 1);                       // the per-tap path's workspace bound
+    wgrad_thin_kernel<<<nb, 256, 0, s>>>(x, x_cs, gy, gy_cs, (float*)work, M, Cin, Cout);
+    CRESTE_CHECK_LAUNCH("wgrad_thin");
+    wgrad_reduce4_kernel<<<(Cout * Cin + 63) / 64, 256, 0, s>>>((const float*)work, gw, nb, Cout, Cin, 1, accumulate);
     CRESTE_CHECK_LAUNCH("wgrad_reduce");
     return CRESTE_OK;
   }
