@@ -324,7 +324,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restr
   }
 }
 
-// 1x1 convs with at most four output channels (the reward head, 48 -> 1): a streaming reduction, not a matrix product --
+// 1x1 convs with fewer than eight output channels (the reward head 48 -> 1, the 2- and 6-class BEV projections): a
+// streaming reduction, not a matrix product --
 // thread = (pixel lane, input-channel quad), float4 loads of x, the pixel lanes of a block summed through LDS in a fixed
 // order; partial[block][co][ci] goes to wgrad_reduce4_kernel like every other partial set
 __global__ __launch_bounds__(256) void wgrad_thin_kernel(const float* __restrict__ x, int x_cs, const float* __restrict__ gy,
@@ -333,19 +334,21 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(const float* __restrict
   const int cq = Cin >> 2, pl_n = 256 / cq;
   const int q = threadIdx.x % cq, pl = threadIdx.x / cq;
   const bool active = pl < pl_n;
-  f32x4v acc[4];
+  f32x4v acc[7];
 #pragma unroll
-  for (int co = 0; co < 4; ++co) acc[co] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  for (int co = 0; co < 7; ++co) acc[co] = f32x4v{0.f, 0.f, 0.f, 0.f};
   if (active) {
 #pragma unroll 2
     for (long p = (long)blockIdx.x * pl_n + pl; p < P; p += (long)gridDim.x * pl_n) {
       const f32x4v xv = *reinterpret_cast<const f32x4v*>(x + p * x_cs + q * 4);
 #pragma unroll
-      for (int co = 0; co < 4; ++co)
+      for (int co = 0; co < 7; ++co)
         if (co < Cout) acc[co] += xv * gy[p * gy_cs + co];
     }
   }
-  for (int co = 0; co < Cout; ++co) {
+#pragma unroll
+  for (int co = 0; co < 7; ++co) {
+    if (co >= Cout) break;
     __syncthreads();
     red[threadIdx.x] = acc[co];
     __syncthreads();
@@ -937,7 +940,7 @@ extern "C" int creste_conv_wgrad_f32(const float* x, int x_cs, const float* gy, 
     CRESTE_CHECK_LAUNCH("wgrad_reduce");
     return CRESTE_OK;
   }
-  if (K == 1 && Cout <= 4 && Cin % 4 == 0 && Cin <= 1024 && x_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+  if (K == 1 && Cout < 8 && Cin % 4 == 0 && Cin <= 1024 && x_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
     const int nb = wgrad_chunks(M, 1);                       // the per-tap path's workspace bound
     wgrad_thin_kernel<<<nb, 256, 0, s>>>(x, x_cs, gy, gy_cs, (float*)work, M, Cin, Cout);
     CRESTE_CHECK_LAUNCH("wgrad_thin");

@@ -982,6 +982,10 @@ extern "C" int creste_conv_wgrad_strided_f32(const float* x, int x_cs, const flo
                      K * K <= 65535, "conv_wgrad_strided: bad dims");
   const long M = (long)N * Ho * Wo;
   CRESTE_REQUIRE(M < (1L << 31), "conv_wgrad_strided: N*Ho*Wo overflows int32");
+  // thin 1x1 projections (2 / 6 classes): the streaming reduction of csrc/train.hip (same workspace bound)
+  if (K == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && Ho == H && Wo == W && Cout < 8 && Cin % 4 == 0 && Cin <= 1024 &&
+      x_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+    return creste_conv_wgrad_f32(x, x_cs, gy, gy_cs, gw, N, H, W, Cin, Cout, 1, 0, accumulate, work, stream);
   hipStream_t s = (hipStream_t)stream;
   int nchunk;
   const bool vec = Cin % 4 == 0 && Cout % 4 == 0 && x_cs % 4 == 0 && gy_cs % 4 == 0 &&

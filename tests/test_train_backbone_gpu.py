@@ -34,7 +34,9 @@ def _rel(a, b):
     (2, 64, 20, 24, 64, 3, 2, (0, 1, 0, 1), False),     # strided, tiled
     (2, 96, 32, 32, 64, 7, 2, (3, 3, 3, 3), False),     # BEV stem 7x7/2 (input gradient reaches the splat)
     (1, 64, 17, 19, 128, 1, 2, (0, 0, 0, 0), False),    # ResNet downsample 1x1/2, odd extents
-    (1, 64, 16, 18, 128, 3, 2, (1, 1, 1, 1), False)])   # ResNet 3x3/2
+    (1, 64, 16, 18, 128, 3, 2, (1, 1, 1, 1), False),    # ResNet 3x3/2
+    (2, 128, 24, 40, 6, 1, 1, (0, 0, 0, 0), True),      # 6- / 2-class BEV projections: thin wgrad (streaming reduction)
+    (3, 128, 13, 17, 2, 1, 1, (0, 0, 0, 0), True)])
 def test_conv_general_backward(N, Cin, H, W, Cout, K, s, pad, bias):
     from creste_public_amd import train_backbone as TB, train_ops as T
     g = torch.Generator().manual_seed(Cin + K)

@@ -121,7 +121,7 @@ def test_stale_backward_is_refused():
                                               # last one, partial 16-channel tiles, every tap-split instantiation
                                               (1, 70, 150, 32, 32, 3), (2, 40, 64, 24, 40, 5), (2, 33, 130, 64, 64, 3),
                                               (1, 37, 66, 16, 24, 5), (3, 9, 200, 40, 64, 5), (1, 19, 65, 48, 8, 3), (2, 30, 70, 32, 32, 1),
-                                              (1, 5, 129, 64, 40, 1), (2, 21, 33, 48, 3, 1), (1, 7, 5, 8, 4, 1)])
+                                              (1, 5, 129, 64, 40, 1), (2, 21, 33, 48, 3, 1), (1, 7, 5, 8, 4, 1), (2, 16, 16, 128, 6, 1)])
 def test_conv_wgrad_and_dgrad(N, H, W, Cin, Cout, K):
     from creste_public_amd import train_ops as T
     from creste_public_amd.ops import Act
