@@ -70,6 +70,93 @@ __global__ __launch_bounds__(256) void wgrad_strided_partial_kernel(
   }
 }
 
+// convs with a handful of input channels (the 4-channel RGB-D stem, 3x3/2): the K*K*Cin patch elements (36) play the
+// input-channel role of ONE matrix product per pixel quad -- v_mfma_f32_16x16x4_f32 with A = gy (co x 4 pixels) and
+// B = the im2col patch gathered straight from x (patch element x 4 pixels), 2 x 3 tiles for 32 x 48.  The per-tap kernel
+// above filled 4 of 32 operand lanes and read gy nine times (1.1 ms per step); a VALU outer product was tried and is
+// bound by the L1 (one FMA per loaded dword): here a wave issues 5 loads for 6 MFMAs per 4 pixels.
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+constexpr int WSC_TCO = 2, WSC_TPE = 3;
+__global__ __launch_bounds__(256) void wgrad_smallcin_kernel(
+    const float* __restrict__ x, int x_cs, const float* __restrict__ gy, int gy_cs, float* __restrict__ partial,
+    int N, int H, int W, int Ho, int Wo, int Cin, int Cout, int K, int stride, int pad_t, int pad_l, int wave_px) {
+  __shared__ float red[4][WSC_TCO * 16][WSC_TPE * 16 + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lj = lane >> 4;
+  const int PE = K * K * Cin, M = N * Ho * Wo;
+  // this lane's patch elements (one per pe tile): offsets of the tap relative to the window origin
+  int eky[WSC_TPE], ekx[WSC_TPE], eoff[WSC_TPE];
+  bool ev[WSC_TPE];
+#pragma unroll
+  for (int t = 0; t < WSC_TPE; ++t) {
+    const int pe = t * 16 + lr;
+    ev[t] = pe < PE;
+    const int tap = pe / Cin, ci = pe - tap * Cin;
+    eky[t] = tap / K - pad_t; ekx[t] = tap % K - pad_l;
+    eoff[t] = (eky[t] * W + ekx[t]) * x_cs + ci;
+  }
+  int coc[WSC_TCO];
+  bool cv[WSC_TCO];
+#pragma unroll
+  for (int c = 0; c < WSC_TCO; ++c) { cv[c] = c * 16 + lr < Cout; coc[c] = cv[c] ? c * 16 + lr : 0; }
+  f32x4w acc[WSC_TCO][WSC_TPE];
+#pragma unroll
+  for (int c = 0; c < WSC_TCO; ++c)
+#pragma unroll
+    for (int t = 0; t < WSC_TPE; ++t) acc[c][t] = f32x4w{0.f, 0.f, 0.f, 0.f};
+  const long p0l = ((long)blockIdx.x * 4 + wave) * wave_px;
+  const int p0 = (int)min((long)M, p0l), p1 = (int)min((long)M, p0l + wave_px);
+  const int nsteps = (p1 - p0 + 3) >> 2;
+  // branch-free loads: invalid lanes read element 0 and are zeroed (a predicated load compiles to a branch + wait)
+  for (int st = 0; st < nsteps; ++st) {
+    const int q = p0 + 4 * st + lj;
+    const bool qv = q < p1;
+    const int qq = qv ? q : 0;
+    const int rowi = qq / Wo, ox = qq - rowi * Wo, n = rowi / Ho, oy = rowi - n * Ho;
+    const int iy0 = oy * stride, ix0 = ox * stride;
+    const long base = (((long)n * H + iy0) * W + ix0) * x_cs;
+    float a[WSC_TCO], b[WSC_TPE];
+#pragma unroll
+    for (int c = 0; c < WSC_TCO; ++c) {
+      const float v = gy[(long)qq * gy_cs + coc[c]];
+      a[c] = (qv && cv[c]) ? v : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < WSC_TPE; ++t) {
+      const bool ok = qv && ev[t] && (unsigned)(iy0 + eky[t]) < (unsigned)H && (unsigned)(ix0 + ekx[t]) < (unsigned)W;
+      const float v = x[ok ? base + eoff[t] : 0];
+      b[t] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < WSC_TCO; ++c)
+#pragma unroll
+      for (int t = 0; t < WSC_TPE; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[t], acc[c][t], 0, 0, 0);
+  }
+  // D layout: col (pe) = lane & 15, row (co) = 4 * (lane >> 4) + r; the four waves' tiles are summed in a fixed order
+#pragma unroll
+  for (int c = 0; c < WSC_TCO; ++c)
+#pragma unroll
+    for (int t = 0; t < WSC_TPE; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][c * 16 + 4 * lj + r][t * 16 + lr] = acc[c][t][r];
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.x * K * K * Cout * Cin;
+  for (int e = threadIdx.x; e < Cout * PE; e += 256) {
+    const int co = e / PE, pe = e - co * PE;
+    const float v = (red[0][co][pe] + red[1][co][pe]) + (red[2][co][pe] + red[3][co][pe]);
+    const int tap = pe / Cin, ci = pe - tap * Cin;
+    out[((size_t)tap * Cout + co) * Cin + ci] = v;
+  }
+}
+
+static inline bool wgrad_smallcin_ok(int Cin, int Cout, int K) {
+  return Cin < 8 && Cout <= WSC_TCO * 16 && K * K * Cin <= WSC_TPE * 16;
+}
+static inline int wgrad_smallcin_chunks(long M) {
+  const long cap = (M + 1023) / 1024;                 // at least 256 pixels per wave
+  return (int)(cap < 512 ? (cap < 1 ? 1 : cap) : 512);
+}
+
 // LDS-tiled variant for the wide layers: a workgroup (2 x 2 waves) owns a (64*WM) x (64*WN) block of one tap's
 // [Cout x Cin] gradient and walks its pixel chunk in steps of 16; per step the gy rows (A^T, 16 x BM) and the
 // shifted x rows (B, 16 x BN) are staged ONCE in LDS (float4 global loads, zero fill outside the image) and feed
@@ -971,7 +1058,9 @@ using namespace creste;
 
 extern "C" int64_t creste_conv_wgrad_strided_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int K) {
   if (N <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || K <= 0) return -1;
-  return (int64_t)wgrad_chunks((long)N * Ho * Wo, K) * K * K * Cout * Cin * 4;
+  const long M = (long)N * Ho * Wo;
+  const int chunks = wgrad_smallcin_ok(Cin, Cout, K) ? wgrad_smallcin_chunks(M) : wgrad_chunks(M, K);
+  return (int64_t)chunks * K * K * Cout * Cin * 4;
 }
 
 extern "C" int creste_conv_wgrad_strided_f32(const float* x, int x_cs, const float* gy, int gy_cs, float* gw, int N,
@@ -990,7 +1079,15 @@ extern "C" int creste_conv_wgrad_strided_f32(const float* x, int x_cs, const flo
   int nchunk;
   const bool vec = Cin % 4 == 0 && Cout % 4 == 0 && x_cs % 4 == 0 && gy_cs % 4 == 0 &&
                    ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0;
-  if (vec && Cin >= 32 && Cout >= 32) {
+  if (wgrad_smallcin_ok(Cin, Cout, K)) {
+    nchunk = wgrad_smallcin_chunks(M);
+    long wave_px = (M + 4L * nchunk - 1) / (4L * nchunk);
+    wave_px = (wave_px + 3) / 4 * 4;
+    nchunk = (int)((M + 4 * wave_px - 1) / (4 * wave_px));
+    wgrad_smallcin_kernel<<<nchunk, 256, 0, s>>>(x, x_cs, gy, gy_cs, (float*)work, N, H, W, Ho, Wo, Cin, Cout, K, stride,
+                                                 pad_t, pad_l, (int)wave_px);
+    CRESTE_CHECK_LAUNCH("wgrad_smallcin");
+  } else if (vec && Cin >= 32 && Cout >= 32) {
     const bool big = Cin > 64 && Cout > 64;
     const int bm = big ? 128 : 64;
     const int tiles_co = (Cout + bm - 1) / bm, tiles_ci = (Cin + bm - 1) / bm;
