@@ -72,13 +72,15 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(const float* __restr
   }
 }
 
-// ---------------------------------------------------------------------------- row-walk wgrad (K = 3, 5)
+// ------------------------------------------------------------------------- row-walk wgrad (K = 1, 3, 5)
 // The per-tap kernel above reads both operands K*K times (one workgroup per tap): at 5x5 on a 256x256 grid that is
 // 11 GB of L2 traffic per call and the matrix cores wait on it.  Here a workgroup walks a band of rows of one
 // 64-pixel column segment with the last K rows of x (plus the K-1 halo columns) in an LDS ring and the current gy row
 // beside it: every element is fetched once, and all K*K taps are formed from the ring.  A wave owns one
 // 16(co) x 16(ci) tile for NTAP taps (v_mfma_f32_16x16x4_f32: 4 pixels per issue; 40 channels pad to 48, not 64).
 // LDS pixel strides are = 16 mod 32 floats, so the four 16-lane pixel groups of an operand read hit distinct banks.
+// Workgroups are sized small (a whole kernel per wave where the accumulators allow) so that several share a CU and one's
+// row hand-over overlaps another's matrix phase; the partial sets (one per workgroup) go to wgrad_reduce4_kernel.
 constexpr int WR_TW = 64;   // pixels per column segment
 constexpr int WR_XI = 3;    // float4 prefetch registers per thread: x row
 constexpr int WR_XI1 = 4;   //   1x1 convs (two-wave workgroups)
