@@ -624,12 +624,14 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const float* __restri
 // partial[blk][tap][c] = sum over the block's output pixels of gy[q][c] * x[q*s + tap - pad][c]
 constexpr int DW_BLOCKS = 2048;           // upper bound; see dw_blocks()
 static inline int dw_blocks(int C, int K) { const int b = 4194304 / (C * K * K); return b < 256 ? 256 : (b > DW_BLOCKS ? DW_BLOCKS : b); }
-template <int K>
+constexpr int DW_G = 4;                   // output pixels per step of the wgrad walk
+template <int K, int S>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                            float* __restrict__ partial, int N, int H, int W, int C,
-                                                           int Ho, int Wo, int stride, int pad_t, int pad_l) {
+                                                           int Ho, int Wo, int pad_t, int pad_l) {
   extern __shared__ float sm[];   // [rows][Ct] per tap, reused tap by tap
-  const long M = (long)N * Ho * Wo;
+  constexpr int WC = (DW_G - 1) * S + K;          // input columns under DW_G adjacent outputs
+  constexpr int SH = DW_G * S, KEEP = WC > SH ? WC - SH : 0;
   {                                // blockIdx.y walks channel tiles of 256
     const int c0 = blockIdx.y * 256;
     const int Ct = min(256, C - c0), rows = 256 / Ct;
@@ -639,50 +641,64 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
 #pragma unroll
     for (int t = 0; t < K * K; ++t) s[t] = 0.f;
     if (active) {
-      // every (block, row slot) owns a CONTIGUOUS range of output pixels and slides a K x K register window along
-      // the image row: per output pixel only the `stride` new columns are loaded (K or 2K loads instead of K*K --
-      // the strided block-cyclic walk re-fetched every tap from L2: 100 B of L2 traffic per output element)
+      // every (block, row slot) owns a CONTIGUOUS range of units = (image row, group of DW_G adjacent outputs) and keeps
+      // the K x WC input window of the group in registers: along a row the KEEP columns shared with the next group
+      // slide over and only DW_G * S new columns are loaded -- all of a step's loads (DW_G cotangents + K * DW_G * S
+      // inputs) are independent and in flight together.  (One output per step with K dependent-free loads left the
+      // walk latency-bound at 2-3 waves per SIMD: 200-400 us for tensors that stream in 40-60.)
+      const int gpr = (Wo + DW_G - 1) / DW_G;
+      const long U = (long)N * Ho * gpr;
       const long nslot = (long)gridDim.x * rows;
-      const long per = (M + nslot - 1) / nslot;
-      const long q0 = ((long)blockIdx.x * rows + row) * per, q1 = min(M, q0 + per);
-      float win[K][K];
-      int ox = 0, oy = 0, n = 0;
-      if (q0 < q1) { ox = (int)(q0 % Wo); const long r = q0 / Wo; oy = (int)(r % Ho); n = (int)(r / Ho); }
-      bool fresh = true;
-      for (long q = q0; q < q1; ++q) {
-        const float g = gy[q * C + c];
+      const long per = (U + nslot - 1) / nslot;
+      const long u0 = ((long)blockIdx.x * rows + row) * per, u1 = min(U, u0 + per);
+      float win[K][WC];
+      for (long u = u0; u < u1; ++u) {
+        const long r = u / gpr;
+        const int gi = (int)(u - r * gpr), n = (int)(r / Ho), oy = (int)(r - (long)n * Ho);
+        const int ox0 = gi * DW_G;
+        const bool cont = u > u0 && gi != 0;             // the previous unit was the group to the left
+        float g[DW_G];
+#pragma unroll
+        for (int j = 0; j < DW_G; ++j) {
+          const bool ok = ox0 + j < Wo;
+          const float v = gy[(r * Wo + (ok ? ox0 + j : 0)) * C + c];
+          g[j] = ok ? v : 0.f;
+        }
         const float* xn = x + (long)n * H * W * C + c;
-        const int ix0 = ox * stride - pad_l;
-        // columns [first_new, K) of the window are loaded; the others slide over from the previous pixel
-        const int first_new = fresh ? 0 : K - stride;
-        if (!fresh) {
+        const int ix0 = ox0 * S - pad_l, iy0 = oy * S - pad_t;
+        auto load_cols = [&](int from) __attribute__((always_inline)) {
+#pragma unroll
+          for (int ky = 0; ky < K; ++ky) {
+            const int iy = iy0 + ky;
+            const bool yok = (unsigned)iy < (unsigned)H;
+            const long rowoff = (long)(yok ? iy : 0) * W;
+#pragma unroll
+            for (int j = 0; j < WC; ++j) {
+              if (j >= from) {
+                const int ix = ix0 + j;
+                const bool ok = yok && (unsigned)ix < (unsigned)W;
+                const float xv = xn[(rowoff + (ok ? ix : 0)) * C];   // branch-free: invalid taps read a valid address
+                win[ky][j] = ok ? xv : 0.f;
+              }
+            }
+          }
+        };
+        if (cont && KEEP > 0) {
+#pragma unroll
+          for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+            for (int j = 0; j < KEEP; ++j) win[ky][j] = win[ky][j + SH];
+          load_cols(KEEP);
+        } else {
+          load_cols(0);
+        }
+#pragma unroll
+        for (int j = 0; j < DW_G; ++j)
 #pragma unroll
           for (int ky = 0; ky < K; ++ky)
 #pragma unroll
             for (int kx = 0; kx < K; ++kx)
-              win[ky][kx] = (stride == 1) ? (kx + 1 < K ? win[ky][kx + 1] : 0.f) : (kx + 2 < K ? win[ky][kx + 2] : 0.f);
-        }
-#pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-          const int iy = oy * stride + ky - pad_t;
-          const bool yok = (unsigned)iy < (unsigned)H;
-          const long rowoff = (long)(yok ? iy : 0) * W;
-#pragma unroll
-          for (int kx = 0; kx < K; ++kx) {
-            if (kx >= first_new) {                       // wave-uniform (fresh / stride are uniform)
-              const int ix = ix0 + kx;
-              const bool ok = yok && (unsigned)ix < (unsigned)W;
-              const float xv = xn[(rowoff + (ok ? ix : 0)) * C];
-              win[ky][kx] = ok ? xv : 0.f;
-            }
-          }
-        }
-#pragma unroll
-        for (int ky = 0; ky < K; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < K; ++kx) s[ky * K + kx] = __builtin_fmaf(g, win[ky][kx], s[ky * K + kx]);   // (the library is built with -ffp-contract=off)
-        fresh = false;
-        if (++ox == Wo) { ox = 0; fresh = true; if (++oy == Ho) { oy = 0; ++n; } }
+              s[ky * K + kx] = __builtin_fmaf(g[j], win[ky][j * S + kx], s[ky * K + kx]);   // (-ffp-contract=off build)
       }
     }
     const int cw = Ct;                           // channels handled by this block
@@ -1201,14 +1217,18 @@ extern "C" int creste_dwconv_wgrad_f32(const float* x, const float* gy, float* g
   CRESTE_REQUIRE(K == 3 || K == 5, "dwconv_wgrad: kernel size %d not built (3 or 5)", K);
   CRESTE_REQUIRE(stride == 1 || stride == 2, "dwconv_wgrad: stride %d not built (1 or 2: the window slides by it)", stride);
   const int rows = C >= 256 ? 1 : 256 / C;
-  const long M = (long)N * Ho * Wo;
-  const long per = (M + rows - 1) / rows;
+  const long U = (long)N * Ho * ((Wo + DW_G - 1) / DW_G);            // (row, group of DW_G outputs) units
+  const long per = (U + rows - 1) / rows;
   const int blocks = (int)(per < dw_blocks(C, K) ? per : dw_blocks(C, K));
   const size_t smem = 256 * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(blocks, (C + 255) / 256);
-  if (K == 3) dwconv_wgrad_kernel<3><<<grid, 256, smem, s>>>(x, gy, (float*)work, N, H, W, C, Ho, Wo, stride, pad_t, pad_l);
-  else dwconv_wgrad_kernel<5><<<grid, 256, smem, s>>>(x, gy, (float*)work, N, H, W, C, Ho, Wo, stride, pad_t, pad_l);
+#define CRESTE_DWW(K_, S_) dwconv_wgrad_kernel<K_, S_><<<grid, 256, smem, s>>>(x, gy, (float*)work, N, H, W, C, Ho, Wo, pad_t, pad_l)
+  if (K == 3 && stride == 1) CRESTE_DWW(3, 1);
+  else if (K == 3) CRESTE_DWW(3, 2);
+  else if (stride == 1) CRESTE_DWW(5, 1);
+  else CRESTE_DWW(5, 2);
+#undef CRESTE_DWW
   CRESTE_CHECK_LAUNCH("dwconv_wgrad");
   sum_partials_kernel<<<K * K * C, 64, 0, s>>>((const float*)work, gw_taps, blocks, K * K * C, 1.f, accumulate);
   CRESTE_CHECK_LAUNCH("dwconv_wgrad_sum");
