@@ -151,7 +151,8 @@ class InpaintingResNet18MultiHead(Inpainting):
 
     def _forward(self, x):
         require_hip(x, "InpaintingResNet18MultiHead")
-        if self.training:
-            raise NotImplementedError("BEV-head training (backward kernels) is not in this round")
+        if self.training:       # HIP training engine (creste_public_amd/train_bev.py), autograd-aware
+            from ....train_bev import bev_heads_forward_train
+            return [dict(preds=p, features=f) for p, f in bev_heads_forward_train(self, x)]
         outs = self.forward_act(ops.nchw_to_nhwc(x.contiguous()))
         return [dict(preds=o["preds"].nchw(), features=o["features"].nchw()) for o in outs]

@@ -60,6 +60,7 @@ class DepthCompletion(nn.Module):
     def forward(self, x):
         require_hip(x, "DepthCompletion")
         if self.training:
-            raise NotImplementedError("encoder training (backward kernels) is not in this round; "
-                                      "run the perception backbone in eval() mode")
+            raise NotImplementedError("the encoder's HIP training engine covers DistillationBackbone / TerrainNet as a whole "
+                                      "(creste_public_amd/train_backbone.py); call those in train() mode, or this "
+                                      "module in eval() mode")
         return self._pack_outputs(self.forward_act(ops.nchw_to_nhwc(x.contiguous().float())))

@@ -476,3 +476,7 @@ def test_bev_heads_training_step():
         if e > 5e-3:
             bad.append((name, f"{e:.1e}"))
     assert not bad, bad[:20]
+    # the module's own forward in train() mode is the same engine (reference call: Inpainting.forward, inpainting.py:30-50)
+    out_m = net({"bev_features": bev.cuda()})
+    for (pred, _), p in zip(outs, prefixes):
+        assert torch.equal(out_m[f"{p}_preds"], pred), p
