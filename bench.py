@@ -12,9 +12,14 @@ solve_mdp=False, the deployment graph of scripts/runtime/compile.py).  One "step
 over one batch; inputs are resident in HBM when the timed region starts; frames shard across GPUs as
 independent replicas (no data-path collective): `value` = frames of all ranks / max-over-ranks time.
 
-The JSON line also carries `roofline` for the dominant kernel (the fp32-MFMA implicit-GEMM conv:
-algorithmic FLOPs / HIP-event time per launch, summed over every launch of the timed steps) and
-`cpu_baseline` (the CPU oracle, i.e. the reference's PyTorch op sequence, timed on this host).
+`value` is measured at the reference's arithmetic: fp32-equivalent operands (`bf16x6`: every fp32 operand as three
+bf16 pieces = 24 significand bits, six piece products per multiply, fp32 accumulation); the narrower `f16x3` / `bf16`
+modes are side entries of `modes_frames_per_s`.  The JSON line also carries `roofline` for the dominant kernel
+(algorithmic FLOPs / HIP-event time per launch, summed over every launch of the timed steps), `roofline_splat` /
+`roofline_vi` for the two HBM-bound kernels of the north star (HIP events around the BEV splat call inside the timed
+steps; the value-iteration kernel alone), `value_host_fed` (the same steps with every batch copied from pinned host
+memory inside the timed region, double-buffered on a copy stream) and `cpu_baseline` (the CPU oracle, i.e. the
+reference's PyTorch op sequence, timed on this host).
 """
 import argparse
 import json
@@ -87,11 +92,23 @@ class ConvProfiler:
 
     def __init__(self):
         self.records = []
+        self.splat = []          # (event0, event1, algorithmic bytes) of every BEV splat call
 
     def install(self):
         from creste_public_amd import ops
-        self._ops, self._orig = ops, ops.conv2d
+        self._ops, self._orig, self._orig_splat = ops, ops.conv2d, ops.bev_splat
         prof = self
+
+        def timed_splat(xyz, feats, off_xy, vox_xy, GH, GW, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = prof._orig_splat(xyz, feats, off_xy, vox_xy, GH, GW, *a, **kw)
+            e1.record()
+            B, P, F = xyz.shape[0], xyz.shape[1], feats.C
+            # 4 * (F*P + 2*P + F*G + G) bytes per frame -- features and xy read once, BEV map + densities written once
+            prof.splat.append((e0, e1, 4.0 * B * (F * P + 2 * P + F * GH * GW + GH * GW)))
+            return r
+        ops.bev_splat = timed_splat
 
         def timed(x, pc, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -107,6 +124,22 @@ class ConvProfiler:
 
     def uninstall(self):
         self._ops.conv2d = self._orig
+        self._ops.bev_splat = self._orig_splat
+
+    def splat_roofline(self):
+        if not self.splat:
+            return None
+        ms = [e0.elapsed_time(e1) for e0, e1, _ in self.splat]
+        by = self.splat[0][2]
+        avg = sum(ms) / len(ms)
+        return {"bound": "hbm", "kernel": "creste_bev_splat_mode_f32 (splat_key + splat_build_reg + splat_fill_rec + "
+                                          "splat_sort_rec + splat_gather8: the whole call)",
+                "achieved": round(by / (avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(by / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes": by, "avg_call_ms": round(avg, 4),
+                "min_call_ms": round(min(ms), 4), "calls": len(ms), "traffic": None,
+                "note": "HIP events around every BEV splat call INSIDE the timed steps (the network's own predicted depths "
+                        "and fused features, batch 16); bytes = 4*(F*P + 2*P + F*G + G) per frame (SURVEY 8d: F=96, "
+                        "P=46208, G=65536), one read of the inputs and one write of the outputs"}
 
     def summary(self):
         by = {}
@@ -381,8 +414,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16x6", "f16x3", "bf16x3", "bf16"],
-                    help="operand precision of the stride-1 1x1/3x3 convs on the matrix cores")
+    ap.add_argument("--precision", default="bf16x6", choices=["f32", "bf16x6", "f16x3", "bf16x3", "bf16"],
+                    help="operand precision of the convs on the matrix cores; the headline runs the fp32-equivalent "
+                         "bf16x6 (the reference computes in fp32 end to end)")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (H2D inside the timed region) run")
     ap.add_argument("--no-irl", action="store_true", help="skip the IRL train-step timing")
     ap.add_argument("--no-modes", action="store_true", help="skip the short extra runs of the other precisions")
     ap.add_argument("--layers", default="", help="write a per-conv-shape timing table to this file")
@@ -416,7 +451,7 @@ def main():
     l2c = synth.lidar2camrect(args.batch, IMG_H, IMG_W).to(device)    # float64 projection
     p2p = synth.make_p2p(args.batch, IMG_H, IMG_W).to(device)
 
-    def step():
+    def step(rgbd=rgbd, scan=scan):
         """RGB + LiDAR scan -> costmap: project the scan into the sparse millimetre depth channel of the
         RGB-D tensor (HIP scatter-max), then the perception -> BEV -> costmap forward."""
         with torch.no_grad():
@@ -444,6 +479,50 @@ def main():
     assert torch.isfinite(out["traversability_preds"]).all()
     from creste_public_amd import dist_utils
     elapsed = dist_utils.max_over_ranks(elapsed, device)     # the job is as slow as its slowest rank
+
+    host_fed = None
+    if not args.no_host_fed:
+        # the same steps with every batch arriving from PINNED HOST memory inside the timed region: RGB-D frames
+        # (channel 3 = the depth plane the LiDAR kernel fills) + the LiDAR scan, copied on a copy stream into one of two
+        # device buffers while the previous batch computes
+        h_rgbd, h_scan = rgbd.cpu().pin_memory(), scan.cpu().pin_memory()
+        bufs = [(torch.empty_like(rgbd), torch.empty_like(scan)) for _ in range(2)]
+        cstream, cur = torch.cuda.Stream(device=device), torch.cuda.current_stream()
+        ready = [torch.cuda.Event() for _ in range(2)]
+        free = [torch.cuda.Event() for _ in range(2)]
+
+        def enqueue_copy(k):
+            with torch.cuda.stream(cstream):
+                cstream.wait_event(free[k])              # the step that last read buffer k has finished
+                bufs[k][0].copy_(h_rgbd, non_blocking=True)
+                bufs[k][1].copy_(h_scan, non_blocking=True)
+                ready[k].record(cstream)
+
+        def host_fed_steps(n):
+            enqueue_copy(0)
+            for i in range(n):
+                k = i & 1
+                if i + 1 < n:
+                    enqueue_copy(k ^ 1)
+                cur.wait_event(ready[k])
+                o = step(*bufs[k])
+                free[k].record(cur)
+            return o
+        for k in range(2):
+            free[k].record(cur)
+        host_fed_steps(2)
+        fence()
+        t1 = time.perf_counter()
+        out_h = host_fed_steps(args.steps)
+        fence()
+        el_h = dist_utils.max_over_ranks(time.perf_counter() - t1, device)
+        assert torch.equal(out_h["traversability_preds"], out["traversability_preds"])
+        host_fed = {"value": round(args.batch * args.gpus * args.steps / el_h, 3), "ms_per_step": round(el_h / args.steps * 1e3, 3),
+                    "h2d_bytes_per_step": int(h_rgbd.numel() * 4 + h_scan.numel() * 4),
+                    "note": "pinned host batch (RGB-D frames + LiDAR scan) -> device on a copy stream, two device buffers: "
+                            "the copy of batch k+1 overlaps the compute of batch k; the first copy of the timed region "
+                            "is exposed; outputs bit-identical to the resident run"}
+        del bufs, h_rgbd, h_scan
 
     modes = {}
     if args.gpus == 1 and not args.no_modes:
@@ -500,8 +579,8 @@ def main():
                                    "reward FCN), random-init weights",
                        "batch_per_gpu": args.batch, "image": [IMG_H, IMG_W], "lidar": [128, 1024],
                        "bev": [256, 256], "parallelism": f"{args.gpus} independent replicas (frame-sharded, no collective)",
-                       "inputs": "resident in HBM when the timed region starts (a host-resident batch of 189 MB would add "
-                                 "~3 ms per step over PCIe Gen5: excluded)"},
+                       "inputs": "resident in HBM when the timed region starts (`value`); `value_host_fed` = the same steps "
+                                 "with every 214 MB batch copied from pinned host memory inside the timed region"},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": round(PEAK[dprec], 1), "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK[dprec], 4), "traffic": traffic,
@@ -513,14 +592,28 @@ def main():
                                  "symbol in the timed steps / their HIP-event time; peak = dense peak of the MFMA "
                                  "instruction issued; mfma_issue_util counts the piece products actually issued"},
         }
+        sr = prof.splat_roofline()
+        if sr is not None:
+            line["roofline_splat"] = sr
+        if host_fed is not None:
+            line["value_host_fed"] = host_fed["value"]
+            line["host_fed"] = host_fed
         if modes:
             line["modes_frames_per_s"] = dict(modes, **{args.precision: line["value"]})
             line["modes_note"] = (f"every mode timed over the same {args.steps} steps after 1 warm-up; " +
                                   "; ".join(f"{k} = {v}" for k, v in DTYPE.items()))
             line["fp32_equivalent_frames_per_s"] = {k: line["modes_frames_per_s"][k] for k in ("f32", "bf16x6")}
+            line["narrower_than_fp32_frames_per_s"] = {k: line["modes_frames_per_s"][k] for k in ("f16x3", "bf16x3", "bf16")}
         if args.gpus == 1 and not args.no_irl:
             line["latency"] = latency_extras(model, device)
             line["irl"] = irl_extras(model, device)
+            vi = line["irl"]["vi_8x256x256"]
+            line["roofline_vi"] = {"bound": "hbm", "kernel": "creste_value_iteration_f32 (all sweeps + q / policy read-out)",
+                                   "achieved": vi["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": vi["frac_of_hbm_peak"], "ms": vi["ms"], "sweeps": vi["sweeps"], "traffic": None,
+                                   "note": "r ~ U[0,1) [8,256,256], gamma 0.99, threshold 1e-3; bytes = B*H*W*(12*sweeps + 72) "
+                                           "(SURVEY 8d: the HBM-streaming figure of a sweep-per-launch solver; the state is "
+                                           "LDS / L2 resident here, so the fraction may exceed 1)"}
             line["distill"] = distill_extras(device)
             line["ssc"] = ssc_extras(device)
         if args.gpus == 1 and not args.no_cpu_baseline:
