@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libcreste_hip.so")
 
-ABI_VERSION = 4          # creste_abi_version() of the library this binding was written against
+ABI_VERSION = 5          # creste_abi_version() of the library this binding was written against
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
 
@@ -23,12 +23,11 @@ class HipLibraryError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [("in_", C.c_void_p), ("wpk", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
                 ("a_scale", C.c_void_p), ("row_mask", C.c_void_p), ("out", C.c_void_p),
-                ("up_src", C.c_void_p)] + \
+                ("work", C.c_void_p)] + \
                [(n, C.c_int32) for n in ("N", "H", "W", "Cin", "in_cs", "Ho", "Wo", "Cout", "out_cs",
                                          "out_co", "res_cs", "KH", "KW", "stride", "pad_t", "pad_l",
-                                         "act", "prec", "up_H", "up_W", "up_C", "up_cs")] + \
-               [("up_rh", C.c_float), ("up_rw", C.c_float),
-                ("a_amax", C.c_void_p), ("out_amax", C.c_void_p), ("w_unscale", C.c_void_p)]
+                                         "act", "prec", "algo", "reserved0")] + \
+               [("a_amax", C.c_void_p), ("out_amax", C.c_void_p), ("w_unscale", C.c_void_p)]
 
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
@@ -39,7 +38,10 @@ SIGNATURES = {
     "creste_abi_version": (_i, []),
     "creste_conv2d_nhwc": (_i, [C.POINTER(ConvDesc), _vp]),
     "creste_conv_supported": (_i, [_i, _i, _i, _i]),
-    "creste_conv_supported_upsample": (_i, [_i, _i, _i, _i]),
+    "creste_conv_wino_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "creste_conv_wino_weight_bytes": (_i64, [_i, _i, _i]),
+    "creste_conv_wino_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "creste_conv_wino_workspace_bytes": (_i64, [_i, _i, _i, _i]),
     "creste_conv_packed_weight_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "creste_conv_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "creste_conv_pack_weight_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -190,7 +192,7 @@ def is_launch(name: str) -> bool:
     """Entry points that launch work on a stream: int return and a trailing void* stream (csrc/plan_dispatch.inc)."""
     res, args = SIGNATURES[name]
     return (res is _i and bool(args) and args[-1] is _vp and not name.startswith("creste_hip_model")
-            and name not in ("creste_conv_supported", "creste_conv_supported_upsample", "creste_se_partial_count"))
+            and name not in ("creste_conv_supported", "creste_se_partial_count"))
 
 
 def load(path: str | None = None):

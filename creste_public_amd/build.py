@@ -19,7 +19,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libcreste_hip.so")
 ARCH = "gfx950"
-SOURCES = ["error.cpp", "plan_runtime.cpp", "conv_igemm.hip", "conv_patch.hip", "pointwise.hip", "bev_splat.hip", "value_iteration.hip",
+SOURCES = ["error.cpp", "plan_runtime.cpp", "conv_igemm.hip", "conv_patch.hip", "conv_wino.hip", "pointwise.hip", "bev_splat.hip", "value_iteration.hip",
            "svf.hip", "planner.hip", "lidar.hip", "train.hip", "train_backbone.hip", "losses.hip", "labels.hip", "mbconv.hip", "supcon_mfma.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}",
          "-Wall", "-Wno-unused-function"]

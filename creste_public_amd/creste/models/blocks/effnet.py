@@ -215,10 +215,6 @@ class Up(nn.Module):
         return u[1](u[0](cat), out=out)
 
     def forward_act(self, x1: Act, x2: Act, out: Act = None) -> Act:
-        u = self._u()
-        if u[0].fuses_upsample():       # upsample + concat happen inside the first conv's loader
-            Ho, Wo, rh, rw = self._geom(x1, x2)
-            return u[1](u[0](x2, up=(x1, Ho, Wo, rh, rw)), out=out)
         return self.convs_act(self.concat_act(x1, x2), out=out)
 
     def forward(self, x1, x2):
@@ -230,6 +226,8 @@ class EffNet(nn.Module):
     def __init__(self, name, inC, outC, image_size, downsample, return_2nd_last_layer_output=True,
                  apply_final_batch_norm=False):
         super().__init__()
+        from ....hipnn import hook_invalidate
+        hook_invalidate(self)      # load_state_dict drops the packed / BN-folded weight caches (hipnn.invalidate_caches)
         if name != "efficientnet-b0":
             raise NotImplementedError
         self.trunk = EfficientNetB0Trunk(inC, image_size)

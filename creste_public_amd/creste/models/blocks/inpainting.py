@@ -24,6 +24,8 @@ class Inpainting(nn.Module):
 
     def __init__(self, input_key=None, output_prefix=None, learnable_loss_weight=False):
         super().__init__()
+        from ....hipnn import hook_invalidate
+        hook_invalidate(self)      # load_state_dict drops the packed / BN-folded weight caches (hipnn.invalidate_caches)
         self.input_key = input_key or "merged_bev_features"
         self.output_prefix = output_prefix or "inpainting"
         self.log_var = nn.Parameter(torch.tensor([0.0])) if learnable_loss_weight else None
@@ -91,10 +93,7 @@ class DeconvHead(nn.Module):
         c3, proj = self._units()
         sf, (rh, rw) = up_scales(self.up2[0].scale_factor)
         Ho, Wo = up_out_size(h.H, h.W, sf)
-        if c3.fuses_upsample():
-            feat = c3(None, up=(h, Ho, Wo, rh, rw))
-        else:
-            feat = c3(ops.upsample_concat(h, None, Ho, Wo, rh, rw))
+        feat = c3(ops.upsample_concat(h, None, Ho, Wo, rh, rw))
         return proj(feat, out=pred_out), feat
 
     def from_concat_act(self, cat: Act, pred_out: Act = None):
@@ -138,13 +137,12 @@ class InpaintingResNet18MultiHead(Inpainting):
         x1 = x
         for blk in list(self.layer2) + list(self.layer3):
             x = blk.forward_act(x)
-        fused = self.out_heads[0].up1._u()[0].fuses_upsample()
-        # un-fused engines: the x4-upsampled concat is identical for every head and is computed once
-        cat = None if fused else self.out_heads[0].up1.concat_act(x, x1)
+        # the x4-upsampled concat is identical for every head and is computed once
+        cat = self.out_heads[0].up1.concat_act(x, x1)
         ret, co = [], 0
         for head, n in zip(self.out_heads, self.num_classes):
             out = preds_buf.slice(co, n) if preds_buf is not None else None
-            pred, fea = head.forward_act(x, x1, pred_out=out) if fused else head.from_concat_act(cat, pred_out=out)
+            pred, fea = head.from_concat_act(cat, pred_out=out)
             ret.append(dict(preds=pred, features=fea))
             co += n
         return ret

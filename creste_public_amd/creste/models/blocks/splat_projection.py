@@ -42,6 +42,8 @@ class Camera2World(nn.Module):
 class Camera2MapMulti(nn.Module):
     def __init__(self, model_cfg, mode="bilinear", scatter_mode="mean"):
         super().__init__()
+        from ....hipnn import hook_invalidate
+        hook_invalidate(self)      # load_state_dict drops the packed / BN-folded weight caches (hipnn.invalidate_caches)
         self.model_cfg = model_cfg
         pcr = torch.tensor(model_cfg["point_cloud_range"])
         self.register_buffer("point_cloud_range", pcr)

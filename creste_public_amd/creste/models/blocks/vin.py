@@ -18,6 +18,8 @@ from .conv import MultiScaleFCN, _cfg_get
 class VIN(nn.Module):
     def __init__(self, reward_cfg, qvalue_cfg):
         super().__init__()
+        from ....hipnn import hook_invalidate
+        hook_invalidate(self)      # load_state_dict drops the packed / BN-folded weight caches (hipnn.invalidate_caches)
         self.reward_cfg, self.qvalue_cfg = reward_cfg, qvalue_cfg
         self.discount = _cfg_get(qvalue_cfg, "discount", 0.95)
         if reward_cfg["name"] != "MultiScaleFCN":

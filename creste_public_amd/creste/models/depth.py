@@ -16,6 +16,8 @@ from .vision_encoder import VisionEncoder
 class DepthCompletion(nn.Module):
     def __init__(self, model_cfg):
         super().__init__()
+        from ...hipnn import hook_invalidate
+        hook_invalidate(self)      # load_state_dict drops the packed / BN-folded weight caches (hipnn.invalidate_caches)
         self.vision_cfg = model_cfg["vision_backbone"]
         self.depth_cfg = model_cfg["depth_head"]
         self.discretize_cfg = model_cfg["discretize"]

@@ -9,6 +9,8 @@ from .blocks.effnet import EffNet
 class VisionEncoder(nn.Module):
     def __init__(self, vision_cfg):
         super().__init__()
+        from ...hipnn import hook_invalidate
+        hook_invalidate(self)      # load_state_dict drops the packed / BN-folded weight caches (hipnn.invalidate_caches)
         self.vision_cfg = vision_cfg
         self.input_type = vision_cfg["input_type"]
         self.name = vision_cfg["name"]

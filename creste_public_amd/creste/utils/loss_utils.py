@@ -104,14 +104,21 @@ class MaxEntIRLLoss(Loss):
     def _visitation_hip(self, exp_svf, gt, fov, tensor_dict):
         """The same on the device: the expert polylines and every sample's sub-optimal counterfactuals are rasterised
         by ONE launch each of csrc/planner.hip (max_steps per reference call = per group), masking / normalisation /
-        mixing by one launch of creste_irl_visitation_mix_f32 -- instead of ~12 tensor ops and a host sync per sample."""
+        mixing by one launch of creste_irl_visitation_mix_f32 -- instead of ~12 tensor ops and a host sync per sample.
+
+        Deviations from the host path (documented, both covered by tests/test_model_gpu.py): counterfactual vertices
+        arrive as numpy float64 and the reference keeps float64 through the /map_ds, clamp and .long(); here they are
+        rounded to float32 before the rasterisation (as the expert poses already are in the reference) -- a visited
+        cell can differ only for a sub-sampled point within one float32 ulp of a cell border.  Counterfactual sets of
+        different lengths in one batch are padded with their last vertex: a zero-length segment adds no sub-sampled
+        point other than that vertex and does not change max_steps, so the visitation maps are unchanged."""
         from ... import _lib
         from ...ops import _stream
         lib = _lib.load()
         dev = exp_svf.device
         H, W = self.map_sz
         B = exp_svf.shape[0]
-        xy = (gt if gt.ndim == 3 else gt[:, :, :2, 2]).detach().float().contiguous()
+        xy = (gt if gt.ndim == 3 else gt[:, :, :2, 2]).detach().to(dev).float().contiguous()
 
         def raster(xy_dev, group, ngroups):
             n, T = xy_dev.shape[0], xy_dev.shape[1]
@@ -137,9 +144,9 @@ class MaxEntIRLLoss(Loss):
                 ptr[i + 1] = ptr[i] + n
         visit_c = cf_ptr = None
         if sets:
-            Ts = {w.shape[1] for _, w in sets}
-            if len(Ts) != 1:
-                raise NotImplementedError("counterfactual trajectories of different lengths in one batch")
+            Tmax = max(w.shape[1] for _, w in sets)
+            sets = [(i, w if w.shape[1] == Tmax else np.concatenate([w, np.repeat(w[:, -1:], Tmax - w.shape[1], axis=1)], axis=1))
+                    for i, w in sets]
             allxy = torch.from_numpy(np.concatenate([w for _, w in sets], axis=0)).to(dev)
             group = torch.from_numpy(np.concatenate([np.full(w.shape[0], j, dtype=np.int32) for j, (_, w) in enumerate(sets)])).to(dev)
             visit_c = raster(allxy.contiguous(), group, len(sets))

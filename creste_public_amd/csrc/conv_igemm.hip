@@ -237,6 +237,17 @@ int conv_patch_pack(const float* w, const float* scale, void* wpk, float* w_unsc
                     int prec, hipStream_t s);
 int conv_patch_run(const creste_conv_desc* d, hipStream_t s);
 }  // namespace creste
+namespace creste {   // conv_wino.hip
+bool conv_wino_supported(int prec, int KH, int KW, int stride, int Cin, int Cout);
+int64_t conv_wino_weight_bytes(int Cout, int Cin, int prec);
+int conv_wino_pack(const float* w, const float* scale, void* wpk, int Cout, int Cin, int prec, hipStream_t s);
+int64_t conv_wino_workspace_bytes(int N, int Ho, int Wo, int Cout);
+int conv_wino_run(const creste_conv_desc* d, hipStream_t s);
+}  // namespace creste
+
+namespace creste {
+size_t conv_desc_bytes() { return sizeof(creste_conv_desc); }     // csrc/plan_runtime.cpp checks a plan file against it
+}
 
 using namespace creste;
 
@@ -245,9 +256,23 @@ extern "C" int creste_conv_supported(int prec, int KH, int KW, int stride) {
   return conv_patch_supported(prec, KH, KW, stride) ? 1 : 0;
 }
 
-extern "C" int creste_conv_supported_upsample(int prec, int KH, int KW, int stride) {
-  return prec != CRESTE_PREC_F32 && prec != CRESTE_PREC_F16X3 && KH == 3 && KW == 3 && stride == 1 &&
-         conv_patch_supported(prec, KH, KW, stride);
+extern "C" int creste_conv_wino_supported(int prec, int KH, int KW, int stride, int Cin, int Cout) {
+  return conv_wino_supported(prec, KH, KW, stride, Cin, Cout) ? 1 : 0;
+}
+
+extern "C" int64_t creste_conv_wino_weight_bytes(int Cout, int Cin, int prec) {
+  return conv_wino_supported(prec, 3, 3, 1, Cin, Cout) ? conv_wino_weight_bytes(Cout, Cin, prec) : -1;
+}
+
+extern "C" int creste_conv_wino_pack_weight(const float* w, const float* scale, void* wpk, int Cout, int Cin, int prec,
+                                            void* stream) {
+  CRESTE_REQUIRE(w && wpk && conv_wino_supported(prec, 3, 3, 1, Cin, Cout), "conv_wino_pack_weight: bad args / shape not built");
+  return conv_wino_pack(w, scale, wpk, Cout, Cin, prec, (hipStream_t)stream);
+}
+
+extern "C" int64_t creste_conv_wino_workspace_bytes(int N, int Ho, int Wo, int Cout) {
+  if (N <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0) return -1;
+  return conv_wino_workspace_bytes(N, Ho, Wo, Cout);
 }
 
 extern "C" int64_t creste_conv_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int prec) {
@@ -286,20 +311,14 @@ extern "C" int creste_conv_pack_weight_f16(const float* w, const float* scale, v
 
 extern "C" int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream) {
   CRESTE_REQUIRE(d != nullptr, "conv2d: null descriptor");
-  CRESTE_REQUIRE(d->wpk && d->out && (d->in || (d->up_src && d->up_C == d->Cin)), "conv2d: null tensor pointer");
-  if (d->up_src) {
-    CRESTE_REQUIRE(creste_conv_supported_upsample(d->prec, d->KH, d->KW, d->stride),
-                   "conv2d: fused upsample input is built for stride-1 3x3 convs on the bf16 MFMA engine only");
-    CRESTE_REQUIRE(d->up_C > 0 && d->up_C <= d->Cin && d->up_C % 4 == 0 && d->up_cs % 4 == 0 && d->up_cs >= d->up_C &&
-                       d->up_H > 0 && d->up_W > 0 && d->H < 65536 && d->W < 65536 && !d->a_scale,
-                   "conv2d: bad fused-upsample descriptor");
-  }
+  CRESTE_REQUIRE(d->wpk && d->out && d->in, "conv2d: null tensor pointer");
+  CRESTE_REQUIRE(d->algo == CRESTE_ALGO_DIRECT || d->algo == CRESTE_ALGO_WINOGRAD, "conv2d: unknown algo %d", d->algo);
   CRESTE_REQUIRE(d->prec == CRESTE_PREC_F32 || conv_patch_supported(d->prec, d->KH, d->KW, d->stride),
                  "conv2d: precision %d not built for %dx%d stride %d", d->prec, d->KH, d->KW, d->stride);
   CRESTE_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 &&
                      d->Wo > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0,
                  "conv2d: non-positive dimension");
-  CRESTE_REQUIRE(d->Cin % 4 == 0 && (!d->in || (d->in_cs % 4 == 0 && d->in_cs >= d->Cin - (d->up_src ? d->up_C : 0))),
+  CRESTE_REQUIRE(d->Cin % 4 == 0 && d->in_cs % 4 == 0 && d->in_cs >= d->Cin,
                  "conv2d: Cin (%d) and in_cs (%d) must be multiples of 4, in_cs >= Cin", d->Cin, d->in_cs);
   CRESTE_REQUIRE((reinterpret_cast<uintptr_t>(d->in) & 15) == 0, "conv2d: input not 16-byte aligned");
   CRESTE_REQUIRE(d->out_cs >= d->out_co + d->Cout, "conv2d: output slice exceeds out_cs");
@@ -318,6 +337,7 @@ extern "C" int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream) {
                  "conv2d: %dx%d input exceeds the row kernel's packed coordinate range", d->H, d->W);
   CRESTE_REQUIRE(d->prec != CRESTE_PREC_F16X3 || (d->a_amax && d->w_unscale),
                  "conv2d: F16X3 needs a_amax (device bound of |in|) and w_unscale (from creste_conv_pack_weight_f16)");
+  if (d->algo == CRESTE_ALGO_WINOGRAD) return conv_wino_run(d, (hipStream_t)stream);
   if (d->prec != CRESTE_PREC_F32) return conv_patch_run(d, (hipStream_t)stream);
   ConvArgs a;
   a.in = d->in; a.wpk = (const float*)d->wpk; a.bias = d->bias; a.res = d->res;

@@ -80,9 +80,6 @@ struct PatchArgs {
   const float* a_amax;       // F16X3: device upper bound of |in|
   float* out_amax;           // running max |out| (any precision), or nullptr
   const float* w_unscale;    // F16X3: [Cout] inverse weight scale
-  const float* up_src;       // fused bilinear upsample + concat source (3x3 kernel only), or nullptr
-  int up_H, up_W, up_C, up_cs;
-  float up_rh, up_rw;
   int N, H, W, Cin, in_cs;
   int Ho, Wo, Cout, out_cs, out_co, res_cs;
   int pad_t, pad_l;
@@ -400,12 +397,12 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
 //     steps of chunk c and written (with the bf16 split) between two barriers at the chunk boundary;
 //   => 4 barriers per 16-channel chunk instead of 9, 36 (bf16x3) MFMAs per wave per interval, 70 KB of
 //      LDS so two 8-wave workgroups share a CU and cover each other's barriers.
-// UP = the loader also forms the bilinear-upsample half of a concat input (separate instantiation: its
-// address arithmetic costs ~40 VGPRs, which the plain kernels at 128 VGPRs/lane cannot spare).
+// (A loader variant that formed cat([skip, bilinear_up(x)]) in place was built in round 1, measured slower than the
+// separate upsample_concat pass in every mode -- the 4-tap gather lands on the loader's critical path -- and removed.)
 // (the f16x3 128-channel tile takes the 256-register budget too: at 128 registers it spilled 52 bytes per lane -- same
 // box, batch-16 step 42.80 -> 42.62 ms)
-template <int SPLIT, int TN, bool F16, bool UP>
-__global__ __launch_bounds__(512, (SPLIT * TN >= 6 || (F16 && !UP && TN == 2)) ? 2 : PATCH_WAVES_PER_SIMD) void conv_patch3_kernel(const PatchArgs p) {
+template <int SPLIT, int TN, bool F16>
+__global__ __launch_bounds__(512, (SPLIT * TN >= 6 || (F16 && TN == 2)) ? 2 : PATCH_WAVES_PER_SIMD) void conv_patch3_kernel(const PatchArgs p) {
   typedef typename Piece<F16>::V8 V8;
   typedef typename Piece<F16>::V4 V4;
   constexpr int K = 3;
@@ -425,7 +422,7 @@ __global__ __launch_bounds__(512, (SPLIT * TN >= 6 || (F16 && !UP && TN == 2)) ?
   // 256-channel f16x3 tiles run one workgroup per CU anyway (118 KB): a SECOND halo-patch buffer (+22 KB) lets every
   // wave convert and store its prefetched patch rows right after the row step that loaded them -- the conversion VALU
   // work overlaps the other wave's MFMAs and the chunk-boundary barrier disappears (3 barriers per chunk, not 4)
-  constexpr bool DBA = F16 && !UP && TN == 4;
+  constexpr bool DBA = F16 && TN == 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const abuf0 = smem;
   char* const bbase = smem + (DBA ? 2 : 1) * A_BYTES;
@@ -458,38 +455,12 @@ __global__ __launch_bounds__(512, (SPLIT * TN >= 6 || (F16 && !UP && TN == 2)) ?
     const bool ok = pix < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
     a_yx[r] = ok ? (iy << 16) | ix : -1;
   }
-  const int c_skip = UP ? p.Cin - p.up_C : p.Cin;           // channels below this come from `in`
-  // plain kernels: BRANCH-FREE prefetch (see conv_patch_kernel) -- scale, gate and zeroing happen in store_a
+  // BRANCH-FREE prefetch (see conv_patch_kernel) -- scale, gate and zeroing happen in store_a
   auto load_a = [&](int r, int c) __attribute__((always_inline)) -> f32x4 {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const int ch = c * PT_CK + cq * 4;
-    if constexpr (!UP) {
-      const bool ok = a_yx[r] >= 0 && ch < p.Cin;
-      const int iy = a_yx[r] >> 16, ix = a_yx[r] & 0xffff;
-      return *reinterpret_cast<const f32x4*>(ok ? p.in + ((size_t)(img * p.H + iy) * p.W + ix) * p.in_cs + ch : p.in);
-    }
-    if (a_yx[r] >= 0 && ch < p.Cin) {
-      const int iy = a_yx[r] >> 16, ix = a_yx[r] & 0xffff;
-      if (!UP || ch < c_skip) {
-        v = *reinterpret_cast<const f32x4*>(p.in + ((size_t)(img * p.H + iy) * p.W + ix) * p.in_cs + ch);
-        if (p.a_scale) v *= *reinterpret_cast<const f32x4*>(p.a_scale + (size_t)img * p.Cin + ch);
-      } else if (UP) {
-        // fused nn.Upsample(bilinear, align_corners=False): PyTorch's source index rule
-        float sy = p.up_rh * ((float)iy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
-        float sx = p.up_rw * ((float)ix + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
-        const int y0 = (int)sy, x0 = (int)sx;
-        const int y1 = y0 + (y0 < p.up_H - 1 ? 1 : 0), x1 = x0 + (x0 < p.up_W - 1 ? 1 : 0);
-        const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
-        const float* b = p.up_src + (size_t)img * p.up_H * p.up_W * p.up_cs + (ch - c_skip);
-        const f32x4 v00 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * p.up_W + x0) * p.up_cs);
-        const f32x4 v01 = *reinterpret_cast<const f32x4*>(b + ((size_t)y0 * p.up_W + x1) * p.up_cs);
-        const f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * p.up_W + x0) * p.up_cs);
-        const f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((size_t)y1 * p.up_W + x1) * p.up_cs);
-        v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
-      }
-      if (F16) v *= a_mul;
-    }
-    return v;
+    const bool ok = a_yx[r] >= 0 && ch < p.Cin;
+    const int iy = a_yx[r] >> 16, ix = a_yx[r] & 0xffff;
+    return *reinterpret_cast<const f32x4*>(ok ? p.in + ((size_t)(img * p.H + iy) * p.W + ix) * p.in_cs + ch : p.in);
   };
   auto load_gate = [&](int c) __attribute__((always_inline)) -> f32x4 {
     const int ch = c * PT_CK + cq * 4;
@@ -499,12 +470,10 @@ __global__ __launch_bounds__(512, (SPLIT * TN >= 6 || (F16 && !UP && TN == 2)) ?
   auto store_a = [&](int r, int c, f32x4 v) __attribute__((always_inline)) {
     if (r * 128 + (tid >> 2) >= NPIX) return;
     char* dst = abuf0 + (DBA ? (c & 1) * A_BYTES : 0) + a_lofs0 + r * (128 * 16);
-    if constexpr (!UP) {
-      const bool ok = a_yx[r] >= 0 && c * PT_CK + cq * 4 < p.Cin;
-      if (p.a_scale) v *= gate;
-      if (F16) v *= a_mul;
-      if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    const bool ok = a_yx[r] >= 0 && c * PT_CK + cq * 4 < p.Cin;
+    if (p.a_scale) v *= gate;
+    if (F16) v *= a_mul;
+    if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 rem = v;
 #pragma unroll
     for (int pl = 0; pl < SPLIT; ++pl) {           // hi, then the bf16 of what is left, ...
@@ -539,7 +508,7 @@ __global__ __launch_bounds__(512, (SPLIT * TN >= 6 || (F16 && !UP && TN == 2)) ?
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   dma_row(0);
-  if (!UP && p.a_scale) gate = load_gate(0);
+  if (p.a_scale) gate = load_gate(0);
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) store_a(r, 0, load_a(r, 0));
   __syncthreads();
@@ -554,7 +523,7 @@ __global__ __launch_bounds__(512, (SPLIT * TN >= 6 || (F16 && !UP && TN == 2)) ?
     for (int ky = 0; ky < 3; ++ky, ++g) {
       if (g + 1 < nrows) dma_row(g + 1);
       if (more_a) ra[ky] = load_a(ky, c + 1);
-      if (!UP && ky == 0 && more_a && p.a_scale) gate = load_gate(c + 1);
+      if (ky == 0 && more_a && p.a_scale) gate = load_gate(c + 1);
       const char* Brow = bbase + (g & 1) * ROW_BYTES;
       __builtin_amdgcn_s_setprio(1);            // the matrix phase outranks the other wave's staging work (+0.7 %)
 #pragma unroll
@@ -590,7 +559,7 @@ __global__ __launch_bounds__(512, (SPLIT * TN >= 6 || (F16 && !UP && TN == 2)) ?
     }
   }
 
-  if constexpr (F16 && !UP) {
+  if constexpr (F16) {
     const bool vec_ok = (p.Cout & 3) == 0 && (p.out_cs & 3) == 0 && (p.out_co & 3) == 0 && (!p.res || (p.res_cs & 3) == 0);
     if (vec_ok) {
       patch_epilogue_lds<TN>(acc, p, img, oy0, ox0, tn * BN, wm, wn, lane, o_mul, reinterpret_cast<float*>(smem));
@@ -600,24 +569,16 @@ __global__ __launch_bounds__(512, (SPLIT * TN >= 6 || (F16 && !UP && TN == 2)) ?
   patch_epilogue<TN, F16>(acc, p, img, oy0, ox0, tn * BN, wm, wn, li, lh, o_mul, reinterpret_cast<float*>(smem));
 }
 
-template <int SPLIT, int TN, bool F16, bool UP>
-static int launch_patch3_up(const PatchArgs& a, hipStream_t s) {
-  constexpr int NPIXP = ((PT_TH + 2) * (PT_TW + 2) + 15) / 16 * 16;
-  constexpr int smem = ((F16 && !UP && TN == 4) ? 2 : 1) * SPLIT * 2 * NPIXP * 16 + 2 * 3 * (SPLIT * 2 * 64 * TN * 16);
-  static std::atomic<uint64_t> attr_devs{0};
-  if (smem > 64 * 1024) CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(conv_patch3_kernel<SPLIT, TN, F16, UP>), smem, attr_devs));
-  const int nblk = a.tiles_n * a.tiles_x * a.tiles_y * a.N;
-  conv_patch3_kernel<SPLIT, TN, F16, UP><<<nblk, 512, smem, s>>>(a);
-  CRESTE_CHECK_LAUNCH("conv_patch3");
-  return CRESTE_OK;
-}
-
 template <int SPLIT, int TN, bool F16>
 static int launch_patch3(const PatchArgs& a, hipStream_t s) {
-  if constexpr (!F16) {
-    if (a.up_src) return launch_patch3_up<SPLIT, TN, F16, true>(a, s);
-  }
-  return launch_patch3_up<SPLIT, TN, F16, false>(a, s);
+  constexpr int NPIXP = ((PT_TH + 2) * (PT_TW + 2) + 15) / 16 * 16;
+  constexpr int smem = ((F16 && TN == 4) ? 2 : 1) * SPLIT * 2 * NPIXP * 16 + 2 * 3 * (SPLIT * 2 * 64 * TN * 16);
+  static std::atomic<uint64_t> attr_devs{0};
+  if (smem > 64 * 1024) CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(conv_patch3_kernel<SPLIT, TN, F16>), smem, attr_devs));
+  const int nblk = a.tiles_n * a.tiles_x * a.tiles_y * a.N;
+  conv_patch3_kernel<SPLIT, TN, F16><<<nblk, 512, smem, s>>>(a);
+  CRESTE_CHECK_LAUNCH("conv_patch3");
+  return CRESTE_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -913,8 +874,6 @@ int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
   a.in = d->in; a.wpk = (const char*)d->wpk; a.bias = d->bias; a.res = d->res; a.a_scale = d->a_scale;
   a.row_mask = d->row_mask; a.out = d->out;
   a.a_amax = d->a_amax; a.out_amax = d->out_amax; a.w_unscale = d->w_unscale;
-  a.up_src = d->up_src; a.up_H = d->up_H; a.up_W = d->up_W; a.up_C = d->up_C; a.up_cs = d->up_cs;
-  a.up_rh = d->up_rh; a.up_rw = d->up_rw;
   a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_cs = d->in_cs;
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.out_cs = d->out_cs; a.out_co = d->out_co;
   a.res_cs = d->res_cs; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.act = d->act;
@@ -927,7 +886,7 @@ int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
   // consecutive pixels of the NHWC buffer, every linear pixel index (input, output, residual, row mask) is unchanged;
   // only the per-image squeeze-excite gate needs the pixel's image (gate_hw).  Same box, A/B in isolation: 192->1152 @19x38 x16
   // 152 -> 88 us, 1152->192 86 -> 65, 112->672 @38x76 155 -> 142
-  if (d->KH == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && !d->up_src && d->Ho == d->H && d->Wo == d->W) {
+  if (d->KH == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && d->Ho == d->H && d->Wo == d->W) {
     const long hw = (long)d->H * d->W, P = hw * d->N;
     const long padded = (long)a.tiles_x * a.tiles_y * PT_TH * PT_TW;
     if (P % PT_TW == 0 && padded * 100 > hw * 112 && P / PT_TW < (1L << 30) && hw < (1L << 30)) {

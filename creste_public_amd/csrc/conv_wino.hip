@@ -1,0 +1,419 @@
+// Winograd F(2x2,3x3) for the stride-1 3x3 convolutions, on the split-operand bf16 matrix cores.
+//
+// Why: the fp32-equivalent operand mode (bf16x6: every fp32 operand as three bf16 pieces, six piece products per
+// multiply) already runs the direct 3x3 kernel at the chip's power-limited MFMA ceiling (~1.3 PF of raw bf16 MFMA),
+// so the only lever left is FEWER matrix-core products per output.  F(2x2,3x3) computes a 2x2 output tile from a 4x4
+// input window with 16 multiplies per (cin, cout) pair instead of 36: MFMA work / 2.25, same product grade.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A            (Lavin & Gray; correlation form, as nn.Conv2d computes)
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]    G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]    A^T = [1 1 1 0; 0 1 -1 -1]
+//
+// Three pieces:
+//   wino_pack_kernel   U = G g G^T per (cout, cin) in float64 (BatchNorm scale folded), rounded once to fp32, split
+//                      into bf16 pieces and laid out as the LDS image of the GEMM's weight tiles (pack time).
+//   wino_gemm_kernel   the 16 transform positions are 16 independent GEMMs  M_p[tile, cout] = sum_cin V_p[tile, cin] *
+//                      U_p[cout, cin].  A workgroup owns (position p, 256 consecutive tiles, 64*TN couts).  Every row
+//                      of B^T has exactly two non-zeros (+-1), so V_p[tile, cin] = +-d[i1][j1] +-d[i1][j2] +-d[i2][j1]
+//                      +-d[i2][j2]: the loader forms it from FOUR raw fp32 quads of the NHWC input (no transformed
+//                      tensor ever exists in HBM: it would be 4x the input, 6x with the split), splits it into the
+//                      bf16 pieces and stages it as the A operand; the weight tiles arrive by LDS-DMA.  The 16
+//                      position-workgroups of a tile block sit next to each other in the launch order of one XCD, so
+//                      the raw input is fetched from HBM once and re-read from that XCD's L2.
+//   wino_out_kernel    Y = A^T M A per (tile, channel quad) + bias + residual + activation + row mask + running |max|
+//                      (the direct kernels' epilogue), reading the 16 fp32 products from the workspace.
+// Accumulation is fp32 throughout; the transforms are fp32 adds of at most four terms (input) / float64 (weights).
+#include "common.h"
+
+namespace creste {
+
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+typedef float wf32x16 __attribute__((ext_vector_type(16)));
+typedef float wf32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WN_M = 256;     // tiles (GEMM rows) per workgroup
+constexpr int WN_CK = 16;     // input channels per step = K of one MFMA
+
+// rows of B^T: V[xi] = s1 * d[i1] + s2 * d[i2]
+__device__ __constant__ int kWinoI1[4] = {0, 1, 1, 1};
+__device__ __constant__ int kWinoI2[4] = {2, 2, 2, 3};
+__device__ __constant__ float kWinoS1[4] = {1.f, 1.f, -1.f, 1.f};
+__device__ __constant__ float kWinoS2[4] = {-1.f, 1.f, 1.f, -1.f};
+
+struct WinoArgs {
+  const float* in;
+  const char* wpk;
+  float* M;                  // [16][T][Cout]
+  int N, H, W, Cin, in_cs;
+  int Cout;
+  int tiles_y, tiles_x, T;   // 2x2 output tiles per image column / row, total tiles N*tiles_y*tiles_x
+  int pad_t, pad_l;
+  int nchunk, m_blocks, tiles_n, units;
+};
+
+template <int SPLIT>
+__device__ __forceinline__ wf32x16 wino_split_mfma(const wbf16x8 (&a)[SPLIT], const wbf16x8 (&b)[SPLIT], wf32x16 c) {
+#pragma unroll
+  for (int order = SPLIT - 1; order >= 0; --order)      // smallest piece products first
+#pragma unroll
+    for (int pa = order; pa >= 0; --pa) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[order - pa], c, 0, 0, 0);
+  return c;
+}
+
+template <int SPLIT, int TN>
+__global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoArgs p) {
+  constexpr int A_OCT = WN_M * 16, A_PLANE = 2 * A_OCT, A_BYTES = SPLIT * A_PLANE;       // [piece][k-octet][row][8 bf16]
+  constexpr int U_OCT = 64 * 16, U_PLANE = 2 * U_OCT, U_BYTES = SPLIT * U_PLANE;         // one 64-cout weight unit
+  constexpr int B_BYTES = TN * U_BYTES, B_INSTR = B_BYTES / 1024;
+  constexpr int NT = TN;                       // 32-cout MFMA tiles per wave: the wave pair splits the 64*TN couts
+  static_assert(B_BYTES % 1024 == 0, "weight tile must be whole 1 KiB DMA pieces");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const abase = smem;                    // two A buffers, then two B buffers
+  char* const bbase = smem + 2 * A_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;     // 4 row groups of 64 tiles x 2 channel halves
+  const int li = lane & 31, lh = lane >> 5;
+
+  // launch order: channel tile fastest, then the 16 positions, then the tile block -- the 16 * tiles_n workgroups that
+  // read one tile block's raw input are consecutive on one XCD (private L2)
+  const int nblk = p.m_blocks * 16 * p.tiles_n;
+  int id = xcd_remap(blockIdx.x, nblk);
+  const int tn = id % p.tiles_n; id /= p.tiles_n;
+  const int pos = id & 15;
+  const int mb = id >> 4;
+  const int xi = pos >> 2, nu = pos & 3;
+  const int iy1 = kWinoI1[xi], iy2 = kWinoI2[xi], ix1 = kWinoI1[nu], ix2 = kWinoI2[nu];
+  const float sy1 = kWinoS1[xi], sy2 = kWinoS2[xi], sx1 = kWinoS1[nu], sx2 = kWinoS2[nu];
+
+  // ---- per-thread A staging slots (fixed over chunks): rows r = tid/4 + 128 j, channel quad cq
+  const int cq = tid & 3;
+  const int a_lofs0 = (cq >> 1) * A_OCT + (tid >> 2) * 16 + (cq & 1) * 8;     // + j * 128 * 16
+  int off[2][4];             // element offsets of the four raw pixels (y1x1, y1x2, y2x1, y2x2), -1 = zero
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = mb * WN_M + j * 128 + (tid >> 2);
+    const bool ok = m < p.T;
+    const int per = p.tiles_y * p.tiles_x;
+    const int img = m / per, rem = m - img * per;
+    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    const int y0 = 2 * ty - p.pad_t, x0 = 2 * tx - p.pad_l;
+    const int ys[2] = {y0 + iy1, y0 + iy2}, xs[2] = {x0 + ix1, x0 + ix2};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const bool in = ok && (unsigned)ys[a] < (unsigned)p.H && (unsigned)xs[b] < (unsigned)p.W;
+        off[j][a * 2 + b] = in ? ((img * p.H + ys[a]) * p.W + xs[b]) * p.in_cs : -1;
+      }
+  }
+  // BRANCH-FREE prefetch (a predicated global load compiles to a branch with an s_waitcnt behind it): an absent pixel
+  // reads the tensor's first quad and is zeroed when the value is combined
+  auto load_a = [&](int j, int k, int c) __attribute__((always_inline)) -> wf32x4 {
+    const int ch = c * WN_CK + cq * 4;
+    const bool ok = off[j][k] >= 0 && ch < p.Cin;
+    return *reinterpret_cast<const wf32x4*>(ok ? p.in + (size_t)off[j][k] + ch : p.in);
+  };
+  auto store_a = [&](int j, int c, const wf32x4 (&d)[4], char* buf) __attribute__((always_inline)) {
+    const bool chok = c * WN_CK + cq * 4 < p.Cin;
+    wf32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d0 = (chok && off[j][0] >= 0) ? d[0][e] : 0.f, d1 = (chok && off[j][1] >= 0) ? d[1][e] : 0.f;
+      const float d2 = (chok && off[j][2] >= 0) ? d[2][e] : 0.f, d3 = (chok && off[j][3] >= 0) ? d[3][e] : 0.f;
+      // multiplications by +-1 are exact: each fma is ONE rounding of a two-term sum
+      const float r1 = __fmaf_rn(d1, sx2, d0 * sx1), r2 = __fmaf_rn(d3, sx2, d2 * sx1);
+      v[e] = __fmaf_rn(r2, sy2, r1 * sy1);
+    }
+    char* dst = buf + a_lofs0 + j * (128 * 16);
+    wf32x4 rem = v;
+#pragma unroll
+    for (int pl = 0; pl < SPLIT; ++pl) {           // hi, then the bf16 of what is left, ...
+      const wbf16x4 piece = __builtin_convertvector(rem, wbf16x4);
+      *reinterpret_cast<wbf16x4*>(dst + pl * A_PLANE) = piece;
+      if (pl + 1 < SPLIT) rem -= __builtin_convertvector(piece, wf32x4);
+    }
+  };
+  // weight tile of chunk c: per 64-cout unit U_BYTES contiguous bytes, copied by LDS-DMA in 1 KiB pieces
+  const char* wbase = p.wpk + ((size_t)pos * p.units + (size_t)tn * TN) * p.nchunk * U_BYTES;
+  auto dma_b = [&](int c) __attribute__((always_inline)) {
+    char* dst = bbase + (c & 1) * B_BYTES;
+#pragma unroll
+    for (int jj = 0; jj < (B_INSTR + 7) / 8; ++jj) {
+      const int i = wave + 8 * jj;
+      if (i < B_INSTR) {
+        const int u = i / (U_BYTES / 1024), r = i % (U_BYTES / 1024);
+        const char* src = wbase + ((size_t)u * p.nchunk + c) * U_BYTES + r * 1024 + lane * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  wf32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- prologue: chunk 0
+  dma_b(0);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    wf32x4 d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = load_a(j, k, 0);
+    store_a(j, 0, d, abase);
+  }
+  __syncthreads();
+
+  for (int c = 0; c < p.nchunk; ++c) {
+    const char* A = abase + (c & 1) * A_BYTES;
+    const char* B = bbase + (c & 1) * B_BYTES;
+    char* Anext = abase + ((c + 1) & 1) * A_BYTES;
+    const bool more = c + 1 < p.nchunk;
+    wf32x4 ra[2][4];
+    if (more) {
+      dma_b(c + 1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ra[j][k] = load_a(j, k, c + 1);
+    }
+    // ---- MFMAs of chunk c: weights as the first operand (D = U * V^T: a lane owns one tile, its registers the couts)
+    wbf16x8 af[2][SPLIT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = wm * 64 + mt * 32 + li;
+#pragma unroll
+      for (int pl = 0; pl < SPLIT; ++pl)
+        af[mt][pl] = *reinterpret_cast<const wbf16x8*>(A + pl * A_PLANE + lh * A_OCT + row * 16);
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      wbf16x8 bfr[SPLIT];
+      const int n = (wn * NT + nt) * 32 + li;
+#pragma unroll
+      for (int pl = 0; pl < SPLIT; ++pl)
+        bfr[pl] = *reinterpret_cast<const wbf16x8*>(B + (n >> 6) * U_BYTES + pl * U_PLANE + lh * U_OCT + (n & 63) * 16);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = wino_split_mfma<SPLIT>(bfr, af[mt], acc[mt][nt]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) store_a(j, c + 1, ra[j], Anext);
+    }
+    __syncthreads();       // chunk c consumed by every wave; chunk c+1 staged (ds writes + DMA drained)
+  }
+
+  // ---- products to the workspace: M[pos][tile][cout].  Lane = tile, registers 4g..4g+3 = four consecutive couts: one
+  // 16-byte store; the eight stores of a wave that share a 128-byte line are issued back to back
+  float* Mp = p.M + (size_t)pos * p.T * p.Cout;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int m = mb * WN_M + wm * 64 + mt * 32 + li;
+    if (m >= p.T) continue;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = tn * (64 * TN) + (wn * NT + nt) * 32 + 8 * g + 4 * lh;
+        if (n < p.Cout)
+          *reinterpret_cast<wf32x4*>(Mp + (size_t)m * p.Cout + n) =
+              wf32x4{acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+      }
+  }
+}
+
+struct WinoOutArgs {
+  const float* M;
+  const float* bias;
+  const float* res;
+  const float* row_mask;
+  float* out;
+  float* out_amax;
+  int N, Ho, Wo, Cout, out_cs, out_co, res_cs, act;
+  int tiles_y, tiles_x, T;
+};
+
+// thread = (tile, channel quad): 16 x 16-byte loads (one per transform position, each coalesced over the channel
+// quads of a tile), 24 vector adds, the epilogue, four 16-byte stores
+__global__ __launch_bounds__(256) void wino_out_kernel(const WinoOutArgs p) {
+  __shared__ float scratch[4];
+  const int q4 = p.Cout >> 2;
+  const long idx = blockIdx.x * 256L + threadIdx.x;
+  const bool valid = idx < (long)p.T * q4;
+  const int tile = valid ? (int)(idx / q4) : 0;
+  const int n = valid ? (int)(idx - (long)tile * q4) * 4 : 0;
+  float vmax = 0.f;
+  if (valid) {
+    wf32x4 m[16];
+    const float* src = p.M + (size_t)tile * p.Cout + n;
+    const size_t plane = (size_t)p.T * p.Cout;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m[k] = __builtin_nontemporal_load(reinterpret_cast<const wf32x4*>(src + k * plane));
+    wf32x4 t[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      t[r][0] = (m[4 * r] + m[4 * r + 1]) + m[4 * r + 2];
+      t[r][1] = (m[4 * r + 1] - m[4 * r + 2]) - m[4 * r + 3];
+    }
+    wf32x4 y[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      y[0][j] = (t[0][j] + t[1][j]) + t[2][j];
+      y[1][j] = (t[1][j] - t[2][j]) - t[3][j];
+    }
+    const int per = p.tiles_y * p.tiles_x;
+    const int img = tile / per, rem = tile - img * per;
+    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    const wf32x4 bs = p.bias ? *reinterpret_cast<const wf32x4*>(p.bias + n) : wf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int oy = 2 * ty + i, ox = 2 * tx + j;
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        const long mrow = ((long)img * p.Ho + oy) * p.Wo + ox;
+        wf32x4 v = y[i][j] + bs;
+        if (p.res) v += *reinterpret_cast<const wf32x4*>(p.res + mrow * p.res_cs + n);
+        const float rmask = p.row_mask ? p.row_mask[mrow] : 1.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = act_apply(v[e], p.act) * rmask;
+          vmax = fmaxf(vmax, fabsf(v[e]));
+        }
+        *reinterpret_cast<wf32x4*>(p.out + mrow * p.out_cs + p.out_co + n) = v;
+      }
+  }
+  if (p.out_amax) block_amax_update(vmax, p.out_amax, scratch);
+}
+
+// U = G g G^T in float64 from the OIHW fp32 weights (x BatchNorm scale, applied in fp32 as the direct packers do),
+// rounded once to fp32, split into bf16 pieces: [pos][unit][chunk][piece][k-octet][64][8]
+__global__ void wino_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, __bf16* __restrict__ out,
+                                 int Cout, int Cin, int units, int nchunk, int split) {
+  const long total = (long)units * 64 * nchunk * WN_CK;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % (nchunk * WN_CK)), co = (int)(i / (nchunk * WN_CK));
+    double g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        float v = 0.f;
+        if (co < Cout && ci < Cin) {
+          v = w[(((long)co * Cin + ci) * 3 + a) * 3 + b];
+          if (scale) v *= scale[co];
+        }
+        g[a][b] = (double)v;
+      }
+    double Gg[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      Gg[0][b] = g[0][b];
+      Gg[1][b] = 0.5 * (g[0][b] + g[1][b] + g[2][b]);
+      Gg[2][b] = 0.5 * (g[0][b] - g[1][b] + g[2][b]);
+      Gg[3][b] = g[2][b];
+    }
+    const int unit = co >> 6, nn = co & 63, c = ci / WN_CK, oct = (ci % WN_CK) >> 3, e = ci & 7;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const double u4[4] = {Gg[a][0], 0.5 * (Gg[a][0] + Gg[a][1] + Gg[a][2]), 0.5 * (Gg[a][0] - Gg[a][1] + Gg[a][2]), Gg[a][2]};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int pos = a * 4 + b;
+        float v = (float)u4[b];
+        __bf16* dst = out + ((((size_t)pos * units + unit) * nchunk + c) * split) * (2 * 64 * 8) + (size_t)oct * 64 * 8 + nn * 8 + e;
+        for (int pl = 0; pl < split; ++pl) {
+          const __bf16 piece = (__bf16)v;
+          dst[(size_t)pl * (2 * 64 * 8)] = piece;
+          v -= (float)piece;
+        }
+      }
+    }
+  }
+}
+
+static inline int wino_split(int prec) {
+  return prec == CRESTE_PREC_BF16X6 ? 3 : (prec == CRESTE_PREC_BF16X3 ? 2 : (prec == CRESTE_PREC_BF16 ? 1 : 0));
+}
+static inline int wino_units(int Cout) { return ((Cout + 63) / 64 + 3) / 4 * 4; }       // padded to the widest tile (TN = 4)
+
+bool conv_wino_supported(int prec, int KH, int KW, int stride, int Cin, int Cout) {
+  return wino_split(prec) > 0 && KH == 3 && KW == 3 && stride == 1 && Cin > 0 && Cout > 0 && Cin % 4 == 0 && Cout % 4 == 0;
+}
+
+int64_t conv_wino_weight_bytes(int Cout, int Cin, int prec) {
+  const long nchunk = (Cin + WN_CK - 1) / WN_CK;
+  return 16L * wino_units(Cout) * nchunk * wino_split(prec) * 2 * 64 * 16;
+}
+
+int conv_wino_pack(const float* w, const float* scale, void* wpk, int Cout, int Cin, int prec, hipStream_t s) {
+  const int units = wino_units(Cout), nchunk = (Cin + WN_CK - 1) / WN_CK;
+  const long total = (long)units * 64 * nchunk * WN_CK;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  wino_pack_kernel<<<blocks, 256, 0, s>>>(w, scale, (__bf16*)wpk, Cout, Cin, units, nchunk, wino_split(prec));
+  CRESTE_CHECK_LAUNCH("wino_pack");
+  return CRESTE_OK;
+}
+
+int64_t conv_wino_workspace_bytes(int N, int Ho, int Wo, int Cout) {
+  return 16L * N * ((Ho + 1) / 2) * ((Wo + 1) / 2) * Cout * 4;
+}
+
+template <int SPLIT, int TN>
+static int launch_wino_gemm(const WinoArgs& a, hipStream_t s) {
+  constexpr int smem = 2 * (SPLIT * 2 * WN_M * 16) + 2 * (TN * SPLIT * 2 * 64 * 16);
+  static std::atomic<uint64_t> attr_devs{0};
+  if (smem > 64 * 1024) CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino_gemm_kernel<SPLIT, TN>), smem, attr_devs));
+  wino_gemm_kernel<SPLIT, TN><<<a.m_blocks * 16 * a.tiles_n, 512, smem, s>>>(a);
+  CRESTE_CHECK_LAUNCH("wino_gemm");
+  return CRESTE_OK;
+}
+
+int conv_wino_run(const creste_conv_desc* d, hipStream_t s) {
+  CRESTE_REQUIRE(conv_wino_supported(d->prec, d->KH, d->KW, d->stride, d->Cin, d->Cout),
+                 "conv2d: the Winograd path is built for stride-1 3x3 convs in the bf16 split modes, Cin and Cout multiples of 4");
+  CRESTE_REQUIRE(d->work && !d->a_scale, "conv2d: the Winograd path needs its workspace and takes no per-sample input gate");
+  CRESTE_REQUIRE((d->out_cs & 3) == 0 && (d->out_co & 3) == 0 && (!d->res || (d->res_cs & 3) == 0) &&
+                     (reinterpret_cast<uintptr_t>(d->out) & 15) == 0,
+                 "conv2d: the Winograd path needs 16-byte aligned output / residual channel slices");
+  CRESTE_REQUIRE((long)d->N * d->H * d->W * d->in_cs < (1L << 31), "conv2d: the Winograd loader indexes the input with 32 bits");
+  WinoArgs a;
+  a.in = d->in; a.wpk = (const char*)d->wpk; a.M = (float*)d->work;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_cs = d->in_cs; a.Cout = d->Cout;
+  a.tiles_y = (d->Ho + 1) / 2; a.tiles_x = (d->Wo + 1) / 2;
+  const long T = (long)d->N * a.tiles_y * a.tiles_x;
+  CRESTE_REQUIRE(T * 16 * d->Cout < (1L << 40) && T < (1L << 27), "conv2d: Winograd workspace too large");
+  a.T = (int)T;
+  a.pad_t = d->pad_t; a.pad_l = d->pad_l;
+  a.nchunk = (d->Cin + WN_CK - 1) / WN_CK;
+  a.m_blocks = (int)((T + WN_M - 1) / WN_M);
+  a.units = wino_units(d->Cout);
+  // 256-cout tiles where the layer has them, else 128 (a 64-wide tile would amortise the loader's transform over too few products)
+  const int tn = d->Cout > 128 ? 4 : 2;
+  a.tiles_n = (d->Cout + 64 * tn - 1) / (64 * tn);
+  const int split = wino_split(d->prec);
+  int rc;
+  if (tn == 4) rc = split == 3 ? launch_wino_gemm<3, 4>(a, s) : split == 2 ? launch_wino_gemm<2, 4>(a, s) : launch_wino_gemm<1, 4>(a, s);
+  else rc = split == 3 ? launch_wino_gemm<3, 2>(a, s) : split == 2 ? launch_wino_gemm<2, 2>(a, s) : launch_wino_gemm<1, 2>(a, s);
+  if (rc != CRESTE_OK) return rc;
+  WinoOutArgs o;
+  o.M = a.M; o.bias = d->bias; o.res = d->res; o.row_mask = d->row_mask; o.out = d->out; o.out_amax = d->out_amax;
+  o.N = d->N; o.Ho = d->Ho; o.Wo = d->Wo; o.Cout = d->Cout; o.out_cs = d->out_cs; o.out_co = d->out_co; o.res_cs = d->res_cs;
+  o.act = d->act; o.tiles_y = a.tiles_y; o.tiles_x = a.tiles_x; o.T = a.T;
+  const long nthreads = T * (d->Cout / 4);
+  wino_out_kernel<<<(unsigned)((nthreads + 255) / 256), 256, 0, s>>>(o);
+  CRESTE_CHECK_LAUNCH("wino_out");
+  return CRESTE_OK;
+}
+
+}  // namespace creste

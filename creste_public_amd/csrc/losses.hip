@@ -341,6 +341,10 @@ __device__ __forceinline__ int bce_label(const float* __restrict__ gt, int Cg, l
 }
 
 // MODE 0: partial sums (w*nll, w, correct, labelled);  MODE 1: gradient (needs out4[2] = sum of weights)
+// A label outside [0, C) that is not ignore_index (a 255 "unlabelled" value without ignore_index, a negative / NaN float
+// label, distribution labels with more channels than classes) never indexes pred / class_weights: the pixel is skipped
+// in the gradient and the LOSS becomes NaN -- torch.nn.CrossEntropyLoss raises a device assert for the same input; a
+// silent finite loss would hide the bad label (tests/test_train_terrain_gpu.py::test_bev_ce_rejects_out_of_range_labels)
 template <int MODE>
 __global__ __launch_bounds__(256) void bev_ce_kernel(const float* __restrict__ pred, int cs, int C,
                                                      const float* __restrict__ gt, int Cg, long HW, long P,
@@ -360,6 +364,10 @@ __global__ __launch_bounds__(256) void bev_ce_kernel(const float* __restrict__ p
     if (in) {
       y = bce_label(gt, Cg, HW, p, class_dim, eps);
       use = y != ignore_index;
+      if (use && (y < 0 || y >= C)) {
+        use = false;
+        if (MODE == 0) a0 = __int_as_float(0x7fc00000);
+      }
       for (int c = 0; c < C; ++c) { const float v = x[c]; if (v > mx) { mx = v; am = c; } }
       for (int c = 0; c < C; ++c) se += expf(x[c] - mx);
     }

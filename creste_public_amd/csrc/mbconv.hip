@@ -499,6 +499,9 @@ extern "C" int creste_stem_dw_f32(const float* x, int N, int H, int W, const flo
   CRESTE_REQUIRE(stem_plan(N, H1, W1, C1, &p), "stem_dw: %d stem channels not built (multiple of 4 dividing 1024, <= 64)", C1);
   StemArgs a{x, w_stem, b_stem, w_dw, b_dw, out, partial, out_amax, H, W, C1, H1, W1, pad_t, pad_l, dpad_t, dpad_l,
              p.rows_per_band, p.nbands, p.nstrips};
+  static std::atomic<uint64_t> stem_devs{0};
+  if (p.smem > 64 * 1024)      // C1 = 64: 67.7 KB of dynamic LDS needs the per-device opt-in (the shipped stem, C1 = 32, does not)
+    CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(stem_dw_kernel<STEM_TW>), (int)p.smem, stem_devs));
   stem_dw_kernel<STEM_TW><<<dim3(p.nstrips * p.nbands, N), 256, p.smem, (hipStream_t)stream>>>(a);
   CRESTE_CHECK_LAUNCH("stem_dw");
   return CRESTE_OK;

@@ -21,7 +21,9 @@
 
 namespace creste {
 void set_error(const char* fmt, ...);
+size_t conv_desc_bytes();            // sizeof(creste_conv_desc) of this build (csrc/conv_igemm.hip)
 }
+extern "C" int creste_abi_version(void);
 
 namespace {
 
@@ -35,6 +37,7 @@ union PlanArg {
 struct PlanFn {
   const char* name;
   int nargs;
+  const char* sig;                 // one character per argument: i / l / f / d scalars, p pointer, D creste_conv_desc
   int (*call)(const PlanArg*, void*);
 };
 
@@ -135,7 +138,16 @@ extern "C" int creste_hip_model_load(const char* path, int flags, void** handle)
   r.bytes(magic, 12);
   if (!r.ok || memcmp(magic, "CRESTEPLAN\0\0", 12) != 0) PLAN_FAIL("model_load: %s is not a creste plan file", path);
   const uint32_t version = r.get<uint32_t>(), desc_size = r.get<uint32_t>();
-  if (version != 1) PLAN_FAIL("model_load: plan format version %u, this library reads 1", version);
+  if (version != 2) PLAN_FAIL("model_load: plan format version %u, this library reads 2", version);
+  // the recorded arguments are only meaningful to the library generation that recorded them: same C ABI, same
+  // descriptor layout (a plan from another ABI would hand creste_conv2d_nhwc a short or mis-laid-out descriptor)
+  const uint32_t abi = r.get<uint32_t>();
+  if (!r.ok || (int)abi != creste_abi_version())
+    PLAN_FAIL("model_load: the plan was exported for C-ABI version %u, this library is version %d: re-export it", abi,
+              creste_abi_version());
+  if (desc_size != creste::conv_desc_bytes())
+    PLAN_FAIL("model_load: the plan's conv descriptor is %u bytes, this library's creste_conv_desc is %zu", desc_size,
+              creste::conv_desc_bytes());
   m->info = r.str();
   const uint32_t nseg = r.get<uint32_t>();
   if (!r.ok || nseg > 4096) PLAN_FAIL("model_load: corrupt header");
@@ -214,6 +226,10 @@ extern "C" int creste_hip_model_load(const char* path, int flags, void** handle)
     call.args.resize(na);
     for (uint32_t a = 0; a < na; ++a) {
       const uint32_t kind = r.get<uint32_t>();
+      static const char kKindChar[] = {'i', 'l', 'f', 'd', 'p', 'D'};
+      if (!r.ok || kind > K_DESC || kKindChar[kind] != call.fn->sig[a])
+        PLAN_FAIL("model_load: call %u (%s) argument %u has kind %u, the entry point takes '%c'", c, call.fn->name, a, kind,
+                  call.fn->sig[a]);
       PlanArg& v = call.args[a];
       v.l = 0;
       if (kind == K_I32) v.i = r.get<int32_t>();

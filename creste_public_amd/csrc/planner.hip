@@ -115,7 +115,13 @@ extern "C" int creste_trajectory_scores_grouped_f32(const float* xy, int N, int 
   CRESTE_REQUIRE(xy && scores && work && (costmap || visit), "trajectory_scores: null pointer");
   CRESTE_REQUIRE(n_groups >= 1 && (group || n_groups == 1), "trajectory_scores: bad grouping");
   CRESTE_REQUIRE(N > 0 && T >= 1 && H > 0 && W > 0 && map_ds > 0.f, "trajectory_scores: bad dims");
-  CRESTE_REQUIRE((long)H * W <= 1179648, "trajectory_scores: grid %dx%d does not fit the LDS bitmap", H, W);
+  // one bit per cell in LDS: bounded by what THIS device grants a workgroup (160 KiB on gfx950)
+  int dev = 0, lds_max = 0;
+  CRESTE_HIP(hipGetDevice(&dev));
+  CRESTE_HIP(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+  const long max_cells = (long)(lds_max < 147456 ? lds_max : 147456) * 8;
+  CRESTE_REQUIRE((long)H * W <= max_cells, "trajectory_scores: grid %dx%d does not fit the %d-byte LDS bitmap of this device", H,
+                 W, (int)(max_cells / 8));
   hipStream_t s = (hipStream_t)stream;
   CRESTE_HIP(hipMemsetAsync(work, 0, sizeof(int) * (size_t)n_groups, s));
   if (T > 1) {

@@ -110,7 +110,7 @@ def load(path: str, device="cuda:0", example_inputs=None) -> CompiledModel:
 # reference scripts/runtime/compile.py:160-210 (torch.jit.trace -> a module the C++ stack loads without Python).
 PLAN_MAGIC = b"CRESTEPLAN\0\0"
 _DTYPES = {torch.float32: 0, torch.int64: 1, torch.uint8: 2, torch.bool: 2}
-_DESC_PTR_FIELDS = ("in_", "wpk", "bias", "res", "a_scale", "row_mask", "out", "up_src", "a_amax", "out_amax", "w_unscale")
+_DESC_PTR_FIELDS = ("in_", "wpk", "bias", "res", "a_scale", "row_mask", "out", "work", "a_amax", "out_amax", "w_unscale")
 
 
 def _snapshot(device):
@@ -240,7 +240,7 @@ def export_plan(model: torch.nn.Module, example_inputs, path: str, warmup: int =
     seg_sizes = [None] * len(used_segments)
     for i, si in used_segments.items():
         seg_sizes[si] = after[i][1]
-    blob = [PLAN_MAGIC, struct.pack("<II", 1, C.sizeof(_lib.ConvDesc)), s_(info), struct.pack("<I", len(seg_sizes))]
+    blob = [PLAN_MAGIC, struct.pack("<III", 2, C.sizeof(_lib.ConvDesc), _lib.ABI_VERSION), s_(info), struct.pack("<I", len(seg_sizes))]
     blob += [struct.pack("<Q", sz) for sz in seg_sizes]
     for group in (inputs, outputs):
         blob.append(struct.pack("<I", len(group)))

@@ -200,6 +200,12 @@ class HookedArena:
             h.wait()
         if is_dist():
             self.flat /= dist.get_world_size()
+        else:
+            # one process: a parameter no gradient reached keeps `.grad = None`, as plain autograd leaves it, so the
+            # optimiser skips it (under a process group it contributes zeros to the average: DDP semantics)
+            for p, fin in zip(self.order, self.finished):
+                if not fin:
+                    p.grad = None
         return self
 
     def close(self):

@@ -15,11 +15,9 @@ from . import ops
 from .ops import ACT_NONE, ACT_RELU, ACT_SWISH, Act, HipLibraryError  # noqa: F401
 
 
-# The 3x3 patch kernel can form cat([skip, bilinear_up(x1)]) inside its loader (tested in
-# tests/test_kernels_gpu.py).  Measured on MI355X it LOSES to the separate upsample_concat pass
-# (bf16x6 222.6 -> 218.5 frames/s, bf16 484 -> 388): the 4-tap gather sits on the loader's critical path
-# and the three BEV heads no longer share one concat.  Kept off.
-FUSE_UPSAMPLE = False
+# (Round 1 built a 3x3 loader that formed cat([skip, bilinear_up(x1)]) in place; measured on MI355X it lost to the
+# separate upsample_concat pass in every mode -- bf16x6 222.6 -> 218.5 frames/s, bf16 484 -> 388: the 4-tap gather sits
+# on the loader's critical path and the three BEV heads no longer share one concat -- and was removed in round 3.)
 
 PRECISIONS = {"f32": ops.PREC_F32, "bf16": ops.PREC_BF16, "bf16x3": ops.PREC_BF16X3, "bf16x6": ops.PREC_BF16X6,
               "f16x3": ops.PREC_F16X3}
@@ -53,8 +51,18 @@ def invalidate_caches():
     The caches are keyed on (data_ptr, tensor._version): `load_state_dict`, optimiser steps and any in-place op on
     the parameter bump the version and re-pack automatically.  Writes THROUGH `.data` (`p.data.copy_(..)`,
     `p.data.mul_(..)`, EMA updates, BN running statistics edited via `.data`) do not -- call this after such an
-    update.  The mirror modules call it from `load_state_dict` / `train()` / `eval()` as well."""
+    update.  What IS hooked: every mirror module that can be used stand-alone (MaxEntIRL, TerrainNet,
+    DistillationBackbone, DepthCompletion, VisionEncoder / EffNet, Camera2MapMulti, Inpainting heads, VIN) registers a
+    `load_state_dict` post-hook that calls this (`hook_invalidate`), so checkpoint loaders that assign through
+    `param.data.copy_` inside `load_state_dict` are covered too.  `train()` / `eval()` need no hook: the folded
+    BatchNorm caches are only read in eval mode and keyed on the running statistics' versions.  The epoch is global:
+    one call re-packs every model of the process on its next forward."""
     ops.CACHE_EPOCH += 1
+
+
+def hook_invalidate(module: nn.Module):
+    """register the `load_state_dict` post-hook described in `invalidate_caches` on `module`"""
+    module.register_load_state_dict_post_hook(lambda m, keys: invalidate_caches())
 
 
 def _sig(tensors):
@@ -118,11 +126,8 @@ class ConvUnit:
         return self._packed
 
     def __call__(self, x: Act, out: Act | None = None, res: Act | None = None, a_scale=None,
-                 row_mask=None, up=None) -> Act:
-        return ops.conv2d(x, self.packed(), out=out, res=res, a_scale=a_scale, row_mask=row_mask, up=up)
-
-    def fuses_upsample(self) -> bool:
-        return FUSE_UPSAMPLE and ops.conv_supports_upsample(self.packed())
+                 row_mask=None) -> Act:
+        return ops.conv2d(x, self.packed(), out=out, res=res, a_scale=a_scale, row_mask=row_mask)
 
 
 class Cached:

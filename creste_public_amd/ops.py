@@ -137,6 +137,7 @@ class PackedConv:
     act: int
     prec: int = PREC_F32
     w_unscale: torch.Tensor | None = None   # F16X3: [Cout] inverse power-of-two weight scale
+    algo: int = 0                           # ALGO_DIRECT | ALGO_WINOGRAD: how `wpk` is packed
 
     def out_hw(self, H, W):
         return ((H + self.pad_t + self.pad_b - self.KH) // self.stride + 1,
@@ -156,14 +157,24 @@ def conv_precision(prec: int, k: int, stride: int, cin: int) -> int:
     return prec
 
 
-def conv_supports_upsample(pc: "PackedConv") -> bool:
-    """True when `pc` can take its input as cat([skip, bilinear_upsample(x1)]) without materialising it."""
-    return bool(_lib.load().creste_conv_supported_upsample(pc.prec, pc.KH, pc.KW, pc.stride))
+ALGO_DIRECT, ALGO_WINOGRAD = 0, 1
+# Winograd F(2x2,3x3) policy (hipnn.set_winograd): the stride-1 3x3 convs of the fp32-equivalent `bf16x6` mode with at
+# least WINOGRAD_MIN_C input AND output channels.  2.25x fewer matrix-core products, paid for with the transforms and an
+# fp32 round trip of the 16 per-position products: a win for wide layers only (csrc/conv_wino.hip).
+WINOGRAD = True
+WINOGRAD_MIN_C = 128
 
 
-def pack_conv(weight: torch.Tensor, bias, bn, stride, pad, act, prec=PREC_F32) -> PackedConv:
+def conv_algo(prec: int, k: int, stride: int, pad, cin: int, cout: int) -> int:
+    if WINOGRAD and prec == PREC_BF16X6 and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1) \
+            and min(cin, cout) >= WINOGRAD_MIN_C and _lib.load().creste_conv_wino_supported(prec, k, k, stride, cin, cout):
+        return ALGO_WINOGRAD
+    return ALGO_DIRECT
+
+
+def pack_conv(weight: torch.Tensor, bias, bn, stride, pad, act, prec=PREC_F32, algo=None) -> PackedConv:
     """weight OIHW (CUDA fp32); bn = None or (gamma, beta, mean, var, eps) -> folded eval-mode BN.
-    pad = int | (pad_t, pad_b, pad_l, pad_r)."""
+    pad = int | (pad_t, pad_b, pad_l, pad_r).  algo: None = the policy of `conv_algo`, or ALGO_DIRECT / ALGO_WINOGRAD."""
     lib = _lib.load()
     w = _chk(weight.detach().contiguous(), name="conv weight")
     Cout, Cin, KH, KW = w.shape
@@ -176,11 +187,23 @@ def pack_conv(weight: torch.Tensor, bias, bn, stride, pad, act, prec=PREC_F32) -
         b = shift if b is None else b * scale + shift
     if b is not None:
         b = b.contiguous()
+    if isinstance(pad, int):
+        pad = (pad, pad, pad, pad)
+    if algo is None:
+        algo = conv_algo(prec, KH, stride, pad, Cin, Cout) if KH == KW else ALGO_DIRECT
+    sp = scale.data_ptr() if scale is not None else None
+    if algo == ALGO_WINOGRAD:
+        nbytes = lib.creste_conv_wino_weight_bytes(Cout, Cin, prec)
+        if nbytes <= 0 or (KH, KW, stride) != (3, 3, 1):
+            raise HipLibraryError("pack_conv: the Winograd path is not built for this shape / precision")
+        wpk = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        _lib.check(lib.creste_conv_wino_pack_weight(w.data_ptr(), sp, wpk.data_ptr(), Cout, Cin, prec, _stream()),
+                   "conv_wino_pack_weight")
+        return PackedConv(wpk, b, Cin, Cout, KH, KW, stride, pad[0], pad[2], pad[1], pad[3], act, prec, None, ALGO_WINOGRAD)
     nbytes = lib.creste_conv_packed_weight_bytes(Cout, Cin, KH, KW, prec)
     if nbytes <= 0:
         raise HipLibraryError("conv_packed_weight_bytes: unsupported shape/precision")
     wpk = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    sp = scale.data_ptr() if scale is not None else None
     unscale = None
     if prec == PREC_F16X3:
         unscale = torch.empty(Cout, dtype=torch.float32, device=w.device)
@@ -189,41 +212,25 @@ def pack_conv(weight: torch.Tensor, bias, bn, stride, pad, act, prec=PREC_F32) -
     else:
         _lib.check(lib.creste_conv_pack_weight(w.data_ptr(), sp, wpk.data_ptr(), Cout, Cin, KH, KW, prec,
                                                _stream()), "conv_pack_weight")
-    if isinstance(pad, int):
-        pad = (pad, pad, pad, pad)
     return PackedConv(wpk, b, Cin, Cout, KH, KW, stride, pad[0], pad[2], pad[1], pad[3], act, prec, unscale)
 
 
-def conv2d(x: Act | None, pc: PackedConv, out: Act | None = None, res: Act | None = None,
-           a_scale: torch.Tensor | None = None, row_mask: torch.Tensor | None = None, up=None) -> Act:
-    """up = (x1: Act, H, W, rh, rw): the conv input is cat([x, bilinear_upsample(x1 -> HxW)]) formed inside
-    the kernel's loader (x may be None: upsample only)."""
+def conv2d(x: Act, pc: PackedConv, out: Act | None = None, res: Act | None = None,
+           a_scale: torch.Tensor | None = None, row_mask: torch.Tensor | None = None) -> Act:
     lib = _lib.load()
-    if up is not None:
-        x1, H, W, rh, rw = up
-        _chk(x1.buf, name="conv upsample source")
-        N, cin, dev = x1.N, x1.C + (x.C if x is not None else 0), x1.buf.device
-        if x is not None and (x.N, x.H, x.W) != (N, H, W):
-            raise HipLibraryError("conv2d: skip tensor and upsampled size disagree")
-    else:
-        N, H, W, cin, dev = x.N, x.H, x.W, x.C, x.buf.device
-    if x is not None:
-        _chk(x.buf, name="conv input")
+    N, H, W, cin, dev = x.N, x.H, x.W, x.C, x.buf.device
+    _chk(x.buf, name="conv input")
     if cin != pc.Cin:
         raise HipLibraryError(f"conv2d: input has {cin} channels, weights expect {pc.Cin}")
     Ho, Wo = pc.out_hw(H, W)
-    fresh = out is None
     if out is None:
         out = Act.empty(N, Ho, Wo, pc.Cout, dev)
     if (out.N, out.H, out.W, out.C) != (N, Ho, Wo, pc.Cout):
         raise HipLibraryError(f"conv2d: output slice {(out.N, out.H, out.W, out.C)} != "
                               f"{(N, Ho, Wo, pc.Cout)}")
     d = ConvDesc()
-    d.in_ = x.ptr if x is not None else None
+    d.in_ = x.ptr
     d.wpk, d.out = pc.wpk.data_ptr(), out.buf.data_ptr()
-    if up is not None:
-        d.up_src, d.up_H, d.up_W, d.up_C, d.up_cs = x1.ptr, x1.H, x1.W, x1.C, x1.cs
-        d.up_rh, d.up_rw = float(rh), float(rw)
     d.bias = pc.bias.data_ptr() if pc.bias is not None else None
     if res is not None:
         if (res.N, res.H, res.W, res.C) != (out.N, out.H, out.W, out.C):
@@ -241,13 +248,15 @@ def conv2d(x: Act | None, pc: PackedConv, out: Act | None = None, res: Act | Non
         if row_mask.numel() != N * Ho * Wo:
             raise HipLibraryError("conv2d: row_mask must have N*Ho*Wo elements")
         d.row_mask = row_mask.data_ptr()
-    d.N, d.H, d.W, d.Cin, d.in_cs = N, H, W, pc.Cin, (x.cs if x is not None else 0)
+    d.N, d.H, d.W, d.Cin, d.in_cs = N, H, W, pc.Cin, x.cs
     d.Ho, d.Wo, d.Cout, d.out_cs, d.out_co = Ho, Wo, pc.Cout, out.cs, out.co
     d.KH, d.KW, d.stride, d.pad_t, d.pad_l = pc.KH, pc.KW, pc.stride, pc.pad_t, pc.pad_l
-    d.act, d.prec = pc.act, pc.prec
+    d.act, d.prec, d.algo = pc.act, pc.prec, pc.algo
+    work = None
+    if pc.algo == ALGO_WINOGRAD:       # fp32 products of the 16 transform positions (stream-ordered reuse by the allocator)
+        work = torch.empty(lib.creste_conv_wino_workspace_bytes(N, Ho, Wo, pc.Cout), dtype=torch.uint8, device=dev)
+        d.work = work.data_ptr()
     if pc.prec == PREC_F16X3:
-        if up is not None:
-            raise HipLibraryError("conv2d: the fused upsample loader is not built for f16x3")
         d.a_amax, d.w_unscale = absmax(x).data_ptr(), pc.w_unscale.data_ptr()
     if TRACK_AMAX or pc.prec == PREC_F16X3:     # also into a caller's slice: the bound of THAT slice (its Act object)
         out.amax = _AmaxPool.slot(dev)

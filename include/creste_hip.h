@@ -48,6 +48,8 @@ extern "C" {
                                 v_mfma_f32_32x32x16_f16, fp32 accumulate: product error <= 2^-21 (below the
                                 fp32 accumulation round-off of a K>=16 dot product) at 5.3x the fp32 MFMA
                                 rate; needs creste_conv_desc.a_amax / w_unscale */
+#define CRESTE_ALGO_DIRECT 0   /* implicit GEMM over the K*K taps (every shape) */
+#define CRESTE_ALGO_WINOGRAD 1 /* F(2x2,3x3): stride-1 3x3 convs, see creste_conv_wino_* below */
 
 const char* creste_last_error(void);
 int creste_abi_version(void);
@@ -71,20 +73,16 @@ typedef struct creste_conv_desc {
   const float* a_scale;  /* [N,Cin] per-sample input-channel gate (squeeze-excite), or NULL */
   const float* row_mask; /* [N*Ho*Wo] multiplied into every output row after the activation, or NULL */
   float* out;            /* [N,Ho,Wo,out_cs], written at channel offset out_co */
-  const float* up_src;   /* optional fused nn.Upsample(bilinear)+torch.cat (reference effnet.py:25-28): when
-                            non-NULL the conv input is cat([in[..., 0:Cin-up_C], upsample(up_src)], channel)
-                            with up_src [N,up_H,up_W,up_cs] resized to HxW by the PyTorch align_corners=False
-                            rule (source index = up_r*(dst+0.5)-0.5 clamped at 0); `in` may be NULL when
-                            up_C == Cin.  Only where creste_conv_supported_upsample() says so. */
+  void* work;            /* CRESTE_ALGO_WINOGRAD: caller-owned workspace of creste_conv_wino_workspace_bytes(); else NULL */
   int32_t N, H, W, Cin, in_cs;
   int32_t Ho, Wo, Cout, out_cs, out_co, res_cs;
   int32_t KH, KW, stride, pad_t, pad_l;
   int32_t act;  /* CRESTE_ACT_* */
   int32_t prec; /* CRESTE_PREC_* */
-  int32_t up_H, up_W, up_C, up_cs;
-  float up_rh, up_rw;
+  int32_t algo; /* CRESTE_ALGO_* : how `wpk` was packed and which kernels run */
+  int32_t reserved0;
   /* Dynamic-range bookkeeping of the fp16-split engine (CRESTE_PREC_F16X3); all three may be NULL otherwise.
-   * a_amax   device float: an UPPER BOUND of max|in| over the slice read (and of up_src); the kernel scales
+   * a_amax   device float: an UPPER BOUND of max|in| over the slice read; the kernel scales
    *          the operand by a power of two so that the bound lands in [2^14, 2^15) -- exact, undone in the
    *          epilogue.  |a_scale| must be <= 1 (the squeeze-excite gate is a sigmoid).
    * out_amax device float, zero-initialised by the caller: atomically raised to max|out| by every
@@ -101,8 +99,21 @@ int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream);
  * 3x3; F16X3 covers stride-1 1x1, 3x3, 5x5, 7x7 and stride-2 1x1, 3x3, 7x7 (every dense conv of the reference path:
  * effnet.py / inpainting.py / conv.py). */
 int creste_conv_supported(int prec, int KH, int KW, int stride);
-/* 1 when the fused bilinear-upsample+concat input (up_src) is built for this configuration. */
-int creste_conv_supported_upsample(int prec, int KH, int KW, int stride);
+/* ---- Winograd F(2x2,3x3) path of the stride-1 3x3 convs (CRESTE_ALGO_WINOGRAD), same operator as above: the reference's
+ * nn.Conv2d(k=3, padding=1) + BatchNorm + ReLU of effnet.py:16-23 (Up blocks), inpainting.py:52-68 (DeconvHead) and
+ * depth.py:126.  2.25x fewer matrix-core products per output than the direct form, with the SAME fp32-equivalent
+ * split-operand products (CRESTE_PREC_BF16X6) and fp32 accumulation: per 2x2 output tile and channel the 4x4 input
+ * window d is transformed (V = B^T d B, +-1 coefficients, formed by the GEMM kernel's own loader), the 16 transform
+ * positions are 16 independent [tiles x Cin] x [Cin x Cout] GEMMs against the pre-transformed weights U = G g G^T
+ * (formed in float64 at pack time, BatchNorm scale folded), and the outputs Y = A^T M A get the usual epilogue
+ * (bias + residual + activation + row mask + running |max|) in a second kernel that reads the fp32 products M from
+ * `work`.  creste_conv_wino_supported: 1 when this shape / precision is built. */
+int creste_conv_wino_supported(int prec, int KH, int KW, int stride, int Cin, int Cout);
+int64_t creste_conv_wino_weight_bytes(int Cout, int Cin, int prec);
+int creste_conv_wino_pack_weight(const float* w_oihw, const float* scale, void* wpk, int Cout, int Cin, int prec,
+                                 void* stream);
+/* bytes of `work` for an output of N x Ho x Wo x Cout: 16 positions x N*ceil(Ho/2)*ceil(Wo/2) tiles x Cout floats */
+int64_t creste_conv_wino_workspace_bytes(int N, int Ho, int Wo, int Cout);
 /* Size in BYTES of the packed weight for (Cout,Cin,KH,KW) at precision `prec`. */
 int64_t creste_conv_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int prec);
 /* Pack a torch OIHW fp32 weight (device pointer, contiguous) into the GEMM layout, optionally

@@ -113,7 +113,6 @@ def test_hot_kernels_stay_out_of_scratch():
         "conv_patch_row_kernelILi7E": 48,
         "wgrad_rows_kernelILi5ELi25E": 40,            # 100 accumulators at 3 waves/SIMD: the row-prefetch registers spill
                                                       # around the matrix loop (3 scratch ops per row, none inside it)
-        "Lb0ELb1EEEvNS_9PatchArgsE": 400,             # fused-upsample loader variants (hipnn.FUSE_UPSAMPLE = False)
     }
     bad = []
     for name, u in usage.items():
@@ -121,3 +120,29 @@ def test_hot_kernels_stay_out_of_scratch():
         if u.get("scratch", 0) > lim:
             bad.append((name, u["scratch"], lim))
     assert not bad, bad
+
+
+def test_plan_loader_rejects_foreign_abi_and_descriptor_layout(tmp_path):
+    """creste_hip_model_load checks the plan header BEFORE touching the device: a plan exported under another C-ABI
+    version or with another creste_conv_desc layout must not load (its recorded arguments would be misread)."""
+    import struct
+    handle = _lib.load()
+    desc = ctypes.sizeof(_lib.ConvDesc)
+
+    def try_load(version, desc_size, abi):
+        p = tmp_path / f"h_{version}_{desc_size}_{abi}.plan"
+        p.write_bytes(b"CRESTEPLAN\0\0" + struct.pack("<III", version, desc_size, abi) + struct.pack("<I", 0) + struct.pack("<I", 0))
+        h = ctypes.c_void_p()
+        rc = handle.creste_hip_model_load(str(p).encode(), 0, ctypes.byref(h))
+        return rc, handle.creste_last_error().decode()
+
+    rc, msg = try_load(1, desc, _lib.ABI_VERSION)
+    assert rc != 0 and "format version" in msg
+    rc, msg = try_load(2, desc, _lib.ABI_VERSION - 1)
+    assert rc != 0 and "C-ABI version" in msg
+    rc, msg = try_load(2, desc - 8, _lib.ABI_VERSION)
+    assert rc != 0 and "descriptor" in msg
+    # the per-argument kind signatures the loader validates against are generated with the thunks
+    inc = open(os.path.join(ROOT, "creste_public_amd", "csrc", "plan_dispatch.inc")).read()
+    assert '{"creste_conv2d_nhwc", 1, "D", thunk_creste_conv2d_nhwc}' in inc
+    assert re.search(r'\{"creste_fill_u32", 3, "pil", ', inc)

@@ -110,6 +110,63 @@ def test_conv_patch_bf16(ops, case, prec, tol):
     assert float((got - ref).abs().max()) < 60 * tol * float(ref.abs().max().clamp_min(1.0))
 
 
+WINO_CASES = [
+    # N, Cin, H, W, Cout, act, bias, bn, res, mask, out_slice
+    (1, 496, 9, 11, 496, 1, False, True, False, False, False),      # up3-like channels (two 256-cout tiles, ragged chunk)
+    (2, 64, 37, 70, 96, 1, False, True, True, False, False),        # odd extents (half tiles at the right / bottom), residual
+    (1, 36, 12, 40, 40, 0, False, False, False, False, False),      # Cin not /16, Cout < 64
+    (2, 256, 16, 16, 128, 1, True, True, False, True, True),        # 128-cout tile, bias, row mask, output channel slice
+    (3, 128, 33, 34, 320, 2, False, True, True, False, False),      # three images: tile blocks cross image borders
+    (1, 132, 128, 153, 132, 1, False, True, False, False, False),   # the reference's 128 x 153 map (odd width)
+]
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16x6", 2e-6), ("bf16x3", 8e-5)])
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv_winograd(ops, case, prec, tol):
+    """Winograd F(2x2,3x3) path of the stride-1 3x3 convs (csrc/conv_wino.hip) against a float64 conv -- same bound as
+    the direct split-operand kernels -- and against the DIRECT kernel of the same mode."""
+    N, Cin, H, W, Cout, act, use_bias, use_bn, use_res, use_mask, use_slice = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g) if use_bias else None
+    bn = (torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1,
+          torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5, 1e-3) if use_bn else None
+    ref = F.conv2d(x.double(), w.double(), None if b is None else b.double(), padding=1)
+    if bn is not None:
+        ref = F.batch_norm(ref, bn[2].double(), bn[3].double(), bn[0].double(), bn[1].double(), False, 0.0, bn[4])
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if res is not None:
+        ref = ref + res.double()
+    ref = {0: lambda t: t, 1: F.relu, 2: lambda t: t * torch.sigmoid(t)}[act](ref)
+    mask = (torch.rand(N * H * W, generator=g) > 0.3).float() if use_mask else None
+    if mask is not None:
+        ref = ref * mask.view(N, 1, H, W).double()
+    code = {"bf16x6": ops.PREC_BF16X6, "bf16x3": ops.PREC_BF16X3}[prec]
+    bn_d = None if bn is None else tuple(dev(t) if isinstance(t, torch.Tensor) else t for t in bn)
+    outs = {}
+    for algo in (ops.ALGO_WINOGRAD, ops.ALGO_DIRECT):
+        pc = ops.pack_conv(dev(w), None if b is None else dev(b), bn_d, 1, 1, act, code, algo=algo)
+        assert pc.algo == algo
+        out = None
+        if use_slice:
+            buf = ops.Act.empty(N, H, W, Cout, "cuda", cs=Cout + 24)
+            ops.fill_(buf.buf, 7.0)
+            out = buf.slice(8, Cout)
+        y = ops.conv2d(to_act(ops, x), pc, out=out, res=None if res is None else to_act(ops, res),
+                       row_mask=None if mask is None else dev(mask))
+        if use_slice:      # nothing outside the slice is touched
+            assert float(y.buf[..., :8].min()) == 7.0 and float(y.buf[..., 8 + Cout:].max()) == 7.0
+        outs[algo] = from_act(y).double()
+    got = outs[ops.ALGO_WINOGRAD]
+    assert got.shape == ref.shape
+    rel = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-12))
+    rel_direct = float((outs[ops.ALGO_DIRECT] - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-12))
+    assert rel < tol, f"{prec} winograd: relative rms error {rel:.2e} (direct kernel: {rel_direct:.2e})"
+    assert float((got - ref).abs().max()) < 60 * tol * float(ref.abs().max().clamp_min(1.0))
+
+
 S2_CASES = [c for c in CONV_CASES if c[6] == 2] + [
     (2, 96, 64, 70, 64, 7, 2, (3, 3, 3, 3), 1, False, True, False),    # BEV stem, several tiles, partial in x
     (1, 64, 33, 65, 128, 3, 2, (1, 1, 1, 1), 1, False, True, True),    # odd extents, residual, two 64-channel units
@@ -185,31 +242,6 @@ def test_conv_f16x3_dynamic_range(ops, xs, ws, K):
     # per output channel (the weight scale differs by 10^6 across channels)
     err = (got - ref).pow(2).mean(dim=(0, 2, 3)).sqrt() / ref.pow(2).mean(dim=(0, 2, 3)).sqrt()
     assert float(err.max()) < (2e-5 if xs == "outlier" else 2e-6), f"relative rms error {float(err.max()):.2e}"
-
-
-@pytest.mark.parametrize("prec,tol", [("bf16x6", 3e-6), ("bf16x3", 8e-5)])
-@pytest.mark.parametrize("sf,c2", [(2, 24), (4, 64), ((128 / 64, 153 / 76), 8), (2, 0)])
-def test_conv_fused_upsample_concat(ops, sf, c2, prec, tol):
-    """3x3 conv whose input cat([skip, bilinear_up(x1)]) is formed inside the kernel's loader."""
-    g = torch.Generator().manual_seed(17)
-    H1, W1 = (64, 76) if isinstance(sf, tuple) else (13, 21)
-    N, C1, Cout = 2, 40, 72
-    x1 = torch.randn(N, C1, H1, W1, generator=g)
-    up = torch.nn.Upsample(scale_factor=sf, mode="bilinear", align_corners=False)(x1)
-    Ho, Wo = up.shape[-2:]
-    skip = torch.randn(N, c2, Ho, Wo, generator=g) if c2 else None
-    w = torch.randn(Cout, C1 + c2, 3, 3, generator=g) / ((C1 + c2) * 9) ** 0.5
-    cat = up if skip is None else torch.cat([skip, up], dim=1)
-    ref = F.relu(F.conv2d(cat.double(), w.double(), padding=1))
-    code = {"bf16x6": ops.PREC_BF16X6, "bf16x3": ops.PREC_BF16X3}[prec]
-    pc = ops.pack_conv(dev(w), None, None, 1, 1, ops.ACT_RELU, code)
-    assert ops.conv_supports_upsample(pc)
-    sfh, sfw = sf if isinstance(sf, tuple) else (sf, sf)
-    rh, rw = np.float32(1.0 / sfh), np.float32(1.0 / sfw)
-    got = from_act(ops.conv2d(None if skip is None else to_act(ops, skip), pc,
-                              up=(to_act(ops, x1), Ho, Wo, rh, rw))).double()
-    rel = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
-    assert rel < tol, f"{prec}: relative rms error {rel:.2e}"
 
 
 def test_conv_slices_gate_and_rowmask(ops):

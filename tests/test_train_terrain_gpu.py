@@ -426,3 +426,31 @@ def test_splat_backward_sum_and_max_modes(mode):
     # d/dcoords -> d/dxyz: X = (-y + off)/vox, Y = (-x + off)/vox
     gx_ref = torch.stack([-xy.grad[..., 1] / vox[1], -xy.grad[..., 0] / vox[0], torch.zeros(B, P, dtype=torch.float64)], dim=-1)
     assert _p95(g_xyz.cpu(), gx_ref) < 1e-4
+
+
+def test_bev_ce_rejects_out_of_range_labels():
+    """A label outside [0, C) that is not ignore_index must neither index pred / class_weights out of bounds nor yield
+    a silently finite loss (torch.nn.CrossEntropyLoss raises for it): the fused kernel skips the pixel in the
+    gradient and returns a NaN loss; with the value declared as ignore_index the loss is the reference's."""
+    from creste_public_amd.loss_ops import BevCEFn
+    torch.manual_seed(0)
+    B, C, H, W = 2, 6, 16, 16
+    pred = torch.randn(B, C, H, W, device="cuda", requires_grad=True)
+    gt = torch.zeros(B, 2, H, W, device="cuda")
+    gt[:, 1] = torch.randint(0, C, (B, H, W), device="cuda").float()
+    gt[0, 1, 3, 4] = 255.0                                  # "unlabelled" marker, far outside the class range
+    gt[1, 1, 0, 0] = -3.0
+    fov = torch.ones(B, H, W, dtype=torch.bool, device="cuda")
+    cw = torch.rand(C, device="cuda") + 0.5
+    loss, stats = BevCEFn.apply(pred, gt, fov, cw, 1, None, 1e-5)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isnan(loss)
+    assert torch.isfinite(pred.grad).all() and float(pred.grad[0, :, 3, 4].abs().sum()) == 0.0
+    # the same labels with 255 ignored and the negative one made valid: equal to torch's CrossEntropyLoss
+    gt[1, 1, 0, 0] = 2.0
+    pred2 = pred.detach().clone().requires_grad_(True)
+    loss2, _ = BevCEFn.apply(pred2, gt, fov, cw, 1, 255, 1e-5)
+    ref = torch.nn.functional.cross_entropy(pred.detach().permute(0, 2, 3, 1).reshape(-1, C), gt[:, 1].long().reshape(-1),
+                                            weight=cw, ignore_index=255)
+    torch.testing.assert_close(loss2, ref, rtol=1e-5, atol=1e-6)
