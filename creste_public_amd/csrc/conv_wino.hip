@@ -23,6 +23,7 @@
 //                      (the direct kernels' epilogue), reading the 16 fp32 products from the workspace.
 // Accumulation is fp32 throughout; the transforms are fp32 adds of at most four terms (input) / float64 (weights).
 #include "common.h"
+#include <stdlib.h>
 
 namespace creste {
 
@@ -43,12 +44,13 @@ __device__ __constant__ float kWinoS2[4] = {-1.f, 1.f, 1.f, -1.f};
 struct WinoArgs {
   const float* in;
   const char* wpk;
-  float* M;                  // [16][T][Cout]
+  float* M;                  // [16][Cout / 4][T][4]
   int N, H, W, Cin, in_cs;
   int Cout;
   int tiles_y, tiles_x, T;   // 2x2 output tiles per image column / row, total tiles N*tiles_y*tiles_x
   int pad_t, pad_l;
   int nchunk, m_blocks, tiles_n, units;
+  int dbg;
 };
 
 template <int SPLIT>
@@ -60,12 +62,19 @@ __device__ __forceinline__ wf32x16 wino_split_mfma(const wbf16x8 (&a)[SPLIT], co
   return c;
 }
 
+// Ping-pong schedule.  The two waves that share a SIMD (wave w and w + 4) share its matrix pipe and its VALU issue:
+// with both in the same phase the MFMAs of one queue behind the other's and then both stage at once (first version of
+// this kernel: 67 % of the direct kernel's MFMA rate).  So the halves run half a step apart --
+//     waves 0-3:  | MFMA(c)            | stage their rows of A(c+1) |
+//     waves 4-7:  | stage A(c+1) rows  | MFMA(c)                    |      (two barriers per 16-channel chunk)
+// -- every SIMD always has exactly one wave on the matrix pipe and one on the loader's VALU / LDS work, and a half
+// issues its raw loads for the next staging phase at the head of its MFMA phase (>= 1500 cycles ahead of their use).
 template <int SPLIT, int TN>
 __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoArgs p) {
   constexpr int A_OCT = WN_M * 16, A_PLANE = 2 * A_OCT, A_BYTES = SPLIT * A_PLANE;       // [piece][k-octet][row][8 bf16]
   constexpr int U_OCT = 64 * 16, U_PLANE = 2 * U_OCT, U_BYTES = SPLIT * U_PLANE;         // one 64-cout weight unit
   constexpr int B_BYTES = TN * U_BYTES, B_INSTR = B_BYTES / 1024;
-  constexpr int NT = TN;                       // 32-cout MFMA tiles per wave: the wave pair splits the 64*TN couts
+  constexpr int NT = TN;                       // 32-cout MFMA tiles per wave: a wave owns 64 tiles x 32*TN couts
   static_assert(B_BYTES % 1024 == 0, "weight tile must be whole 1 KiB DMA pieces");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -75,7 +84,8 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;     // 4 row groups of 64 tiles x 2 channel halves
+  const int half = wave >> 2;                  // waves w and w + 4 share a SIMD
+  const int wm = wave & 3, wn = half;          // 4 row groups of 64 tiles x 2 channel halves
   const int li = lane & 31, lh = lane >> 5;
 
   // launch order: channel tile fastest, then the 16 positions, then the tile block -- the 16 * tiles_n workgroups that
@@ -87,66 +97,79 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoArgs p) {
   const int mb = id >> 4;
   const int xi = pos >> 2, nu = pos & 3;
   const int iy1 = kWinoI1[xi], iy2 = kWinoI2[xi], ix1 = kWinoI1[nu], ix2 = kWinoI2[nu];
-  const float sy1 = kWinoS1[xi], sy2 = kWinoS2[xi], sx1 = kWinoS1[nu], sx2 = kWinoS2[nu];
 
-  // ---- per-thread A staging slots (fixed over chunks): rows r = tid/4 + 128 j, channel quad cq
-  const int cq = tid & 3;
-  const int a_lofs0 = (cq >> 1) * A_OCT + (tid >> 2) * 16 + (cq & 1) * 8;     // + j * 128 * 16
-  int off[2][4];             // element offsets of the four raw pixels (y1x1, y1x2, y2x1, y2x2), -1 = zero
+  // ---- per-thread A staging slots (fixed over chunks): half h stages rows h*128 + u/4 + 64 j (u = thread within the
+  // half), channel quad cq.  Absent pixels (image border, rows past the last tile) read a CLAMPED address and enter
+  // with multiplier 0 -- no predicated loads (they compile to branches with an s_waitcnt behind them), no selects
+  const int u = tid & 255, cq = u & 3;
+  const int a_lofs0 = (cq >> 1) * A_OCT + (half * 128 + (u >> 2)) * 16 + (cq & 1) * 8;     // + j * 64 * 16
+  int off[2][4];             // element offsets of the four raw pixels (y1x1, y1x2, y2x1, y2x2)
+  float mx1[2], mx2[2], my1[2], my2[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int m = mb * WN_M + j * 128 + (tid >> 2);
-    const bool ok = m < p.T;
+    const int m0 = mb * WN_M + half * 128 + j * 64 + (u >> 2);
+    const bool ok = m0 < p.T;
+    const int m = ok ? m0 : p.T - 1;
     const int per = p.tiles_y * p.tiles_x;
     const int img = m / per, rem = m - img * per;
     const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
     const int y0 = 2 * ty - p.pad_t, x0 = 2 * tx - p.pad_l;
     const int ys[2] = {y0 + iy1, y0 + iy2}, xs[2] = {x0 + ix1, x0 + ix2};
+    const bool yok[2] = {(unsigned)ys[0] < (unsigned)p.H, (unsigned)ys[1] < (unsigned)p.H};
+    const bool xok[2] = {(unsigned)xs[0] < (unsigned)p.W, (unsigned)xs[1] < (unsigned)p.W};
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        const bool in = ok && (unsigned)ys[a] < (unsigned)p.H && (unsigned)xs[b] < (unsigned)p.W;
-        off[j][a * 2 + b] = in ? ((img * p.H + ys[a]) * p.W + xs[b]) * p.in_cs : -1;
+        const int yc = min(max(ys[a], 0), p.H - 1), xc = min(max(xs[b], 0), p.W - 1);
+        off[j][a * 2 + b] = ((img * p.H + yc) * p.W + xc) * p.in_cs;
       }
+    my1[j] = ok && yok[0] ? kWinoS1[xi] : 0.f; my2[j] = ok && yok[1] ? kWinoS2[xi] : 0.f;
+    mx1[j] = xok[0] ? kWinoS1[nu] : 0.f; mx2[j] = xok[1] ? kWinoS2[nu] : 0.f;
   }
-  // BRANCH-FREE prefetch (a predicated global load compiles to a branch with an s_waitcnt behind it): an absent pixel
-  // reads the tensor's first quad and is zeroed when the value is combined
-  auto load_a = [&](int j, int k, int c) __attribute__((always_inline)) -> wf32x4 {
-    const int ch = c * WN_CK + cq * 4;
-    const bool ok = off[j][k] >= 0 && ch < p.Cin;
-    return *reinterpret_cast<const wf32x4*>(ok ? p.in + (size_t)off[j][k] + ch : p.in);
+  auto load_a = [&](wf32x4 (&d)[2][4], int c) __attribute__((always_inline)) {
+    const int ch0 = c * WN_CK + cq * 4, ch = ch0 < p.Cin ? ch0 : 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[j][k] = *reinterpret_cast<const wf32x4*>(p.in + (size_t)(off[j][k] + ch));
   };
-  auto store_a = [&](int j, int c, const wf32x4 (&d)[4], char* buf) __attribute__((always_inline)) {
+  auto store_a = [&](const wf32x4 (&d)[2][4], int c, char* buf) __attribute__((always_inline)) {
     const bool chok = c * WN_CK + cq * 4 < p.Cin;
-    wf32x4 v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float d0 = (chok && off[j][0] >= 0) ? d[0][e] : 0.f, d1 = (chok && off[j][1] >= 0) ? d[1][e] : 0.f;
-      const float d2 = (chok && off[j][2] >= 0) ? d[2][e] : 0.f, d3 = (chok && off[j][3] >= 0) ? d[3][e] : 0.f;
-      // multiplications by +-1 are exact: each fma is ONE rounding of a two-term sum
-      const float r1 = __fmaf_rn(d1, sx2, d0 * sx1), r2 = __fmaf_rn(d3, sx2, d2 * sx1);
-      v[e] = __fmaf_rn(r2, sy2, r1 * sy1);
-    }
-    char* dst = buf + a_lofs0 + j * (128 * 16);
-    wf32x4 rem = v;
+    for (int j = 0; j < 2; ++j) {
+      const float a1 = chok ? my1[j] : 0.f, a2 = chok ? my2[j] : 0.f;
+      wf32x4 v;
 #pragma unroll
-    for (int pl = 0; pl < SPLIT; ++pl) {           // hi, then the bf16 of what is left, ...
-      const wbf16x4 piece = __builtin_convertvector(rem, wbf16x4);
-      *reinterpret_cast<wbf16x4*>(dst + pl * A_PLANE) = piece;
-      if (pl + 1 < SPLIT) rem -= __builtin_convertvector(piece, wf32x4);
+      for (int e = 0; e < 4; ++e) {
+        // multiplications by +-1 / 0 are exact: each fma is ONE rounding of a two-term sum
+        const float r1 = __fmaf_rn(d[j][1][e], mx2[j], d[j][0][e] * mx1[j]);
+        const float r2 = __fmaf_rn(d[j][3][e], mx2[j], d[j][2][e] * mx1[j]);
+        v[e] = __fmaf_rn(r2, a2, r1 * a1);
+      }
+      char* dst = buf + a_lofs0 + j * (64 * 16);
+      wf32x4 rem = v;
+#pragma unroll
+      for (int pl = 0; pl < SPLIT; ++pl) {           // hi, then the bf16 of what is left, ...
+        const wbf16x4 piece = __builtin_convertvector(rem, wbf16x4);
+        *reinterpret_cast<wbf16x4*>(dst + pl * A_PLANE) = piece;
+        if (pl + 1 < SPLIT) rem -= __builtin_convertvector(piece, wf32x4);
+      }
     }
   };
-  // weight tile of chunk c: per 64-cout unit U_BYTES contiguous bytes, copied by LDS-DMA in 1 KiB pieces
+  // weight tile of chunk c: per 64-cout unit U_BYTES contiguous bytes, copied by LDS-DMA in 1 KiB pieces; each half
+  // copies one half of the pieces during its staging phase
   const char* wbase = p.wpk + ((size_t)pos * p.units + (size_t)tn * TN) * p.nchunk * U_BYTES;
-  auto dma_b = [&](int c) __attribute__((always_inline)) {
+  auto dma_b = [&](int c, int part, int nparts) __attribute__((always_inline)) {
     char* dst = bbase + (c & 1) * B_BYTES;
+    const int w4 = wave & 3;
 #pragma unroll
-    for (int jj = 0; jj < (B_INSTR + 7) / 8; ++jj) {
-      const int i = wave + 8 * jj;
+    for (int jj = 0; jj < (B_INSTR + 3) / 4; ++jj) {
+      if (jj % nparts != part) continue;
+      const int i = w4 + 4 * jj;
       if (i < B_INSTR) {
-        const int u = i / (U_BYTES / 1024), r = i % (U_BYTES / 1024);
-        const char* src = wbase + ((size_t)u * p.nchunk + c) * U_BYTES + r * 1024 + lane * 16;
+        const int uu = i / (U_BYTES / 1024), r = i % (U_BYTES / 1024);
+        const char* src = wbase + ((size_t)uu * p.nchunk + c) * U_BYTES + r * 1024 + lane * 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
       }
@@ -161,31 +184,10 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // ---- prologue: chunk 0
-  dma_b(0);
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    wf32x4 d[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) d[k] = load_a(j, k, 0);
-    store_a(j, 0, d, abase);
-  }
-  __syncthreads();
-
-  for (int c = 0; c < p.nchunk; ++c) {
+  // weights as the first MFMA operand (D = U * V^T: a lane owns one tile, its registers the couts)
+  auto mfma_chunk = [&](int c) __attribute__((always_inline)) {
     const char* A = abase + (c & 1) * A_BYTES;
     const char* B = bbase + (c & 1) * B_BYTES;
-    char* Anext = abase + ((c + 1) & 1) * A_BYTES;
-    const bool more = c + 1 < p.nchunk;
-    wf32x4 ra[2][4];
-    if (more) {
-      dma_b(c + 1);
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) ra[j][k] = load_a(j, k, c + 1);
-    }
-    // ---- MFMAs of chunk c: weights as the first operand (D = U * V^T: a lane owns one tile, its registers the couts)
     wbf16x8 af[2][SPLIT];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -206,16 +208,39 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoArgs p) {
       for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = wino_split_mfma<SPLIT>(bfr, af[mt], acc[mt][nt]);
     }
     __builtin_amdgcn_s_setprio(0);
-    if (more) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) store_a(j, c + 1, ra[j], Anext);
+  };
+
+  // ---- prologue: chunk 0 staged by everyone; the second half already holds the raw quads of chunk 1
+  wf32x4 ra[2][4];
+  dma_b(0, half, 2);
+  load_a(ra, 0);
+  store_a(ra, 0, abase);
+  if (half == 1 && p.nchunk > 1) load_a(ra, 1);
+  __syncthreads();
+
+  // phase q: half h computes chunk (q - h) / 2 when q + h is even, else stages the chunk the other half computes next
+  for (int q = 0; q < 2 * p.nchunk; ++q) {
+    if (((q + half) & 1) == 0) {
+      // head of the compute phase: this half's share of the NEXT chunk's weight tile (LDS-DMA) and the raw quads of its
+      // own next staging phase go out together and land behind the MFMAs.  (The DMA must NOT sit in the staging phase:
+      // with an LDS-DMA in flight hipcc waits vmcnt(0) at the first use of any ordinary load result, i.e. the whole
+      // DMA latency in front of the transform.)
+      const int c = (q - half) >> 1, cn = c + 1 + half;
+      if (c + 1 < p.nchunk && !(p.dbg & 1)) dma_b(c + 1, half, 2);
+      if (cn < p.nchunk && !(p.dbg & 2)) load_a(ra, cn);
+      if (!(p.dbg & 8)) mfma_chunk(c);
+    } else {
+      const int cst = half == 0 ? (q + 1) >> 1 : (q >> 1) + 1;
+      if (cst < p.nchunk && !(p.dbg & 4)) store_a(ra, cst, abase + (cst & 1) * A_BYTES);
     }
-    __syncthreads();       // chunk c consumed by every wave; chunk c+1 staged (ds writes + DMA drained)
+    __syncthreads();         // ds writes + DMA of the staging half drained, the computing half done with its buffers
   }
 
-  // ---- products to the workspace: M[pos][tile][cout].  Lane = tile, registers 4g..4g+3 = four consecutive couts: one
-  // 16-byte store; the eight stores of a wave that share a 128-byte line are issued back to back
-  float* Mp = p.M + (size_t)pos * p.T * p.Cout;
+  // ---- products to the workspace: M[pos][cout / 4][tile][4].  Lane = tile, registers 4g..4g+3 = four consecutive couts:
+  // the 32 lanes of a half-wave write 512 contiguous bytes per instruction (a [tile][cout] image made every lane's
+  // 16 bytes a separate line: 2.3 ms of exposed store time per 496 -> 496 layer, a third of the kernel)
+  const int Q = p.Cout >> 2;
+  float* Mp = p.M + (size_t)pos * Q * p.T * 4;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int m = mb * WN_M + wm * 64 + mt * 32 + li;
@@ -226,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoArgs p) {
       for (int g = 0; g < 4; ++g) {
         const int n = tn * (64 * TN) + (wn * NT + nt) * 32 + 8 * g + 4 * lh;
         if (n < p.Cout)
-          *reinterpret_cast<wf32x4*>(Mp + (size_t)m * p.Cout + n) =
+          *reinterpret_cast<wf32x4*>(Mp + ((size_t)(n >> 2) * p.T + m) * 4) =
               wf32x4{acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
       }
   }
@@ -243,55 +268,65 @@ struct WinoOutArgs {
   int tiles_y, tiles_x, T;
 };
 
-// thread = (tile, channel quad): 16 x 16-byte loads (one per transform position, each coalesced over the channel
-// quads of a tile), 24 vector adds, the epilogue, four 16-byte stores
+// One workgroup = 16 consecutive tiles x 64 couts.  Read side: thread = (tile, channel quad), 16 x 16-byte loads (one per
+// transform position; the 16 tiles of a quad are 256 contiguous bytes of M), 24 vector adds.  The 2x2 outputs then
+// cross an LDS tile so that the write side runs thread = (pixel, channel quad): 16 lanes write 256 contiguous bytes
+// of one NHWC pixel and read bias / residual the same way (the direct kernels' epilogue).
+constexpr int WO_TILES = 16, WO_QUADS = 16, WO_ROW = WO_QUADS * 4 + 4;       // LDS row: 64 couts + 16 bytes of padding
 __global__ __launch_bounds__(256) void wino_out_kernel(const WinoOutArgs p) {
+  __shared__ __attribute__((aligned(16))) float tilebuf[WO_TILES * 4 * WO_ROW];
   __shared__ float scratch[4];
-  const int q4 = p.Cout >> 2;
-  const long idx = blockIdx.x * 256L + threadIdx.x;
-  const bool valid = idx < (long)p.T * q4;
-  const int tile = valid ? (int)(idx / q4) : 0;
-  const int n = valid ? (int)(idx - (long)tile * q4) * 4 : 0;
-  float vmax = 0.f;
-  if (valid) {
-    wf32x4 m[16];
-    const float* src = p.M + (size_t)tile * p.Cout + n;
-    const size_t plane = (size_t)p.T * p.Cout;
+  const int Q = p.Cout >> 2;
+  const int t = threadIdx.x;
+  const int tile0 = blockIdx.x * WO_TILES, quad0 = blockIdx.y * WO_QUADS;
+  {
+    const int tl = t & (WO_TILES - 1), ql = t >> 4;
+    const int tile = tile0 + tl, quad = quad0 + ql;
+    if (tile < p.T && quad < Q) {
+      wf32x4 m[16];
+      const float* src = p.M + ((size_t)quad * p.T + tile) * 4;
+      const size_t plane = (size_t)Q * p.T * 4;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) m[k] = __builtin_nontemporal_load(reinterpret_cast<const wf32x4*>(src + k * plane));
-    wf32x4 t[4][2];
+      for (int k = 0; k < 16; ++k) m[k] = __builtin_nontemporal_load(reinterpret_cast<const wf32x4*>(src + k * plane));
+      wf32x4 tt[4][2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      t[r][0] = (m[4 * r] + m[4 * r + 1]) + m[4 * r + 2];
-      t[r][1] = (m[4 * r + 1] - m[4 * r + 2]) - m[4 * r + 3];
-    }
-    wf32x4 y[2][2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      y[0][j] = (t[0][j] + t[1][j]) + t[2][j];
-      y[1][j] = (t[1][j] - t[2][j]) - t[3][j];
-    }
-    const int per = p.tiles_y * p.tiles_x;
-    const int img = tile / per, rem = tile - img * per;
-    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-    const wf32x4 bs = p.bias ? *reinterpret_cast<const wf32x4*>(p.bias + n) : wf32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int r = 0; r < 4; ++r) {
+        tt[r][0] = (m[4 * r] + m[4 * r + 1]) + m[4 * r + 2];
+        tt[r][1] = (m[4 * r + 1] - m[4 * r + 2]) - m[4 * r + 3];
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int oy = 2 * ty + i, ox = 2 * tx + j;
-        if (oy >= p.Ho || ox >= p.Wo) continue;
-        const long mrow = ((long)img * p.Ho + oy) * p.Wo + ox;
-        wf32x4 v = y[i][j] + bs;
-        if (p.res) v += *reinterpret_cast<const wf32x4*>(p.res + mrow * p.res_cs + n);
-        const float rmask = p.row_mask ? p.row_mask[mrow] : 1.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = act_apply(v[e], p.act) * rmask;
-          vmax = fmaxf(vmax, fabsf(v[e]));
-        }
-        *reinterpret_cast<wf32x4*>(p.out + mrow * p.out_cs + p.out_co + n) = v;
+        *reinterpret_cast<wf32x4*>(tilebuf + (tl * 4 + j) * WO_ROW + ql * 4) = (tt[0][j] + tt[1][j]) + tt[2][j];
+        *reinterpret_cast<wf32x4*>(tilebuf + (tl * 4 + 2 + j) * WO_ROW + ql * 4) = (tt[1][j] - tt[2][j]) - tt[3][j];
       }
+    }
+  }
+  __syncthreads();
+  float vmax = 0.f;
+  const int cq = t & 15, n = (quad0 + cq) * 4;
+  const int per = p.tiles_y * p.tiles_x;
+  if (quad0 + cq < Q) {
+    const wf32x4 bs = p.bias ? *reinterpret_cast<const wf32x4*>(p.bias + n) : wf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int pl = pass * 16 + (t >> 4);          // pixel slot: tile pl / 4, (i, j) = pl % 4
+      const int tile = tile0 + (pl >> 2);
+      if (tile >= p.T) continue;
+      const int img = tile / per, rem = tile - img * per;
+      const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+      const int oy = 2 * ty + ((pl >> 1) & 1), ox = 2 * tx + (pl & 1);
+      if (oy >= p.Ho || ox >= p.Wo) continue;
+      const long mrow = ((long)img * p.Ho + oy) * p.Wo + ox;
+      wf32x4 v = *reinterpret_cast<const wf32x4*>(tilebuf + pl * WO_ROW + cq * 4) + bs;
+      if (p.res) v += *reinterpret_cast<const wf32x4*>(p.res + mrow * p.res_cs + n);
+      const float rmask = p.row_mask ? p.row_mask[mrow] : 1.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = act_apply(v[e], p.act) * rmask;
+        vmax = fmaxf(vmax, fabsf(v[e]));
+      }
+      *reinterpret_cast<wf32x4*>(p.out + mrow * p.out_cs + p.out_co + n) = v;
+    }
   }
   if (p.out_amax) block_amax_update(vmax, p.out_amax, scratch);
 }
@@ -398,6 +433,7 @@ int conv_wino_run(const creste_conv_desc* d, hipStream_t s) {
   a.nchunk = (d->Cin + WN_CK - 1) / WN_CK;
   a.m_blocks = (int)((T + WN_M - 1) / WN_M);
   a.units = wino_units(d->Cout);
+  { const char* e = getenv("CRESTE_WINO_DBG"); a.dbg = e ? atoi(e) : 0; }
   // 256-cout tiles where the layer has them, else 128 (a 64-wide tile would amortise the loader's transform over too few products)
   const int tn = d->Cout > 128 ? 4 : 2;
   a.tiles_n = (d->Cout + 64 * tn - 1) / (64 * tn);
@@ -410,8 +446,8 @@ int conv_wino_run(const creste_conv_desc* d, hipStream_t s) {
   o.M = a.M; o.bias = d->bias; o.res = d->res; o.row_mask = d->row_mask; o.out = d->out; o.out_amax = d->out_amax;
   o.N = d->N; o.Ho = d->Ho; o.Wo = d->Wo; o.Cout = d->Cout; o.out_cs = d->out_cs; o.out_co = d->out_co; o.res_cs = d->res_cs;
   o.act = d->act; o.tiles_y = a.tiles_y; o.tiles_x = a.tiles_x; o.T = a.T;
-  const long nthreads = T * (d->Cout / 4);
-  wino_out_kernel<<<(unsigned)((nthreads + 255) / 256), 256, 0, s>>>(o);
+  const dim3 ogrid((unsigned)((T + WO_TILES - 1) / WO_TILES), (unsigned)((d->Cout / 4 + WO_QUADS - 1) / WO_QUADS));
+  wino_out_kernel<<<ogrid, 256, 0, s>>>(o);
   CRESTE_CHECK_LAUNCH("wino_out");
   return CRESTE_OK;
 }
