@@ -23,7 +23,6 @@
 //                      (the direct kernels' epilogue), reading the 16 fp32 products from the workspace.
 // Accumulation is fp32 throughout; the transforms are fp32 adds of at most four terms (input) / float64 (weights).
 #include "common.h"
-#include <stdlib.h>
 
 namespace creste {
 
@@ -50,35 +49,50 @@ struct WinoArgs {
   int tiles_y, tiles_x, T;   // 2x2 output tiles per image column / row, total tiles N*tiles_y*tiles_x
   int pad_t, pad_l;
   int nchunk, m_blocks, tiles_n, units;
-  int dbg;
 };
 
+// piece products of one weight fragment against the two row tiles' fragments, smallest products first; consecutive MFMAs
+// go to DIFFERENT accumulators (a chain of six dependent MFMAs leaves the pipe waiting on its own result)
 template <int SPLIT>
-__device__ __forceinline__ wf32x16 wino_split_mfma(const wbf16x8 (&a)[SPLIT], const wbf16x8 (&b)[SPLIT], wf32x16 c) {
+__device__ __forceinline__ void wino_split_mfma2(const wbf16x8 (&a)[SPLIT], const wbf16x8 (&b0)[SPLIT],
+                                                 const wbf16x8 (&b1)[SPLIT], wf32x16& c0, wf32x16& c1) {
 #pragma unroll
-  for (int order = SPLIT - 1; order >= 0; --order)      // smallest piece products first
+  for (int order = SPLIT - 1; order >= 0; --order)
 #pragma unroll
-    for (int pa = order; pa >= 0; --pa) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b[order - pa], c, 0, 0, 0);
-  return c;
+    for (int pa = order; pa >= 0; --pa) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b0[order - pa], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b1[order - pa], c1, 0, 0, 0);
+    }
 }
 
-// Ping-pong schedule.  The two waves that share a SIMD (wave w and w + 4) share its matrix pipe and its VALU issue:
-// with both in the same phase the MFMAs of one queue behind the other's and then both stage at once (first version of
-// this kernel: 67 % of the direct kernel's MFMA rate).  So the halves run half a step apart --
-//     waves 0-3:  | MFMA(c)            | stage their rows of A(c+1) |
-//     waves 4-7:  | stage A(c+1) rows  | MFMA(c)                    |      (two barriers per 16-channel chunk)
-// -- every SIMD always has exactly one wave on the matrix pipe and one on the loader's VALU / LDS work, and a half
-// issues its raw loads for the next staging phase at the head of its MFMA phase (>= 1500 cycles ahead of their use).
+// Schedule (measured on the 496 -> 496 layer at 152 x 304 x 16; each line is what the timing stamps / ablations showed):
+//   * PING-PONG.  The two waves that share a SIMD (wave w and w + 4) share its matrix pipe and its VALU issue: with both
+//     in the same phase the MFMAs of one queue behind the other's and then both stage at once.  The halves run half a
+//     step apart -- waves 0-3: | MFMA(c) | stage their rows of A(c+1) |, waves 4-7: | stage | MFMA(c) | -- so every SIMD
+//     always has one wave on the matrix pipe and one on the loader's VALU / LDS / DMA work; two barriers per chunk.
+//   * ALL loop traffic is LDS-DMA, issued about two phases ahead of the barrier that publishes it (weight tile of chunk
+//     c+1 at the head of even phase 2c; the raw quads of a half's next staging phase right after it has read the current
+//     ones), raw s_barrier with COUNTED s_waitcnt (__syncthreads() drains the DMA queue every phase; ordinary loads
+//     beside an LDS-DMA make hipcc wait vmcnt(0) at their first use).
+//   * PERSISTENT workgroups, one per CU: the 256 KB of products a workgroup stores per item took ~30 us of its ~107 us
+//     when it had to drain before the CU could start the next workgroup (all CUs finish together and the bursts collide in
+//     HBM).  Now the stores are issued behind the NEXT item's first DMAs and drain under its main loop.
+//   * B fragments of the next 32-cout tile are read while the current tile's MFMAs run (the ds_read latency was exposed
+//     five times per phase: 2000-2260 cycles for 48 MFMAs instead of 1536).
+// Items (tile block, position, channel tile) are dealt so that the 32 CUs of an XCD work on the 16 * tiles_n panels of
+// the SAME tile block at the same time: its raw input comes from HBM once and is re-read from that XCD's L2.
 template <int SPLIT, int TN>
 __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoArgs p) {
   constexpr int A_OCT = WN_M * 16, A_PLANE = 2 * A_OCT, A_BYTES = SPLIT * A_PLANE;       // [piece][k-octet][row][8 bf16]
   constexpr int U_OCT = 64 * 16, U_PLANE = 2 * U_OCT, U_BYTES = SPLIT * U_PLANE;         // one 64-cout weight unit
   constexpr int B_BYTES = TN * U_BYTES, B_INSTR = B_BYTES / 1024;
   constexpr int NT = TN;                       // 32-cout MFMA tiles per wave: a wave owns 64 tiles x 32*TN couts
+  constexpr int kB = B_INSTR / 8;              // weight pieces EVERY wave issues per chunk (some issue one more: over-waits)
+  constexpr int kStores = 2 * NT * 4;          // product stores per wave and item (always all of them: see below)
   static_assert(B_BYTES % 1024 == 0, "weight tile must be whole 1 KiB DMA pieces");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const abase = smem;                    // two A buffers, then two B buffers
+  char* const abase = smem;                    // two A buffers, two B buffers, 8 x 8 KiB of raw quads in flight
   char* const bbase = smem + 2 * A_BYTES;
 
   const int tid = threadIdx.x;
@@ -87,52 +101,73 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoArgs p) {
   const int half = wave >> 2;                  // waves w and w + 4 share a SIMD
   const int wm = wave & 3, wn = half;          // 4 row groups of 64 tiles x 2 channel halves
   const int li = lane & 31, lh = lane >> 5;
-
-  // launch order: channel tile fastest, then the 16 positions, then the tile block -- the 16 * tiles_n workgroups that
-  // read one tile block's raw input are consecutive on one XCD (private L2)
-  const int nblk = p.m_blocks * 16 * p.tiles_n;
-  int id = xcd_remap(blockIdx.x, nblk);
-  const int tn = id % p.tiles_n; id /= p.tiles_n;
-  const int pos = id & 15;
-  const int mb = id >> 4;
-  const int xi = pos >> 2, nu = pos & 3;
-  const int iy1 = kWinoI1[xi], iy2 = kWinoI2[xi], ix1 = kWinoI1[nu], ix2 = kWinoI2[nu];
-
-  // ---- per-thread A staging slots (fixed over chunks): half h stages rows h*128 + u/4 + 64 j (u = thread within the
-  // half), channel quad cq.  Absent pixels (image border, rows past the last tile) read a CLAMPED address and enter
-  // with multiplier 0 -- no predicated loads (they compile to branches with an s_waitcnt behind them), no selects
   const int u = tid & 255, cq = u & 3;
   const int a_lofs0 = (cq >> 1) * A_OCT + (half * 128 + (u >> 2)) * 16 + (cq & 1) * 8;     // + j * 64 * 16
-  int off[2][4];             // element offsets of the four raw pixels (y1x1, y1x2, y2x1, y2x2)
-  float mx1[2], mx2[2], my1[2], my2[2];
+  char* const rawbase = smem + 2 * A_BYTES + 2 * B_BYTES + wave * 8192;
+  const int Q = p.Cout >> 2;
+  const int per = p.tiles_y * p.tiles_x;
+
+  // ---- item schedule: workgroup b sits on XCD b % 8 (round-robin dispatch); slot s of that XCD is panel s % P of its
+  // tile block s / P, and the XCD's CUs take slots j, j + cus, ...   (placement is speed only)
+  const int cus = gridDim.x >> 3;              // workgroups per XCD
+  const int xcd = blockIdx.x & 7, P = 16 * p.tiles_n;
+  int slot = blockIdx.x >> 3;
+
+  // per-item state
+  int mb, pos, tn;
+  int off[2][4];             // element offsets of the four raw pixels (y1x1, y1x2, y2x1, y2x2), clamped into the tensor
+  float mx1[2], mx2[2], my1[2], my2[2];       // +-1, or 0 for an absent pixel / row
+  const char* wbase;
+  auto setup = [&](int s) __attribute__((always_inline)) -> bool {
+    const int mbl = s / P, pnl = s - mbl * P;
+    mb = mbl * 8 + xcd;
+    if (mb >= p.m_blocks) return false;
+    pos = pnl / p.tiles_n; tn = pnl - pos * p.tiles_n;
+    const int xi = pos >> 2, nu = pos & 3;
+    const int iy1 = kWinoI1[xi], iy2 = kWinoI2[xi], ix1 = kWinoI1[nu], ix2 = kWinoI2[nu];
+    // half h stages rows h*128 + u/4 + 64 j (u = thread within the half), channel quad cq.  Absent pixels (image border,
+    // rows past the last tile) read a CLAMPED address and enter with multiplier 0: no predicated loads, no selects
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int m0 = mb * WN_M + half * 128 + j * 64 + (u >> 2);
-    const bool ok = m0 < p.T;
-    const int m = ok ? m0 : p.T - 1;
-    const int per = p.tiles_y * p.tiles_x;
-    const int img = m / per, rem = m - img * per;
-    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-    const int y0 = 2 * ty - p.pad_t, x0 = 2 * tx - p.pad_l;
-    const int ys[2] = {y0 + iy1, y0 + iy2}, xs[2] = {x0 + ix1, x0 + ix2};
-    const bool yok[2] = {(unsigned)ys[0] < (unsigned)p.H, (unsigned)ys[1] < (unsigned)p.H};
-    const bool xok[2] = {(unsigned)xs[0] < (unsigned)p.W, (unsigned)xs[1] < (unsigned)p.W};
+    for (int j = 0; j < 2; ++j) {
+      const int m0 = mb * WN_M + half * 128 + j * 64 + (u >> 2);
+      const bool ok = m0 < p.T;
+      const int m = ok ? m0 : p.T - 1;
+      const int img = m / per, rem = m - img * per;
+      const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+      const int y0 = 2 * ty - p.pad_t, x0 = 2 * tx - p.pad_l;
+      const int ys[2] = {y0 + iy1, y0 + iy2}, xs[2] = {x0 + ix1, x0 + ix2};
+      const bool yok[2] = {(unsigned)ys[0] < (unsigned)p.H, (unsigned)ys[1] < (unsigned)p.H};
+      const bool xok[2] = {(unsigned)xs[0] < (unsigned)p.W, (unsigned)xs[1] < (unsigned)p.W};
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int yc = min(max(ys[a], 0), p.H - 1), xc = min(max(xs[b], 0), p.W - 1);
-        off[j][a * 2 + b] = ((img * p.H + yc) * p.W + xc) * p.in_cs;
-      }
-    my1[j] = ok && yok[0] ? kWinoS1[xi] : 0.f; my2[j] = ok && yok[1] ? kWinoS2[xi] : 0.f;
-    mx1[j] = xok[0] ? kWinoS1[nu] : 0.f; mx2[j] = xok[1] ? kWinoS2[nu] : 0.f;
-  }
-  auto load_a = [&](wf32x4 (&d)[2][4], int c) __attribute__((always_inline)) {
+        for (int b = 0; b < 2; ++b) {
+          const int yc = min(max(ys[a], 0), p.H - 1), xc = min(max(xs[b], 0), p.W - 1);
+          off[j][a * 2 + b] = ((img * p.H + yc) * p.W + xc) * p.in_cs;
+        }
+      my1[j] = ok && yok[0] ? kWinoS1[xi] : 0.f; my2[j] = ok && yok[1] ? kWinoS2[xi] : 0.f;
+      mx1[j] = xok[0] ? kWinoS1[nu] : 0.f; mx2[j] = xok[1] ? kWinoS2[nu] : 0.f;
+    }
+    wbase = p.wpk + ((size_t)pos * p.units + (size_t)tn * TN) * p.nchunk * U_BYTES;
+    return true;
+  };
+
+  // Raw quads travel global -> LDS by DMA: a wave owns 8 KiB of the raw area, piece (j, k) = its 64 lanes' 16 bytes of
+  // pixel k of row group j, and every lane later reads back exactly the 16 bytes it fetched.
+  auto dma_raw = [&](int c) __attribute__((always_inline)) {
     const int ch0 = c * WN_CK + cq * 4, ch = ch0 < p.Cin ? ch0 : 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) d[j][k] = *reinterpret_cast<const wf32x4*>(p.in + (size_t)(off[j][k] + ch));
+      for (int k = 0; k < 4; ++k)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.in + (size_t)(off[j][k] + ch)),
+                                         (__attribute__((address_space(3))) void*)(rawbase + (j * 4 + k) * 1024), 16, 0, 0);
+  };
+  auto read_raw = [&](wf32x4 (&d)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[j][k] = *reinterpret_cast<const wf32x4*>(rawbase + (j * 4 + k) * 1024 + lane * 16);
   };
   auto store_a = [&](const wf32x4 (&d)[2][4], int c, char* buf) __attribute__((always_inline)) {
     const bool chok = c * WN_CK + cq * 4 < p.Cin;
@@ -157,16 +192,13 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoArgs p) {
       }
     }
   };
-  // weight tile of chunk c: per 64-cout unit U_BYTES contiguous bytes, copied by LDS-DMA in 1 KiB pieces; each half
-  // copies one half of the pieces during its staging phase
-  const char* wbase = p.wpk + ((size_t)pos * p.units + (size_t)tn * TN) * p.nchunk * U_BYTES;
-  auto dma_b = [&](int c, int part, int nparts) __attribute__((always_inline)) {
+  // weight tile of chunk c: per 64-cout unit U_BYTES contiguous bytes, copied by LDS-DMA in 1 KiB pieces (every wave its
+  // pieces wave, wave + 8, ...)
+  auto dma_b = [&](int c) __attribute__((always_inline)) {
     char* dst = bbase + (c & 1) * B_BYTES;
-    const int w4 = wave & 3;
 #pragma unroll
-    for (int jj = 0; jj < (B_INSTR + 3) / 4; ++jj) {
-      if (jj % nparts != part) continue;
-      const int i = w4 + 4 * jj;
+    for (int jj = 0; jj < (B_INSTR + 7) / 8; ++jj) {
+      const int i = wave + 8 * jj;
       if (i < B_INSTR) {
         const int uu = i / (U_BYTES / 1024), r = i % (U_BYTES / 1024);
         const char* src = wbase + ((size_t)uu * p.nchunk + c) * U_BYTES + r * 1024 + lane * 16;
@@ -177,18 +209,27 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoArgs p) {
   };
 
   wf32x16 acc[2][NT];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
 
   // weights as the first MFMA operand (D = U * V^T: a lane owns one tile, its registers the couts)
   auto mfma_chunk = [&](int c) __attribute__((always_inline)) {
     const char* A = abase + (c & 1) * A_BYTES;
     const char* B = bbase + (c & 1) * B_BYTES;
-    wbf16x8 af[2][SPLIT];
+    wbf16x8 af[2][SPLIT], bfr[2][SPLIT];
+    auto read_b = [&](int nt, wbf16x8 (&dst)[SPLIT]) __attribute__((always_inline)) {
+      const int n = (wn * NT + nt) * 32 + li;
+#pragma unroll
+      for (int pl = 0; pl < SPLIT; ++pl)
+        dst[pl] = *reinterpret_cast<const wbf16x8*>(B + (n >> 6) * U_BYTES + pl * U_PLANE + lh * U_OCT + (n & 63) * 16);
+    };
+    read_b(0, bfr[0]);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       const int row = wm * 64 + mt * 32 + li;
@@ -196,65 +237,117 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoArgs p) {
       for (int pl = 0; pl < SPLIT; ++pl)
         af[mt][pl] = *reinterpret_cast<const wbf16x8*>(A + pl * A_PLANE + lh * A_OCT + row * 16);
     }
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      wbf16x8 bfr[SPLIT];
-      const int n = (wn * NT + nt) * 32 + li;
-#pragma unroll
-      for (int pl = 0; pl < SPLIT; ++pl)
-        bfr[pl] = *reinterpret_cast<const wbf16x8*>(B + (n >> 6) * U_BYTES + pl * U_PLANE + lh * U_OCT + (n & 63) * 16);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = wino_split_mfma<SPLIT>(bfr, af[mt], acc[mt][nt]);
+      if (nt + 1 < NT) read_b(nt + 1, bfr[(nt + 1) & 1]);     // lands behind this tile's 4 * SPLIT MFMAs
+      wino_split_mfma2<SPLIT>(bfr[nt & 1], af[0], af[1], acc[0][nt], acc[1][nt]);
     }
-    __builtin_amdgcn_s_setprio(0);
   };
 
-  // ---- prologue: chunk 0 staged by everyone; the second half already holds the raw quads of chunk 1
+  if (!setup(slot)) return;
+  zero_acc();
+  dma_b(0);
+  dma_raw(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
   wf32x4 ra[2][4];
-  dma_b(0, half, 2);
-  load_a(ra, 0);
-  store_a(ra, 0, abase);
-  if (half == 1 && p.nchunk > 1) load_a(ra, 1);
-  __syncthreads();
+#ifdef WINO_TRACE
+  long long t_head = 0, t_loop = 0, t_tail = 0, t_work = 0, t_mf = 0, t_st = 0, w_mf = 0, w_st = 0, w_raw = 0, t0 = __builtin_readcyclecounter(), tw, tx; int n_items = 0;
+#endif
+  for (;;) {
+#ifdef WINO_TRACE
+    long long ta = __builtin_readcyclecounter();
+#endif
+    // ---- item head: chunk 0's weight tile and raw quads have landed (counted waits at the end of the previous item)
+    asm volatile("s_barrier" ::: "memory");
+    read_raw(ra);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (p.nchunk > 1) dma_raw(1);
+    store_a(ra, 0, abase);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-  // phase q: half h computes chunk (q - h) / 2 when q + h is even, else stages the chunk the other half computes next
-  for (int q = 0; q < 2 * p.nchunk; ++q) {
-    if (((q + half) & 1) == 0) {
-      // head of the compute phase: this half's share of the NEXT chunk's weight tile (LDS-DMA) and the raw quads of its
-      // own next staging phase go out together and land behind the MFMAs.  (The DMA must NOT sit in the staging phase:
-      // with an LDS-DMA in flight hipcc waits vmcnt(0) at the first use of any ordinary load result, i.e. the whole
-      // DMA latency in front of the transform.)
-      const int c = (q - half) >> 1, cn = c + 1 + half;
-      if (c + 1 < p.nchunk && !(p.dbg & 1)) dma_b(c + 1, half, 2);
-      if (cn < p.nchunk && !(p.dbg & 2)) load_a(ra, cn);
-      if (!(p.dbg & 8)) mfma_chunk(c);
-    } else {
-      const int cst = half == 0 ? (q + 1) >> 1 : (q >> 1) + 1;
-      if (cst < p.nchunk && !(p.dbg & 4)) store_a(ra, cst, abase + (cst & 1) * A_BYTES);
-    }
-    __syncthreads();         // ds writes + DMA of the staging half drained, the computing half done with its buffers
-  }
-
-  // ---- products to the workspace: M[pos][cout / 4][tile][4].  Lane = tile, registers 4g..4g+3 = four consecutive couts:
-  // the 32 lanes of a half-wave write 512 contiguous bytes per instruction (a [tile][cout] image made every lane's
-  // 16 bytes a separate line: 2.3 ms of exposed store time per 496 -> 496 layer, a third of the kernel)
-  const int Q = p.Cout >> 2;
-  float* Mp = p.M + (size_t)pos * Q * p.T * 4;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int m = mb * WN_M + wm * 64 + mt * 32 + li;
-    if (m >= p.T) continue;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = tn * (64 * TN) + (wn * NT + nt) * 32 + 8 * g + 4 * lh;
-        if (n < p.Cout)
-          *reinterpret_cast<wf32x4*>(Mp + ((size_t)(n >> 2) * p.T + m) * 4) =
-              wf32x4{acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+#ifdef WINO_TRACE
+    long long tb = __builtin_readcyclecounter();
+#endif
+    // phase q: half h computes chunk (q - h) / 2 when q + h is even, else stages the chunk the other half computes next
+    for (int q = 0; q < 2 * p.nchunk; ++q) {
+#ifdef WINO_TRACE
+      tw = __builtin_readcyclecounter();
+#endif
+      const int cw = (q >> 1) + 1;             // weight tile fetched in even phases
+      if (!(q & 1) && cw < p.nchunk) dma_b(cw);
+      if (((q + half) & 1) == 0) {
+        mfma_chunk((q - half) >> 1);
+      } else {
+        const int cst = half == 0 ? (q + 1) >> 1 : (q >> 1) + 1;
+        if (cst < p.nchunk) {
+          // raw quads of chunk cst (issued two phases ago): the only younger operations are kB weight pieces
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kB) : "memory");
+#ifdef WINO_TRACE
+          w_raw += __builtin_readcyclecounter() - tw;
+#endif
+          read_raw(ra);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (cst + 1 < p.nchunk) dma_raw(cst + 1);
+          store_a(ra, cst, abase + (cst & 1) * A_BYTES);
+        }
       }
+#ifdef WINO_TRACE
+      tx = __builtin_readcyclecounter();
+      t_work += tx - tw;
+      if (((q + half) & 1) == 0) t_mf += tx - tw; else t_st += tx - tw;
+#endif
+      // end of an odd phase 2c+1: chunk c+1's weight tile (issued at the head of phase 2c) must have landed; the only
+      // younger operations of ANY wave are the 8 raw pieces of chunk c+2 it re-issued while staging (this phase or the last)
+      if (q & 1) {
+        if ((q >> 1) + 2 < p.nchunk) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+#ifdef WINO_TRACE
+      if (((q + half) & 1) == 0) w_mf += __builtin_readcyclecounter() - tx; else w_st += __builtin_readcyclecounter() - tx;
+#endif
+    }
+
+#ifdef WINO_TRACE
+    long long tc = __builtin_readcyclecounter();
+#endif
+    // ---- item tail.  Every LDS buffer is free (last barrier passed).  Products go to M[pos][cout / 4][tile][4]: lane =
+    // tile, registers 4g..4g+3 = four consecutive couts, so the 32 lanes of a half-wave write 512 contiguous bytes per
+    // instruction.  ALL kStores stores are issued (rows past the last tile / couts past Cout go to a junk line behind
+    // the workspace): the count lets the next item's first DMAs be waited for with vmcnt(kStores) while the stores drain
+    float* Mp = p.M + (size_t)pos * Q * p.T * 4;
+    float* const junk = p.M + (size_t)16 * Q * p.T * 4 + lane * 4;
+    const int mb_cur = mb, tn_cur = tn;
+    slot += cus;
+    const bool more = setup(slot);
+    if (more) { dma_b(0); dma_raw(0); }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int m = mb_cur * WN_M + wm * 64 + mt * 32 + li;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = tn_cur * (64 * TN) + (wn * NT + nt) * 32 + 8 * g + 4 * lh;
+          float* dst = (m < p.T && n < p.Cout) ? Mp + ((size_t)(n >> 2) * p.T + m) * 4 : junk;
+          *reinterpret_cast<wf32x4*>(dst) =
+              wf32x4{acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+        }
+    }
+#ifdef WINO_TRACE
+    { long long td = __builtin_readcyclecounter(); t_head += tb - ta; t_loop += tc - tb; t_tail += td - tc; ++n_items; }
+#endif
+    if (!more) break;
+    zero_acc();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStores) : "memory");      // the next item's chunk-0 DMAs have landed
   }
+#ifdef WINO_TRACE
+  if (blockIdx.x == 100 && (wave & 3) == 0 && lane == 0)
+    printf("wave %d items %d total %lld head %lld loop %lld (work %lld: mfma %lld stage %lld; wait after mfma %lld after stage %lld) tail %lld raw-wait %lld per item\n", wave, n_items,
+           (long long)(__builtin_readcyclecounter() - t0) / n_items, t_head / n_items, t_loop / n_items, t_work / n_items, t_mf / n_items, t_st / n_items, w_mf / n_items, w_st / n_items, t_tail / n_items, w_raw / n_items);
+#endif
 }
 
 struct WinoOutArgs {
@@ -378,7 +471,7 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, const float* __res
 }
 
 static inline int wino_split(int prec) {
-  return prec == CRESTE_PREC_BF16X6 ? 3 : (prec == CRESTE_PREC_BF16X3 ? 2 : (prec == CRESTE_PREC_BF16 ? 1 : 0));
+  return prec == CRESTE_PREC_BF16X6 ? 3 : (prec == CRESTE_PREC_BF16X3 ? 2 : 0);     // the fp32-grade split modes
 }
 static inline int wino_units(int Cout) { return ((Cout + 63) / 64 + 3) / 4 * 4; }       // padded to the widest tile (TN = 4)
 
@@ -401,15 +494,24 @@ int conv_wino_pack(const float* w, const float* scale, void* wpk, int Cout, int 
 }
 
 int64_t conv_wino_workspace_bytes(int N, int Ho, int Wo, int Cout) {
-  return 16L * N * ((Ho + 1) / 2) * ((Wo + 1) / 2) * Cout * 4;
+  return 16L * N * ((Ho + 1) / 2) * ((Wo + 1) / 2) * Cout * 4 + 4096;       // + the junk line of the GEMM's padded stores
 }
 
 template <int SPLIT, int TN>
 static int launch_wino_gemm(const WinoArgs& a, hipStream_t s) {
-  constexpr int smem = 2 * (SPLIT * 2 * WN_M * 16) + 2 * (TN * SPLIT * 2 * 64 * 16);
+  constexpr int smem = 2 * (SPLIT * 2 * WN_M * 16) + 2 * (TN * SPLIT * 2 * 64 * 16) + 8 * 8192;
+  static_assert(smem <= 160 * 1024, "Winograd GEMM tile does not fit the LDS");
   static std::atomic<uint64_t> attr_devs{0};
-  if (smem > 64 * 1024) CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino_gemm_kernel<SPLIT, TN>), smem, attr_devs));
-  wino_gemm_kernel<SPLIT, TN><<<a.m_blocks * 16 * a.tiles_n, 512, smem, s>>>(a);
+  CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino_gemm_kernel<SPLIT, TN>), smem, attr_devs));
+  // persistent: one workgroup per CU (a multiple of the 8 XCDs), never more than there are items
+  int dev = 0, cus = 0;
+  CRESTE_HIP(hipGetDevice(&dev));
+  CRESTE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const long items = (long)a.m_blocks * 16 * a.tiles_n;
+  long per_xcd = cus / 8 > 0 ? cus / 8 : 1;
+  const long need = (items + 7) / 8;
+  if (per_xcd > need) per_xcd = need;
+  wino_gemm_kernel<SPLIT, TN><<<(unsigned)(per_xcd * 8), 512, smem, s>>>(a);
   CRESTE_CHECK_LAUNCH("wino_gemm");
   return CRESTE_OK;
 }
@@ -433,14 +535,13 @@ int conv_wino_run(const creste_conv_desc* d, hipStream_t s) {
   a.nchunk = (d->Cin + WN_CK - 1) / WN_CK;
   a.m_blocks = (int)((T + WN_M - 1) / WN_M);
   a.units = wino_units(d->Cout);
-  { const char* e = getenv("CRESTE_WINO_DBG"); a.dbg = e ? atoi(e) : 0; }
   // 256-cout tiles where the layer has them, else 128 (a 64-wide tile would amortise the loader's transform over too few products)
   const int tn = d->Cout > 128 ? 4 : 2;
   a.tiles_n = (d->Cout + 64 * tn - 1) / (64 * tn);
   const int split = wino_split(d->prec);
   int rc;
-  if (tn == 4) rc = split == 3 ? launch_wino_gemm<3, 4>(a, s) : split == 2 ? launch_wino_gemm<2, 4>(a, s) : launch_wino_gemm<1, 4>(a, s);
-  else rc = split == 3 ? launch_wino_gemm<3, 2>(a, s) : split == 2 ? launch_wino_gemm<2, 2>(a, s) : launch_wino_gemm<1, 2>(a, s);
+  if (tn == 4) rc = split == 3 ? launch_wino_gemm<3, 4>(a, s) : launch_wino_gemm<2, 4>(a, s);
+  else rc = split == 3 ? launch_wino_gemm<3, 2>(a, s) : launch_wino_gemm<2, 2>(a, s);
   if (rc != CRESTE_OK) return rc;
   WinoOutArgs o;
   o.M = a.M; o.bias = d->bias; o.res = d->res; o.row_mask = d->row_mask; o.out = d->out; o.out_amax = d->out_amax;

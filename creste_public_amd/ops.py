@@ -158,11 +158,13 @@ def conv_precision(prec: int, k: int, stride: int, cin: int) -> int:
 
 
 ALGO_DIRECT, ALGO_WINOGRAD = 0, 1
-# Winograd F(2x2,3x3) policy (hipnn.set_winograd): the stride-1 3x3 convs of the fp32-equivalent `bf16x6` mode with at
-# least WINOGRAD_MIN_C input AND output channels.  2.25x fewer matrix-core products, paid for with the transforms and an
-# fp32 round trip of the 16 per-position products: a win for wide layers only (csrc/conv_wino.hip).
+# Winograd F(2x2,3x3) policy: the stride-1 3x3 convs of the fp32-equivalent `bf16x6` mode with at least WINOGRAD_MIN_C
+# input AND output channels.  2.25x fewer matrix-core products, paid for with the transforms and an fp32 round trip of
+# the 16 per-position products: a win for wide layers only -- measured at batch 16 (scripts/wino_micro.py): 496->496
+# @152x304 14.05 -> 11.17 ms, 472->472 @76x152 3.76 -> 2.63, 432->432 @38x76 1.13 -> 0.64, 320->256 @128x128 1.84 -> 1.39,
+# 256->256 1.54 -> 1.20; 256->128 @256x256 2.80 -> 2.92 (loses: the 128-cout tile amortises the loader over half the products).
 WINOGRAD = True
-WINOGRAD_MIN_C = 128
+WINOGRAD_MIN_C = 256
 
 
 def conv_algo(prec: int, k: int, stride: int, pad, cin: int, cout: int) -> int:
