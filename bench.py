@@ -38,8 +38,10 @@ IMG_H, IMG_W, BATCH = 608, 1216, 16
 # 157.3, v_mfma_f32_32x32x16_{bf16,f16} 2500.  `roofline.frac` = algorithmic conv FLOP/s / that peak; the split modes
 # issue PRODUCTS[mode] MFMA products per algorithmic multiply, so the pipe's issue utilisation (`mfma_issue_util`) is
 # PRODUCTS x frac.
-PEAK = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0, "bf16x6": 2500.0, "f16x3": 2500.0}
-PRODUCTS = {"f32": 1, "bf16": 1, "bf16x3": 3, "bf16x6": 6, "f16x3": 3}
+PEAK = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0, "bf16x6": 2500.0, "f16x3": 2500.0,
+        "bf16x6+winograd": 2500.0, "bf16x3+winograd": 2500.0}
+# piece products issued per ALGORITHMIC multiply of the direct conv (Winograd F(2x2,3x3): 16 multiplies per 36)
+PRODUCTS = {"f32": 1, "bf16": 1, "bf16x3": 3, "bf16x6": 6, "f16x3": 3, "bf16x6+winograd": 6 * 16 / 36, "bf16x3+winograd": 3 * 16 / 36}
 PREC_NAME = {0: "f32", 1: "bf16", 2: "bf16x3", 3: "bf16x6", 4: "f16x3"}
 DTYPE = {"f32": "f32 (exact fp32 products on v_mfma_f32_32x32x2_f32, fp32 accumulate)",
          "bf16x6": "bf16x6 (fp32 operands as 3 bf16 pieces = 24 significand bits, 6 piece products per multiply on the "
@@ -68,6 +70,9 @@ def build_model(device):
 def kernel_symbol(pc, N, Ho, Wo):
     """The kernel a packed conv dispatches to (mirrors csrc/conv_igemm.hip / conv_patch.hip: patch_tn), named as
     rocprofv3 prints it, so bench numbers and profiles/ line up kernel by kernel."""
+    if getattr(pc, "algo", 0) == 1:             # Winograd F(2x2,3x3): GEMM over the 16 transform positions + output transform
+        split = {2: 2, 3: 3}[pc.prec]
+        return (PREC_NAME[pc.prec] + "+winograd", f"wino_gemm_kernel<{split}, {4 if pc.Cout > 128 else 2}> + wino_out_kernel")
     if pc.prec == 0:
         return ("f32", "conv_igemm_f32_kernel<2, 2, 2, 2>" if pc.Cout > 64 else
                 "conv_igemm_f32_kernel<2, 2, 2, 1>" if pc.Cout > 32 else "conv_igemm_f32_kernel<4, 1, 1, 1>")
@@ -584,12 +589,13 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": round(PEAK[dprec], 1), "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK[dprec], 4), "traffic": traffic,
-                         "mfma_products_per_multiply": PRODUCTS[dprec],
+                         "mfma_products_per_multiply": round(PRODUCTS[dprec], 3),
                          "mfma_issue_util": round(PRODUCTS[dprec] * achieved / PEAK[dprec], 4),
                          "launches": d["n"], "avg_launch_ms": round(d["ms"] / d["n"], 4),
                          "conv_share_of_step": round(conv_ms / args.steps / (elapsed / args.steps * 1e3), 4),
-                         "note": "achieved = algorithmic conv FLOPs (2*M*Cout*Cin*K*K) of every launch of this kernel "
-                                 "symbol in the timed steps / their HIP-event time; peak = dense peak of the MFMA "
+                         "note": "achieved = algorithmic conv FLOPs (2*M*Cout*Cin*K*K, the DIRECT conv's count) of every "
+                                 "launch of this kernel symbol in the timed steps / their HIP-event time (a Winograd call "
+                                 "= its GEMM + output-transform kernels together); peak = dense peak of the MFMA "
                                  "instruction issued; mfma_issue_util counts the piece products actually issued"},
         }
         sr = prof.splat_roofline()
