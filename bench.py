@@ -340,9 +340,17 @@ def irl_step_bench(model_infer, device, variant, steps=5):
                                  rng.uniform(-0.3 * GW, 0.3 * GW, size=(2, 1, 2))).astype(np.float32),
                    rank=np.array([0, 1])) for _ in range(B)]
 
-        def step():
+        def step(prefetch=True):
             opt.zero_grad()
-            out = model((rgbd, p2p, expert))
+            inputs = (rgbd, p2p, expert)
+            if prefetch:       # the loader's next batch (the same tensors here): its frozen half overlaps this step's rest
+                if model._prefetched is None:
+                    model.prefetch_backbone(inputs)
+                pf = model._take_prefetched(inputs)
+                model.prefetch_backbone(inputs)
+                out = model._forward_trainable(inputs, pf)
+            else:
+                out = model(inputs)
             td = {f"outputs/{k}": t for k, t in out.items()}
             td.update({"inputs/traversability_label": expert, "inputs/fov_mask": fov,
                        "inputs/counterfactuals_label": cf, "task": "irl"})
@@ -352,11 +360,14 @@ def irl_step_bench(model_infer, device, variant, steps=5):
             opt.step()
             return loss.detach(), out
 
-        step(); step(); torch.cuda.synchronize()              # eager step, then the capturing step
+        step(False); step(False); torch.cuda.synchronize()    # eager step, then the capturing step
+        ms_serial, _ = _median_step_ms(lambda: step(False), steps)
+        step(); step(); torch.cuda.synchronize()
         ms, (loss, out) = _median_step_ms(step, steps)
+        model._prefetched = None
         sweeps = int(model.traversability_head.last_sweeps.item())
         occ = float((out["bev_densities"] > 0).float().mean())
-        res = {"train_step_ms": round(ms, 2), "batch": B, "bev_grid": [GH, GW], "mdp_grid": list(v["map_size"]),
+        res = {"train_step_ms": round(ms, 2), "train_step_serial_ms": round(ms_serial, 2), "batch": B, "bev_grid": [GH, GW], "mdp_grid": list(v["map_size"]),
                "vi_sweeps": sweeps, "encoder_operands": creste_public_amd.get_precision(),
                "loss": round(float(loss), 5), "bev_cells_occupied": round(occ, 3)}
         del model, lm, opt
@@ -385,7 +396,9 @@ def irl_extras(model_infer, device, steps=5):
     """The second half of BASELINE.json's metric: IRL train-step time, at the reference config, at BASELINE configs[2]
     (256x256 MDP grid) and at configs[4]'s per-GPU shape (512x512 BEV, bf16 encoder, counterfactual IRL)."""
     out = {"config": "frames 1216x608; frozen HIP backbone + reward net training kernels + VI + SVF (T=50) + CF-IRL loss "
-                     "(alpha 0.5, 2 counterfactual trajectories per sample) + gradient penalty + Adam"}
+                     "(alpha 0.5, 2 counterfactual trajectories per sample) + gradient penalty + Adam; train_step_ms: the "
+                     "next batch's frozen-backbone forward runs on a side stream under this batch's trainable half "
+                     "(IRLTrainer.training_step(batch, next_batch)); train_step_serial_ms: back to back as the reference"}
     for name in IRL_VARIANTS:
         out[name] = irl_step_bench(model_infer, device, name, steps)
     out["irl_train_step_ms"] = out["reference"]["train_step_ms"]

@@ -71,6 +71,7 @@ class MaxEntIRL(nn.Module):
             p.requires_grad = False
         self.backbone.eval()
         self._fov_u8 = None
+        self._side_stream, self._prefetched = None, None
         if self.weights_path and os.path.isfile(self.weights_path) and not os.path.isfile(self.ckpt_path or ""):
             self.load_weights(self.weights_path)
 
@@ -121,19 +122,86 @@ class MaxEntIRL(nn.Module):
             bool(self.zero_terminal_state))
         return {"exp_svf": svf, "state_preds_grid": grid, "state_preds": states}
 
-    def forward(self, inputs):
-        image, p2p = inputs[0], inputs[1]
-        require_hip(image, "MaxEntIRL")
-        B = image.shape[0]
-        r = self.backbone.forward_act(image, p2p)
-        outputs = self.backbone.pack_outputs(r, B)
+    # ---- frozen half of the forward (perception backbone -> BEV predictions -> pooled / cropped reward input): depends on
+    # no trainable parameter, so in IRL training the NEXT batch's frozen half can run on a second stream while this
+    # batch's reward network / value iteration / SVF / loss / backward / Adam run (reference train_traversability.py:66-105
+    # runs them back to back, 24 of the 46 ms of a step at BASELINE configs[2])
+    @staticmethod
+    def _input_key(inputs):
+        return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in inputs[:2])
+
+    def _frozen_half(self, image, p2p):
         head = self.traversability_head
-        Ho, Wo = r["preds_buf"].H, r["preds_buf"].W
         keys = head.reward_cfg["input_keys"]
         want = [f"{p}_preds" for p in self.backbone.bevclassifier.output_prefix]
         if list(keys) != want:
             raise NotImplementedError(f"reward input_keys {list(keys)} must be the BEV heads' preds {want}")
+        r = self.backbone.forward_act(image, p2p)
+        outputs = self.backbone.pack_outputs(r, image.shape[0])
         view = head.input_view_act(r["preds_buf"])
+        return r, outputs, view
+
+    def prefetch_backbone(self, inputs):
+        """Enqueue the frozen half of `forward(inputs)` on a side stream; the next `forward` with the SAME input tensors
+        (same storage, same version) picks the result up instead of recomputing it.  Returns immediately."""
+        image, p2p = inputs[0], inputs[1]
+        require_hip(image, "MaxEntIRL")
+        main = torch.cuda.current_stream(image.device)
+        if self._side_stream is None or self._side_stream.device != image.device:
+            # LOWEST priority: the frozen half is throughput work (full-chip MFMA kernels); the trainable half on the
+            # caller's stream is a latency chain of ~600 small kernels that must not queue behind it
+            lo = max(torch.cuda.Stream.priority_range())
+            self._side_stream = torch.cuda.Stream(device=image.device, priority=lo)
+        side = self._side_stream
+        side.wait_stream(main)                       # the inputs are ready once the main stream gets here
+        with torch.cuda.stream(side), torch.no_grad():
+            r, outputs, view = self._frozen_half(image, p2p)
+            done = torch.cuda.Event()
+            done.record(side)
+        for t in (image, p2p):                       # keep the inputs' memory until the side stream has read them
+            t.record_stream(side)
+        self._prefetched = (self._input_key(inputs), r, outputs, view, done)
+
+    def _take_prefetched(self, inputs):
+        pf, self._prefetched = self._prefetched, None
+        if pf is None or pf[0] != self._input_key(inputs):
+            return None
+        _, r, outputs, view, done = pf
+        main = torch.cuda.current_stream(inputs[0].device)
+        main.wait_event(done)
+        # the tensors were allocated on the side stream's pool: tell the allocator the main stream uses them too
+        seen = set()
+
+        def mark(o):
+            if torch.is_tensor(o):
+                if o.is_cuda and o.data_ptr() not in seen:
+                    seen.add(o.data_ptr())
+                    o.record_stream(main)
+            elif hasattr(o, "buf"):
+                mark(o.buf)
+                mark(getattr(o, "amax", None))
+            elif isinstance(o, dict):
+                for v in o.values():
+                    mark(v)
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    mark(v)
+        mark(r); mark(outputs); mark(view)
+        return r, outputs, view
+
+    def forward(self, inputs):
+        image, p2p = inputs[0], inputs[1]
+        require_hip(image, "MaxEntIRL")
+        B = image.shape[0]
+        got = self._take_prefetched(inputs)
+        return self._forward_trainable(inputs, got if got is not None else self._frozen_half(image, p2p))
+
+    def _forward_trainable(self, inputs, frozen):
+        """the rest of `forward` given the frozen half's results (r, outputs, view)"""
+        r, outputs, view = frozen if frozen is not None else self._frozen_half(inputs[0], inputs[1])
+        outputs = dict(outputs)
+        head = self.traversability_head
+        Ho, Wo = r["preds_buf"].H, r["preds_buf"].W
         if not self.solve_mdp:
             outputs.update(head.forward_from_view(view, Ho, Wo, None, False))
             return outputs

@@ -31,10 +31,16 @@ def seed_everything(seed: int = 1337):
 
 
 class IRLTrainer:
-    def __init__(self, model: torch.nn.Module, loss_manager: torch.nn.Module, model_cfg, graphs: bool = False):
+    def __init__(self, model: torch.nn.Module, loss_manager: torch.nn.Module, model_cfg, graphs: bool = False,
+                 priority_stream: bool = False):
         """graphs=True: the reward network's launch sequences are captured into hipGraphs after one eager step
-        and replayed (train_ops._Phases) -- same results, static shapes required."""
+        and replayed (train_ops._Phases) -- same results, static shapes required.
+        priority_stream=True: with a look-ahead batch (training_step(batch, next_batch)) the trainable half runs on a
+        high-priority stream.  Measured at batch 8 of 1216x608, bf16x6 backbone: 64x128 MDP grid 38.9 serial -> 35.7
+        pipelined -> 32.4 with the priority stream; 256x256 MDP grid 58.7 -> 53.2 -> 61.3 (its reward-net / weight-gradient
+        kernels fill the chip themselves and then only delay the backbone), so it is opt-in."""
         self.model, self.loss, self.cfg = model, loss_manager, model_cfg
+        self.priority_stream = priority_stream
         if graphs:
             from .creste.models.blocks.conv import MultiScaleFCN
             for m in model.modules():
@@ -51,13 +57,42 @@ class IRLTrainer:
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=sc["gamma"])
         self.epoch, self.global_step = 0, 0
 
-    def training_step(self, batch: dict) -> dict:
-        """batch: {task: {'image','p2p','traversability_label', 'fov_mask', 'counterfactuals_label', ...}}"""
+    def training_step(self, batch: dict, next_batch: dict | None = None) -> dict:
+        """batch: {task: {'image','p2p','traversability_label', 'fov_mask', 'counterfactuals_label', ...}}
+
+        next_batch (optional, the loader's look-ahead): its frozen-backbone forward is enqueued on a side stream right
+        after this batch's has been picked up, and overlaps this batch's trainable half (MaxEntIRL.prefetch_backbone);
+        results are identical to the serial order -- the frozen half depends on no trainable parameter."""
         self.model.train()
+        pipelined = next_batch is not None and hasattr(self.model, "prefetch_backbone")
+        if not (pipelined and self.priority_stream):
+            return self._training_step(batch, next_batch if pipelined else None)
+        # the trainable half is a latency chain of ~600 small kernels: on a HIGH-priority stream its workgroups are
+        # dispatched ahead of the side stream's full-chip backbone kernels instead of queueing behind them
+        main = torch.cuda.current_stream()
+        if getattr(self, "_hp_stream", None) is None:
+            self._hp_stream = torch.cuda.Stream(priority=min(torch.cuda.Stream.priority_range()))
+        self._hp_stream.wait_stream(main)
+        with torch.cuda.stream(self._hp_stream):
+            logs = self._training_step(batch, next_batch)
+        main.wait_stream(self._hp_stream)
+        return logs
+
+    def _training_step(self, batch: dict, next_batch) -> dict:
         logs, total = {}, 0.0
-        for task, data in batch.items():
+        tasks = list(batch.items())
+        for ti, (task, data) in enumerate(tasks):
             self.optimizer.zero_grad()
-            outputs = self.model((data["image"], data["p2p"], data["traversability_label"]))
+            inputs = (data["image"], data["p2p"], data["traversability_label"])
+            nxt = tasks[ti + 1][1] if ti + 1 < len(tasks) else (next(iter(next_batch.values())) if next_batch else None)
+            if nxt is not None and hasattr(self.model, "prefetch_backbone"):
+                if getattr(self.model, "_prefetched", None) is None:          # first step: nothing in flight yet
+                    self.model.prefetch_backbone(inputs)
+                pf = self.model._take_prefetched(inputs)                      # (waits for the side stream's event)
+                self.model.prefetch_backbone((nxt["image"], nxt["p2p"]))      # next frozen half: overlaps what follows
+                outputs = self.model._forward_trainable(inputs, pf)
+            else:
+                outputs = self.model(inputs)
             with torch.no_grad():
                 merged = tu.merge_dict(("inputs", data), ("outputs", outputs))
                 merged["task"] = task

@@ -111,3 +111,46 @@ def test_trainer_on_hip_model(tmp_path):
         assert torch.equal(a, b)
     finally:
         creste_public_amd.set_precision("f32")
+
+
+@pytest.mark.gpu
+def test_irl_trainer_backbone_prefetch_equals_serial_steps():
+    """IRLTrainer.training_step(batch, next_batch): the next batch's frozen-backbone forward runs on a side stream under
+    this batch's trainable half.  The frozen half depends on no trainable parameter, so losses and parameters after three
+    steps over DIFFERENT batches must equal the serial order bit for bit (reference train_traversability.py:66-105)."""
+    import creste_public_amd
+    from creste_public_amd import MaxEntIRL
+    creste_public_amd.set_precision("bf16x6")
+    try:
+        H, W, B = 64, 96, 2
+        cfg = maxent_irl_cfg((H, W), solve_mdp=True)
+
+        def build():
+            seed_everything(1337)
+            m = MaxEntIRL(cfg)
+            synth.randomize_bn(m, seed=1)
+            with torch.no_grad():
+                m.backbone.depthcomp.depthcomp.vision_backbone.model.trunk._bn0.running_var.fill_(1e7)
+                m.traversability_head.r.postpool[0].norm.weight.mul_(0.01)
+            m = m.cuda()
+            return m, IRLTrainer(m, LossManager(cfg).cuda(), cfg)
+
+        def batch(seed):
+            rgbd, p2p = synth.make_frames(B, H, W, seed=seed)
+            return {"irl": {"image": rgbd.cuda(), "p2p": p2p.cuda(),
+                            "traversability_label": synth.make_experts(B, 50, 256, seed=seed + 1).cuda(),
+                            "fov_mask": torch.ones(B, 256, 256, dtype=torch.bool, device="cuda"),
+                            "counterfactuals_label": [None] * B}}
+        batches = [batch(s) for s in (5, 15, 25)]
+        m0, t0 = build()
+        serial = [float(t0.training_step(b)["train/loss"]) for b in batches]
+        m1, t1 = build()
+        piped = [float(t1.training_step(b, next_batch=batches[i + 1] if i + 1 < len(batches) else None)["train/loss"])
+                 for i, b in enumerate(batches)]
+        torch.cuda.synchronize()
+        assert m1._side_stream is not None, "the prefetch path did not run"
+        assert serial == piped, (serial, piped)
+        for (k, a), (_, b) in zip(m0.state_dict().items(), m1.state_dict().items()):
+            assert torch.equal(a, b), k
+    finally:
+        creste_public_amd.set_precision("f32")
