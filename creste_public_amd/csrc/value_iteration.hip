@@ -10,6 +10,7 @@
 // (below) and the batch-global convergence test is a device-side max (atomicMax on the float bits,
 // deltas are >= 0) checked across kernel boundaries; the host only peeks at a `done` flag every few
 // launches.
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -174,6 +175,269 @@ __global__ __launch_bounds__(VM_THREADS) void vi_multi_kernel(const float* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Persistent solver: ONE launch runs the whole iteration.  (The chunk-per-launch form above needs the host to peek at
+// `done` every few launches -- a stream synchronisation inside a call the header promises to be asynchronous, and a
+// forward that cannot be captured into a hipGraph -- and its 64 x 64 tiles put 128 workgroups on 256 CUs.)
+//   * a workgroup owns a TH x TW tile for the whole solve; r, v and the chunk-start copy of v of its (TH+2S) x (TW+2S)
+//     region live in registers (a thread owns 1 x 4 strips of cells), x = r + gamma*v in two LDS planes with a zero frame
+//     (one barrier per sweep: sweep j reads plane j&1 and writes the other);
+//   * per chunk of S sweeps the workgroups exchange their tile interiors through a ping-pong pair of global planes and
+//     meet at a device-scope barrier (all workgroups are co-resident: checked at launch); the halo ring is re-read from
+//     the neighbours' interiors, the interior itself never leaves the registers;
+//   * sweep k's batch-global delta is an atomicMax over tile interiors as before; after the barrier every workgroup
+//     reads the chunk's S deltas and, if the test failed first at sweep j, restores its chunk-start values and redoes
+//     exactly j+1 sweeps -- the same arithmetic and the same sweep count as sweep-per-launch execution.
+// Tiles: 32 x 32 (+8) for the large grids (512 workgroups at 8 x 256 x 256), 16 x 16 (+8) when that leaves CUs idle
+// (256 workgroups at the reference's 8 x 64 x 128, which the tile-per-sample form ran on 8).
+constexpr int VI_MAXW = 16;        // waves per workgroup of the persistent solver (<= 1024 threads)
+struct ViPArgs {
+  const float* r;
+  float* vbuf0;
+  float* vbuf1;
+  VmState* st;
+  unsigned* arrive;      // [nwg] chunk count each workgroup has finished
+  unsigned* go;          // ((chunk + 1) << 8) | (first failing sweep + 1, or 0): the master's verdict for that chunk
+  float* dwg;            // [2][nwg][S] per-workgroup interior deltas of the chunk (parity-indexed)
+  int B, H, W, TH, TW, S, tiles_x, tiles_y, nwg, max_chunks;
+  float gamma, thr;
+};
+
+// Device-scope rendezvous of the co-resident workgroups, once per chunk.  Everything exchanged (tile interiors, deltas,
+// flags) is written and read with agent-scope (sc1) accesses that go to the device's coherence point, so no cache
+// maintenance is needed: an agent-scope release / acquire fence writes back / invalidates the XCD's whole 4 MB L2, and
+// with ~400 of them per chunk and XCD the first version of this kernel spent 130 us per chunk there.  No read-modify-
+// write either: 512 workgroups incrementing one counter and atomicMax-ing eight delta words serialise at the memory
+// side (~15 us and ~25 us per chunk).  Instead every workgroup STORES its S deltas and an arrival flag; workgroup 0
+// polls the flags (one coalesced load per pass), reduces the deltas, applies the convergence test and publishes the
+// verdict in the word everyone else polls.
+template <int S>
+__device__ __forceinline__ int vi_rendezvous(const ViPArgs& p, int chunk, float* red, int* s_first) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's sc1 stores have reached the coherence point
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(p.arrive + blockIdx.x, (unsigned)(chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (blockIdx.x == 0) {
+    for (;;) {
+      int ok = 1;
+      for (int i = tid; i < p.nwg; i += nt)
+        ok &= __hip_atomic_load(p.arrive + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(chunk + 1);
+      if (__syncthreads_and(ok)) break;
+    }
+    float m[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) m[j] = 0.f;
+    const float* d = p.dwg + (size_t)(chunk & 1) * p.nwg * S;
+    for (int i = tid; i < p.nwg; i += nt)
+#pragma unroll
+      for (int j = 0; j < S; ++j) m[j] = fmaxf(m[j], __hip_atomic_load(d + (size_t)i * S + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m[j] = fmaxf(m[j], __shfl_xor(m[j], o));
+      if ((tid & 63) == 0) red[j * VI_MAXW + (tid >> 6)] = m[j];
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int first = -1;
+      for (int j = 0; j < S && first < 0; ++j) {
+        float mm = 0.f;
+        for (int w = 0; w < (nt + 63) / 64; ++w) mm = fmaxf(mm, red[j * VI_MAXW + w]);
+        if (!(mm > p.thr)) first = j;
+      }
+      __hip_atomic_store(p.go, ((unsigned)(chunk + 1) << 8) | (unsigned)(first + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (tid == 0) {
+    unsigned g;
+    while (((g = __hip_atomic_load(p.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 8) != (unsigned)(chunk + 1))
+      __builtin_amdgcn_s_sleep(1);
+    *s_first = (int)(g & 255u) - 1;
+  }
+  __syncthreads();
+  return *s_first;
+}
+
+template <int NSTRIP>
+__global__ __launch_bounds__(NSTRIP == 1 ? 576 : 256) void vi_persist_kernel(const ViPArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ int s_first;
+  const int S = p.S, RH = p.TH + 2 * S, RW = p.TW + 2 * S, LW = RW + 8, SW = RW >> 2, nstr = RH * SW;
+  const int plane = (RH + 2) * LW;
+  float* const xb[2] = {lds, lds + plane};
+  float* const red = lds + 2 * plane;                 // [S][VI_MAXW] per-wave maxima
+  const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6;
+  int id = blockIdx.x;
+  const int tx = id % p.tiles_x; id /= p.tiles_x;
+  const int ty = id % p.tiles_y;
+  const int b = id / p.tiles_y;
+  const int gy0 = ty * p.TH - S, gx0 = tx * p.TW - S;
+  const long pl = (long)b * p.H * p.W;
+
+  float rr[NSTRIP][4], vv[NSTRIP][4], vs[NSTRIP][4];
+  int li[NSTRIP], gofs[NSTRIP];          // LDS index of the strip's first cell (-1: none), global offset of that cell
+  unsigned inb[NSTRIP], inner[NSTRIP];   // 4-bit masks: cell inside the grid / inside this workgroup's tile
+#pragma unroll
+  for (int k = 0; k < NSTRIP; ++k) {
+    const int s = tid + k * nt;
+    li[k] = -1; inb[k] = inner[k] = 0; gofs[k] = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { rr[k][e] = 0.f; vv[k][e] = 0.f; vs[k][e] = 0.f; }
+    if (s < nstr) {
+      const int row = s / SW, c0 = (s - row * SW) * 4;
+      const int gy = gy0 + row, gx = gx0 + c0;
+      li[k] = (row + 1) * LW + 4 + c0;
+      gofs[k] = gy * p.W + gx;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool in = (unsigned)gy < (unsigned)p.H && (unsigned)(gx + e) < (unsigned)p.W;
+        if (in) { inb[k] |= 1u << e; rr[k][e] = p.r[pl + gofs[k] + e]; }
+        if (in && row >= S && row < S + p.TH && c0 + e >= S && c0 + e < S + p.TW) inner[k] |= 1u << e;
+      }
+    }
+  }
+  for (int i = tid; i < 2 * plane; i += nt) lds[i] = 0.f;     // zero frames (and out-of-grid cells) of both planes
+  __syncthreads();
+
+  auto put_x = [&](float* dst) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NSTRIP; ++k)
+      if (li[k] >= 0) {
+        float4 x;
+        x.x = (inb[k] & 1) ? __fadd_rn(rr[k][0], __fmul_rn(vv[k][0], p.gamma)) : 0.f;
+        x.y = (inb[k] & 2) ? __fadd_rn(rr[k][1], __fmul_rn(vv[k][1], p.gamma)) : 0.f;
+        x.z = (inb[k] & 4) ? __fadd_rn(rr[k][2], __fmul_rn(vv[k][2], p.gamma)) : 0.f;
+        x.w = (inb[k] & 8) ? __fadd_rn(rr[k][3], __fmul_rn(vv[k][3], p.gamma)) : 0.f;
+        *reinterpret_cast<float4*>(dst + li[k]) = x;
+      }
+  };
+  // one Jacobi sweep of the whole region: plane `src` -> registers + plane `dst`; returns this thread's interior delta
+  auto sweep = [&](const float* src, float* dst) __attribute__((always_inline)) -> float {
+    float dmax = 0.f;
+#pragma unroll
+    for (int k = 0; k < NSTRIP; ++k) {
+      if (li[k] < 0) continue;
+      float w[3][6];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const float* row = src + li[k] + (dy - 1) * LW;
+        const float4 c = *reinterpret_cast<const float4*>(row);
+        w[dy][0] = row[-1]; w[dy][1] = c.x; w[dy][2] = c.y; w[dy][3] = c.z; w[dy][4] = c.w; w[dy][5] = row[4];
+      }
+      // action-major: the four cells' fma chains of one action are independent and issue back to back (a cell-major
+      // order leaves each 3-deep chain waiting on its own result when there is one wave per SIMD)
+      float mx[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        float sacc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            sacc[e] = __fmaf_rn(kTaps[a][t].w, w[1 + kTaps[a][t].dy][e + 1 + kTaps[a][t].dx], sacc[e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx[e] = fmaxf(mx[e], sacc[e]);
+      }
+      float xn[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float m = mx[e];
+        if (inner[k] & (1u << e)) dmax = fmaxf(dmax, fabsf(__fsub_rn(m, vv[k][e])));
+        vv[k][e] = m;
+        xn[e] = (inb[k] & (1u << e)) ? __fadd_rn(rr[k][e], __fmul_rn(m, p.gamma)) : 0.f;
+      }
+      *reinterpret_cast<float4*>(dst + li[k]) = make_float4(xn[0], xn[1], xn[2], xn[3]);
+    }
+    return dmax;
+  };
+  auto store_interior = [&](float* vdst) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NSTRIP; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (inner[k] & (1u << e)) __hip_atomic_store(vdst + pl + gofs[k] + e, vv[k][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+
+#ifdef VI_TRACE
+  long long t_sw = 0, t_rv = 0, t_halo = 0, tA, tB, tC;
+#endif
+  for (int chunk = 0; chunk < p.max_chunks; ++chunk) {
+    float* const vnext = ((chunk + 1) & 1) ? p.vbuf1 : p.vbuf0;
+#ifdef VI_TRACE
+    tA = __builtin_readcyclecounter();
+#endif
+#pragma unroll
+    for (int k = 0; k < NSTRIP; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vs[k][e] = vv[k][e];
+    put_x(xb[0]);
+    __syncthreads();
+    // per-thread deltas of the chunk's sweeps stay in registers; ONE wave reduction per chunk (a reduction per sweep put six
+    // dependent cross-lane steps, ~700 cycles, on every sweep's critical path)
+    float dm[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      dm[j] = sweep(xb[j & 1], xb[(j + 1) & 1]);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) dm[j] = fmaxf(dm[j], __shfl_xor(dm[j], o));
+      if ((tid & 63) == 0) red[j * VI_MAXW + wave] = dm[j];
+    }
+    __syncthreads();
+    if (tid < S) {
+      float m = 0.f;
+      for (int w = 0; w < (nt + 63) / 64; ++w) m = fmaxf(m, red[tid * VI_MAXW + w]);
+      __hip_atomic_store(p.dwg + ((size_t)(chunk & 1) * p.nwg + blockIdx.x) * S + tid, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    store_interior(vnext);
+#ifdef VI_TRACE
+    tB = __builtin_readcyclecounter();
+#endif
+    const int first = vi_rendezvous<8>(p, chunk, red, &s_first);
+#ifdef VI_TRACE
+    tC = __builtin_readcyclecounter();
+    t_sw += tB - tA; t_rv += tC - tB;
+    if (first >= 0 && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
+      printf("wg %d chunks %d: sweeps+store %lld rendezvous %lld halo %lld cycles per chunk\n", (int)blockIdx.x, chunk + 1,
+             t_sw / (chunk + 1), t_rv / (chunk + 1), t_halo / (chunk + 1));
+#endif
+    if (first >= 0) {
+      // the test failed first at sweep `first` of this chunk: the answer is the chunk-start state advanced first+1 sweeps
+#pragma unroll
+      for (int k = 0; k < NSTRIP; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vv[k][e] = vs[k][e];
+      put_x(xb[0]);
+      __syncthreads();
+      for (int j = 0; j <= first; ++j) {
+        (void)sweep(xb[j & 1], xb[(j + 1) & 1]);
+        __syncthreads();
+      }
+      store_interior(vnext);
+      if (blockIdx.x == 0 && tid == 0) {
+        p.st->converged_at = chunk * S + first + 1;
+        p.st->final_buf = (chunk + 1) & 1;
+        __threadfence();
+        p.st->done = chunk + 1;
+      }
+      return;
+    }
+    // halo ring <- the neighbours' fresh interiors (this tile's own interior is already in registers)
+#pragma unroll
+    for (int k = 0; k < NSTRIP; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if ((inb[k] & ~inner[k]) & (1u << e))
+          vv[k][e] = __hip_atomic_load(vnext + pl + gofs[k] + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef VI_TRACE
+    t_halo += __builtin_readcyclecounter() - tC;
+#endif
+  }
+}
+
 __global__ __launch_bounds__(256) void vi_final2_kernel(const float* __restrict__ r,
                                                         const float* __restrict__ buf0,
                                                         const float* __restrict__ buf1, const VmState* st,
@@ -238,6 +502,49 @@ extern "C" int creste_value_iteration_f32(const float* r, int B, int H, int W, f
   VmState* st = (VmState*)(wp + 2 * vi_align((size_t)B * H * W * 4));
   unsigned* delta = (unsigned*)(st + 1);
 
+  const dim3 fgrid((W + TW - 1) / TW, (H + TH - 1) / TH, B);
+  // ---- persistent solver (one launch, no host synchronisation): tiles of 32 x 32, or 16 x 16 while that still leaves
+  // CUs idle; every workgroup must be resident at once (device-scope barrier)
+  {
+    constexpr int PS = 8;                                           // sweeps per chunk = halo width
+    int dev = 0, cus = 0;
+    CRESTE_HIP(hipGetDevice(&dev));
+    CRESTE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int T = 32;
+    if ((long)B * ((H + 31) / 32) * ((W + 31) / 32) < cus) T = 16;
+    const int tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
+    const long nwg = (long)B * tiles_x * tiles_y;
+    const int RH = T + 2 * PS, RW = T + 2 * PS, nstr = RH * (RW / 4);
+    // one 1 x 4 strip per thread (576 threads for the 48 x 48 region, 256 for 32 x 32): many light waves per SIMD -- with 3
+    // strips per thread and 1.5 waves per SIMD every LDS / barrier / dependent-issue latency was exposed (4.2 us per sweep)
+    const int threads = nstr, nstrip = 1;
+    const size_t psmem = (size_t)(2 * (RH + 2) * (RW + 8) + PS * VI_MAXW) * sizeof(float);
+    int per_cu = 0;
+    const void* fn = reinterpret_cast<const void*>(vi_persist_kernel<1>);
+    CRESTE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, psmem));
+    const char* force_multi = getenv("CRESTE_VI_MULTI");
+    if (nwg <= (long)per_cu * cus && !(force_multi && force_multi[0] == '1')) {
+      const int max_chunks = (max_sweeps + PS - 1) / PS;
+      CRESTE_HIP(hipMemsetAsync(buf0, 0, (size_t)B * H * W * 4, s));
+      CRESTE_HIP(hipMemsetAsync(st, 0, sizeof(VmState) + 4u * (size_t)((nwg + 63) / 64 * 64 + 64 + 2 * nwg * PS), s));
+      // rendezvous area (inside the memset above): arrival flags, the verdict word on its own line, per-workgroup deltas
+      unsigned* arrive = delta;
+      unsigned* go = delta + (nwg + 63) / 64 * 64;
+      float* dwg = (float*)(go + 64);
+      CRESTE_REQUIRE((nwg + 63) / 64 * 64 + 64 + 2 * nwg * PS <= (1L << 20), "value_iteration: workspace too small for the rendezvous area");
+      ViPArgs a{r, buf0, buf1, st, arrive, go, dwg, B, H, W, T, T, PS, tiles_x, tiles_y, (int)nwg, max_chunks, discount, threshold};
+      vi_persist_kernel<1><<<(unsigned)nwg, threads, psmem, s>>>(a);
+      (void)nstrip;
+      CRESTE_CHECK_LAUNCH("vi_persist");
+      // without convergence the last chunk wrote plane max_chunks & 1; *sweeps_out < 0 reports it (the call itself stays
+      // asynchronous: a non-converged solve is a negative sweep count, not an error code)
+      vi_final2_kernel<<<fgrid, 256, 0, s>>>(r, buf0, buf1, st, max_chunks & 1, max_chunks * PS, H, W, discount, v, q, policy,
+                                             sweeps_out);
+      CRESTE_CHECK_LAUNCH("vi_final");
+      return CRESTE_OK;
+    }
+  }
+  // ---- fallback (grids too large to be co-resident): one launch per chunk, host peeks at `done` every few launches.
   // tiling: the whole grid in one tile when it fits 8192 cells (no halo, long chunks), otherwise
   // 64x64 tiles with an 8-cell halo (80x80 region) and 8 sweeps per launch.
   int TH_, TW_, halo, S;
@@ -261,7 +568,6 @@ extern "C" int creste_value_iteration_f32(const float* r, int B, int H, int W, f
     CRESTE_HIP(hipMemcpyAsync(&done, &st->done, 4, hipMemcpyDeviceToHost, s));
     CRESTE_HIP(hipStreamSynchronize(s));
   }
-  const dim3 fgrid((W + TW - 1) / TW, (H + TH - 1) / TH, B);
   // without convergence the last normal launch (index nchunks-1) wrote buf[nchunks & 1]
   vi_final2_kernel<<<fgrid, 256, 0, s>>>(r, buf0, buf1, st, nchunks & 1, nchunks * S, H, W, discount, v, q,
                                          policy, sweeps_out);

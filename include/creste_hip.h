@@ -282,7 +282,12 @@ int creste_bev_splat_mode_f32(const float* xyz, const float* feats, int feats_cs
 /* Value iteration on the 8-connected grid MDP.  reference vin.py:36-46 (transition kernel),
  * :48-80 (Jacobi sweeps, hard-max backup, batch-global convergence test, final q + softmax).
  *   r [B,H,W] -> v [B,H,W], q [B,8,H,W], policy [B,8,H,W]; *sweeps_out (device int) = sweep count.
- *   work: creste_value_iteration_workspace_bytes(B,H,W) bytes. */
+ *   work: creste_value_iteration_workspace_bytes(B,H,W) bytes.
+ * Asynchronous on `stream` like every other entry point: the whole iteration is ONE persistent launch that decides
+ * convergence on the device (hipGraph-capturable).  A solve that hits max_sweeps therefore cannot come back as a return
+ * code: it leaves *sweeps_out = -(sweeps run) and the last iterate in v / q / policy.  Only grids too large for all their
+ * 32 x 32 tiles to be resident at once (beyond about 2000 x 2000 cells per sample at batch 1) fall back to one launch per
+ * chunk with host peeks, which can return CRESTE_ERR_NOCONV. */
 int64_t creste_value_iteration_workspace_bytes(int B, int H, int W);
 int creste_value_iteration_f32(const float* r, int B, int H, int W, float discount, float threshold,
                                int max_sweeps, float* v, float* q, float* policy, int32_t* sweeps_out,

@@ -222,3 +222,43 @@ def test_value_iteration_many_tiles_deterministic(ops):
     assert torch.equal(v1, v2) and torch.equal(q1, q2) and torch.equal(p1, p2)
     # the last sweep moved no cell by more than the threshold: v' = max_a q(v) differs from v by <= ~1e-3 everywhere
     assert float((q1.max(dim=1).values - v1).abs().max()) <= 1.05e-3
+
+
+@pytest.mark.parametrize("shape", [(8, 256, 256), (8, 64, 128), (2, 37, 53), (1, 130, 200), (3, 16, 16)])
+def test_value_iteration_persistent_equals_chunk_per_launch(ops, shape, monkeypatch):
+    """The one-launch persistent solver (device-scope barrier per chunk, convergence decided on the device) and the
+    launch-per-chunk fallback with host peeks run the same arithmetic: v, q, policy and the sweep count are identical."""
+    r = (torch.rand(shape, generator=torch.Generator().manual_seed(sum(shape))) * 1.7).cuda()
+    monkeypatch.setenv("CRESTE_VI_MULTI", "1")
+    v0, q0, p0, s0 = ops.value_iteration(r, 0.99, 1e-3)
+    monkeypatch.delenv("CRESTE_VI_MULTI")
+    v1, q1, p1, s1 = ops.value_iteration(r, 0.99, 1e-3)
+    assert int(s0) == int(s1) > 0
+    assert torch.equal(v0, v1) and torch.equal(q0, q1) and torch.equal(p0, p1)
+
+
+def test_value_iteration_is_stream_asynchronous_and_graph_capturable(ops):
+    """creste_hip.h promises every entry point is asynchronous on its stream: the solve must be capturable into a hipGraph
+    (a host synchronisation inside the call would abort the capture) and replay on fresh rewards."""
+    B, H, W = 8, 64, 128
+    r = torch.rand(B, H, W, generator=torch.Generator().manual_seed(0)).cuda()
+    ref = ops.value_iteration(r, 0.99, 1e-3)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            out = ops.value_iteration(r, 0.99, 1e-3)
+    g.replay()
+    torch.cuda.synchronize()
+    assert int(out[3]) == int(ref[3])
+    assert all(torch.equal(a, b) for a, b in zip(out[:3], ref[:3]))
+    r.copy_(torch.rand(B, H, W, generator=torch.Generator().manual_seed(1)) * 3.0)      # new rewards, same graph
+    g.replay()
+    torch.cuda.synchronize()
+    again = ops.value_iteration(r, 0.99, 1e-3)
+    assert int(out[3]) == int(again[3]) and torch.equal(out[0], again[0]) and torch.equal(out[2], again[2])
+    # a solve that cannot converge in max_sweeps reports a negative sweep count instead of blocking the host
+    v, q, pi, sw = ops.value_iteration(r, 0.99, 1e-3, max_sweeps=16)
+    assert int(sw) == -16 and torch.isfinite(v).all()
