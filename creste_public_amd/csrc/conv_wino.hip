@@ -169,18 +169,27 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoArgs p) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) d[j][k] = *reinterpret_cast<const wf32x4*>(rawbase + (j * 4 + k) * 1024 + lane * 16);
   };
-  auto store_a = [&](const wf32x4 (&d)[2][4], int c, char* buf) __attribute__((always_inline)) {
+  // transform + split + store of a staged chunk, with the NEXT chunk's raw DMA pieces (if `cn` >= 0) issued between the
+  // elements: an LDS-DMA costs the wave ~170 cycles to issue next to its partner's MFMAs (timing stamps: the 8 pieces
+  // were 1300-1500 cycles of a 2700-cycle staging phase when issued back to back in front of the transform); a piece
+  // every ~12 VALU instructions lets the queue drain behind arithmetic instead of in front of it
+  auto store_a = [&](const wf32x4 (&d)[2][4], int c, char* buf, int cn) __attribute__((always_inline)) {
     const bool chok = c * WN_CK + cq * 4 < p.Cin;
+    const int chn0 = cn * WN_CK + cq * 4, chn = chn0 < p.Cin ? chn0 : 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const float a1 = chok ? my1[j] : 0.f, a2 = chok ? my2[j] : 0.f;
       wf32x4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+        if (cn >= 0)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.in + (size_t)(off[j][e] + chn)),
+                                           (__attribute__((address_space(3))) void*)(rawbase + (j * 4 + e) * 1024), 16, 0, 0);
         // multiplications by +-1 / 0 are exact: each fma is ONE rounding of a two-term sum
         const float r1 = __fmaf_rn(d[j][1][e], mx2[j], d[j][0][e] * mx1[j]);
         const float r2 = __fmaf_rn(d[j][3][e], mx2[j], d[j][2][e] * mx1[j]);
         v[e] = __fmaf_rn(r2, a2, r1 * a1);
+        __builtin_amdgcn_sched_barrier(0);
       }
       char* dst = buf + a_lofs0 + j * (64 * 16);
       wf32x4 rem = v;
@@ -190,6 +199,7 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoArgs p) {
         *reinterpret_cast<wbf16x4*>(dst + pl * A_PLANE) = piece;
         if (pl + 1 < SPLIT) rem -= __builtin_convertvector(piece, wf32x4);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   // weight tile of chunk c: per 64-cout unit U_BYTES contiguous bytes, copied by LDS-DMA in 1 KiB pieces (every wave its
@@ -262,8 +272,7 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoArgs p) {
     asm volatile("s_barrier" ::: "memory");
     read_raw(ra);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (p.nchunk > 1) dma_raw(1);
-    store_a(ra, 0, abase);
+    store_a(ra, 0, abase, p.nchunk > 1 ? 1 : -1);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
 #ifdef WINO_TRACE
@@ -288,8 +297,7 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoArgs p) {
 #endif
           read_raw(ra);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (cst + 1 < p.nchunk) dma_raw(cst + 1);
-          store_a(ra, cst, abase + (cst & 1) * A_BYTES);
+          store_a(ra, cst, abase + (cst & 1) * A_BYTES, cst + 1 < p.nchunk ? cst + 1 : -1);
         }
       }
 #ifdef WINO_TRACE
