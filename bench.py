@@ -80,7 +80,7 @@ def kernel_symbol(pc, N, Ho, Wo):
         tn2 = 2 if pc.Cout > 64 and not (pc.KH == 7 and pc.stride == 2) else 1
         return (PREC_NAME[pc.prec], f"conv_patch_row_kernel<{pc.KH}, {pc.stride}, {tn2}>")
     split = {1: 1, 2: 2, 3: 3, 4: 2}[pc.prec]
-    tn = (4 if pc.prec == 4 else 2) if pc.Cout > 128 else 2 if pc.Cout > 64 else 1
+    tn = (4 if (pc.prec == 4 or (pc.KH == 1 and pc.prec == 3)) else 2) if pc.Cout > 128 else 2 if pc.Cout > 64 else 1
     if pc.KH == 1 and pc.Cin < 256 and tn == 4:
         tn = 2
     px_tiles = N * ((Ho + 7) // 8) * ((Wo + 31) // 32)
@@ -249,7 +249,9 @@ def distill_extras(device, steps=5, B=8):
     n = sum(p.numel() for p in model.parameters() if p.grad is not None)
     del tr, model, batch
     torch.cuda.empty_cache()
+    import creste_public_amd as _cpa
     return {"distill_train_step_ms": round(ms, 1), "distill_frames_per_s": round(B / ms * 1e3, 1),
+            "operands": _cpa.get_precision(),
             "distill_config": f"batch {B}, {IMG_W}x{IMG_H}, EfficientNet-B0 U-Net + depth/DINO heads in training mode, "
                               f"{n} parameters with gradients, Adam; loss {float(logs['train/loss']):.3f}"}
 
@@ -283,7 +285,9 @@ def ssc_extras(device, steps=5, B=8):
     n = sum(p.numel() for p in model.parameters() if p.grad is not None)
     del tr, model, batch
     torch.cuda.empty_cache()
+    import creste_public_amd as _cpa
     return {"ssc_train_step_ms": round(ms, 1), "ssc_frames_per_s": round(B / ms * 1e3, 1),
+            "operands": _cpa.get_precision(),
             "ssc_config": f"batch {B}, {IMG_W}x{IMG_H} -> 256x256 BEV, TerrainNet in training mode, SupPixelCon + CE + MSE + "
                           f"depth CE + depth SmoothL1 + elevation SmoothL1, {n} parameters with gradients, Adam; "
                           f"loss {float(logs['train/loss']):.3f}"}
@@ -347,8 +351,8 @@ def irl_step_bench(model_infer, device, variant, steps=5):
                 if model._prefetched is None:
                     model.prefetch_backbone(inputs)
                 pf = model._take_prefetched(inputs)
-                model.prefetch_backbone(inputs)
                 out = model._forward_trainable(inputs, pf)
+                model.prefetch_backbone(inputs)       # behind the value iteration (see IRLTrainer.training_step)
             else:
                 out = model(inputs)
             td = {f"outputs/{k}": t for k, t in out.items()}
@@ -626,6 +630,17 @@ def main():
         if args.gpus == 1 and not args.no_irl:
             line["latency"] = latency_extras(model, device)
             line["irl"] = irl_extras(model, device)
+            # the same steps with the narrower f16x3 operands (fp16 hi+lo = 22 significand bits): side entries
+            if args.precision != "f16x3":
+                creste_public_amd.set_precision("f16x3")
+                try:
+                    m16 = build_model(device)
+                    line["irl_f16x3"] = {k: irl_step_bench(m16, device, k) for k in ("reference", "mdp256")}
+                    line["distill_f16x3"] = distill_extras(device)
+                    line["ssc_f16x3"] = ssc_extras(device)
+                    del m16
+                finally:
+                    creste_public_amd.set_precision(args.precision)
             vi = line["irl"]["vi_8x256x256"]
             line["roofline_vi"] = {"bound": "hbm", "kernel": "creste_value_iteration_f32 (all sweeps + q / policy read-out)",
                                    "achieved": vi["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -143,7 +143,9 @@ class MaxEntIRL(nn.Module):
 
     def prefetch_backbone(self, inputs):
         """Enqueue the frozen half of `forward(inputs)` on a side stream; the next `forward` with the SAME input tensors
-        (same storage, same version) picks the result up instead of recomputing it.  Returns immediately."""
+        (same storage, same version) picks the result up instead of recomputing it.  Returns immediately.  Call it AFTER
+        the current batch's forward (i.e. behind its value iteration, as IRLTrainer does): the persistent MDP solver
+        needs all of its workgroups resident and must not share the device with a stream of full-chip kernels."""
         image, p2p = inputs[0], inputs[1]
         require_hip(image, "MaxEntIRL")
         main = torch.cuda.current_stream(image.device)

@@ -806,7 +806,9 @@ __global__ void pack_weight_patch_kernel(const float* __restrict__ w, const floa
 // few pixel tiles (the deep 19x38 / 38x76 maps) or few input channels (MBConv expand convs: one or two chunks per
 // tile, bound by the output write) take narrower tiles: more, lighter workgroups, two to a CU.
 static inline int patch_tn(int cout, int prec, int cin, int K, long px_tiles) {
-  const int max_tn = cout > 128 ? (prec == CRESTE_PREC_F16X3 ? 4 : 2) : (cout > 64 ? 2 : 1);
+  // 256-wide tiles: f16x3 everywhere; the bf16 split modes only for 1x1 convs (48 MFMAs per wave and barrier instead of 24:
+  // 496->256 @152x304x16 in bf16x6 1.47 -> see DESIGN) -- their 3x3 kernel's weight rows would not fit the LDS at 256
+  const int max_tn = cout > 128 ? ((prec == CRESTE_PREC_F16X3 || (K == 1 && prec == CRESTE_PREC_BF16X6)) ? 4 : 2) : (cout > 64 ? 2 : 1);
   int tn = max_tn;
   if (K == 1 && cin < 256 && tn == 4) tn = 2;            // write-bound expand convs: 256-wide tiles only add latency
   // 1x1 convs are latency chains of a few chunk steps per workgroup: they want MORE, lighter workgroups than the 3x3
@@ -924,6 +926,7 @@ int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
     return split == 3 ? launch_patch3<3, 1, false>(a, s)
                       : split == 2 ? launch_patch3<2, 1, false>(a, s) : launch_patch3<1, 1, false>(a, s);
   }
+  if (bn == 256) return launch_patch<1, 3, 4, false>(a, s);          // bf16x6 only (patch_tn)
   if (bn == 128)
     return split == 3 ? launch_patch<1, 3, 2, false>(a, s)
                       : split == 2 ? launch_patch<1, 2, 2, false>(a, s) : launch_patch<1, 1, 2, false>(a, s);

@@ -89,8 +89,12 @@ class IRLTrainer:
                 if getattr(self.model, "_prefetched", None) is None:          # first step: nothing in flight yet
                     self.model.prefetch_backbone(inputs)
                 pf = self.model._take_prefetched(inputs)                      # (waits for the side stream's event)
-                self.model.prefetch_backbone((nxt["image"], nxt["p2p"]))      # next frozen half: overlaps what follows
-                outputs = self.model._forward_trainable(inputs, pf)
+                outputs = self.model._forward_trainable(inputs, pf)           # reward forward, value iteration, SVF
+                # the next frozen half is enqueued BEHIND the value iteration (the side stream waits for this point of the
+                # main stream): the persistent solver synchronises its workgroups on the device and needs them all
+                # resident -- next to a stream of full-chip conv kernels its unscheduled workgroups starve while the
+                # resident ones spin (measured: a 57 ms step took minutes).  It overlaps loss / backward / Adam instead.
+                self.model.prefetch_backbone((nxt["image"], nxt["p2p"]))
             else:
                 outputs = self.model(inputs)
             with torch.no_grad():

@@ -285,7 +285,10 @@ int creste_bev_splat_mode_f32(const float* xyz, const float* feats, int feats_cs
  *   work: creste_value_iteration_workspace_bytes(B,H,W) bytes.
  * Asynchronous on `stream` like every other entry point: the whole iteration is ONE persistent launch that decides
  * convergence on the device (hipGraph-capturable).  A solve that hits max_sweeps therefore cannot come back as a return
- * code: it leaves *sweeps_out = -(sweeps run) and the last iterate in v / q / policy.  Only grids too large for all their
+ * code: it leaves *sweeps_out = -(sweeps run) and the last iterate in v / q / policy.  The persistent launch synchronises
+ * its workgroups on the device, so they must all become resident: do NOT overlap this call with long-running full-chip
+ * kernels on another stream (its unscheduled workgroups starve while the resident ones spin; CRESTE_VI_MULTI=1 selects
+ * the launch-per-chunk form, which has no such requirement).  Only grids too large for all their
  * 32 x 32 tiles to be resident at once (beyond about 2000 x 2000 cells per sample at batch 1) fall back to one launch per
  * chunk with host peeks, which can return CRESTE_ERR_NOCONV. */
 int64_t creste_value_iteration_workspace_bytes(int B, int H, int W);
