@@ -221,6 +221,23 @@ def conv2d(x: Act, pc: PackedConv, out: Act | None = None, res: Act | None = Non
            a_scale: torch.Tensor | None = None, row_mask: torch.Tensor | None = None) -> Act:
     lib = _lib.load()
     N, H, W, cin, dev = x.N, x.H, x.W, x.C, x.buf.device
+    if pc.algo == ALGO_WINOGRAD and N > 1 and N * H * W * x.cs >= (1 << 30):
+        # the Winograd loader addresses its input with 32-bit byte offsets: batches of more than 4 GiB go in slices
+        Ho, Wo = pc.out_hw(H, W)
+        if out is None:
+            out = Act.empty(N, Ho, Wo, pc.Cout, dev)
+        per = max(1, ((1 << 30) - 1) // (H * W * x.cs))
+        amax = None
+        for n0 in range(0, N, per):
+            n1 = min(N, n0 + per)
+            o = conv2d(Act(x.buf[n0:n1], x.C, x.co, x.amax), pc, out=Act(out.buf[n0:n1], out.C, out.co),
+                       res=None if res is None else Act(res.buf[n0:n1], res.C, res.co),
+                       a_scale=None if a_scale is None else a_scale[n0:n1].contiguous(),
+                       row_mask=None if row_mask is None else row_mask.reshape(N, -1)[n0:n1].contiguous())
+            if o.amax is not None:
+                amax = o.amax if amax is None else max2(amax, o.amax)
+        out.amax = amax
+        return out
     _chk(x.buf, name="conv input")
     if cin != pc.Cin:
         raise HipLibraryError(f"conv2d: input has {cin} channels, weights expect {pc.Cin}")

@@ -542,3 +542,21 @@ def test_expected_svf(ops, golden, name, zts):
     assert torch.equal(states.cpu(), g.t("state_preds"))
     assert torch.equal(grid.cpu(), g.t("state_preds_grid"))
     torch.testing.assert_close(svf.cpu(), g.t("exp_svf"), rtol=1e-5, atol=1e-6)
+
+
+def test_conv_winograd_large_batch_is_sliced(ops, monkeypatch):
+    """inputs of >= 2^30 elements go through the Winograd kernels in batch slices (32-bit byte offsets in the loader);
+    exercised here by lowering the host-side bound."""
+    import builtins
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 32, 12, 16, generator=g)
+    w = torch.randn(32, 32, 3, 3, generator=g) / 17.0
+    pc = ops.pack_conv(dev(w), None, None, 1, 1, ops.ACT_RELU, ops.PREC_BF16X6, algo=ops.ALGO_WINOGRAD)
+    whole = from_act(ops.conv2d(to_act(ops, x), pc))
+    src = open(ops.__file__).read().replace("(1 << 30)", "(12 * 16 * 32 * 2 + 1)")      # two images per slice
+    ns = {"__name__": ops.__name__, "__package__": ops.__package__, "__file__": ops.__file__}
+    exec(compile(src, ops.__file__, "exec"), ns)
+    sliced = from_act(ns["conv2d"](ns["nchw_to_nhwc"](dev(x)), ns["PackedConv"](**pc.__dict__)))
+    assert torch.equal(whole, sliced)
+    ref = F.relu(F.conv2d(x.double(), w.double(), padding=1))
+    assert float((whole.double() - ref).abs().max()) < 1e-4
