@@ -39,9 +39,10 @@ IMG_H, IMG_W, BATCH = 608, 1216, 16
 # issue PRODUCTS[mode] MFMA products per algorithmic multiply, so the pipe's issue utilisation (`mfma_issue_util`) is
 # PRODUCTS x frac.
 PEAK = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0, "bf16x6": 2500.0, "f16x3": 2500.0,
-        "bf16x6+winograd": 2500.0, "bf16x3+winograd": 2500.0}
+        "bf16x6+winograd": 2500.0, "bf16x3+winograd": 2500.0, "bf16x6+winograd4": 2500.0, "bf16x3+winograd4": 2500.0}
 # piece products issued per ALGORITHMIC multiply of the direct conv (Winograd F(2x2,3x3): 16 multiplies per 36)
-PRODUCTS = {"f32": 1, "bf16": 1, "bf16x3": 3, "bf16x6": 6, "f16x3": 3, "bf16x6+winograd": 6 * 16 / 36, "bf16x3+winograd": 3 * 16 / 36}
+PRODUCTS = {"f32": 1, "bf16": 1, "bf16x3": 3, "bf16x6": 6, "f16x3": 3, "bf16x6+winograd": 6 * 16 / 36, "bf16x3+winograd": 3 * 16 / 36,
+            "bf16x6+winograd4": 6 * 36 / 144, "bf16x3+winograd4": 3 * 36 / 144}
 PREC_NAME = {0: "f32", 1: "bf16", 2: "bf16x3", 3: "bf16x6", 4: "f16x3"}
 DTYPE = {"f32": "f32 (exact fp32 products on v_mfma_f32_32x32x2_f32, fp32 accumulate)",
          "bf16x6": "bf16x6 (fp32 operands as 3 bf16 pieces = 24 significand bits, 6 piece products per multiply on the "
@@ -73,6 +74,10 @@ def kernel_symbol(pc, N, Ho, Wo):
     if getattr(pc, "algo", 0) == 1:             # Winograd F(2x2,3x3): GEMM over the 16 transform positions + output transform
         split = {2: 2, 3: 3}[pc.prec]
         return (PREC_NAME[pc.prec] + "+winograd", f"wino_gemm_kernel<{split}, {4 if pc.Cout > 128 else 2}> + wino_out_kernel")
+    if getattr(pc, "algo", 0) == 2:             # Winograd F(4x4,3x3): input transform + GEMM over the 36 positions + output transform
+        split = {2: 2, 3: 3}[pc.prec]
+        return (PREC_NAME[pc.prec] + "+winograd4",
+                f"wino4_in_kernel<{split}> + wino4_gemm_kernel<{split}, {4 if pc.Cout > 128 else 2}> + wino4_out_kernel")
     if pc.prec == 0:
         return ("f32", "conv_igemm_f32_kernel<2, 2, 2, 2>" if pc.Cout > 64 else
                 "conv_igemm_f32_kernel<2, 2, 2, 1>" if pc.Cout > 32 else "conv_igemm_f32_kernel<4, 1, 1, 1>")

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libcreste_hip.so")
 
-ABI_VERSION = 5          # creste_abi_version() of the library this binding was written against
+ABI_VERSION = 6          # creste_abi_version() of the library this binding was written against
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
 
@@ -42,6 +42,10 @@ SIGNATURES = {
     "creste_conv_wino_weight_bytes": (_i64, [_i, _i, _i]),
     "creste_conv_wino_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "creste_conv_wino_workspace_bytes": (_i64, [_i, _i, _i, _i]),
+    "creste_conv_wino4_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "creste_conv_wino4_weight_bytes": (_i64, [_i, _i, _i]),
+    "creste_conv_wino4_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "creste_conv_wino4_workspace_bytes": (_i64, [_i, _i, _i, _i, _i, _i]),
     "creste_conv_packed_weight_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "creste_conv_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "creste_conv_pack_weight_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -244,6 +244,13 @@ int conv_wino_pack(const float* w, const float* scale, void* wpk, int Cout, int 
 int64_t conv_wino_workspace_bytes(int N, int Ho, int Wo, int Cout);
 int conv_wino_run(const creste_conv_desc* d, hipStream_t s);
 }  // namespace creste
+namespace creste {   // conv_wino4.hip
+bool conv_wino4_supported(int prec, int KH, int KW, int stride, int Cin, int Cout);
+int64_t conv_wino4_weight_bytes(int Cout, int Cin, int prec);
+int conv_wino4_pack(const float* w, const float* scale, void* wpk, int Cout, int Cin, int prec, hipStream_t s);
+int64_t conv_wino4_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int prec);
+int conv_wino4_run(const creste_conv_desc* d, hipStream_t s);
+}  // namespace creste
 
 namespace creste {
 size_t conv_desc_bytes() { return sizeof(creste_conv_desc); }     // csrc/plan_runtime.cpp checks a plan file against it
@@ -273,6 +280,25 @@ extern "C" int creste_conv_wino_pack_weight(const float* w, const float* scale, 
 extern "C" int64_t creste_conv_wino_workspace_bytes(int N, int Ho, int Wo, int Cout) {
   if (N <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0) return -1;
   return conv_wino_workspace_bytes(N, Ho, Wo, Cout);
+}
+
+extern "C" int creste_conv_wino4_supported(int prec, int KH, int KW, int stride, int Cin, int Cout) {
+  return conv_wino4_supported(prec, KH, KW, stride, Cin, Cout) ? 1 : 0;
+}
+
+extern "C" int64_t creste_conv_wino4_weight_bytes(int Cout, int Cin, int prec) {
+  return conv_wino4_supported(prec, 3, 3, 1, Cin, Cout) ? conv_wino4_weight_bytes(Cout, Cin, prec) : -1;
+}
+
+extern "C" int creste_conv_wino4_pack_weight(const float* w, const float* scale, void* wpk, int Cout, int Cin, int prec,
+                                             void* stream) {
+  CRESTE_REQUIRE(w && wpk && conv_wino4_supported(prec, 3, 3, 1, Cin, Cout), "conv_wino4_pack_weight: bad args / shape not built");
+  return conv_wino4_pack(w, scale, wpk, Cout, Cin, prec, (hipStream_t)stream);
+}
+
+extern "C" int64_t creste_conv_wino4_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int prec) {
+  if (N <= 0 || Ho <= 0 || Wo <= 0 || !conv_wino4_supported(prec, 3, 3, 1, Cin, Cout)) return -1;
+  return conv_wino4_workspace_bytes(N, Ho, Wo, Cin, Cout, prec);
 }
 
 extern "C" int64_t creste_conv_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int prec) {
@@ -312,7 +338,7 @@ extern "C" int creste_conv_pack_weight_f16(const float* w, const float* scale, v
 extern "C" int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream) {
   CRESTE_REQUIRE(d != nullptr, "conv2d: null descriptor");
   CRESTE_REQUIRE(d->wpk && d->out && d->in, "conv2d: null tensor pointer");
-  CRESTE_REQUIRE(d->algo == CRESTE_ALGO_DIRECT || d->algo == CRESTE_ALGO_WINOGRAD, "conv2d: unknown algo %d", d->algo);
+  CRESTE_REQUIRE(d->algo == CRESTE_ALGO_DIRECT || d->algo == CRESTE_ALGO_WINOGRAD || d->algo == CRESTE_ALGO_WINOGRAD4, "conv2d: unknown algo %d", d->algo);
   CRESTE_REQUIRE(d->prec == CRESTE_PREC_F32 || conv_patch_supported(d->prec, d->KH, d->KW, d->stride),
                  "conv2d: precision %d not built for %dx%d stride %d", d->prec, d->KH, d->KW, d->stride);
   CRESTE_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 &&
@@ -338,6 +364,7 @@ extern "C" int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream) {
   CRESTE_REQUIRE(d->prec != CRESTE_PREC_F16X3 || (d->a_amax && d->w_unscale),
                  "conv2d: F16X3 needs a_amax (device bound of |in|) and w_unscale (from creste_conv_pack_weight_f16)");
   if (d->algo == CRESTE_ALGO_WINOGRAD) return conv_wino_run(d, (hipStream_t)stream);
+  if (d->algo == CRESTE_ALGO_WINOGRAD4) return conv_wino4_run(d, (hipStream_t)stream);
   if (d->prec != CRESTE_PREC_F32) return conv_patch_run(d, (hipStream_t)stream);
   ConvArgs a;
   a.in = d->in; a.wpk = (const float*)d->wpk; a.bias = d->bias; a.res = d->res;

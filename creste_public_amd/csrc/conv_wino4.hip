@@ -1,0 +1,543 @@
+// Winograd F(4x4,3x3) for the wide stride-1 3x3 convolutions, on the split-operand bf16 matrix cores.
+//
+// Why a second Winograd: F(2x2,3x3) (conv_wino.hip) forms its transformed input inside the GEMM's loader, and the timing
+// stamps in profiles/r03_winograd_notes.md show that loader -- not the matrix pipe -- bounding the kernel (an LDS-DMA
+// costs a wave ~170 cycles to issue next to its partner's MFMAs; 41.7 % MFMA-busy).  F(4x4,3x3) needs 36 multiplies per
+// 4x4 output tile and (cin, cout) pair instead of 144 direct / 64 for F(2x2): 1.78x less matrix work again, and with
+// the transformed input materialised ONCE in HBM, already split into bf16 pieces and laid out as the GEMM's LDS image,
+// the GEMM loop is nothing but LDS-DMA + MFMA.  The price is HBM traffic (transformed input = 2.25 x 1.5 of the fp32
+// input, products = 2.25 x the fp32 output, each written and read once) in two bandwidth-bound kernels beside the GEMM.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A          (Lavin & Gray, interpolation points 0, +-1, +-2, inf)
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+//
+// Numerics: transforms in fp32 (weights: float64, rounded once), products fp32-grade (bf16x6) with fp32 accumulation.
+// Relative rms error against float64 on the 496-channel layers: 1.3e-6 (direct fp32 accumulation: 1.8e-7, F(2x2): 1.1e-6).
+//
+//   wino4_pack_kernel  U = G g G^T per (cout, cin), 36 positions, the GEMM's weight-tile LDS image (pack time)
+//   wino4_in_kernel    V = B^T d B per (tile, cin): 6x6 window at stride 4, split into bf16 pieces, written as
+//                      V[pos][tile block][chunk][piece][k-octet][256 tiles][8]  (= the GEMM's A-operand LDS image)
+//   wino4_gemm_kernel  36 independent GEMMs M_p[tile, cout] = sum_cin V_p[tile, cin] U_p[cout, cin]; persistent
+//                      workgroups, three LDS stages, every byte by LDS-DMA, one barrier per 16-channel chunk
+//   wino4_out_kernel   Y = A^T M A per (tile, channel quad) + the direct kernels' epilogue
+#include "common.h"
+
+namespace creste {
+
+typedef __bf16 w4bf16x8 __attribute__((ext_vector_type(8)));
+typedef float w4f32x16 __attribute__((ext_vector_type(16)));
+typedef float w4f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int W4_M = 256;      // tiles (GEMM rows) per tile block
+constexpr int W4_CK = 16;      // input channels per chunk = K of one MFMA
+constexpr int W4_POS = 36;
+constexpr int W4_MBG = 4;      // tile blocks an XCD works on at the same time (weight panels re-read from its L2)
+
+template <int SPLIT>
+__device__ __forceinline__ void w4_split_mfma2(const w4bf16x8 (&a)[SPLIT], const w4bf16x8 (&b0)[SPLIT],
+                                               const w4bf16x8 (&b1)[SPLIT], w4f32x16& c0, w4f32x16& c1) {
+  // smallest products first; consecutive MFMAs go to different accumulators
+#pragma unroll
+  for (int order = SPLIT - 1; order >= 0; --order)
+#pragma unroll
+    for (int pa = order; pa >= 0; --pa) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b0[order - pa], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa], b1[order - pa], c1, 0, 0, 0);
+    }
+}
+
+struct Wino4GemmArgs {
+  const char* V;             // [36][m_blocks][nchunk][SPLIT][2][256][8] bf16
+  const char* wpk;           // [36][units][nchunk][SPLIT][2][64][8] bf16
+  float* M;                  // [36][Cout / 4][T][4]
+  int T, Cout;
+  int nchunk, m_blocks, tiles_n, units;
+};
+
+// Item = (tile block, position, cout tile).  Items are dealt in UNITS of 32 = 8 panels (position, cout tile) x W4_MBG
+// tile blocks; unit u goes to XCD u % 8 (workgroup b sits on XCD b % 8) and its 32 items to that XCD's workgroups, so a
+// weight panel streams through the XCD's L2 once for four tile blocks and a V tile once for its cout tiles.  Placement
+// is speed only.
+template <int SPLIT, int TN>
+__global__ __launch_bounds__(512, 2) void wino4_gemm_kernel(const Wino4GemmArgs p) {
+  constexpr int A_OCT = W4_M * 16, A_PLANE = 2 * A_OCT, A_BYTES = SPLIT * A_PLANE;       // [piece][k-octet][row][8 bf16]
+  constexpr int U_OCT = 64 * 16, U_PLANE = 2 * U_OCT, U_BYTES = SPLIT * U_PLANE;         // one 64-cout weight unit
+  constexpr int B_BYTES = TN * U_BYTES;
+  constexpr int STAGE = A_BYTES + B_BYTES, NS = 3;
+  constexpr int A_INSTR = A_BYTES / 1024, B_INSTR = B_BYTES / 1024;
+  constexpr int kA = A_INSTR / 8, kBw = (B_INSTR + 7) / 8;     // 1 KiB DMA pieces EVERY wave issues per chunk
+  constexpr int kDma = kA + kBw;
+  constexpr int NT = TN;                       // a wave owns 64 tiles x 32*TN couts
+  constexpr int kStores = 2 * NT * 4;
+  static_assert(A_INSTR % 8 == 0 && B_BYTES % 1024 == 0, "tiles must be whole DMA pieces");
+  static_assert(kDma + kStores <= 63, "vmcnt is a 6-bit counter");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;     // 4 row groups of 64 tiles x 2 channel halves
+  const int li = lane & 31, lh = lane >> 5;
+  const int Q = p.Cout >> 2;
+
+  const int cus = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, P = W4_POS * p.tiles_n;
+  const int units_pg = (P + 7) >> 3, nunits = units_pg * ((p.m_blocks + W4_MBG - 1) / W4_MBG);
+  int slot = blockIdx.x >> 3;
+
+  int mb, pos, tn;
+  const char *abase_g, *wbase;
+  // -> true when `slot` names an item (advancing over the holes of ragged units), false at the end
+  auto setup = [&]() __attribute__((always_inline)) -> bool {
+    for (;; slot += cus) {
+      const int unit = (slot >> 5) * 8 + xcd, w = slot & 31;
+      if (unit >= nunits) return false;
+      const int mg = unit / units_pg, pg = unit - mg * units_pg;   // panel groups fastest: neighbouring XCDs share V tiles in the MALL
+      const int pnl = pg * 8 + (w & 7);
+      mb = mg * W4_MBG + (w >> 3);
+      if (pnl >= P || mb >= p.m_blocks) continue;
+      pos = pnl / p.tiles_n; tn = pnl - pos * p.tiles_n;
+      abase_g = p.V + ((size_t)pos * p.m_blocks + mb) * p.nchunk * A_BYTES;
+      wbase = p.wpk + ((size_t)pos * p.units + (size_t)tn * TN) * p.nchunk * U_BYTES;
+      return true;
+    }
+  };
+  auto uniform = [](const char* q) __attribute__((always_inline)) -> const char* {
+    const size_t v = reinterpret_cast<size_t>(q);
+    return reinterpret_cast<const char*>(((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                                         (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+  };
+  // chunk c -> stage c % 3: A tile (contiguous A_BYTES of V) and weight tile (U_BYTES per 64-cout unit), 1 KiB pieces,
+  // scalar base + 32-bit lane offset.  Every wave issues exactly kDma pieces (a wave with no weight piece left re-copies
+  // its previous one: same bytes to the same place), so the counted waits below hold for all of them
+  auto dma = [&](int c) __attribute__((always_inline)) {
+    char* st = smem + (c % NS) * STAGE;
+#pragma unroll
+    for (int jj = 0; jj < kA; ++jj) {
+      const int i = wave + 8 * jj;
+      const char* src = uniform(abase_g + (size_t)c * A_BYTES + i * 1024);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (unsigned)(lane * 16)),
+                                       (__attribute__((address_space(3))) void*)(st + i * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int jj = 0; jj < kBw; ++jj) {
+      int i = wave + 8 * jj;
+      if (i >= B_INSTR) i -= 8;
+      const int uu = i / (U_BYTES / 1024), r = i % (U_BYTES / 1024);
+      const char* src = uniform(wbase + ((size_t)uu * p.nchunk + c) * U_BYTES + r * 1024);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (unsigned)(lane * 16)),
+                                       (__attribute__((address_space(3))) void*)(st + A_BYTES + i * 1024), 16, 0, 0);
+    }
+  };
+
+  w4f32x16 acc[2][NT];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  // weights as the first MFMA operand (D = U * V^T: a lane owns one tile, its registers the couts)
+  auto mfma_chunk = [&](int c) __attribute__((always_inline)) {
+    const char* A = smem + (c % NS) * STAGE;
+    const char* B = A + A_BYTES;
+    w4bf16x8 af[2][SPLIT], bfr[2][SPLIT];
+    auto read_b = [&](int nt, w4bf16x8 (&dst)[SPLIT]) __attribute__((always_inline)) {
+      const int n = (wn * NT + nt) * 32 + li;
+#pragma unroll
+      for (int pl = 0; pl < SPLIT; ++pl)
+        dst[pl] = *reinterpret_cast<const w4bf16x8*>(B + (n >> 6) * U_BYTES + pl * U_PLANE + lh * U_OCT + (n & 63) * 16);
+    };
+    read_b(0, bfr[0]);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = wm * 64 + mt * 32 + li;
+#pragma unroll
+      for (int pl = 0; pl < SPLIT; ++pl)
+        af[mt][pl] = *reinterpret_cast<const w4bf16x8*>(A + pl * A_PLANE + lh * A_OCT + row * 16);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (nt + 1 < NT) read_b(nt + 1, bfr[(nt + 1) & 1]);     // lands behind this tile's 4 * SPLIT MFMAs
+      w4_split_mfma2<SPLIT>(bfr[nt & 1], af[0], af[1], acc[0][nt], acc[1][nt]);
+    }
+  };
+
+  if (!setup()) return;
+  zero_acc();
+  dma(0);
+  if (p.nchunk > 1) dma(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // first item only: later items count past their predecessor's stores
+
+  for (;;) {
+    for (int c = 0; c < p.nchunk; ++c) {
+      // this wave's pieces of chunk c have landed: younger operations are chunk c + 1's kDma pieces and, in the first
+      // two chunks of an item, the kStores product stores of the previous item issued between them
+      if (c + 1 >= p.nchunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (c < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma + kStores) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma) : "memory");
+      // everybody's pieces of chunk c are in, and everybody is done with chunk c - 1 = the stage chunk c + 2 goes to
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (c + 2 < p.nchunk) dma(c + 2);
+      mfma_chunk(c);
+    }
+    // ---- item tail: products to M[pos][cout / 4][tile][4] (lane = tile, registers 4g..4g+3 = four consecutive couts:
+    // a half-wave writes 512 contiguous bytes per instruction).  ALL kStores stores are issued (rows past the last
+    // tile / couts past Cout go to a junk line behind the workspace) so that the next item's waits can count them
+    float* Mp = p.M + (size_t)pos * Q * p.T * 4;
+    float* const junk = p.M + (size_t)W4_POS * Q * p.T * 4 + lane * 4;
+    const int mb_cur = mb, tn_cur = tn;
+    slot += cus;
+    const bool more = setup();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // all waves are done with the last chunk's stage
+    if (more) {
+      dma(0);
+      if (p.nchunk > 1) dma(1);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int m = mb_cur * W4_M + wm * 64 + mt * 32 + li;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = tn_cur * (64 * TN) + (wn * NT + nt) * 32 + 8 * g + 4 * lh;
+          float* dst = (m < p.T && n < p.Cout) ? Mp + ((size_t)(n >> 2) * p.T + m) * 4 : junk;
+          *reinterpret_cast<w4f32x4*>(dst) =
+              w4f32x4{acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+        }
+    }
+    if (!more) break;
+    zero_acc();
+  }
+}
+
+struct Wino4InArgs {
+  const float* in;
+  char* V;
+  int N, H, W, Cin, in_cs;
+  int tiles_y, tiles_x, T;
+  int pad_t, pad_l;
+  int nchunk, m_blocks;
+};
+
+// one row of B^T applied to six values
+__device__ __forceinline__ void w4_bt(const float (&d)[6], float (&t)[6]) {
+  const float a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1], c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+  t[0] = (4.f * d[0] - 5.f * d[2]) + d[4];
+  t[1] = a + b;
+  t[2] = a - b;
+  t[3] = c + e;
+  t[4] = c - e;
+  t[5] = (4.f * d[1] - 5.f * d[3]) + d[5];
+}
+
+// One workgroup = 16 tiles x one 16-channel chunk; thread = (tile, channel): 36 scalar loads (a wave reads 64 contiguous
+// bytes of 4 pixels per instruction; the chunk next door fetches the other half of the line), B^T d B in registers, split,
+// and the bf16 pieces cross an LDS tile so that the write side stores 16 bytes per lane = (position, piece, k-octet, tile)
+// with 16 consecutive tiles = 256 contiguous bytes of V.
+template <int SPLIT>
+__global__ __launch_bounds__(256) void wino4_in_kernel(const Wino4InArgs p) {
+  __shared__ __attribute__((aligned(16))) __bf16 tbuf[W4_POS * SPLIT * 2 * 16 * 8];
+  const int t = threadIdx.x;
+  const int chunk = blockIdx.x, tg = blockIdx.y;
+  const int tl = t >> 4, c = t & 15;
+  const int tile = tg * 16 + tl, ch = chunk * W4_CK + c;
+  const int per = p.tiles_y * p.tiles_x;
+  float d[6][6];
+  {
+    const bool ok = tile < p.T && ch < p.Cin;
+    const int tcl = ok ? tile : 0;
+    const int img = tcl / per, rem = tcl - img * per;
+    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    const int y0 = 4 * ty - p.pad_t, x0 = 4 * tx - p.pad_l;
+    const float* base = p.in + (ok ? ch : 0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int yy = y0 + i;
+      const bool yok = ok && (unsigned)yy < (unsigned)p.H;
+      const size_t rowoff = ((size_t)img * p.H + (yok ? yy : 0)) * p.W;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int xx = x0 + j;
+        const bool in = yok && (unsigned)xx < (unsigned)p.W;
+        const float v = base[(rowoff + (in ? xx : 0)) * p.in_cs];
+        d[i][j] = in ? v : 0.f;
+      }
+    }
+  }
+  // along y, then along x
+  float u[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+    float o[6];
+    w4_bt(col, o);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) u[i][j] = o[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float o[6];
+    w4_bt(u[i], o);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float rem = o[j];
+      __bf16* dst = tbuf + ((((i * 6 + j) * SPLIT) * 2 + (c >> 3)) * 16 + tl) * 8 + (c & 7);
+#pragma unroll
+      for (int pl = 0; pl < SPLIT; ++pl) {          // hi, then the bf16 of what is left, ...
+        const __bf16 piece = (__bf16)rem;
+        dst[pl * (2 * 16 * 8)] = piece;
+        if (pl + 1 < SPLIT) rem -= (float)piece;
+      }
+    }
+  }
+  __syncthreads();
+  const int mb = (tg * 16) >> 8, row0 = (tg * 16) & (W4_M - 1);
+  constexpr int UNITS = W4_POS * SPLIT * 2 * 16;
+  for (int uidx = t; uidx < UNITS; uidx += 256) {
+    const int tlw = uidx & 15, rest = uidx >> 4;     // rest = (pos * SPLIT + piece) * 2 + octet
+    const int pp = rest >> 1, oct = rest & 1;
+    const int pos = pp / SPLIT, pl = pp - pos * SPLIT;
+    char* dst = p.V + (((((size_t)pos * p.m_blocks + mb) * p.nchunk + chunk) * SPLIT + pl) * 2 + oct) * (size_t)(W4_M * 16) +
+                (size_t)(row0 + tlw) * 16;
+    *reinterpret_cast<w4f32x4*>(dst) = *reinterpret_cast<const w4f32x4*>(tbuf + (size_t)uidx * 8);
+  }
+}
+
+struct Wino4OutArgs {
+  const float* M;
+  const float* bias;
+  const float* res;
+  const float* row_mask;
+  float* out;
+  float* out_amax;
+  int N, Ho, Wo, Cout, out_cs, out_co, res_cs, act;
+  int tiles_y, tiles_x, T;
+};
+
+// One workgroup = 16 consecutive tiles x 64 couts.  Read side: thread = (tile, channel quad), 36 x 16-byte loads streamed
+// row by row of the 6x6 product tile (the 16 tiles of a quad are 256 contiguous bytes of M).  The 4x4 outputs cross an LDS
+// tile two output rows at a time so that the write side runs thread = (pixel, channel quad): 16 lanes write 256
+// contiguous bytes of one NHWC pixel and read bias / residual the same way.
+constexpr int W4O_TILES = 16, W4O_QUADS = 16, W4O_ROW = W4O_QUADS * 4 + 4;
+__global__ __launch_bounds__(256) void wino4_out_kernel(const Wino4OutArgs p) {
+  __shared__ __attribute__((aligned(16))) float tilebuf[W4O_TILES * 8 * W4O_ROW];
+  __shared__ float scratch[4];
+  const int Q = p.Cout >> 2;
+  const int t = threadIdx.x;
+  const int tile0 = blockIdx.x * W4O_TILES, quad0 = blockIdx.y * W4O_QUADS;
+  const int tl = t & (W4O_TILES - 1), ql = t >> 4;
+  w4f32x4 y[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) y[a][b] = w4f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const int tile = tile0 + tl, quad = quad0 + ql;
+    if (tile < p.T && quad < Q) {
+      const float* src = p.M + ((size_t)quad * p.T + tile) * 4;
+      const size_t plane = (size_t)Q * p.T * 4;
+      // rows of A^T by column i: y[a][.] += AT[a][i] * r_i[.]
+      constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        w4f32x4 m[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) m[j] = __builtin_nontemporal_load(reinterpret_cast<const w4f32x4*>(src + (i * 6 + j) * plane));
+        const w4f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+        const w4f32x4 r[4] = {(m[0] + s12) + s34, d12 + 2.f * d34, s12 + 4.f * s34, (d12 + 8.f * d34) + m[5]};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          if (AT[a][i] == 0.f) continue;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) y[a][b] = AT[a][i] == 1.f ? y[a][b] + r[b] : (AT[a][i] == -1.f ? y[a][b] - r[b] : y[a][b] + AT[a][i] * r[b]);
+        }
+      }
+    }
+  }
+  float vmax = 0.f;
+  const int cq = t & 15, n = (quad0 + cq) * 4;
+  const int per = p.tiles_y * p.tiles_x;
+  const bool nok = quad0 + cq < Q;
+  const w4f32x4 bs = (nok && p.bias) ? *reinterpret_cast<const w4f32x4*>(p.bias + n) : w4f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h) __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        *reinterpret_cast<w4f32x4*>(tilebuf + (tl * 8 + a * 4 + b) * W4O_ROW + ql * 4) = y[2 * h + a][b];
+    __syncthreads();
+    if (nok) {
+#pragma unroll
+      for (int pass = 0; pass < 8; ++pass) {
+        const int pl = pass * 16 + (t >> 4);          // pixel slot: tile pl / 8, output row 2h + (pl / 4) % 2, column pl % 4
+        const int tile = tile0 + (pl >> 3);
+        if (tile >= p.T) continue;
+        const int img = tile / per, rem = tile - img * per;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        const int oy = 4 * ty + 2 * h + ((pl >> 2) & 1), ox = 4 * tx + (pl & 3);
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        const long mrow = ((long)img * p.Ho + oy) * p.Wo + ox;
+        w4f32x4 v = *reinterpret_cast<const w4f32x4*>(tilebuf + pl * W4O_ROW + cq * 4) + bs;
+        if (p.res) v += *reinterpret_cast<const w4f32x4*>(p.res + mrow * p.res_cs + n);
+        const float rmask = p.row_mask ? p.row_mask[mrow] : 1.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = act_apply(v[e], p.act) * rmask;
+          vmax = fmaxf(vmax, fabsf(v[e]));
+        }
+        *reinterpret_cast<w4f32x4*>(p.out + mrow * p.out_cs + p.out_co + n) = v;
+      }
+    }
+  }
+  if (p.out_amax) block_amax_update(vmax, p.out_amax, scratch);
+}
+
+// U = G g G^T in float64 from the OIHW fp32 weights (x BatchNorm scale, applied in fp32 as the direct packers do),
+// rounded once to fp32, split into bf16 pieces: [pos][unit][chunk][piece][k-octet][64][8]
+__global__ void wino4_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, __bf16* __restrict__ out,
+                                  int Cout, int Cin, int units, int nchunk, int split) {
+  const long total = (long)units * 64 * nchunk * W4_CK;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(idx % (nchunk * W4_CK)), co = (int)(idx / (nchunk * W4_CK));
+    double g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        float v = 0.f;
+        if (co < Cout && ci < Cin) {
+          v = w[(((long)co * Cin + ci) * 3 + a) * 3 + b];
+          if (scale) v *= scale[co];
+        }
+        g[a][b] = (double)v;
+      }
+    const double G[6][3] = {{0.25, 0., 0.}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
+                            {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
+    double Gg[6][3];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) Gg[a][b] = G[a][0] * g[0][b] + G[a][1] * g[1][b] + G[a][2] * g[2][b];
+    const int unit = co >> 6, nn = co & 63, c = ci / W4_CK, oct = (ci % W4_CK) >> 3, e = ci & 7;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const int pos = a * 6 + b;
+        float v = (float)(Gg[a][0] * G[b][0] + Gg[a][1] * G[b][1] + Gg[a][2] * G[b][2]);
+        __bf16* dst = out + ((((size_t)pos * units + unit) * nchunk + c) * split) * (2 * 64 * 8) + (size_t)oct * 64 * 8 + nn * 8 + e;
+        for (int pl = 0; pl < split; ++pl) {
+          const __bf16 piece = (__bf16)v;
+          dst[(size_t)pl * (2 * 64 * 8)] = piece;
+          v -= (float)piece;
+        }
+      }
+  }
+}
+
+static inline int wino4_split(int prec) {
+  return prec == CRESTE_PREC_BF16X6 ? 3 : (prec == CRESTE_PREC_BF16X3 ? 2 : 0);
+}
+static inline int wino4_units(int Cout) { return ((Cout + 63) / 64 + 3) / 4 * 4; }       // padded to the widest tile (TN = 4)
+static inline long wino4_tiles(int N, int Ho, int Wo) { return (long)N * ((Ho + 3) / 4) * ((Wo + 3) / 4); }
+
+bool conv_wino4_supported(int prec, int KH, int KW, int stride, int Cin, int Cout) {
+  return wino4_split(prec) > 0 && KH == 3 && KW == 3 && stride == 1 && Cin > 0 && Cout > 0 && Cout % 4 == 0;
+}
+
+int64_t conv_wino4_weight_bytes(int Cout, int Cin, int prec) {
+  const long nchunk = (Cin + W4_CK - 1) / W4_CK;
+  return (long)W4_POS * wino4_units(Cout) * nchunk * wino4_split(prec) * 2 * 64 * 16;
+}
+
+int conv_wino4_pack(const float* w, const float* scale, void* wpk, int Cout, int Cin, int prec, hipStream_t s) {
+  const int units = wino4_units(Cout), nchunk = (Cin + W4_CK - 1) / W4_CK;
+  const long total = (long)units * 64 * nchunk * W4_CK;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  wino4_pack_kernel<<<blocks, 256, 0, s>>>(w, scale, (__bf16*)wpk, Cout, Cin, units, nchunk, wino4_split(prec));
+  CRESTE_CHECK_LAUNCH("wino4_pack");
+  return CRESTE_OK;
+}
+
+static inline long wino4_v_bytes(long T, int Cin, int prec) {
+  const long m_blocks = (T + W4_M - 1) / W4_M, nchunk = (Cin + W4_CK - 1) / W4_CK;
+  return (long)W4_POS * m_blocks * nchunk * wino4_split(prec) * 2 * W4_M * 16;
+}
+
+int64_t conv_wino4_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int prec) {
+  const long T = wino4_tiles(N, Ho, Wo);
+  return wino4_v_bytes(T, Cin, prec) + (long)W4_POS * T * Cout * 4 + 4096;       // V, M, the junk line of the padded stores
+}
+
+template <int SPLIT, int TN>
+static int launch_wino4_gemm(const Wino4GemmArgs& a, hipStream_t s) {
+  constexpr int smem = 3 * (SPLIT * 2 * W4_M * 16 + TN * SPLIT * 2 * 64 * 16);
+  static_assert(smem <= 160 * 1024, "Winograd GEMM stages do not fit the LDS");
+  static std::atomic<uint64_t> attr_devs{0};
+  CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino4_gemm_kernel<SPLIT, TN>), smem, attr_devs));
+  int dev = 0, cus = 0;
+  CRESTE_HIP(hipGetDevice(&dev));
+  CRESTE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const long items = (long)a.m_blocks * W4_POS * a.tiles_n;
+  long per_xcd = cus / 8 > 0 ? cus / 8 : 1;
+  const long need = (items + 7) / 8;
+  if (per_xcd > need) per_xcd = need;
+  wino4_gemm_kernel<SPLIT, TN><<<(unsigned)(per_xcd * 8), 512, smem, s>>>(a);
+  CRESTE_CHECK_LAUNCH("wino4_gemm");
+  return CRESTE_OK;
+}
+
+int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
+  CRESTE_REQUIRE(conv_wino4_supported(d->prec, d->KH, d->KW, d->stride, d->Cin, d->Cout),
+                 "conv2d: the F(4x4,3x3) path is built for stride-1 3x3 convs in the bf16 split modes, Cout a multiple of 4");
+  CRESTE_REQUIRE(d->work && !d->a_scale, "conv2d: the Winograd path needs its workspace and takes no per-sample input gate");
+  CRESTE_REQUIRE((d->out_cs & 3) == 0 && (d->out_co & 3) == 0 && (!d->res || (d->res_cs & 3) == 0) &&
+                     (reinterpret_cast<uintptr_t>(d->out) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->work) & 15) == 0,
+                 "conv2d: the Winograd path needs 16-byte aligned output / residual channel slices and workspace");
+  const int split = wino4_split(d->prec);
+  const int tiles_y = (d->Ho + 3) / 4, tiles_x = (d->Wo + 3) / 4;
+  const long T = (long)d->N * tiles_y * tiles_x;
+  CRESTE_REQUIRE(T < (1L << 26) && T * d->Cout < (1L << 36), "conv2d: Winograd workspace too large (split the batch)");
+  const int nchunk = (d->Cin + W4_CK - 1) / W4_CK, m_blocks = (int)((T + W4_M - 1) / W4_M);
+  char* V = (char*)d->work;
+  float* M = (float*)(V + wino4_v_bytes(T, d->Cin, d->prec));
+
+  Wino4InArgs ia;
+  ia.in = d->in; ia.V = V; ia.N = d->N; ia.H = d->H; ia.W = d->W; ia.Cin = d->Cin; ia.in_cs = d->in_cs;
+  ia.tiles_y = tiles_y; ia.tiles_x = tiles_x; ia.T = (int)T; ia.pad_t = d->pad_t; ia.pad_l = d->pad_l;
+  ia.nchunk = nchunk; ia.m_blocks = m_blocks;
+  CRESTE_REQUIRE(m_blocks * 16 <= 65535 * 16 && (long)m_blocks * 16 < (1L << 31), "conv2d: too many tiles for one launch");
+  const dim3 igrid((unsigned)nchunk, (unsigned)(m_blocks * 16));
+  if (split == 3) wino4_in_kernel<3><<<igrid, 256, 0, s>>>(ia);
+  else wino4_in_kernel<2><<<igrid, 256, 0, s>>>(ia);
+  CRESTE_CHECK_LAUNCH("wino4_in");
+
+  Wino4GemmArgs a;
+  a.V = V; a.wpk = (const char*)d->wpk; a.M = M; a.T = (int)T; a.Cout = d->Cout;
+  a.nchunk = nchunk; a.m_blocks = m_blocks; a.units = wino4_units(d->Cout);
+  const int tn = d->Cout > 128 ? 4 : 2;
+  a.tiles_n = (d->Cout + 64 * tn - 1) / (64 * tn);
+  int rc;
+  if (tn == 4) rc = split == 3 ? launch_wino4_gemm<3, 4>(a, s) : launch_wino4_gemm<2, 4>(a, s);
+  else rc = split == 3 ? launch_wino4_gemm<3, 2>(a, s) : launch_wino4_gemm<2, 2>(a, s);
+  if (rc != CRESTE_OK) return rc;
+
+  Wino4OutArgs o;
+  o.M = M; o.bias = d->bias; o.res = d->res; o.row_mask = d->row_mask; o.out = d->out; o.out_amax = d->out_amax;
+  o.N = d->N; o.Ho = d->Ho; o.Wo = d->Wo; o.Cout = d->Cout; o.out_cs = d->out_cs; o.out_co = d->out_co; o.res_cs = d->res_cs;
+  o.act = d->act; o.tiles_y = tiles_y; o.tiles_x = tiles_x; o.T = (int)T;
+  const dim3 ogrid((unsigned)((T + W4O_TILES - 1) / W4O_TILES), (unsigned)((d->Cout / 4 + W4O_QUADS - 1) / W4O_QUADS));
+  wino4_out_kernel<<<ogrid, 256, 0, s>>>(o);
+  CRESTE_CHECK_LAUNCH("wino4_out");
+  return CRESTE_OK;
+}
+
+}  // namespace creste

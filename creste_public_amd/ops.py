@@ -157,7 +157,7 @@ def conv_precision(prec: int, k: int, stride: int, cin: int) -> int:
     return prec
 
 
-ALGO_DIRECT, ALGO_WINOGRAD = 0, 1
+ALGO_DIRECT, ALGO_WINOGRAD, ALGO_WINOGRAD4 = 0, 1, 2
 # Winograd F(2x2,3x3) policy: the stride-1 3x3 convs of the fp32-equivalent `bf16x6` mode with at least WINOGRAD_MIN_C
 # input AND output channels.  2.25x fewer matrix-core products, paid for with the transforms and an fp32 round trip of
 # the 16 per-position products: a win for wide layers only -- measured at batch 16 (scripts/wino_micro.py): 496->496
@@ -165,9 +165,17 @@ ALGO_DIRECT, ALGO_WINOGRAD = 0, 1
 # 256->256 1.54 -> 1.20; 256->128 @256x256 2.80 -> 2.92 (loses: the 128-cout tile amortises the loader over half the products).
 WINOGRAD = True
 WINOGRAD_MIN_C = 256
+# F(4x4,3x3) (csrc/conv_wino4.hip): 1.78x fewer products again and a GEMM loop that is LDS-DMA + MFMA only, for the price of
+# the transformed input / the products crossing HBM once each; preferred over F(2x2) where both apply
+WINOGRAD4 = True
+WINOGRAD4_MIN_CIN, WINOGRAD4_MIN_COUT = 256, 128
 
 
 def conv_algo(prec: int, k: int, stride: int, pad, cin: int, cout: int) -> int:
+    if WINOGRAD4 and prec == PREC_BF16X6 and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1) \
+            and cin >= WINOGRAD4_MIN_CIN and cout >= WINOGRAD4_MIN_COUT \
+            and _lib.load().creste_conv_wino4_supported(prec, k, k, stride, cin, cout):
+        return ALGO_WINOGRAD4
     if WINOGRAD and prec == PREC_BF16X6 and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1) \
             and min(cin, cout) >= WINOGRAD_MIN_C and _lib.load().creste_conv_wino_supported(prec, k, k, stride, cin, cout):
         return ALGO_WINOGRAD
@@ -194,14 +202,15 @@ def pack_conv(weight: torch.Tensor, bias, bn, stride, pad, act, prec=PREC_F32, a
     if algo is None:
         algo = conv_algo(prec, KH, stride, pad, Cin, Cout) if KH == KW else ALGO_DIRECT
     sp = scale.data_ptr() if scale is not None else None
-    if algo == ALGO_WINOGRAD:
-        nbytes = lib.creste_conv_wino_weight_bytes(Cout, Cin, prec)
+    if algo in (ALGO_WINOGRAD, ALGO_WINOGRAD4):
+        f4 = algo == ALGO_WINOGRAD4
+        nbytes = (lib.creste_conv_wino4_weight_bytes if f4 else lib.creste_conv_wino_weight_bytes)(Cout, Cin, prec)
         if nbytes <= 0 or (KH, KW, stride) != (3, 3, 1):
             raise HipLibraryError("pack_conv: the Winograd path is not built for this shape / precision")
         wpk = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-        _lib.check(lib.creste_conv_wino_pack_weight(w.data_ptr(), sp, wpk.data_ptr(), Cout, Cin, prec, _stream()),
-                   "conv_wino_pack_weight")
-        return PackedConv(wpk, b, Cin, Cout, KH, KW, stride, pad[0], pad[2], pad[1], pad[3], act, prec, None, ALGO_WINOGRAD)
+        _lib.check((lib.creste_conv_wino4_pack_weight if f4 else lib.creste_conv_wino_pack_weight)(
+            w.data_ptr(), sp, wpk.data_ptr(), Cout, Cin, prec, _stream()), "conv_wino_pack_weight")
+        return PackedConv(wpk, b, Cin, Cout, KH, KW, stride, pad[0], pad[2], pad[1], pad[3], act, prec, None, algo)
     nbytes = lib.creste_conv_packed_weight_bytes(Cout, Cin, KH, KW, prec)
     if nbytes <= 0:
         raise HipLibraryError("conv_packed_weight_bytes: unsupported shape/precision")
@@ -274,6 +283,9 @@ def conv2d(x: Act, pc: PackedConv, out: Act | None = None, res: Act | None = Non
     work = None
     if pc.algo == ALGO_WINOGRAD:       # fp32 products of the 16 transform positions (stream-ordered reuse by the allocator)
         work = torch.empty(lib.creste_conv_wino_workspace_bytes(N, Ho, Wo, pc.Cout), dtype=torch.uint8, device=dev)
+        d.work = work.data_ptr()
+    elif pc.algo == ALGO_WINOGRAD4:    # transformed input (bf16 pieces) + fp32 products of the 36 positions
+        work = torch.empty(lib.creste_conv_wino4_workspace_bytes(N, Ho, Wo, pc.Cin, pc.Cout, pc.prec), dtype=torch.uint8, device=dev)
         d.work = work.data_ptr()
     if pc.prec == PREC_F16X3:
         d.a_amax, d.w_unscale = absmax(x).data_ptr(), pc.w_unscale.data_ptr()

@@ -50,6 +50,7 @@ extern "C" {
                                 rate; needs creste_conv_desc.a_amax / w_unscale */
 #define CRESTE_ALGO_DIRECT 0   /* implicit GEMM over the K*K taps (every shape) */
 #define CRESTE_ALGO_WINOGRAD 1 /* F(2x2,3x3): stride-1 3x3 convs, see creste_conv_wino_* below */
+#define CRESTE_ALGO_WINOGRAD4 2 /* F(4x4,3x3): the same convs, transformed input materialised, see creste_conv_wino4_* */
 
 const char* creste_last_error(void);
 int creste_abi_version(void);
@@ -73,7 +74,7 @@ typedef struct creste_conv_desc {
   const float* a_scale;  /* [N,Cin] per-sample input-channel gate (squeeze-excite), or NULL */
   const float* row_mask; /* [N*Ho*Wo] multiplied into every output row after the activation, or NULL */
   float* out;            /* [N,Ho,Wo,out_cs], written at channel offset out_co */
-  void* work;            /* CRESTE_ALGO_WINOGRAD: caller-owned workspace of creste_conv_wino_workspace_bytes(); else NULL */
+  void* work;            /* CRESTE_ALGO_WINOGRAD / _WINOGRAD4: caller-owned workspace of creste_conv_wino[4]_workspace_bytes(); else NULL */
   int32_t N, H, W, Cin, in_cs;
   int32_t Ho, Wo, Cout, out_cs, out_co, res_cs;
   int32_t KH, KW, stride, pad_t, pad_l;
@@ -114,6 +115,19 @@ int creste_conv_wino_pack_weight(const float* w_oihw, const float* scale, void* 
                                  void* stream);
 /* bytes of `work` for an output of N x Ho x Wo x Cout: 16 positions x N*ceil(Ho/2)*ceil(Wo/2) tiles x Cout floats */
 int64_t creste_conv_wino_workspace_bytes(int N, int Ho, int Wo, int Cout);
+/* ---- Winograd F(4x4,3x3) path (CRESTE_ALGO_WINOGRAD4), same operator and reference call sites as above: 4x fewer
+ * matrix-core products per output than the direct form (36 per 4x4 tile instead of 144), same fp32-equivalent
+ * split-operand products and fp32 accumulation, transforms in fp32 (weights: float64).  Three launches: the input
+ * transform writes V = B^T d B (6x6 windows at stride 4), already split into bf16 pieces and laid out as the GEMM's LDS
+ * image, into `work`; the 36 per-position GEMMs stream V and the packed weights by LDS-DMA and write the fp32 products M
+ * into `work`; the output transform Y = A^T M A applies the usual epilogue.  Relative rms error against float64 on the
+ * 496-channel layers 1.3e-6 (F(2x2): 1.1e-6, direct: 1.8e-7).  `work`: creste_conv_wino4_workspace_bytes(), 16-byte
+ * aligned. */
+int creste_conv_wino4_supported(int prec, int KH, int KW, int stride, int Cin, int Cout);
+int64_t creste_conv_wino4_weight_bytes(int Cout, int Cin, int prec);
+int creste_conv_wino4_pack_weight(const float* w_oihw, const float* scale, void* wpk, int Cout, int Cin, int prec,
+                                  void* stream);
+int64_t creste_conv_wino4_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int prec);
 /* Size in BYTES of the packed weight for (Cout,Cin,KH,KW) at precision `prec`. */
 int64_t creste_conv_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int prec);
 /* Pack a torch OIHW fp32 weight (device pointer, contiguous) into the GEMM layout, optionally

@@ -12,7 +12,7 @@ x = ops.Act(torch.relu(torch.randn(N, H, W, Cin, device="cuda")), Cin)
 w = torch.randn(Cout, Cin, 3, 3, device="cuda") / (Cin * 9) ** 0.5
 out = ops.Act.empty(N, H, W, Cout, "cuda")
 res = {}
-for name, algo in (("direct", ops.ALGO_DIRECT), ("winograd", ops.ALGO_WINOGRAD)):
+for name, algo in (("direct", ops.ALGO_DIRECT), ("winograd", ops.ALGO_WINOGRAD), ("winograd4", ops.ALGO_WINOGRAD4)):
     pc = ops.pack_conv(w, None, None, 1, 1, ops.ACT_RELU, prec, algo=algo)
     for _ in range(2):
         ops.conv2d(x, pc, out=out)
@@ -28,3 +28,5 @@ for name, algo in (("direct", ops.ALGO_DIRECT), ("winograd", ops.ALGO_WINOGRAD))
     print(f"{sys.argv[1]} {name:9s} {Cin}->{Cout} {H}x{W} N={N}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s (algorithmic)")
 d = (res["direct"] - res["winograd"]).double()
 print(f"   winograd vs direct: rel rms {float(d.pow(2).mean().sqrt() / res['direct'].double().pow(2).mean().sqrt()):.2e}")
+d = (res["direct"] - res["winograd4"]).double()
+print(f"   winograd4 vs direct: rel rms {float(d.pow(2).mean().sqrt() / res['direct'].double().pow(2).mean().sqrt()):.2e}")

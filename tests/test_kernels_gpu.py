@@ -102,7 +102,7 @@ def test_conv_patch_bf16(ops, case, prec, tol):
     assert ops.conv_supported(code, K, s)
     pc = ops.pack_conv(dev(w), None if b is None else dev(b),
                        None if bn is None else tuple(dev(t) if isinstance(t, torch.Tensor) else t for t in bn),
-                       s, pad, act, code)
+                       s, pad, act, code, algo=ops.ALGO_DIRECT)      # the DIRECT kernels (Winograd: test_conv_winograd)
     got = from_act(ops.conv2d(to_act(ops, x), pc, res=None if res is None else to_act(ops, res))).double()
     assert got.shape == ref.shape
     rel = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-12))
@@ -118,14 +118,19 @@ WINO_CASES = [
     (2, 256, 16, 16, 128, 1, True, True, False, True, True),        # 128-cout tile, bias, row mask, output channel slice
     (3, 128, 33, 34, 320, 2, False, True, True, False, False),      # three images: tile blocks cross image borders
     (1, 132, 128, 153, 132, 1, False, True, False, False, False),   # the reference's 128 x 153 map (odd width)
+    (5, 32, 64, 60, 64, 1, False, True, False, False, False),       # F(4x4): five tile blocks x one cout tile (ragged panel groups)
+    (9, 16, 128, 128, 272, 0, False, False, False, False, False),   # F(4x4): 36 tile blocks (XCDs with 4 and 5), two cout tiles
 ]
 
 
-@pytest.mark.parametrize("prec,tol", [("bf16x6", 2e-6), ("bf16x3", 8e-5)])
+@pytest.mark.parametrize("variant,prec,tol", [("f2", "bf16x6", 2e-6), ("f2", "bf16x3", 8e-5),
+                                              ("f4", "bf16x6", 6e-6), ("f4", "bf16x3", 1.2e-4)])
 @pytest.mark.parametrize("case", WINO_CASES)
-def test_conv_winograd(ops, case, prec, tol):
-    """Winograd F(2x2,3x3) path of the stride-1 3x3 convs (csrc/conv_wino.hip) against a float64 conv -- same bound as
-    the direct split-operand kernels -- and against the DIRECT kernel of the same mode."""
+def test_conv_winograd(ops, case, variant, prec, tol):
+    """Winograd paths of the stride-1 3x3 convs -- F(2x2,3x3) (csrc/conv_wino.hip, same bound as the direct split-operand
+    kernels) and F(4x4,3x3) (csrc/conv_wino4.hip: fp32 transforms with coefficients up to 8, bound 3x wider) -- against
+    a float64 conv, and against the DIRECT kernel of the same mode."""
+    wino = ops.ALGO_WINOGRAD if variant == "f2" else ops.ALGO_WINOGRAD4
     N, Cin, H, W, Cout, act, use_bias, use_bn, use_res, use_mask, use_slice = case
     g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
     x = torch.randn(N, Cin, H, W, generator=g)
@@ -146,7 +151,7 @@ def test_conv_winograd(ops, case, prec, tol):
     code = {"bf16x6": ops.PREC_BF16X6, "bf16x3": ops.PREC_BF16X3}[prec]
     bn_d = None if bn is None else tuple(dev(t) if isinstance(t, torch.Tensor) else t for t in bn)
     outs = {}
-    for algo in (ops.ALGO_WINOGRAD, ops.ALGO_DIRECT):
+    for algo in (wino, ops.ALGO_DIRECT):
         pc = ops.pack_conv(dev(w), None if b is None else dev(b), bn_d, 1, 1, act, code, algo=algo)
         assert pc.algo == algo
         out = None
@@ -159,7 +164,7 @@ def test_conv_winograd(ops, case, prec, tol):
         if use_slice:      # nothing outside the slice is touched
             assert float(y.buf[..., :8].min()) == 7.0 and float(y.buf[..., 8 + Cout:].max()) == 7.0
         outs[algo] = from_act(y).double()
-    got = outs[ops.ALGO_WINOGRAD]
+    got = outs[wino]
     assert got.shape == ref.shape
     rel = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-12))
     rel_direct = float((outs[ops.ALGO_DIRECT] - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-12))
