@@ -309,6 +309,91 @@ __global__ __launch_bounds__(256) void wino4_in_kernel(const Wino4InArgs p) {
   }
 }
 
+// The form used whenever channel pairs are addressable: thread = (tile, channel PAIR), 16 tiles x 32 channels (two
+// chunks) per workgroup, tile groups the fast grid dimension; the packed bf16 pairs cross the LDS as dwords, one piece
+// at a time (36 KiB: four workgroups per CU)
+typedef __bf16 w4bf16x2 __attribute__((ext_vector_type(2)));
+typedef float w4f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void w4_bt2(const w4f32x2 (&d)[6], w4f32x2 (&t)[6]) {
+  const w4f32x2 a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1], c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+  t[0] = (4.f * d[0] - 5.f * d[2]) + d[4];
+  t[1] = a + b;
+  t[2] = a - b;
+  t[3] = c + e;
+  t[4] = c - e;
+  t[5] = (4.f * d[1] - 5.f * d[3]) + d[5];
+}
+template <int SPLIT>
+__global__ __launch_bounds__(256) void wino4_in2_kernel(const Wino4InArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned tbuf[W4_POS * 4 * 16 * 4];      // [pos][chunk half * 2 + octet][tile][4 pairs]
+  const int t = threadIdx.x;
+  const int tg = blockIdx.x, chunk0 = blockIdx.y * 2;
+  const int tl = t >> 4, cp = t & 15;
+  const int tile = tg * 16 + tl, ch = chunk0 * W4_CK + cp * 2;
+  const int per = p.tiles_y * p.tiles_x;
+  w4f32x2 u[6][6];
+  {
+    w4f32x2 d[6][6];
+    const bool ok = tile < p.T && ch < p.Cin;
+    const int tcl = ok ? tile : 0;
+    const int img = tcl / per, rem = tcl - img * per;
+    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    const int y0 = 4 * ty - p.pad_t, x0 = 4 * tx - p.pad_l;
+    const float* base = p.in + (ok ? ch : 0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int yy = y0 + i;
+      const bool yok = ok && (unsigned)yy < (unsigned)p.H;
+      const size_t rowoff = ((size_t)img * p.H + (yok ? yy : 0)) * p.W;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int xx = x0 + j;
+        const bool in = yok && (unsigned)xx < (unsigned)p.W;
+        const w4f32x2 v = *reinterpret_cast<const w4f32x2*>(base + (rowoff + (in ? xx : 0)) * p.in_cs);
+        d[i][j] = in ? v : w4f32x2{0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const w4f32x2 col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+      w4f32x2 o[6];
+      w4_bt2(col, o);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) u[i][j] = o[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    w4f32x2 o[6];
+    w4_bt2(u[i], o);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) u[i][j] = o[j];
+  }
+  const int mb = (tg * 16) >> 8, row0 = (tg * 16) & (W4_M - 1);
+  constexpr int UNITS = W4_POS * 4 * 16;       // 16-byte units of one piece: (position, chunk half * 2 + octet, tile)
+#pragma unroll
+  for (int pl = 0; pl < SPLIT; ++pl) {
+    if (pl) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const w4bf16x2 piece = __builtin_convertvector(u[i][j], w4bf16x2);
+        tbuf[(((i * 6 + j) * 4 + (cp >> 2)) * 16 + tl) * 4 + (cp & 3)] = __builtin_bit_cast(unsigned, piece);
+        if (pl + 1 < SPLIT) u[i][j] -= __builtin_convertvector(piece, w4f32x2);
+      }
+    __syncthreads();
+    for (int uidx = t; uidx < UNITS; uidx += 256) {
+      const int tlw = uidx & 15, co = (uidx >> 4) & 3, pos = uidx >> 6;
+      const int chunk = chunk0 + (co >> 1), oct = co & 1;
+      if (chunk >= p.nchunk) continue;
+      char* dst = p.V + (((((size_t)pos * p.m_blocks + mb) * p.nchunk + chunk) * SPLIT + pl) * 2 + oct) * (size_t)(W4_M * 16) +
+                  (size_t)(row0 + tlw) * 16;
+      *reinterpret_cast<w4f32x4*>(dst) = *reinterpret_cast<const w4f32x4*>(tbuf + (size_t)uidx * 4);
+    }
+  }
+}
+
 struct Wino4OutArgs {
   const float* M;
   const float* bias;
@@ -516,7 +601,13 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
   ia.nchunk = nchunk; ia.m_blocks = m_blocks;
   CRESTE_REQUIRE(m_blocks * 16 <= 65535 * 16 && (long)m_blocks * 16 < (1L << 31), "conv2d: too many tiles for one launch");
   const dim3 igrid((unsigned)nchunk, (unsigned)(m_blocks * 16));
-  if (split == 3) wino4_in_kernel<3><<<igrid, 256, 0, s>>>(ia);
+  // channel-pair form (8-byte loads, packed conversions, dword LDS traffic, 4 workgroups per CU) wherever pairs are
+  // addressable: same 4.0 TB/s on the 496-channel layer, 1.29 -> 1.09 ms on 256 channels at 256 x 256 x 16
+  if ((d->Cin & 1) == 0 && (d->in_cs & 1) == 0 && (reinterpret_cast<uintptr_t>(d->in) & 7) == 0) {
+    const dim3 g2((unsigned)(m_blocks * 16), (unsigned)((nchunk + 1) / 2));
+    if (split == 3) wino4_in2_kernel<3><<<g2, 256, 0, s>>>(ia);
+    else wino4_in2_kernel<2><<<g2, 256, 0, s>>>(ia);
+  } else if (split == 3) wino4_in_kernel<3><<<igrid, 256, 0, s>>>(ia);
   else wino4_in_kernel<2><<<igrid, 256, 0, s>>>(ia);
   CRESTE_CHECK_LAUNCH("wino4_in");
 
