@@ -588,7 +588,10 @@ def main():
         pj = os.path.join(ROOT, "profiles", "roofline_counters.json")
         if os.path.exists(pj):
             try:
-                traffic = json.load(open(pj)).get(kname, {}).get("hbm_bytes_per_launch")
+                # a Winograd call is several kernels ("a + b + c"): HBM bytes of one call = the sum over its kernels
+                cnt = json.load(open(pj))
+                parts = [cnt.get(k.strip(), {}).get("hbm_bytes_per_launch") for k in kname.split(" + ")]
+                traffic = sum(parts) if all(v is not None for v in parts) else None
             except Exception:
                 traffic = None
         line = {

@@ -225,93 +225,12 @@ struct Wino4InArgs {
   int nchunk, m_blocks;
 };
 
-// one row of B^T applied to six values
-__device__ __forceinline__ void w4_bt(const float (&d)[6], float (&t)[6]) {
-  const float a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1], c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
-  t[0] = (4.f * d[0] - 5.f * d[2]) + d[4];
-  t[1] = a + b;
-  t[2] = a - b;
-  t[3] = c + e;
-  t[4] = c - e;
-  t[5] = (4.f * d[1] - 5.f * d[3]) + d[5];
-}
-
-// One workgroup = 16 tiles x one 16-channel chunk; thread = (tile, channel): 36 scalar loads (a wave reads 64 contiguous
-// bytes of 4 pixels per instruction; the chunk next door fetches the other half of the line), B^T d B in registers, split,
-// and the bf16 pieces cross an LDS tile so that the write side stores 16 bytes per lane = (position, piece, k-octet, tile)
-// with 16 consecutive tiles = 256 contiguous bytes of V.
-template <int SPLIT>
-__global__ __launch_bounds__(256) void wino4_in_kernel(const Wino4InArgs p) {
-  __shared__ __attribute__((aligned(16))) __bf16 tbuf[W4_POS * SPLIT * 2 * 16 * 8];
-  const int t = threadIdx.x;
-  const int chunk = blockIdx.x, tg = blockIdx.y;
-  const int tl = t >> 4, c = t & 15;
-  const int tile = tg * 16 + tl, ch = chunk * W4_CK + c;
-  const int per = p.tiles_y * p.tiles_x;
-  float d[6][6];
-  {
-    const bool ok = tile < p.T && ch < p.Cin;
-    const int tcl = ok ? tile : 0;
-    const int img = tcl / per, rem = tcl - img * per;
-    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-    const int y0 = 4 * ty - p.pad_t, x0 = 4 * tx - p.pad_l;
-    const float* base = p.in + (ok ? ch : 0);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int yy = y0 + i;
-      const bool yok = ok && (unsigned)yy < (unsigned)p.H;
-      const size_t rowoff = ((size_t)img * p.H + (yok ? yy : 0)) * p.W;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const int xx = x0 + j;
-        const bool in = yok && (unsigned)xx < (unsigned)p.W;
-        const float v = base[(rowoff + (in ? xx : 0)) * p.in_cs];
-        d[i][j] = in ? v : 0.f;
-      }
-    }
-  }
-  // along y, then along x
-  float u[6][6];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
-    float o[6];
-    w4_bt(col, o);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) u[i][j] = o[i];
-  }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    float o[6];
-    w4_bt(u[i], o);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      float rem = o[j];
-      __bf16* dst = tbuf + ((((i * 6 + j) * SPLIT) * 2 + (c >> 3)) * 16 + tl) * 8 + (c & 7);
-#pragma unroll
-      for (int pl = 0; pl < SPLIT; ++pl) {          // hi, then the bf16 of what is left, ...
-        const __bf16 piece = (__bf16)rem;
-        dst[pl * (2 * 16 * 8)] = piece;
-        if (pl + 1 < SPLIT) rem -= (float)piece;
-      }
-    }
-  }
-  __syncthreads();
-  const int mb = (tg * 16) >> 8, row0 = (tg * 16) & (W4_M - 1);
-  constexpr int UNITS = W4_POS * SPLIT * 2 * 16;
-  for (int uidx = t; uidx < UNITS; uidx += 256) {
-    const int tlw = uidx & 15, rest = uidx >> 4;     // rest = (pos * SPLIT + piece) * 2 + octet
-    const int pp = rest >> 1, oct = rest & 1;
-    const int pos = pp / SPLIT, pl = pp - pos * SPLIT;
-    char* dst = p.V + (((((size_t)pos * p.m_blocks + mb) * p.nchunk + chunk) * SPLIT + pl) * 2 + oct) * (size_t)(W4_M * 16) +
-                (size_t)(row0 + tlw) * 16;
-    *reinterpret_cast<w4f32x4*>(dst) = *reinterpret_cast<const w4f32x4*>(tbuf + (size_t)uidx * 8);
-  }
-}
-
-// The form used whenever channel pairs are addressable: thread = (tile, channel PAIR), 16 tiles x 32 channels (two
-// chunks) per workgroup, tile groups the fast grid dimension; the packed bf16 pairs cross the LDS as dwords, one piece
-// at a time (36 KiB: four workgroups per CU)
+// One workgroup = 16 tiles x 32 channels (two chunks), tile groups the fast grid dimension; thread = (tile, channel
+// PAIR): 36 8-byte loads (a wave reads the 128 contiguous bytes of 4 pixels per instruction), B^T d B on packed pairs in
+// registers, split; the packed bf16 pairs cross an LDS tile as dwords, ONE PIECE AT A TIME (36 KiB: four workgroups per
+// CU), so that the write side stores 16 bytes per lane = (position, chunk, k-octet, tile) with 16 consecutive tiles =
+// 256 contiguous bytes of V.  (Measured forms, profiles/r03_winograd_notes.md: the 496-channel layer sits at 4.0 TB/s
+// whatever the structure; this one is 15 % faster than scalar channels + all pieces in LDS on 256 channels at 256 x 256.)
 typedef __bf16 w4bf16x2 __attribute__((ext_vector_type(2)));
 typedef float w4f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void w4_bt2(const w4f32x2 (&d)[6], w4f32x2 (&t)[6]) {
@@ -324,7 +243,7 @@ __device__ __forceinline__ void w4_bt2(const w4f32x2 (&d)[6], w4f32x2 (&t)[6]) {
   t[5] = (4.f * d[1] - 5.f * d[3]) + d[5];
 }
 template <int SPLIT>
-__global__ __launch_bounds__(256) void wino4_in2_kernel(const Wino4InArgs p) {
+__global__ __launch_bounds__(256) void wino4_in_kernel(const Wino4InArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned tbuf[W4_POS * 4 * 16 * 4];      // [pos][chunk half * 2 + octet][tile][4 pairs]
   const int t = threadIdx.x;
   const int tg = blockIdx.x, chunk0 = blockIdx.y * 2;
@@ -535,7 +454,7 @@ static inline int wino4_units(int Cout) { return ((Cout + 63) / 64 + 3) / 4 * 4;
 static inline long wino4_tiles(int N, int Ho, int Wo) { return (long)N * ((Ho + 3) / 4) * ((Wo + 3) / 4); }
 
 bool conv_wino4_supported(int prec, int KH, int KW, int stride, int Cin, int Cout) {
-  return wino4_split(prec) > 0 && KH == 3 && KW == 3 && stride == 1 && Cin > 0 && Cout > 0 && Cout % 4 == 0;
+  return wino4_split(prec) > 0 && KH == 3 && KW == 3 && stride == 1 && Cin > 0 && Cout > 0 && Cin % 4 == 0 && Cout % 4 == 0;
 }
 
 int64_t conv_wino4_weight_bytes(int Cout, int Cin, int prec) {
@@ -599,15 +518,10 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
   ia.in = d->in; ia.V = V; ia.N = d->N; ia.H = d->H; ia.W = d->W; ia.Cin = d->Cin; ia.in_cs = d->in_cs;
   ia.tiles_y = tiles_y; ia.tiles_x = tiles_x; ia.T = (int)T; ia.pad_t = d->pad_t; ia.pad_l = d->pad_l;
   ia.nchunk = nchunk; ia.m_blocks = m_blocks;
-  CRESTE_REQUIRE(m_blocks * 16 <= 65535 * 16 && (long)m_blocks * 16 < (1L << 31), "conv2d: too many tiles for one launch");
-  const dim3 igrid((unsigned)nchunk, (unsigned)(m_blocks * 16));
-  // channel-pair form (8-byte loads, packed conversions, dword LDS traffic, 4 workgroups per CU) wherever pairs are
-  // addressable: same 4.0 TB/s on the 496-channel layer, 1.29 -> 1.09 ms on 256 channels at 256 x 256 x 16
-  if ((d->Cin & 1) == 0 && (d->in_cs & 1) == 0 && (reinterpret_cast<uintptr_t>(d->in) & 7) == 0) {
-    const dim3 g2((unsigned)(m_blocks * 16), (unsigned)((nchunk + 1) / 2));
-    if (split == 3) wino4_in2_kernel<3><<<g2, 256, 0, s>>>(ia);
-    else wino4_in2_kernel<2><<<g2, 256, 0, s>>>(ia);
-  } else if (split == 3) wino4_in_kernel<3><<<igrid, 256, 0, s>>>(ia);
+  CRESTE_REQUIRE((d->Cin & 3) == 0 && (d->in_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(d->in) & 15) == 0,
+                 "conv2d: the F(4x4,3x3) input transform reads channel pairs (Cin / in_cs multiples of 4, as every NHWC conv here)");
+  const dim3 igrid((unsigned)(m_blocks * 16), (unsigned)((nchunk + 1) / 2));      // tile groups fast: m_blocks < 2^18
+  if (split == 3) wino4_in_kernel<3><<<igrid, 256, 0, s>>>(ia);
   else wino4_in_kernel<2><<<igrid, 256, 0, s>>>(ia);
   CRESTE_CHECK_LAUNCH("wino4_in");
 

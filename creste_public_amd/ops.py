@@ -172,7 +172,7 @@ WINOGRAD4_MIN_CIN, WINOGRAD4_MIN_COUT = 256, 128
 
 
 def conv_algo(prec: int, k: int, stride: int, pad, cin: int, cout: int) -> int:
-    if WINOGRAD4 and prec == PREC_BF16X6 and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1) \
+    if WINOGRAD4 and prec in (PREC_BF16X6, PREC_BF16X3) and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1) \
             and cin >= WINOGRAD4_MIN_CIN and cout >= WINOGRAD4_MIN_COUT \
             and _lib.load().creste_conv_wino4_supported(prec, k, k, stride, cin, cout):
         return ALGO_WINOGRAD4
