@@ -102,6 +102,7 @@ SIGNATURES = {
     "creste_upsample_bwd_nhwc_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _f, _f, _vp]),
     "creste_conv_wgrad_strided_workspace_bytes": (_i64, [_i] * 6),
     "creste_conv_wgrad_strided_f32": (_i, [_vp, _i, _vp, _i, _vp] + [_i] * 12 + [_vp, _vp]),
+    "creste_conv_wgrad_bf16x6": (_i, [_vp, _i, _vp, _i, _vp] + [_i] * 12 + [_vp, _vp]),
     "creste_conv_wgrad_f16x3": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp] + [_i] * 12 + [_vp, _vp]),
     "creste_dwconv_dgrad_f32": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "creste_dwconv_wgrad_workspace_bytes": (_i64, [_i, _i]),

@@ -410,15 +410,26 @@ __global__ __launch_bounds__(256) void wgrad_f16_kernel(
 // x-column images; the per-tap kernel above streams every operand 9 x tiles times through L2: 55 GB for the
 // 496 -> 496 layer), every fragment stays an aligned ds_read_b128, and both loader halves do the same amount of
 // conversion work.  36 MFMAs and 20 operand reads per wave and step (two waves per SIMD), one barrier per column.
-constexpr int W3_KS = 32, W3_NOCT = W3_KS / 8, W3_OCT = 128 * 16, W3_PLANE = W3_NOCT * W3_OCT, W3_IMG = 2 * W3_PLANE;
-constexpr int W3_SMEM = 2 * W3_IMG + 4 * W3_IMG;           // gy column double buffer + ring of four x columns
+constexpr int W3_KS = 32, W3_NOCT = W3_KS / 8, W3_OCT = 128 * 16, W3_PLANE = W3_NOCT * W3_OCT;
+constexpr int w3_smem(int pieces) { return 6 * pieces * W3_PLANE; }   // gy column double buffer + ring of four x columns
 // channel row r of an octet image sits at 16-byte slot r ^ ((r >> 4) & 3): the loader's rows 4q + c (fixed c) and the
 // MFMA fragment reads' consecutive rows both fall on 16 distinct slots per ds_*_b128 lane group
 __device__ __forceinline__ int w3_swz(int r) { return r ^ ((r >> 4) & 3); }
-__global__ __launch_bounds__(512, 1) void wgrad_f16_col3_kernel(
+// F16 = true: the f16x3 scheme above (two fp16 pieces, operands rescaled from their |max| bounds, 3 products).
+// F16 = false: bf16x6 -- three bf16 pieces = 24 significand bits, no rescaling, 6 products (fp32-equivalent, the mode
+// the forward's bf16x6 convs run in): 24 KiB column images, 144 KiB of LDS.
+typedef __bf16 w3b8 __attribute__((ext_vector_type(8)));
+template <bool F16> struct W3Elt { typedef h8 vec; typedef _Float16 elt; };
+template <> struct W3Elt<false> { typedef w3b8 vec; typedef __bf16 elt; };
+template <bool F16>
+__global__ __launch_bounds__(512, 1) void wgrad_col3_kernel(
     const float* __restrict__ x, int x_cs, const float* __restrict__ gy, int gy_cs, float* __restrict__ partial,
     const float* __restrict__ x_amax, const float* __restrict__ gy_amax, int N, int H, int W, int Cin, int Cout,
     int pad_t, int pad_l, int nbands, int nseg, int seg_w, int tiles_co, int tiles_ci) {
+  constexpr int P = F16 ? 2 : 3;
+  constexpr int W3_IMG = P * W3_PLANE;
+  typedef typename W3Elt<F16>::vec ev8;
+  typedef typename W3Elt<F16>::elt elt;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Aimg = smem;                                   // [2][W3_IMG]
   char* const Bimg = smem + 2 * W3_IMG;                      // [4][W3_IMG], slot = (source column + 1) & 3
@@ -440,8 +451,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16_col3_kernel(
   const int co0 = tco * 128, ci0 = tci * 128;
   const int y0 = band * W3_KS;
   const int xs = seg * seg_w, xe = min(W, xs + seg_w);
-  float a_inv, b_inv;
-  const float a_mul = f16_operand_scale(*gy_amax, &a_inv), b_mul = f16_operand_scale(*x_amax, &b_inv);
+  float a_inv = 1.f, b_inv = 1.f, a_mul = 1.f, b_mul = 1.f;
+  if (F16) { a_mul = f16_operand_scale(*gy_amax, &a_inv); b_mul = f16_operand_scale(*x_amax, &b_inv); }
 
   // loader: waves 0..3 (one per SIMD; the other wave of each SIMD only issues MFMAs, so conversion VALU work and
   // matrix work overlap): threads 0..127 stage the next gy column, 128..255 the next x column; a thread owns one
@@ -473,16 +484,19 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16_col3_kernel(
     char* base = img + loct * W3_OCT;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      h8 hi, lo;
+      ev8 pc[P];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float v = rv[j][c] * ((okmask >> j & 1) ? mul : 0.f);
-        hi[j] = (_Float16)v;
-        lo[j] = (_Float16)(v - (float)hi[j]);
+        float v = rv[j][c] * ((okmask >> j & 1) ? mul : 0.f);
+#pragma unroll
+        for (int pl = 0; pl < P; ++pl) {          // hi, then the rounding of what is left, ...
+          pc[pl][j] = (elt)v;
+          if (pl + 1 < P) v -= (float)pc[pl][j];
+        }
       }
       const int pos = w3_swz(quad * 4 + c) * 16;
-      *reinterpret_cast<h8*>(base + pos) = hi;
-      *reinterpret_cast<h8*>(base + W3_PLANE + pos) = lo;
+#pragma unroll
+      for (int pl = 0; pl < P; ++pl) *reinterpret_cast<ev8*>(base + pl * W3_PLANE + pos) = pc[pl];
     }
   };
   auto bslot = [&](int srccol) { return Bimg + ((srccol + 1) & 3) * W3_IMG; };
@@ -515,25 +529,29 @@ __global__ __launch_bounds__(512, 1) void wgrad_f16_col3_kernel(
     const char* A = Aimg + ((col - xs) & 1) * W3_IMG;
 #pragma unroll
     for (int ks = 0; ks < W3_KS / 16; ++ks) {
-      h8 a[2][2];
+      ev8 a[2][P];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-          a[i][pl] = *reinterpret_cast<const h8*>(A + pl * W3_PLANE + (ks * 2 + lh) * W3_OCT + w3_swz(wm * 64 + i * 32 + li) * 16);
+        for (int pl = 0; pl < P; ++pl)
+          a[i][pl] = *reinterpret_cast<const ev8*>(A + pl * W3_PLANE + (ks * 2 + lh) * W3_OCT + w3_swz(wm * 64 + i * 32 + li) * 16);
 #pragma unroll
       for (int kxi = 0; kxi < 3; ++kxi) {
         const char* B = bslot(col - pad_l + kxi);
-        h8 b[2];
+        ev8 b[P];
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-          b[pl] = *reinterpret_cast<const h8*>(B + pl * W3_PLANE + (ks * 2 + lh) * W3_OCT + w3_swz(wn * 32 + li) * 16);
+        for (int pl = 0; pl < P; ++pl)
+          b[pl] = *reinterpret_cast<const ev8*>(B + pl * W3_PLANE + (ks * 2 + lh) * W3_OCT + w3_swz(wn * 32 + li) * 16);
+        // piece products, smallest first: (1,0) (0,1) (0,0) for two pieces; (2,0) (1,1) (0,2) (1,0) (0,1) (0,0) for three
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          c[kxi][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b[0], c[kxi][i], 0, 0, 0);
-          c[kxi][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[1], c[kxi][i], 0, 0, 0);
-          c[kxi][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b[0], c[kxi][i], 0, 0, 0);
-        }
+        for (int order = P - 1; order >= 0; --order)
+#pragma unroll
+          for (int pa = order; pa >= 0; --pa)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              if constexpr (F16) c[kxi][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][pa], b[order - pa], c[kxi][i], 0, 0, 0);
+              else c[kxi][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[order - pa], c[kxi][i], 0, 0, 0);
+            }
       }
     }
     __syncthreads();
@@ -1163,7 +1181,7 @@ extern "C" int creste_conv_wgrad_f16x3(const float* x, int x_cs, const float* gy
                  "conv_wgrad_f16x3: channel counts / strides must be multiples of 4, tensors 16-byte aligned");
   if (K == 3 && stride == 1 && Ho == H && Wo == W && Cin >= 64 && Cout >= 64) {          // kernel-row / column-walk variant
     static std::atomic<uint64_t> attr_devs{0};
-    CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wgrad_f16_col3_kernel), W3_SMEM, attr_devs));
+    CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wgrad_col3_kernel<true>), w3_smem(2), attr_devs));
     const int nbands = (H + W3_KS - 1) / W3_KS;
     const long base = (long)N * nbands;                            // chunks before column segmentation
     const long tiles3 = (long)tiles_co * tiles_ci * 3;
@@ -1176,7 +1194,7 @@ extern "C" int creste_conv_wgrad_f16x3(const float* x, int x_cs, const float* gy
       const int seg_w = (int)((W + nseg - 1) / nseg);
       nseg = (W + seg_w - 1) / seg_w;
       const int nchunk3 = (int)(base * nseg);
-      wgrad_f16_col3_kernel<<<(unsigned)(nchunk3 * tiles3), 512, W3_SMEM, s>>>(x, x_cs, gy, gy_cs, (float*)work, x_amax, gy_amax,
+      wgrad_col3_kernel<true><<<(unsigned)(nchunk3 * tiles3), 512, w3_smem(2), s>>>(x, x_cs, gy, gy_cs, (float*)work, x_amax, gy_amax,
                                                                              N, H, W, Cin, Cout, pad_t, pad_l, nbands,
                                                                              (int)nseg, seg_w, tiles_co, tiles_ci);
       CRESTE_CHECK_LAUNCH("wgrad_f16_col3");
@@ -1194,6 +1212,48 @@ extern "C" int creste_conv_wgrad_f16x3(const float* x, int x_cs, const float* gy
                                                                                     Cout, Cin, K * K, accumulate);
   CRESTE_CHECK_LAUNCH("wgrad_strided_reduce");
   return CRESTE_OK;
+}
+
+// Weight gradient at the fp32-equivalent bf16x6 operand grade (three bf16 pieces per operand, six piece products on the
+// bf16 MFMA, fp32 accumulation): the stride-1 "same" 3x3 convs with >= 64 channels on both sides run the column-walk
+// kernel above; every other shape is the exact-fp32 MFMA path (creste_conv_wgrad_strided_f32), same arguments.
+extern "C" int creste_conv_wgrad_bf16x6(const float* x, int x_cs, const float* gy, int gy_cs, float* gw, int N, int H, int W,
+                                        int Ho, int Wo, int Cin, int Cout, int K, int stride, int pad_t, int pad_l,
+                                        int accumulate, void* work, void* stream) {
+  CRESTE_REQUIRE(x && gy && gw && work, "conv_wgrad_bf16x6: null pointer");
+  CRESTE_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cout > 0 && K > 0 && stride > 0, "conv_wgrad_bf16x6: bad dims");
+  const bool quads = Cin % 4 == 0 && Cout % 4 == 0 && x_cs % 4 == 0 && gy_cs % 4 == 0 &&
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0;
+  const long M = (long)N * Ho * Wo;
+  if (quads && K == 3 && stride == 1 && Ho == H && Wo == W && Cin >= 64 && Cout >= 64 && M < (1L << 31)) {
+    const int tiles_co = (Cout + 127) / 128, tiles_ci = (Cin + 127) / 128;
+    const long cap = wgrad_chunks(M, K);
+    const int nbands = (H + W3_KS - 1) / W3_KS;
+    const long base = (long)N * nbands;
+    const long tiles3 = (long)tiles_co * tiles_ci * 3;
+    long nseg = (512 + tiles3 * base - 1) / (tiles3 * base);
+    const long seg_cap = cap / base > 0 ? cap / base : 1;
+    nseg = nseg < 1 ? 1 : (nseg > seg_cap ? seg_cap : nseg);
+    if (nseg > W) nseg = W;
+    if (base <= cap && base * nseg <= cap) {
+      hipStream_t s = (hipStream_t)stream;
+      static std::atomic<uint64_t> attr_devs{0};
+      CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wgrad_col3_kernel<false>), w3_smem(3), attr_devs));
+      const int seg_w = (int)((W + nseg - 1) / nseg);
+      nseg = (W + seg_w - 1) / seg_w;
+      const int nchunk3 = (int)(base * nseg);
+      wgrad_col3_kernel<false><<<(unsigned)(nchunk3 * tiles3), 512, w3_smem(3), s>>>(x, x_cs, gy, gy_cs, (float*)work, nullptr, nullptr,
+                                                                                    N, H, W, Cin, Cout, pad_t, pad_l, nbands,
+                                                                                    (int)nseg, seg_w, tiles_co, tiles_ci);
+      CRESTE_CHECK_LAUNCH("wgrad_bf16_col3");
+      wgrad_strided_reduce_kernel<<<(unsigned)(((long)Cout * Cin * 9 + 63) / 64), 256, 0, s>>>((const float*)work, gw, nchunk3, Cout,
+                                                                                 Cin, 9, accumulate);
+      CRESTE_CHECK_LAUNCH("wgrad_strided_reduce");
+      return CRESTE_OK;
+    }
+  }
+  return creste_conv_wgrad_strided_f32(x, x_cs, gy, gy_cs, gw, N, H, W, Ho, Wo, Cin, Cout, K, stride, pad_t, pad_l, accumulate,
+                                       work, stream);
 }
 
 extern "C" int creste_dwconv_dgrad_f32(const float* gy, const float* w, float* gx, int N, int H, int W, int C, int Ho,

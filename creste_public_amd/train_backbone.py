@@ -125,9 +125,11 @@ class ConvG:
                                                        x.W, gy.H, gy.W, Cin, Cout, self.K, self.s, self.pad[0],
                                                        self.pad[2], acc, work.data_ptr(), _stream()), "conv_wgrad_f16x3")
             else:
-                _lib.check(lib.creste_conv_wgrad_strided_f32(x.ptr, x.cs, gy.ptr, gy.cs, gw.data_ptr(), x.N, x.H, x.W,
-                                                             gy.H, gy.W, Cin, Cout, self.K, self.s, self.pad[0],
-                                                             self.pad[2], acc, work.data_ptr(), _stream()),
+                # bf16x6: the wide 3x3 convs at the forward's operand grade (six bf16 piece products), the rest exact fp32
+                fn = lib.creste_conv_wgrad_bf16x6 if hipnn._precision == ops.PREC_BF16X6 else lib.creste_conv_wgrad_strided_f32
+                _lib.check(fn(x.ptr, x.cs, gy.ptr, gy.cs, gw.data_ptr(), x.N, x.H, x.W,
+                              gy.H, gy.W, Cin, Cout, self.K, self.s, self.pad[0],
+                              self.pad[2], acc, work.data_ptr(), _stream()),
                            "conv_wgrad_strided")
             if self.conv.bias is not None:
                 gb, accb = _acc(grads, self.conv.bias)

@@ -411,6 +411,12 @@ int creste_conv_wgrad_strided_f32(const float* x, int x_cs, const float* gy, int
 int creste_conv_wgrad_f16x3(const float* x, int x_cs, const float* gy, int gy_cs, float* gw, const float* x_amax,
                             const float* gy_amax, int N, int H, int W, int Ho, int Wo, int Cin, int Cout, int K,
                             int stride, int pad_t, int pad_l, int accumulate, void* work, void* stream);
+/* Same gradient at the fp32-equivalent bf16x6 operand grade (three bf16 pieces per operand, six piece products on
+ * the bf16 MFMA, fp32 accumulation; no operand bounds needed): the stride-1 "same" 3x3 convs with >= 64 channels on
+ * both sides; any other shape runs creste_conv_wgrad_strided_f32.  Same workspace. */
+int creste_conv_wgrad_bf16x6(const float* x, int x_cs, const float* gy, int gy_cs, float* gw, int N, int H, int W,
+                             int Ho, int Wo, int Cin, int Cout, int K, int stride, int pad_t, int pad_l,
+                             int accumulate, void* work, void* stream);
 /* depthwise conv backward (weights tap-major [K*K][C] as in creste_dwconv2d_nhwc_f32): input gradient and
  * per-tap weight gradient gw_taps[K*K][C] (+)=. */
 int creste_dwconv_dgrad_f32(const float* gy, const float* w, float* gx, int N, int H, int W, int C, int Ho, int Wo,

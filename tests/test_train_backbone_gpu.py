@@ -374,9 +374,12 @@ def test_depth_expectation_backward():
     # one-sided padding
     (1, 64, 70, 50, 64, 3, 1, (1, 1, 1, 1), 1.0), (3, 160, 33, 40, 200, 3, 1, (1, 1, 1, 1), 1e-3),
     (1, 64, 40, 37, 72, 3, 1, (0, 2, 2, 0), 1.0)])
-def test_conv_backward_f16x3(N, Cin, H, W, Cout, K, s, pad, gscale):
-    """the training convs in the f16x3 operand mode: forward / dgrad on the patch engine, wgrad on the fp16-split
-    MFMA kernel; gradient tensors of any magnitude (1e-7 .. 1e4) keep fp32-grade accuracy through the |max| scaling"""
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6"])
+def test_conv_backward_f16x3(N, Cin, H, W, Cout, K, s, pad, gscale, mode):
+    """the training convs in the split-operand modes: forward / dgrad on the patch engine; wgrad on the fp16-split MFMA
+    kernel (f16x3: gradient tensors of any magnitude, 1e-7 .. 1e4, keep fp32-grade accuracy through the |max| scaling)
+    or, in bf16x6, on the three-piece bf16 variant of the column-walk kernel for the wide 3x3 convs (exact fp32 MFMA
+    for the other shapes)"""
     import creste_public_amd
     from creste_public_amd import train_backbone as TB, train_ops as T
     g = torch.Generator().manual_seed(Cin + K)
@@ -387,7 +390,7 @@ def test_conv_backward_f16x3(N, Cin, H, W, Cout, K, s, pad, gscale):
     y = ref(F.pad(xr, (pad[2], pad[3], pad[0], pad[1])))
     gy = torch.randn(y.shape, generator=g) * gscale
     y.backward(gy.double())
-    creste_public_amd.set_precision("f16x3")
+    creste_public_amd.set_precision(mode)
     try:
         op = TB.ConvG(conv.cuda(), pad=pad)
         ya = op.fwd(T.as_act(x.cuda()))
