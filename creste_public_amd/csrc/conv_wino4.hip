@@ -246,7 +246,9 @@ template <int SPLIT>
 __global__ __launch_bounds__(256) void wino4_in_kernel(const Wino4InArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned tbuf[W4_POS * 4 * 16 * 4];      // [pos][chunk half * 2 + octet][tile][4 pairs]
   const int t = threadIdx.x;
-  const int tg = blockIdx.x, chunk0 = blockIdx.y * 2;
+  // gridDim.x is a multiple of 16: workgroup (x, y) sits on XCD x % 8.  Every XCD gets a contiguous range of tile groups,
+  // so the 6x6 windows' shared pixels (2 of 6 columns / rows) are re-read from ITS L2 (round-robin: 2.4x the input fetched)
+  const int tg = xcd_remap(blockIdx.x, gridDim.x), chunk0 = blockIdx.y * 2;
   const int tl = t >> 4, cp = t & 15;
   const int tile = tg * 16 + tl, ch = chunk0 * W4_CK + cp * 2;
   const int per = p.tiles_y * p.tiles_x;
