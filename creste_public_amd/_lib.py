@@ -26,8 +26,9 @@ class ConvDesc(C.Structure):
                 ("work", C.c_void_p)] + \
                [(n, C.c_int32) for n in ("N", "H", "W", "Cin", "in_cs", "Ho", "Wo", "Cout", "out_cs",
                                          "out_co", "res_cs", "KH", "KW", "stride", "pad_t", "pad_l",
-                                         "act", "prec", "algo", "reserved0")] + \
-               [("a_amax", C.c_void_p), ("out_amax", C.c_void_p), ("w_unscale", C.c_void_p)]
+                                         "act", "prec", "algo", "flags")] + \
+               [("a_amax", C.c_void_p), ("out_amax", C.c_void_p), ("w_unscale", C.c_void_p), ("up_src", C.c_void_p)] + \
+               [(n, C.c_int32) for n in ("up_H", "up_W", "up_C", "up_cs")]
 
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64

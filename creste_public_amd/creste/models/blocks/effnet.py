@@ -208,7 +208,8 @@ class Up(nn.Module):
 
     def concat_act(self, x1: Act, x2: Act) -> Act:
         Ho, Wo, rh, rw = self._geom(x1, x2)
-        return ops.upsample_concat(x1, x2, Ho, Wo, rh, rw)
+        # not formed yet: the F(4x4,3x3) conv that consumes it builds it inside its input transform (ops.LazyUpCat)
+        return ops.upsample_concat_lazy(x1, x2, Ho, Wo, rh, rw)
 
     def convs_act(self, cat: Act, out: Act = None) -> Act:
         u = self._u()

@@ -337,14 +337,20 @@ extern "C" int creste_conv_pack_weight_f16(const float* w, const float* scale, v
 
 extern "C" int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream) {
   CRESTE_REQUIRE(d != nullptr, "conv2d: null descriptor");
-  CRESTE_REQUIRE(d->wpk && d->out && d->in, "conv2d: null tensor pointer");
+  CRESTE_REQUIRE(d->wpk && d->out && (d->in || (d->up_src && d->up_C == d->Cin)), "conv2d: null tensor pointer");
+  if (d->up_src) {
+    CRESTE_REQUIRE(d->algo == CRESTE_ALGO_WINOGRAD4, "conv2d: the fused upsample + concat input is built for CRESTE_ALGO_WINOGRAD4 only");
+    CRESTE_REQUIRE(d->up_C > 0 && d->up_C % 4 == 0 && d->up_C <= d->Cin && d->up_cs % 4 == 0 && d->up_cs >= d->up_C &&
+                       d->H == 2 * d->up_H && d->W == 2 * d->up_W && (reinterpret_cast<uintptr_t>(d->up_src) & 15) == 0,
+                   "conv2d: up_src must be [N, H/2, W/2, up_cs] with up_C (%d) a multiple of 4 and <= Cin (%d)", d->up_C, d->Cin);
+  }
   CRESTE_REQUIRE(d->algo == CRESTE_ALGO_DIRECT || d->algo == CRESTE_ALGO_WINOGRAD || d->algo == CRESTE_ALGO_WINOGRAD4, "conv2d: unknown algo %d", d->algo);
   CRESTE_REQUIRE(d->prec == CRESTE_PREC_F32 || conv_patch_supported(d->prec, d->KH, d->KW, d->stride),
                  "conv2d: precision %d not built for %dx%d stride %d", d->prec, d->KH, d->KW, d->stride);
   CRESTE_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->Ho > 0 &&
                      d->Wo > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0,
                  "conv2d: non-positive dimension");
-  CRESTE_REQUIRE(d->Cin % 4 == 0 && d->in_cs % 4 == 0 && d->in_cs >= d->Cin,
+  CRESTE_REQUIRE(d->Cin % 4 == 0 && (!d->in || (d->in_cs % 4 == 0 && d->in_cs >= d->Cin - (d->up_src ? d->up_C : 0))),
                  "conv2d: Cin (%d) and in_cs (%d) must be multiples of 4, in_cs >= Cin", d->Cin, d->in_cs);
   CRESTE_REQUIRE((reinterpret_cast<uintptr_t>(d->in) & 15) == 0, "conv2d: input not 16-byte aligned");
   CRESTE_REQUIRE(d->out_cs >= d->out_co + d->Cout, "conv2d: output slice exceeds out_cs");

@@ -223,6 +223,8 @@ struct Wino4InArgs {
   int tiles_y, tiles_x, T;
   int pad_t, pad_l;
   int nchunk, m_blocks;
+  const float* up_src;       // UP: channels >= Cin - up_C are the exact 2x bilinear upsample of up_src [N, H/2, W/2, up_cs]
+  int up_C, up_cs;
 };
 
 // One workgroup = 16 tiles x 32 channels (two chunks), tile groups the fast grid dimension; thread = (tile, channel
@@ -242,7 +244,13 @@ __device__ __forceinline__ void w4_bt2(const w4f32x2 (&d)[6], w4f32x2 (&t)[6]) {
   t[4] = c - e;
   t[5] = (4.f * d[1] - 5.f * d[3]) + d[5];
 }
-template <int SPLIT>
+// UP: the conv input is cat([in, up2x(up_src)]) (the reference's Up block / DeconvHead.up2) and is never materialised:
+// a pair of upsampled channels forms its 6x6 window from the 4x4 source patch the window maps to -- source rows
+// 2ty-1 .. 2ty+2, weights 0.25 / 0.75 -- with the expression of the stand-alone kernel (csrc/pointwise.hip:
+// wy0 * (hx * v00 + lx * v01) + wy1 * (hx * v10 + lx * v11), horizontal sums shared by the rows that use them), so the
+// result is bit-identical to upsampling first.  Windows that touch the image border (clamped taps, zero padding) take
+// the generic per-pixel path.
+template <int SPLIT, bool UP>
 __global__ __launch_bounds__(256) void wino4_in_kernel(const Wino4InArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned tbuf[W4_POS * 4 * 16 * 4];      // [pos][chunk half * 2 + octet][tile][4 pairs]
   const int t = threadIdx.x;
@@ -260,18 +268,75 @@ __global__ __launch_bounds__(256) void wino4_in_kernel(const Wino4InArgs p) {
     const int img = tcl / per, rem = tcl - img * per;
     const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
     const int y0 = 4 * ty - p.pad_t, x0 = 4 * tx - p.pad_l;
-    const float* base = p.in + (ok ? ch : 0);
+    const int C2 = UP ? p.Cin - p.up_C : p.Cin;
+    if (UP && ok && ch >= C2) {
+      const int H1 = p.H >> 1, W1 = p.W >> 1;
+      const float* src = p.up_src + (size_t)img * H1 * W1 * p.up_cs + (ch - C2);
+      const bool inner = p.pad_t == 1 && p.pad_l == 1 && y0 >= 0 && y0 + 5 < p.H && x0 >= 0 && x0 + 5 < p.W;
+      if (inner) {
+        // window rows y0 + i, i = 0..5 (y0 odd): source rows (2ty - 1 + (i >> 1), + 1), weight of the second 0.25 / 0.75
+        w4f32x2 P[4][4];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int yy = y0 + i;
-      const bool yok = ok && (unsigned)yy < (unsigned)p.H;
-      const size_t rowoff = ((size_t)img * p.H + (yok ? yy : 0)) * p.W;
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const int xx = x0 + j;
-        const bool in = yok && (unsigned)xx < (unsigned)p.W;
-        const w4f32x2 v = *reinterpret_cast<const w4f32x2*>(base + (rowoff + (in ? xx : 0)) * p.in_cs);
-        d[i][j] = in ? v : w4f32x2{0.f, 0.f};
+          for (int b = 0; b < 4; ++b)
+            P[a][b] = *reinterpret_cast<const w4f32x2*>(src + ((size_t)(2 * ty - 1 + a) * W1 + (2 * tx - 1 + b)) * p.up_cs);
+        w4f32x2 hz[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const float lx = (j & 1) ? 0.75f : 0.25f, hx = 1.f - lx;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) hz[a][j] = hx * P[a][j >> 1] + lx * P[a][(j >> 1) + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const float wy1 = (i & 1) ? 0.75f : 0.25f, wy0 = 1.f - wy1;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) d[i][j] = wy0 * hz[i >> 1][j] + wy1 * hz[(i >> 1) + 1][j];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int oy = y0 + i;
+          float sy = 0.5f * ((float)oy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+          const int ya = (int)sy, yb = ya + (ya < H1 - 1 ? 1 : 0);
+          const float wy1 = sy - (float)ya, wy0 = 1.f - wy1;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            const int ox = x0 + j;
+            const bool in = (unsigned)oy < (unsigned)p.H && (unsigned)ox < (unsigned)p.W;
+            float sx = 0.5f * ((float)ox + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
+            const int xa = (int)sx, xb = xa + (xa < W1 - 1 ? 1 : 0);
+            const float lx = sx - (float)xa, hx = 1.f - lx;
+            const int yac = in ? ya : 0, ybc = in ? yb : 0, xac = in ? xa : 0, xbc = in ? xb : 0;
+            const w4f32x2 v00 = *reinterpret_cast<const w4f32x2*>(src + ((size_t)yac * W1 + xac) * p.up_cs);
+            const w4f32x2 v01 = *reinterpret_cast<const w4f32x2*>(src + ((size_t)yac * W1 + xbc) * p.up_cs);
+            const w4f32x2 v10 = *reinterpret_cast<const w4f32x2*>(src + ((size_t)ybc * W1 + xac) * p.up_cs);
+            const w4f32x2 v11 = *reinterpret_cast<const w4f32x2*>(src + ((size_t)ybc * W1 + xbc) * p.up_cs);
+            const w4f32x2 v = wy0 * (hx * v00 + lx * v01) + wy1 * (hx * v10 + lx * v11);
+            d[i][j] = in ? v : w4f32x2{0.f, 0.f};
+          }
+        }
+      }
+    } else if (!ok) {                 // rows past the last tile / channels past Cin: zeros (p.in may be null with UP)
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d[i][j] = w4f32x2{0.f, 0.f};
+    } else {
+      const float* base = p.in + ch;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int yy = y0 + i;
+        const bool yok = ok && (unsigned)yy < (unsigned)p.H;
+        const size_t rowoff = ((size_t)img * p.H + (yok ? yy : 0)) * p.W;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int xx = x0 + j;
+          const bool in = yok && (unsigned)xx < (unsigned)p.W;
+          const w4f32x2 v = *reinterpret_cast<const w4f32x2*>(base + (rowoff + (in ? xx : 0)) * p.in_cs);
+          d[i][j] = in ? v : w4f32x2{0.f, 0.f};
+        }
       }
     }
 #pragma unroll
@@ -520,11 +585,17 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
   ia.in = d->in; ia.V = V; ia.N = d->N; ia.H = d->H; ia.W = d->W; ia.Cin = d->Cin; ia.in_cs = d->in_cs;
   ia.tiles_y = tiles_y; ia.tiles_x = tiles_x; ia.T = (int)T; ia.pad_t = d->pad_t; ia.pad_l = d->pad_l;
   ia.nchunk = nchunk; ia.m_blocks = m_blocks;
-  CRESTE_REQUIRE((d->Cin & 3) == 0 && (d->in_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(d->in) & 15) == 0,
+  ia.up_src = d->up_src; ia.up_C = d->up_C; ia.up_cs = d->up_cs;
+  CRESTE_REQUIRE((d->Cin & 3) == 0 && (!d->in || ((d->in_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(d->in) & 15) == 0)),
                  "conv2d: the F(4x4,3x3) input transform reads channel pairs (Cin / in_cs multiples of 4, as every NHWC conv here)");
   const dim3 igrid((unsigned)(m_blocks * 16), (unsigned)((nchunk + 1) / 2));      // tile groups fast: m_blocks < 2^18
-  if (split == 3) wino4_in_kernel<3><<<igrid, 256, 0, s>>>(ia);
-  else wino4_in_kernel<2><<<igrid, 256, 0, s>>>(ia);
+  if (d->flags & CRESTE_CONV_V_VALID) {
+    // the caller vouches that `work` holds V of this very input (creste_hip.h)
+  } else if (d->up_src) {
+    if (split == 3) wino4_in_kernel<3, true><<<igrid, 256, 0, s>>>(ia);
+    else wino4_in_kernel<2, true><<<igrid, 256, 0, s>>>(ia);
+  } else if (split == 3) wino4_in_kernel<3, false><<<igrid, 256, 0, s>>>(ia);
+  else wino4_in_kernel<2, false><<<igrid, 256, 0, s>>>(ia);
   CRESTE_CHECK_LAUNCH("wino4_in");
 
   Wino4GemmArgs a;

@@ -110,7 +110,7 @@ def load(path: str, device="cuda:0", example_inputs=None) -> CompiledModel:
 # reference scripts/runtime/compile.py:160-210 (torch.jit.trace -> a module the C++ stack loads without Python).
 PLAN_MAGIC = b"CRESTEPLAN\0\0"
 _DTYPES = {torch.float32: 0, torch.int64: 1, torch.uint8: 2, torch.bool: 2}
-_DESC_PTR_FIELDS = ("in_", "wpk", "bias", "res", "a_scale", "row_mask", "out", "work", "a_amax", "out_amax", "w_unscale")
+_DESC_PTR_FIELDS = ("in_", "wpk", "bias", "res", "a_scale", "row_mask", "out", "work", "a_amax", "out_amax", "w_unscale", "up_src")
 
 
 def _snapshot(device):

@@ -121,6 +121,41 @@ def absmax(x: Act) -> torch.Tensor:
     return x.amax
 
 
+FUSE_UPSAMPLE = True       # conv2d forms cat([skip, up2x(x1)]) inside the F(4x4) input transform instead of materialising it
+
+
+class LazyUpCat:
+    """cat([skip, bilinear_upsample(x1)], C) that has not been formed yet (reference Up.forward, effnet.py:16-23;
+    DeconvHead.up2, inpainting.py:81).  `conv2d` consumes it directly when the conv runs on the F(4x4,3x3) path and the
+    upsample is the exact 2x one (csrc/conv_wino4.hip forms the tensor inside its input transform, bit-identically);
+    everything else calls `materialise()` (cached: the BEV heads share one x4 concat)."""
+
+    def __init__(self, x1: Act, skip, Ho, Wo, rh, rw):
+        self.x1, self.skip, self.Ho, self.Wo, self.rh, self.rw = x1, skip, Ho, Wo, rh, rw
+        self._mat = None
+        self._w4 = None            # (key, workspace) of the last F(4x4) conv over the materialised tensor
+
+    N = property(lambda self: self.x1.N)
+    H = property(lambda self: self.Ho)
+    W = property(lambda self: self.Wo)
+    C = property(lambda self: self.x1.C + (self.skip.C if self.skip is not None else 0))
+
+    @property
+    def exact2x(self):
+        return (self.Ho == 2 * self.x1.H and self.Wo == 2 * self.x1.W and float(self.rh) == 0.5 and float(self.rw) == 0.5
+                and self.x1.C % 4 == 0 and self.x1.co % 4 == 0
+                and (self.skip is None or ((self.skip.H, self.skip.W) == (self.Ho, self.Wo) and self.skip.co % 4 == 0)))
+
+    def materialise(self) -> Act:
+        if self._mat is None:
+            self._mat = upsample_concat(self.x1, self.skip, self.Ho, self.Wo, self.rh, self.rw)
+        return self._mat
+
+
+def upsample_concat_lazy(x1: Act, skip, Ho, Wo, rh, rw) -> LazyUpCat:
+    return LazyUpCat(x1, skip, Ho, Wo, rh, rw)
+
+
 @dataclass
 class PackedConv:
     wpk: torch.Tensor          # packed GEMM weights (uint8 storage)
@@ -229,7 +264,15 @@ def pack_conv(weight: torch.Tensor, bias, bn, stride, pad, act, prec=PREC_F32, a
 def conv2d(x: Act, pc: PackedConv, out: Act | None = None, res: Act | None = None,
            a_scale: torch.Tensor | None = None, row_mask: torch.Tensor | None = None) -> Act:
     lib = _lib.load()
+    up, shared = None, None
+    if isinstance(x, LazyUpCat):
+        if FUSE_UPSAMPLE and pc.algo == ALGO_WINOGRAD4 and x.exact2x and a_scale is None:
+            up, x = x, (x.skip if x.skip is not None else x.x1)       # x: the tensor that owns device / batch below
+        else:
+            shared, x = x, x.materialise()        # several convs read this tensor: they share its transformed image
     N, H, W, cin, dev = x.N, x.H, x.W, x.C, x.buf.device
+    if up is not None:
+        H, W, cin = up.H, up.W, up.C
     if pc.algo == ALGO_WINOGRAD and N > 1 and N * H * W * x.cs >= (1 << 30):
         # the Winograd loader addresses its input with 32-bit byte offsets: batches of more than 4 GiB go in slices
         Ho, Wo = pc.out_hw(H, W)
@@ -258,6 +301,11 @@ def conv2d(x: Act, pc: PackedConv, out: Act | None = None, res: Act | None = Non
                               f"{(N, Ho, Wo, pc.Cout)}")
     d = ConvDesc()
     d.in_ = x.ptr
+    in_cs = x.cs
+    if up is not None:
+        _chk(up.x1.buf, name="conv upsample source")
+        d.in_, in_cs = (up.skip.ptr, up.skip.cs) if up.skip is not None else (None, 0)
+        d.up_src, d.up_H, d.up_W, d.up_C, d.up_cs = up.x1.ptr, up.x1.H, up.x1.W, up.x1.C, up.x1.cs
     d.wpk, d.out = pc.wpk.data_ptr(), out.buf.data_ptr()
     d.bias = pc.bias.data_ptr() if pc.bias is not None else None
     if res is not None:
@@ -276,7 +324,7 @@ def conv2d(x: Act, pc: PackedConv, out: Act | None = None, res: Act | None = Non
         if row_mask.numel() != N * Ho * Wo:
             raise HipLibraryError("conv2d: row_mask must have N*Ho*Wo elements")
         d.row_mask = row_mask.data_ptr()
-    d.N, d.H, d.W, d.Cin, d.in_cs = N, H, W, pc.Cin, x.cs
+    d.N, d.H, d.W, d.Cin, d.in_cs = N, H, W, pc.Cin, in_cs
     d.Ho, d.Wo, d.Cout, d.out_cs, d.out_co = Ho, Wo, pc.Cout, out.cs, out.co
     d.KH, d.KW, d.stride, d.pad_t, d.pad_l = pc.KH, pc.KW, pc.stride, pc.pad_t, pc.pad_l
     d.act, d.prec, d.algo = pc.act, pc.prec, pc.algo
@@ -285,7 +333,15 @@ def conv2d(x: Act, pc: PackedConv, out: Act | None = None, res: Act | None = Non
         work = torch.empty(lib.creste_conv_wino_workspace_bytes(N, Ho, Wo, pc.Cout), dtype=torch.uint8, device=dev)
         d.work = work.data_ptr()
     elif pc.algo == ALGO_WINOGRAD4:    # transformed input (bf16 pieces) + fp32 products of the 36 positions
-        work = torch.empty(lib.creste_conv_wino4_workspace_bytes(N, Ho, Wo, pc.Cin, pc.Cout, pc.prec), dtype=torch.uint8, device=dev)
+        need = lib.creste_conv_wino4_workspace_bytes(N, Ho, Wo, pc.Cin, pc.Cout, pc.prec)
+        key = (pc.Cin, pc.prec, pc.pad_t, pc.pad_l, x.ptr, x.cs, x.buf._version)
+        if shared is not None and shared._w4 is not None and shared._w4[0] == key and shared._w4[1].numel() >= need:
+            work = shared._w4[1]              # the input transform of this tensor is already there (same stream)
+            d.flags = 1                       # CRESTE_CONV_V_VALID
+        else:
+            work = torch.empty(need, dtype=torch.uint8, device=dev)
+            if shared is not None:
+                shared._w4 = (key, work)
         d.work = work.data_ptr()
     if pc.prec == PREC_F16X3:
         d.a_amax, d.w_unscale = absmax(x).data_ptr(), pc.w_unscale.data_ptr()

@@ -50,6 +50,10 @@ extern "C" {
                                 rate; needs creste_conv_desc.a_amax / w_unscale */
 #define CRESTE_ALGO_DIRECT 0   /* implicit GEMM over the K*K taps (every shape) */
 #define CRESTE_ALGO_WINOGRAD 1 /* F(2x2,3x3): stride-1 3x3 convs, see creste_conv_wino_* below */
+/* creste_conv_desc.flags.  V_VALID (CRESTE_ALGO_WINOGRAD4): `work` already holds the transformed input of THIS input
+ * tensor (same N, H, W, Cin, padding, precision) from a previous call on the same stream -- several convs that read one
+ * tensor (the three BEV heads' first conv, inpainting.py:141-146) run the input transform once. */
+#define CRESTE_CONV_V_VALID 1
 #define CRESTE_ALGO_WINOGRAD4 2 /* F(4x4,3x3): the same convs, transformed input materialised, see creste_conv_wino4_* */
 
 const char* creste_last_error(void);
@@ -81,7 +85,7 @@ typedef struct creste_conv_desc {
   int32_t act;  /* CRESTE_ACT_* */
   int32_t prec; /* CRESTE_PREC_* */
   int32_t algo; /* CRESTE_ALGO_* : how `wpk` was packed and which kernels run */
-  int32_t reserved0;
+  int32_t flags; /* CRESTE_CONV_* bits, 0 by default */
   /* Dynamic-range bookkeeping of the fp16-split engine (CRESTE_PREC_F16X3); all three may be NULL otherwise.
    * a_amax   device float: an UPPER BOUND of max|in| over the slice read; the kernel scales
    *          the operand by a power of two so that the bound lands in [2^14, 2^15) -- exact, undone in the
@@ -93,6 +97,13 @@ typedef struct creste_conv_desc {
   const float* a_amax;
   float* out_amax;
   const float* w_unscale;
+  /* CRESTE_ALGO_WINOGRAD4 only, or NULL: the conv's input is cat([in (Cin - up_C channels), bilinear_up2x(up_src)], C)
+   * -- reference `Up.forward` (effnet.py:16-23: nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False) + cat) and
+   * DeconvHead.up2 (inpainting.py:81, no skip: `in` may be NULL when up_C == Cin) -- formed inside the input transform
+   * with the expression of creste_upsample_concat_nhwc_f32 (bit-identical to materialising the tensor first).
+   * up_src [N, up_H, up_W, up_cs] with H == 2 up_H, W == 2 up_W, up_C % 4 == 0. */
+  const float* up_src;
+  int32_t up_H, up_W, up_C, up_cs;
 } creste_conv_desc;
 
 int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream);

@@ -565,3 +565,47 @@ def test_conv_winograd_large_batch_is_sliced(ops, monkeypatch):
     assert torch.equal(whole, sliced)
     ref = F.relu(F.conv2d(x.double(), w.double(), padding=1))
     assert float((whole.double() - ref).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("N,C1,C2,H1,W1,Cout", [
+    (2, 256, 0, 16, 24, 128),      # DeconvHead.up2: no skip connection
+    (1, 320, 176, 19, 38, 256),    # Up block: skip + upsampled channels, pair chunks straddling the boundary (176 = 5.5 x 32)
+    (3, 256, 64, 9, 11, 132),      # odd low-resolution extents: partial tiles, borders everywhere
+])
+def test_conv_winograd4_fused_upsample_concat(ops, N, C1, C2, H1, W1, Cout):
+    """F(4x4,3x3) conv over cat([skip, up2x(x1)]) formed inside the input transform (ops.LazyUpCat) == the same conv over
+    the materialised tensor, bit for bit (reference Up.forward effnet.py:16-23 / DeconvHead.up2 inpainting.py:81)."""
+    g = torch.Generator().manual_seed(N * 1000 + C1)
+    x1 = to_act(ops, torch.randn(N, C1, H1, W1, generator=g))
+    skip = to_act(ops, torch.randn(N, C2, 2 * H1, 2 * W1, generator=g)) if C2 else None
+    w = torch.randn(Cout, C1 + C2, 3, 3, generator=g) / ((C1 + C2) * 9) ** 0.5
+    pc = ops.pack_conv(dev(w), None, None, 1, 1, ops.ACT_RELU, ops.PREC_BF16X6, algo=ops.ALGO_WINOGRAD4)
+    lazy = ops.upsample_concat_lazy(x1, skip, 2 * H1, 2 * W1, 0.5, 0.5)
+    assert lazy.exact2x
+    fused = ops.conv2d(lazy, pc)
+    assert lazy._mat is None                      # never materialised
+    plain = ops.conv2d(ops.upsample_concat(x1, skip, 2 * H1, 2 * W1, 0.5, 0.5), pc)
+    assert torch.equal(fused.buf, plain.buf)
+    # the policy's other branches materialise once and cache
+    pcd = ops.pack_conv(dev(w), None, None, 1, 1, ops.ACT_RELU, ops.PREC_BF16X6, algo=ops.ALGO_DIRECT)
+    y = ops.conv2d(lazy, pcd)
+    assert lazy._mat is not None and ops.conv2d(lazy, pcd).buf.shape == y.buf.shape
+
+
+def test_conv_winograd4_shared_input_transform(ops):
+    """three F(4x4,3x3) convs over ONE materialised upsample + concat (the BEV heads' first conv, inpainting.py:141-146):
+    the input transform runs once (CRESTE_CONV_V_VALID) and every output equals the stand-alone conv bit for bit."""
+    g = torch.Generator().manual_seed(11)
+    x1 = to_act(ops, torch.randn(2, 256, 8, 12, generator=g))
+    skip = to_act(ops, torch.randn(2, 64, 32, 48, generator=g))
+    lazy = ops.upsample_concat_lazy(x1, skip, 32, 48, 0.25, 0.25)
+    assert not lazy.exact2x
+    outs, refs = [], []
+    for Cout in (256, 256, 128):
+        w = torch.randn(Cout, 320, 3, 3, generator=g) / (320 * 9) ** 0.5
+        pc = ops.pack_conv(dev(w), None, None, 1, 1, ops.ACT_RELU, ops.PREC_BF16X6, algo=ops.ALGO_WINOGRAD4)
+        outs.append(ops.conv2d(lazy, pc).buf.clone())
+        refs.append(ops.conv2d(ops.upsample_concat(x1, skip, 32, 48, 0.25, 0.25), pc).buf.clone())
+    assert lazy._w4 is not None
+    for a, b in zip(outs, refs):
+        assert torch.equal(a, b)
