@@ -104,6 +104,9 @@ SIGNATURES = {
     "creste_conv_wgrad_strided_workspace_bytes": (_i64, [_i] * 6),
     "creste_conv_wgrad_strided_f32": (_i, [_vp, _i, _vp, _i, _vp] + [_i] * 12 + [_vp, _vp]),
     "creste_conv_wgrad_bf16x6": (_i, [_vp, _i, _vp, _i, _vp] + [_i] * 12 + [_vp, _vp]),
+    "creste_conv_wgrad_wino4_supported": (_i, [_i] * 8),
+    "creste_conv_wgrad_wino4_workspace_bytes": (_i64, [_i] * 5),
+    "creste_conv_wgrad_wino4": (_i, [_vp, _i, _vp, _i, _vp] + [_i] * 8 + [_vp, _vp]),
     "creste_conv_wgrad_f16x3": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp] + [_i] * 12 + [_vp, _vp]),
     "creste_dwconv_dgrad_f32": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "creste_dwconv_wgrad_workspace_bytes": (_i64, [_i, _i]),

@@ -54,6 +54,7 @@ struct Wino4GemmArgs {
   float* M;                  // [36][Cout / 4][T][4]
   int T, Cout;
   int nchunk, m_blocks, tiles_n, units;
+  int npos;                  // 36 (forward) or 36 x K-segments (weight gradient)
 };
 
 // Item = (tile block, position, cout tile).  Items are dealt in UNITS of 32 = 8 panels (position, cout tile) x W4_MBG
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_kernel(const Wino4GemmArgs 
   const int Q = p.Cout >> 2;
 
   const int cus = gridDim.x >> 3;
-  const int xcd = blockIdx.x & 7, P = W4_POS * p.tiles_n;
+  const int xcd = blockIdx.x & 7, P = p.npos * p.tiles_n;
   const int units_pg = (P + 7) >> 3, nunits = units_pg * ((p.m_blocks + W4_MBG - 1) / W4_MBG);
   int slot = blockIdx.x >> 3;
 
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_kernel(const Wino4GemmArgs 
     // a half-wave writes 512 contiguous bytes per instruction).  ALL kStores stores are issued (rows past the last
     // tile / couts past Cout go to a junk line behind the workspace) so that the next item's waits can count them
     float* Mp = p.M + (size_t)pos * Q * p.T * 4;
-    float* const junk = p.M + (size_t)W4_POS * Q * p.T * 4 + lane * 4;
+    float* const junk = p.M + (size_t)p.npos * Q * p.T * 4 + lane * 4;
     const int mb_cur = mb, tn_cur = tn;
     slot += cus;
     const bool more = setup();
@@ -557,7 +558,7 @@ static int launch_wino4_gemm(const Wino4GemmArgs& a, hipStream_t s) {
   int dev = 0, cus = 0;
   CRESTE_HIP(hipGetDevice(&dev));
   CRESTE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  const long items = (long)a.m_blocks * W4_POS * a.tiles_n;
+  const long items = (long)a.m_blocks * a.npos * a.tiles_n;
   long per_xcd = cus / 8 > 0 ? cus / 8 : 1;
   const long need = (items + 7) / 8;
   if (per_xcd > need) per_xcd = need;
@@ -600,7 +601,7 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
 
   Wino4GemmArgs a;
   a.V = V; a.wpk = (const char*)d->wpk; a.M = M; a.T = (int)T; a.Cout = d->Cout;
-  a.nchunk = nchunk; a.m_blocks = m_blocks; a.units = wino4_units(d->Cout);
+  a.nchunk = nchunk; a.m_blocks = m_blocks; a.units = wino4_units(d->Cout); a.npos = W4_POS;
   const int tn = d->Cout > 128 ? 4 : 2;
   a.tiles_n = (d->Cout + 64 * tn - 1) / (64 * tn);
   int rc;
@@ -618,4 +619,282 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
   return CRESTE_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW of the same convs through the same transform: with V = B^T d B (input windows) and Yh = A dY A^T (4x4 tiles of the
+// output gradient, A = (A^T)^T: 6x4), dU_p[co, ci] = sum over tiles of Yh_p[tile, co] V_p[tile, ci] per position p, and
+// dW = G^T dU G.  36 GEMMs with K = TILES: both operands are written K-major ([row][8 tiles] 16-byte units, the
+// forward GEMM's operand images with tiles in the place of channels), the tile range is cut into SEG segments that
+// become extra "positions" (36 x SEG independent GEMMs of M = Cin rows, N = Cout columns), and the forward's
+// wino4_gemm_kernel runs unchanged.  4x fewer matrix products than the direct weight gradient, same bf16x6 grade.
+struct Wino4WgInArgs {
+  const float* src;          // x [N,H,W,cs] (window 6x6 at 4t - pad) or gy [N,H,W,cs] (4x4 tile at 4t)
+  char* dst;                 // A image (rows = channels of x) or B image (64-channel units of gy)
+  int N, H, W, C, cs;
+  int tiles_y, tiles_x, T;
+  int pad_t, pad_l;
+  int nchunk;                // 16-tile chunks per segment
+  int blocks;                // A image: 256-row blocks;  B image: 64-row units (padded)
+};
+
+// one column of A applied to four values: (A v)[0..5]
+__device__ __forceinline__ void w4_a(const float (&v)[4], float (&t)[6]) {
+  const float s01 = v[1] + v[2], d01 = v[1] - v[2];
+  t[0] = v[0];
+  t[1] = (v[0] + s01) + v[3];
+  t[2] = (v[0] - v[1]) + (v[2] - v[3]);
+  t[3] = (v[0] + 2.f * v[1]) + (4.f * v[2] + 8.f * v[3]);
+  t[4] = (v[0] - 2.f * v[1]) + (4.f * v[2] - 8.f * v[3]);
+  t[5] = v[3];
+  (void)s01; (void)d01;
+}
+__device__ __forceinline__ void w4_bt1(const float (&d)[6], float (&t)[6]) {
+  const float a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1], c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+  t[0] = (4.f * d[0] - 5.f * d[2]) + d[4];
+  t[1] = a + b;
+  t[2] = a - b;
+  t[3] = c + e;
+  t[4] = c - e;
+  t[5] = (4.f * d[1] - 5.f * d[3]) + d[5];
+}
+
+// Workgroup = 16 consecutive tiles (= one K chunk) x 32 channels; thread = (tile PAIR, channel): scalar loads with the
+// lanes along channels (128 contiguous bytes per pixel), two tiles transformed in registers, their bf16 pieces packed
+// into one dword = K elements 2q, 2q + 1 of the channel's 16-byte unit.  GY: the operand is the output gradient.
+template <int SPLIT, bool GY>
+__global__ __launch_bounds__(256) void wino4_wg_in_kernel(const Wino4WgInArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned tbuf[W4_POS * 2 * 32 * 4];      // [pos][octet][channel][4 tile pairs]
+  const int t = threadIdx.x;
+  const int chunk_lin = blockIdx.x;            // global 16-tile chunk: segment = chunk_lin / nchunk
+  const int c = t & 31, tp = t >> 5;           // channel within the group, tile pair 0..7
+  const int ch = blockIdx.y * 32 + c;
+  const int per = p.tiles_y * p.tiles_x;
+  float u[2][6][6];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int tile = chunk_lin * 16 + tp * 2 + h;
+    const bool ok = tile < p.T && ch < p.C;
+    const int tcl = ok ? tile : 0;
+    const int img = tcl / per, rem = tcl - img * per;
+    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    const float* base = p.src + (ok ? ch : 0);
+    if (GY) {
+      float g[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int yy = 4 * ty + i;
+        const bool yok = ok && yy < p.H;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int xx = 4 * tx + j;
+          const bool in = yok && xx < p.W;
+          const float v = base[(((size_t)img * p.H + (in ? yy : 0)) * p.W + (in ? xx : 0)) * p.cs];
+          g[i][j] = in ? v : 0.f;
+        }
+      }
+      float m[6][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float col[4] = {g[0][j], g[1][j], g[2][j], g[3][j]};
+        float o[6];
+        w4_a(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m[i][j] = o[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        float o[6];
+        w4_a(m[i], o);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) u[h][i][j] = o[j];
+      }
+    } else {
+      float d[6][6];
+      const int y0 = 4 * ty - p.pad_t, x0 = 4 * tx - p.pad_l;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int yy = y0 + i;
+        const bool yok = ok && (unsigned)yy < (unsigned)p.H;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int xx = x0 + j;
+          const bool in = yok && (unsigned)xx < (unsigned)p.W;
+          const float v = base[(((size_t)img * p.H + (in ? yy : 0)) * p.W + (in ? xx : 0)) * p.cs];
+          d[i][j] = in ? v : 0.f;
+        }
+      }
+      float m[6][6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+        float o[6];
+        w4_bt1(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m[i][j] = o[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        float o[6];
+        w4_bt1(m[i], o);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) u[h][i][j] = o[j];
+      }
+    }
+  }
+  const int seg = chunk_lin / p.nchunk, chunk = chunk_lin - seg * p.nchunk;
+  constexpr int UNITS = W4_POS * 2 * 32;       // 16-byte units of one piece: (position, octet, channel)
+#pragma unroll
+  for (int pl = 0; pl < SPLIT; ++pl) {
+    if (pl) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const w4f32x2 pair{u[0][i][j], u[1][i][j]};
+        const w4bf16x2 piece = __builtin_convertvector(pair, w4bf16x2);
+        tbuf[(((i * 6 + j) * 2 + (tp >> 2)) * 32 + c) * 4 + (tp & 3)] = __builtin_bit_cast(unsigned, piece);
+        if (pl + 1 < SPLIT) {
+          const w4f32x2 back = __builtin_convertvector(piece, w4f32x2);
+          u[0][i][j] -= back[0]; u[1][i][j] -= back[1];
+        }
+      }
+    __syncthreads();
+    for (int uidx = t; uidx < UNITS; uidx += 256) {
+      const int cw = uidx & 31, oct = (uidx >> 5) & 1, pos = uidx >> 6;
+      const int chw = blockIdx.y * 32 + cw;
+      const size_t posp = (size_t)seg * W4_POS + pos;
+      char* dst;
+      if (GY) {      // B image: [pos'][64-channel unit][chunk][piece][octet][64][8]
+        if ((chw >> 6) >= p.blocks) continue;
+        dst = p.dst + ((((posp * p.blocks + (chw >> 6)) * p.nchunk + chunk) * SPLIT + pl) * 2 + oct) * (size_t)(64 * 16) + (size_t)(chw & 63) * 16;
+      } else {       // A image: [pos'][256-channel block][chunk][piece][octet][256][8]
+        if ((chw >> 8) >= p.blocks) continue;
+        dst = p.dst + ((((posp * p.blocks + (chw >> 8)) * p.nchunk + chunk) * SPLIT + pl) * 2 + oct) * (size_t)(W4_M * 16) + (size_t)(chw & 255) * 16;
+      }
+      *reinterpret_cast<w4f32x4*>(dst) = *reinterpret_cast<const w4f32x4*>(tbuf + (size_t)uidx * 4);
+    }
+  }
+}
+
+// gw[co][ci][3][3] (+)= G^T (sum over segments of dU) G; thread = (ci, cout quad); M = [seg * 36 + pos][Cout / 4][Cin][4]
+__global__ __launch_bounds__(256) void wino4_wg_out_kernel(const float* __restrict__ M, float* __restrict__ gw, int Cin, int Cout,
+                                                          int nseg, int accumulate) {
+  const int Q = Cout >> 2;
+  const long idx = blockIdx.x * 256L + threadIdx.x;
+  if (idx >= (long)Q * Cin) return;
+  const int ci = (int)(idx % Cin), q = (int)(idx / Cin);
+  const size_t plane = (size_t)Q * Cin * 4;
+  const float* src = M + ((size_t)q * Cin + ci) * 4;
+  w4f32x4 dU[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      w4f32x4 acc = *reinterpret_cast<const w4f32x4*>(src + (size_t)(i * 6 + j) * plane);
+      for (int sgi = 1; sgi < nseg; ++sgi) acc += *reinterpret_cast<const w4f32x4*>(src + ((size_t)sgi * W4_POS + i * 6 + j) * plane);
+      dU[i][j] = acc;
+    }
+  // G^T (3x6): rows [1/4 -1/6 -1/6 1/24 1/24 0; 0 -1/6 1/6 1/12 -1/12 0; 0 -1/6 -1/6 1/6 1/6 1]
+  auto gt = [](const w4f32x4 (&v)[6], w4f32x4 (&o)[3]) __attribute__((always_inline)) {
+    const w4f32x4 s12 = v[1] + v[2], d21 = v[2] - v[1], s34 = v[3] + v[4], d34 = v[3] - v[4];
+    o[0] = (0.25f * v[0] - (1.f / 6.f) * s12) + (1.f / 24.f) * s34;
+    o[1] = (1.f / 6.f) * d21 + (1.f / 12.f) * d34;
+    o[2] = ((1.f / 6.f) * s34 - (1.f / 6.f) * s12) + v[5];
+  };
+  w4f32x4 r[3][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const w4f32x4 col[6] = {dU[0][j], dU[1][j], dU[2][j], dU[3][j], dU[4][j], dU[5][j]};
+    w4f32x4 o[3];
+    gt(col, o);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) r[a][j] = o[a];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    w4f32x4 o[3];
+    gt(r[a], o);
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float* dstp = gw + (((size_t)(q * 4 + e) * Cin + ci) * 3 + a) * 3 + b;
+        *dstp = accumulate ? *dstp + o[b][e] : o[b][e];
+      }
+  }
+}
+
+static inline int wino4_wg_segments(long T) {
+  // enough items for four rounds of the chip on the widest layers (2 x 2 tiles x 36 x SEG), K of >= 64 chunks per segment
+  long chunks = (T + 15) / 16;
+  int seg = 7;
+  while (seg > 1 && chunks / seg < 64) --seg;
+  return seg;
+}
+
+bool conv_wgrad_wino4_supported(int K, int stride, int H, int W, int Ho, int Wo, int Cin, int Cout) {
+  return K == 3 && stride == 1 && Ho == H && Wo == W && Cin % 4 == 0 && Cout % 4 == 0 && Cin >= 128 && Cout >= 128;
+}
+
+int64_t conv_wgrad_wino4_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+  const long T = wino4_tiles(N, H, W);
+  const int seg = wino4_wg_segments(T);
+  const long nchunk = ((T + seg - 1) / seg + 15) / 16;
+  const long mbl = (Cin + W4_M - 1) / W4_M, units = wino4_units(Cout);
+  const long a_bytes = (long)W4_POS * seg * mbl * nchunk * 3 * 2 * W4_M * 16;
+  const long b_bytes = (long)W4_POS * seg * units * nchunk * 3 * 2 * 64 * 16;
+  return a_bytes + b_bytes + (long)W4_POS * seg * Cout * Cin * 4 + 4096;
+}
+
+int conv_wgrad_wino4_run(const float* x, int x_cs, const float* gy, int gy_cs, float* gw, int N, int H, int W, int Cin, int Cout,
+                         int pad_t, int pad_l, int accumulate, void* work, hipStream_t s) {
+  const int tiles_y = (H + 3) / 4, tiles_x = (W + 3) / 4;
+  const long T = (long)N * tiles_y * tiles_x;
+  CRESTE_REQUIRE(T < (1L << 26), "conv_wgrad_wino4: too many tiles");
+  const int seg = wino4_wg_segments(T);
+  const int nchunk = (int)(((T + seg - 1) / seg + 15) / 16);
+  const int mbl = (Cin + W4_M - 1) / W4_M, units = wino4_units(Cout);
+  char* Aimg = (char*)work;
+  char* Bimg = Aimg + (long)W4_POS * seg * mbl * nchunk * 3 * 2 * W4_M * 16;
+  float* M = (float*)(Bimg + (long)W4_POS * seg * units * nchunk * 3 * 2 * 64 * 16);
+  Wino4WgInArgs ia;
+  ia.N = N; ia.H = H; ia.W = W; ia.tiles_y = tiles_y; ia.tiles_x = tiles_x; ia.T = (int)T; ia.pad_t = pad_t; ia.pad_l = pad_l;
+  ia.nchunk = nchunk;
+  ia.src = x; ia.dst = Aimg; ia.C = Cin; ia.cs = x_cs; ia.blocks = mbl;
+  wino4_wg_in_kernel<3, false><<<dim3((unsigned)(seg * nchunk), (unsigned)((Cin + 31) / 32)), 256, 0, s>>>(ia);
+  CRESTE_CHECK_LAUNCH("wino4_wg_in(x)");
+  ia.src = gy; ia.dst = Bimg; ia.C = Cout; ia.cs = gy_cs; ia.blocks = units;
+  wino4_wg_in_kernel<3, true><<<dim3((unsigned)(seg * nchunk), (unsigned)((units * 64 + 31) / 32)), 256, 0, s>>>(ia);
+  CRESTE_CHECK_LAUNCH("wino4_wg_in(gy)");
+  Wino4GemmArgs a;
+  a.V = Aimg; a.wpk = Bimg; a.M = M; a.T = Cin; a.Cout = Cout; a.nchunk = nchunk; a.m_blocks = mbl; a.units = units;
+  a.npos = W4_POS * seg;
+  const int tn = Cout > 128 ? 4 : 2;
+  a.tiles_n = (Cout + 64 * tn - 1) / (64 * tn);
+  const int rc = tn == 4 ? launch_wino4_gemm<3, 4>(a, s) : launch_wino4_gemm<3, 2>(a, s);
+  if (rc != CRESTE_OK) return rc;
+  wino4_wg_out_kernel<<<(unsigned)(((long)(Cout / 4) * Cin + 255) / 256), 256, 0, s>>>(M, gw, Cin, Cout, seg, accumulate);
+  CRESTE_CHECK_LAUNCH("wino4_wg_out");
+  return CRESTE_OK;
+}
+
 }  // namespace creste
+
+extern "C" int creste_conv_wgrad_wino4_supported(int K, int stride, int H, int W, int Ho, int Wo, int Cin, int Cout) {
+  return creste::conv_wgrad_wino4_supported(K, stride, H, W, Ho, Wo, Cin, Cout) ? 1 : 0;
+}
+
+extern "C" int64_t creste_conv_wgrad_wino4_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return -1;
+  return creste::conv_wgrad_wino4_workspace_bytes(N, H, W, Cin, Cout);
+}
+
+extern "C" int creste_conv_wgrad_wino4(const float* x, int x_cs, const float* gy, int gy_cs, float* gw, int N, int H, int W,
+                                       int Cin, int Cout, int pad_t, int pad_l, int accumulate, void* work, void* stream) {
+  using namespace creste;
+  CRESTE_REQUIRE(x && gy && gw && work, "conv_wgrad_wino4: null pointer");
+  CRESTE_REQUIRE(N > 0 && conv_wgrad_wino4_supported(3, 1, H, W, H, W, Cin, Cout),
+                 "conv_wgrad_wino4: built for stride-1 same-size 3x3 convs with >= 128 channels (multiples of 4) on both sides");
+  CRESTE_REQUIRE(x_cs >= Cin && gy_cs >= Cout && (reinterpret_cast<uintptr_t>(work) & 15) == 0, "conv_wgrad_wino4: bad strides / workspace alignment");
+  return conv_wgrad_wino4_run(x, x_cs, gy, gy_cs, gw, N, H, W, Cin, Cout, pad_t, pad_l, accumulate, work, (hipStream_t)stream);
+}

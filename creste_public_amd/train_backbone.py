@@ -26,6 +26,9 @@ from .train_ops import grad_slot as _acc
 DROP_CONNECT = 0.2          # efficientnet_pytorch global_params.drop_connect_rate of efficientnet-b0
 
 
+WGRAD_WINOGRAD, WGRAD_WINOGRAD_MIN_C = True, 128      # weight gradients of the wide 3x3 convs through F(4x4,3x3) (bf16x6 grade)
+
+
 def _lib_():
     return _lib.load()
 
@@ -115,22 +118,34 @@ class ConvG:
         x = self.x
         if grads is not None:
             gw, acc = _acc(grads, w)
-            work = torch.empty(lib.creste_conv_wgrad_strided_workspace_bytes(gy.N, gy.H, gy.W, Cin, Cout, self.K),
-                               dtype=torch.uint8, device=w.device)
-            if (hipnn._precision == ops.PREC_F16X3 and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 8 and Cout >= 8
-                    and x.cs % 4 == 0 and gy.cs % 4 == 0 and x.co % 4 == 0 and gy.co % 4 == 0):
-                # f16x3 wgrad: fp16 hi+lo operands from the tensors' |max| bounds, fp32 accumulation
-                _lib.check(lib.creste_conv_wgrad_f16x3(x.ptr, x.cs, gy.ptr, gy.cs, gw.data_ptr(),
-                                                       ops.absmax(x).data_ptr(), ops.absmax(gy).data_ptr(), x.N, x.H,
-                                                       x.W, gy.H, gy.W, Cin, Cout, self.K, self.s, self.pad[0],
-                                                       self.pad[2], acc, work.data_ptr(), _stream()), "conv_wgrad_f16x3")
+            quads = (Cin % 4 == 0 and Cout % 4 == 0 and x.cs % 4 == 0 and gy.cs % 4 == 0 and x.co % 4 == 0 and gy.co % 4 == 0)
+            if (WGRAD_WINOGRAD and hipnn._precision in (ops.PREC_BF16X6, ops.PREC_F16X3) and quads and self.pad[0] == 1 and self.pad[2] == 1
+                    and min(Cin, Cout) >= WGRAD_WINOGRAD_MIN_C
+                    and lib.creste_conv_wgrad_wino4_supported(self.K, self.s, x.H, x.W, gy.H, gy.W, Cin, Cout)):
+                # wide 3x3 (bf16x6, and f16x3 -- at the wider bf16x6 grade): through the F(4x4,3x3) transform, 4x fewer
+                # matrix products (csrc/conv_wino4.hip)
+                work = torch.empty(lib.creste_conv_wgrad_wino4_workspace_bytes(x.N, x.H, x.W, Cin, Cout), dtype=torch.uint8,
+                                   device=w.device)
+                _lib.check(lib.creste_conv_wgrad_wino4(x.ptr, x.cs, gy.ptr, gy.cs, gw.data_ptr(), x.N, x.H, x.W, Cin, Cout,
+                                                       self.pad[0], self.pad[2], acc, work.data_ptr(), _stream()),
+                           "conv_wgrad_wino4")
             else:
-                # bf16x6: the wide 3x3 convs at the forward's operand grade (six bf16 piece products), the rest exact fp32
-                fn = lib.creste_conv_wgrad_bf16x6 if hipnn._precision == ops.PREC_BF16X6 else lib.creste_conv_wgrad_strided_f32
-                _lib.check(fn(x.ptr, x.cs, gy.ptr, gy.cs, gw.data_ptr(), x.N, x.H, x.W,
-                              gy.H, gy.W, Cin, Cout, self.K, self.s, self.pad[0],
-                              self.pad[2], acc, work.data_ptr(), _stream()),
-                           "conv_wgrad_strided")
+                work = torch.empty(lib.creste_conv_wgrad_strided_workspace_bytes(gy.N, gy.H, gy.W, Cin, Cout, self.K),
+                                   dtype=torch.uint8, device=w.device)
+                if (hipnn._precision == ops.PREC_F16X3 and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 8 and Cout >= 8
+                        and x.cs % 4 == 0 and gy.cs % 4 == 0 and x.co % 4 == 0 and gy.co % 4 == 0):
+                    # f16x3 wgrad: fp16 hi+lo operands from the tensors' |max| bounds, fp32 accumulation
+                    _lib.check(lib.creste_conv_wgrad_f16x3(x.ptr, x.cs, gy.ptr, gy.cs, gw.data_ptr(),
+                                                           ops.absmax(x).data_ptr(), ops.absmax(gy).data_ptr(), x.N, x.H,
+                                                           x.W, gy.H, gy.W, Cin, Cout, self.K, self.s, self.pad[0],
+                                                           self.pad[2], acc, work.data_ptr(), _stream()), "conv_wgrad_f16x3")
+                else:
+                    # bf16x6: the wide 3x3 convs at the forward's operand grade (six bf16 piece products), the rest exact fp32
+                    fn = lib.creste_conv_wgrad_bf16x6 if hipnn._precision == ops.PREC_BF16X6 else lib.creste_conv_wgrad_strided_f32
+                    _lib.check(fn(x.ptr, x.cs, gy.ptr, gy.cs, gw.data_ptr(), x.N, x.H, x.W,
+                                  gy.H, gy.W, Cin, Cout, self.K, self.s, self.pad[0],
+                                  self.pad[2], acc, work.data_ptr(), _stream()),
+                               "conv_wgrad_strided")
             if self.conv.bias is not None:
                 gb, accb = _acc(grads, self.conv.bias)
                 s = sample_reduce(gy, None, 1.0, per_sample=False).view(-1)

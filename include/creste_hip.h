@@ -428,6 +428,14 @@ int creste_conv_wgrad_f16x3(const float* x, int x_cs, const float* gy, int gy_cs
 int creste_conv_wgrad_bf16x6(const float* x, int x_cs, const float* gy, int gy_cs, float* gw, int N, int H, int W,
                              int Ho, int Wo, int Cin, int Cout, int K, int stride, int pad_t, int pad_l,
                              int accumulate, void* work, void* stream);
+/* The same gradient through the F(4x4,3x3) transform (csrc/conv_wino4.hip): dU_p = sum over tiles of (A dY A^T)_p (x)
+ * (B^T d B)_p per transform position, dW = G^T dU G -- 36 x SEG GEMMs over the tiles on the forward's GEMM kernel, 4x
+ * fewer matrix products than the direct form at the same bf16x6 grade (fp32 transforms: rel. error ~3x the direct
+ * kernel's).  Stride-1 same-size 3x3 convs, >= 128 channels on both sides; own workspace. */
+int creste_conv_wgrad_wino4_supported(int K, int stride, int H, int W, int Ho, int Wo, int Cin, int Cout);
+int64_t creste_conv_wgrad_wino4_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int creste_conv_wgrad_wino4(const float* x, int x_cs, const float* gy, int gy_cs, float* gw, int N, int H, int W, int Cin,
+                            int Cout, int pad_t, int pad_l, int accumulate, void* work, void* stream);
 /* depthwise conv backward (weights tap-major [K*K][C] as in creste_dwconv2d_nhwc_f32): input gradient and
  * per-tap weight gradient gw_taps[K*K][C] (+)=. */
 int creste_dwconv_dgrad_f32(const float* gy, const float* w, float* gx, int N, int H, int W, int C, int Ho, int Wo,

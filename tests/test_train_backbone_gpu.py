@@ -483,3 +483,26 @@ def test_bev_heads_training_step():
     out_m = net({"bev_features": bev.cuda()})
     for (pred, _), p in zip(outs, prefixes):
         assert torch.equal(out_m[f"{p}_preds"], pred), p
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,acc", [(2, 256, 20, 28, 256, False), (3, 272, 37, 19, 132, True),
+                                                (8, 128, 64, 64, 320, False)])
+def test_conv_wgrad_winograd(N, Cin, H, W, Cout, acc):
+    """weight gradient of the wide 3x3 convs through the F(4x4,3x3) transform (csrc/conv_wino4.hip: A dY A^T and B^T d B
+    images with the tiles as the GEMM's K, split-K segments, G^T dU G) against float64 autograd; partial tiles at the
+    right / bottom edges, channel counts that are not multiples of the 256 / 64 blocks, accumulation into gw."""
+    from creste_public_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(N + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    gy = torch.randn(N, Cout, H, W, generator=g)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, padding=1).backward(gy.double())
+    assert lib.creste_conv_wgrad_wino4_supported(3, 1, H, W, H, W, Cin, Cout)
+    xa, ga = ops.nchw_to_nhwc(x.cuda()), ops.nchw_to_nhwc(gy.cuda())
+    gw = torch.full((Cout, Cin, 3, 3), 0.5 if acc else float("nan"), device="cuda")
+    work = torch.empty(lib.creste_conv_wgrad_wino4_workspace_bytes(N, H, W, Cin, Cout), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.creste_conv_wgrad_wino4(xa.ptr, xa.cs, ga.ptr, ga.cs, gw.data_ptr(), N, H, W, Cin, Cout, 1, 1, int(acc),
+                                           work.data_ptr(), torch.cuda.current_stream().cuda_stream), "conv_wgrad_wino4")
+    ref = w.grad + (0.5 if acc else 0.0)
+    assert _rel(gw, ref) < 1e-5
