@@ -26,7 +26,7 @@ from .train_ops import grad_slot as _acc
 DROP_CONNECT = 0.2          # efficientnet_pytorch global_params.drop_connect_rate of efficientnet-b0
 
 
-WGRAD_WINOGRAD, WGRAD_WINOGRAD_MIN_C = True, 128      # weight gradients of the wide 3x3 convs through F(4x4,3x3) (bf16x6 grade)
+WGRAD_WINOGRAD, WGRAD_WINOGRAD_MIN_C = True, 256      # weight gradients of the wide 3x3 convs through F(4x4,3x3) (bf16x6 grade)
 
 
 def _lib_():
