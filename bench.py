@@ -83,7 +83,10 @@ def kernel_symbol(pc, N, Ho, Wo):
                 "conv_igemm_f32_kernel<2, 2, 2, 1>" if pc.Cout > 32 else "conv_igemm_f32_kernel<4, 1, 1, 1>")
     if pc.stride == 2 or pc.KH > 3:             # f16x3 only: row-at-a-time kernel
         tn2 = 2 if pc.Cout > 64 and not (pc.KH == 7 and pc.stride == 2) else 1
-        return (PREC_NAME[pc.prec], f"conv_patch_row_kernel<{pc.KH}, {pc.stride}, {tn2}>")
+        if pc.prec == 3:                        # bf16x6: three pieces, 64-cout tiles (128 for the 1x1/2 downsamples)
+            tn2 = 2 if (pc.KH == 1 and pc.Cout > 64) else 1
+            return (PREC_NAME[pc.prec], f"conv_patch_row_kernel<{pc.KH}, {pc.stride}, {tn2}, 3, false>")
+        return (PREC_NAME[pc.prec], f"conv_patch_row_kernel<{pc.KH}, {pc.stride}, {tn2}, 2, true>")
     split = {1: 1, 2: 2, 3: 3, 4: 2}[pc.prec]
     tn = (4 if (pc.prec == 4 or (pc.KH == 1 and pc.prec == 3)) else 2) if pc.Cout > 128 else 2 if pc.Cout > 64 else 1
     if pc.KH == 1 and pc.Cin < 256 and tn == 4:

@@ -173,7 +173,8 @@ __device__ __forceinline__ void patch_epilogue_lds(const f32x16 (&acc)[2][TN], c
       __syncthreads();
       const int n = nbase + (wn * TN + nt) * 32 + rq * 4;
       if (oy < p.Ho && n < p.Cout) {
-        const f32x4 us = *reinterpret_cast<const f32x4*>(p.w_unscale + n) * o_mul;       // exact: powers of two
+        const f32x4 us = p.w_unscale ? *reinterpret_cast<const f32x4*>(p.w_unscale + n) * o_mul        // exact: powers of two
+                                     : f32x4{o_mul, o_mul, o_mul, o_mul};
         const f32x4 bs = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -590,18 +591,19 @@ static int launch_patch3(const PatchArgs& a, hipStream_t s) {
 //     fragment (32 consecutive output columns = every other input column) read consecutive 16-byte slots;
 //   * the K weight tiles of one kernel row arrive by LDS-DMA, double-buffered; K * 6 * TN MFMAs per wave and barrier
 //     interval; the next chunk's patch is prefetched branch-free during the K row steps and converted once.
-template <int K, int S, int TN>
+// SPLIT / F16: f16x3 (two fp16 pieces, operands rescaled from their |max| bounds) or bf16x6 (three bf16 pieces, no scaling)
+template <int K, int S, int TN, int SPLIT = 2, bool F16 = true>
 __global__ __launch_bounds__(512, 1) void conv_patch_row_kernel(const PatchArgs p) {
-  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  typedef typename Piece<F16>::V8 h8;
+  typedef typename Piece<F16>::V4 h4;
   static_assert(S == 1 || S == 2, "stride 1 or 2");
   constexpr int PH = S * PT_TH + K - S, PW = S * PT_TW + K - S;    // input patch extent
   constexpr int PWH = (PW + 1) / 2, PROW = S == 2 ? 2 * PWH : PW;  // slots per column parity / per patch row
   constexpr int NSLOT = PH * PROW, NSLOTP = (NSLOT + 15) / 16 * 16;
   constexpr int NPIX = PH * PW;
   constexpr int BN = 64 * TN;
-  constexpr int A_OCT = NSLOTP * 16, A_PLANE = 2 * A_OCT, A_BYTES = 2 * A_PLANE;
-  constexpr int U_OCT = 64 * 16, U_PLANE = 2 * U_OCT, U_BYTES = 2 * U_PLANE;
+  constexpr int A_OCT = NSLOTP * 16, A_PLANE = 2 * A_OCT, A_BYTES = SPLIT * A_PLANE;
+  constexpr int U_OCT = 64 * 16, U_PLANE = 2 * U_OCT, U_BYTES = SPLIT * U_PLANE;
   constexpr int UROW_BYTES = K * U_BYTES, UROW_INSTR = UROW_BYTES / 1024;
   constexpr int B_BYTES = TN * U_BYTES;
   constexpr int ROW_BYTES = K * B_BYTES, ROW_INSTR = ROW_BYTES / 1024;
@@ -626,8 +628,8 @@ __global__ __launch_bounds__(512, 1) void conv_patch_row_kernel(const PatchArgs 
   const int img = id / p.tiles_y;
   const int oy0 = ty * PT_TH, ox0 = tx * PT_TW;
 
-  float o_mul = 1.f;
-  const float a_mul = f16_operand_scale(*p.a_amax, &o_mul);
+  float o_mul = 1.f, a_mul = 1.f;
+  if constexpr (F16) a_mul = f16_operand_scale(*p.a_amax, &o_mul);
 
   // staging slots: thread = (patch pixel, channel quad); rounds of 128 pixels
   const int cq = tid & 3;
@@ -652,12 +654,14 @@ __global__ __launch_bounds__(512, 1) void conv_patch_row_kernel(const PatchArgs 
   auto store_a = [&](int r, int c, f32x4 v) __attribute__((always_inline)) {
     if (a_lofs[r] < 0) return;
     const bool ok = a_yx[r] >= 0 && c * PT_CK + cq * 4 < p.Cin;
-    v *= a_mul;
+    if constexpr (F16) v *= a_mul;
     if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-    const h4 hi = __builtin_convertvector(v, h4);
-    const h4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), h4);
-    *reinterpret_cast<h4*>(abuf + a_lofs[r]) = hi;
-    *reinterpret_cast<h4*>(abuf + A_PLANE + a_lofs[r]) = lo;
+#pragma unroll
+    for (int pl = 0; pl < SPLIT; ++pl) {          // hi, then the rounding of what is left, ...
+      const h4 piece = __builtin_convertvector(v, h4);
+      *reinterpret_cast<h4*>(abuf + pl * A_PLANE + a_lofs[r]) = piece;
+      if (pl + 1 < SPLIT) v -= __builtin_convertvector(piece, f32x4);
+    }
   };
   const size_t nrows_w = (size_t)p.nchunk * K;
   const char* wrow0 = p.wpk + (size_t)tn * TN * nrows_w * UROW_BYTES;
@@ -704,25 +708,25 @@ __global__ __launch_bounds__(512, 1) void conv_patch_row_kernel(const PatchArgs 
       const char* Brow = bbase + (g & 1) * ROW_BYTES;
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
-        h8 af[2][2];
+        h8 af[2][SPLIT];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           const int slot = S == 2 ? (S * (wm * 2 + mt) + ky) * PROW + (kx & 1) * PWH + li + (kx >> 1)
                                   : (wm * 2 + mt + ky) * PROW + li + kx;
 #pragma unroll
-          for (int pl = 0; pl < 2; ++pl)
+          for (int pl = 0; pl < SPLIT; ++pl)
             af[mt][pl] = *reinterpret_cast<const h8*>(abuf + pl * A_PLANE + lh * A_OCT + slot * 16);
         }
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt) {
-          h8 bfr[2];
+          h8 bfr[SPLIT];
           const int n = (wn * TN + nt) * 32 + li;
 #pragma unroll
-          for (int pl = 0; pl < 2; ++pl)
+          for (int pl = 0; pl < SPLIT; ++pl)
             bfr[pl] = *reinterpret_cast<const h8*>(Brow + (n >> 6) * UROW_BYTES + kx * U_BYTES + pl * U_PLANE + lh * U_OCT +
                                                    (n & 63) * 16);
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = split_mfma<2, h8>(bfr, af[mt], acc[mt][nt]);
+          for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = split_mfma<SPLIT, h8>(bfr, af[mt], acc[mt][nt]);
         }
       }
       __syncthreads();
@@ -735,19 +739,19 @@ __global__ __launch_bounds__(512, 1) void conv_patch_row_kernel(const PatchArgs 
   }
   const bool vec_ok = (p.Cout & 3) == 0 && (p.out_cs & 3) == 0 && (p.out_co & 3) == 0 && (!p.res || (p.res_cs & 3) == 0);
   if (vec_ok) patch_epilogue_lds<TN>(acc, p, img, oy0, ox0, tn * BN, wm, wn, lane, o_mul, reinterpret_cast<float*>(smem));
-  else patch_epilogue<TN, true>(acc, p, img, oy0, ox0, tn * BN, wm, wn, li, lh, o_mul, reinterpret_cast<float*>(smem));
+  else patch_epilogue<TN, F16>(acc, p, img, oy0, ox0, tn * BN, wm, wn, li, lh, o_mul, reinterpret_cast<float*>(smem));
 }
 
-template <int K, int S, int TN>
+template <int K, int S, int TN, int SPLIT = 2, bool F16 = true>
 static int launch_patch_row(const PatchArgs& a, hipStream_t s) {
   constexpr int PH = S * PT_TH + K - S, PW = S * PT_TW + K - S, PROW = S == 2 ? 2 * ((PW + 1) / 2) : PW;
   constexpr int NSLOTP = (PH * PROW + 15) / 16 * 16;
-  constexpr int smem = 2 * 2 * NSLOTP * 16 + 2 * K * (2 * 2 * 64 * TN * 16);
+  constexpr int smem = SPLIT * 2 * NSLOTP * 16 + 2 * K * (SPLIT * 2 * 64 * TN * 16);
   static_assert(smem <= 160 * 1024, "stride-2 patch does not fit the LDS");
   static std::atomic<uint64_t> attr_devs{0};
-  CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(conv_patch_row_kernel<K, S, TN>), smem, attr_devs));
+  CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(conv_patch_row_kernel<K, S, TN, SPLIT, F16>), smem, attr_devs));
   const int nblk = a.tiles_n * a.tiles_x * a.tiles_y * a.N;
-  conv_patch_row_kernel<K, S, TN><<<nblk, 512, smem, s>>>(a);
+  conv_patch_row_kernel<K, S, TN, SPLIT, F16><<<nblk, 512, smem, s>>>(a);
   CRESTE_CHECK_LAUNCH("conv_patch_row");
   return CRESTE_OK;
 }
@@ -843,6 +847,8 @@ static int launch_patch(const PatchArgs& a, hipStream_t s) {
 bool conv_patch_supported(int prec, int KH, int KW, int stride) {
   if (prec == CRESTE_PREC_F16X3 && KH == KW && (KH == 1 || KH == 3 || KH == 7) && stride == 2) return true;
   if (prec == CRESTE_PREC_F16X3 && KH == KW && (KH == 5 || KH == 7) && stride == 1) return true;
+  // bf16x6 on the row kernel where three pieces of the halo patch fit the LDS (not the 7x7/2 stem: 141 + 86 KiB)
+  if (prec == CRESTE_PREC_BF16X6 && KH == KW && (((KH == 1 || KH == 3) && stride == 2) || ((KH == 5 || KH == 7) && stride == 1))) return true;
   return (prec == CRESTE_PREC_BF16 || prec == CRESTE_PREC_BF16X3 || prec == CRESTE_PREC_BF16X6 ||
           prec == CRESTE_PREC_F16X3) && KH == KW && (KH == 1 || KH == 3) && stride == 1;
 }
@@ -901,7 +907,14 @@ int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
   a.tiles_n = (d->Cout + bn - 1) / bn;
   const int split = patch_split(d->prec);
   const int K = d->KH;
-  if (d->stride == 2 || K > 3) {        // f16x3 only (conv_patch_supported): the row-at-a-time kernels
+  if ((d->stride == 2 || K > 3) && d->prec == CRESTE_PREC_BF16X6) {      // three bf16 pieces: 64-cout tiles (the LDS budget)
+    a.tiles_n = (d->Cout + 63) / 64;
+    if (d->stride == 1) return K == 7 ? launch_patch_row<7, 1, 1, 3, false>(a, s) : launch_patch_row<5, 1, 1, 3, false>(a, s);
+    if (K == 3) return launch_patch_row<3, 2, 1, 3, false>(a, s);
+    if (d->Cout > 64) { a.tiles_n = (d->Cout + 127) / 128; return launch_patch_row<1, 2, 2, 3, false>(a, s); }
+    return launch_patch_row<1, 2, 1, 3, false>(a, s);
+  }
+  if (d->stride == 2 || K > 3) {        // f16x3 (conv_patch_supported): the row-at-a-time kernels
     const int tn2 = d->Cout > 64 && !(K == 7 && d->stride == 2) ? 2 : 1;      // tiles of 64 or 128 channels
     a.tiles_n = (d->Cout + 64 * tn2 - 1) / (64 * tn2);
     if (d->stride == 1) {

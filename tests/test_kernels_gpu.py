@@ -184,10 +184,17 @@ S2_CASES = [c for c in CONV_CASES if c[6] == 2] + [
 ]
 
 
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6"])
 @pytest.mark.parametrize("case", S2_CASES)
-def test_conv_patch_stride2_f16x3(ops, case):
-    """stride-2 convs (K = 1, 3, 7) and stride-1 5x5 / 7x7 convs on the f16x3 row kernel vs a float64 conv: fp32-grade"""
+def test_conv_patch_stride2_f16x3(ops, case, mode):
+    """stride-2 convs (K = 1, 3, 7) and stride-1 5x5 / 7x7 convs on the row kernel vs a float64 conv, fp32-grade: f16x3
+    (two fp16 pieces) and bf16x6 (three bf16 pieces; every shape but the 7x7/2 stem, whose halo patch does not fit the LDS
+    in three pieces and stays on the exact-fp32 engine)"""
     N, Cin, H, W, Cout, K, s, pad, act, use_bias, use_bn, use_res = case
+    prec = ops.PREC_F16X3 if mode == "f16x3" else ops.PREC_BF16X6
+    if mode == "bf16x6" and (K, s) == (7, 2):
+        assert not ops.conv_supported(prec, K, s)
+        return
     g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
     x = torch.randn(N, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
@@ -202,16 +209,18 @@ def test_conv_patch_stride2_f16x3(ops, case):
     if res is not None:
         ref = ref + res.double()
     ref = {0: lambda t: t, 1: F.relu, 2: lambda t: t * torch.sigmoid(t)}[act](ref)
-    assert ops.conv_supported(ops.PREC_F16X3, K, s)
+    assert ops.conv_supported(prec, K, s)
     pc = ops.pack_conv(dev(w), None if b is None else dev(b),
                        None if bn is None else tuple(dev(t) if isinstance(t, torch.Tensor) else t for t in bn),
-                       s, pad, act, ops.PREC_F16X3)
+                       s, pad, act, prec)
+    assert pc.prec == prec
     out = ops.conv2d(to_act(ops, x), pc, res=None if res is None else to_act(ops, res))
     got = out.nchw().cpu().double()
     assert got.shape == ref.shape
     err = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-30))
     assert err < 2e-6, err
-    assert float(out.amax.cpu()) >= float(got.abs().max()) * (1 - 1e-6)
+    if mode == "f16x3":
+        assert float(out.amax.cpu()) >= float(got.abs().max()) * (1 - 1e-6)
 
 
 @pytest.mark.parametrize("xs,ws", [(1e-20, 1.0), (1e-6, 1e3), (1.0, 1e-12), (3e4, 1.0), (1e15, 1e15), ("outlier", 1.0),
