@@ -165,6 +165,54 @@ class ConvProfiler:
         return by
 
 
+def gemm_kernel_probe(step):
+    """One extra (untimed) step with HIP events around the GEMM KERNEL of every F(4x4,3x3) conv call (library probe:
+    creste_conv_wino4_gemm_probe): the matrix-core kernel alone, without its two bandwidth-bound transform kernels."""
+    import ctypes as C
+    from creste_public_amd import ops, _lib
+    import creste_public_amd.hipnn as hipnn
+    lib = _lib.load()
+    orig = ops.conv2d
+    ms_tot, raw, alg, calls = 0.0, 0.0, 0.0, 0
+
+    def probed(x, pc, **kw):
+        nonlocal ms_tot, raw, alg, calls
+        if getattr(pc, "algo", 0) != 2:
+            return orig(x, pc, **kw)
+        lib.creste_conv_wino4_gemm_probe(1)
+        y = orig(x, pc, **kw)
+        lib.creste_conv_wino4_gemm_probe(0)
+        ms = C.c_float(0.0)
+        _lib.check(lib.creste_conv_wino4_gemm_last_ms(C.byref(ms)), "gemm_last_ms")
+        T = y.N * ((y.H + 3) // 4) * ((y.W + 3) // 4)
+        tn = 256 if pc.Cout > 128 else 128
+        mp, kp, np_ = (T + 255) // 256 * 256, (pc.Cin + 15) // 16 * 16, (pc.Cout + tn - 1) // tn * tn
+        split = {2: 3, 3: 6}[pc.prec]                     # piece products per multiply
+        ms_tot += ms.value
+        raw += 36.0 * mp * kp * np_ * 2.0 * split         # issued, padded tiles included
+        alg += 2.0 * y.N * y.H * y.W * pc.Cout * pc.Cin * 9
+        calls += 1
+        return y
+    ops.conv2d = probed
+    hipnn.ops.conv2d = probed
+    try:
+        step()
+        torch.cuda.synchronize()
+    finally:
+        ops.conv2d = orig
+        hipnn.ops.conv2d = orig
+    if not calls:
+        return None
+    return {"kernel": "wino4_gemm_kernel<SPLIT, TN> (the GEMM kernel of every F(4x4,3x3) conv call of one step)",
+            "calls_per_step": calls, "ms_per_step": round(ms_tot, 3),
+            "piece_products_pflops": round(raw / (ms_tot * 1e-3) / 1e15, 4),
+            "mfma_issue_util": round(raw / (ms_tot * 1e-3) / 1e12 / 2500.0, 4),
+            "algorithmic_tflops": round(alg / (ms_tot * 1e-3) / 1e12, 1),
+            "note": "HIP events around the GEMM kernel alone (library probe), one untimed step after the timed ones; "
+                    "piece products = 36 positions x padded tiles x padded Cin x padded Cout x 2 x pieces, issued on "
+                    "v_mfma_f32_32x32x16_bf16 (dense peak 2500 TFLOP/s); PMC of the same kernel: profiles/r03_pmc_wino4_496.txt"}
+
+
 def cpu_baseline(batches=(1, 16), runs=5, budget_s=210.0):
     """The oracle (CPU restatement of the reference's PyTorch path) on this host's cores: batch 1 and batch 16,
     median of `runs` timed runs after 1 warm-up each (SURVEY 8d / BASELINE.md section 2).  `value` is the better of the
@@ -507,6 +555,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof.uninstall()
     assert torch.isfinite(out["traversability_preds"]).all()
+    gemm_probe = gemm_kernel_probe(step) if rank == 0 else None
     from creste_public_amd import dist_utils
     elapsed = dist_utils.max_over_ranks(elapsed, device)     # the job is as slow as its slowest rank
 
@@ -626,6 +675,8 @@ def main():
                                  "= its GEMM + output-transform kernels together); peak = dense peak of the MFMA "
                                  "instruction issued; mfma_issue_util counts the piece products actually issued"},
         }
+        if gemm_probe is not None:
+            line["roofline"]["gemm_kernel"] = gemm_probe
         sr = prof.splat_roofline()
         if sr is not None:
             line["roofline_splat"] = sr

@@ -47,6 +47,8 @@ SIGNATURES = {
     "creste_conv_wino4_weight_bytes": (_i64, [_i, _i, _i]),
     "creste_conv_wino4_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "creste_conv_wino4_workspace_bytes": (_i64, [_i, _i, _i, _i, _i, _i]),
+    "creste_conv_wino4_gemm_probe": (_i, [_i]),
+    "creste_conv_wino4_gemm_last_ms": (_i, [_vp]),
     "creste_conv_packed_weight_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "creste_conv_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "creste_conv_pack_weight_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

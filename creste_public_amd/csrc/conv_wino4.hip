@@ -549,6 +549,10 @@ int64_t conv_wino4_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int
   return wino4_v_bytes(T, Cin, prec) + (long)W4_POS * T * Cout * 4 + 4096;       // V, M, the junk line of the padded stores
 }
 
+// measurement aid (bench.py): HIP events around the GEMM kernel of the next creste_conv2d_nhwc(CRESTE_ALGO_WINOGRAD4) call
+static std::atomic<bool> g_w4_probe{false};
+static hipEvent_t g_w4_ev[2] = {nullptr, nullptr};
+
 template <int SPLIT, int TN>
 static int launch_wino4_gemm(const Wino4GemmArgs& a, hipStream_t s) {
   constexpr int smem = 3 * (SPLIT * 2 * W4_M * 16 + TN * SPLIT * 2 * 64 * 16);
@@ -605,9 +609,15 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
   const int tn = d->Cout > 128 ? 4 : 2;
   a.tiles_n = (d->Cout + 64 * tn - 1) / (64 * tn);
   int rc;
+  const bool probe = g_w4_probe.load(std::memory_order_relaxed);
+  if (probe) {
+    if (!g_w4_ev[0]) { CRESTE_HIP(hipEventCreate(&g_w4_ev[0])); CRESTE_HIP(hipEventCreate(&g_w4_ev[1])); }
+    CRESTE_HIP(hipEventRecord(g_w4_ev[0], s));
+  }
   if (tn == 4) rc = split == 3 ? launch_wino4_gemm<3, 4>(a, s) : launch_wino4_gemm<2, 4>(a, s);
   else rc = split == 3 ? launch_wino4_gemm<3, 2>(a, s) : launch_wino4_gemm<2, 2>(a, s);
   if (rc != CRESTE_OK) return rc;
+  if (probe) CRESTE_HIP(hipEventRecord(g_w4_ev[1], s));
 
   Wino4OutArgs o;
   o.M = M; o.bias = d->bias; o.res = d->res; o.row_mask = d->row_mask; o.out = d->out; o.out_amax = d->out_amax;
@@ -897,4 +907,17 @@ extern "C" int creste_conv_wgrad_wino4(const float* x, int x_cs, const float* gy
                  "conv_wgrad_wino4: built for stride-1 same-size 3x3 convs with >= 128 channels (multiples of 4) on both sides");
   CRESTE_REQUIRE(x_cs >= Cin && gy_cs >= Cout && (reinterpret_cast<uintptr_t>(work) & 15) == 0, "conv_wgrad_wino4: bad strides / workspace alignment");
   return conv_wgrad_wino4_run(x, x_cs, gy, gy_cs, gw, N, H, W, Cin, Cout, pad_t, pad_l, accumulate, work, (hipStream_t)stream);
+}
+
+extern "C" int creste_conv_wino4_gemm_probe(int enable) {
+  creste::g_w4_probe.store(enable != 0);
+  return CRESTE_OK;
+}
+
+extern "C" int creste_conv_wino4_gemm_last_ms(float* ms) {
+  using namespace creste;
+  CRESTE_REQUIRE(ms && g_w4_ev[0] && g_w4_ev[1], "conv_wino4_gemm_last_ms: no probed call yet");
+  CRESTE_HIP(hipEventSynchronize(g_w4_ev[1]));
+  CRESTE_HIP(hipEventElapsedTime(ms, g_w4_ev[0], g_w4_ev[1]));
+  return CRESTE_OK;
 }

@@ -139,6 +139,10 @@ int64_t creste_conv_wino4_weight_bytes(int Cout, int Cin, int prec);
 int creste_conv_wino4_pack_weight(const float* w_oihw, const float* scale, void* wpk, int Cout, int Cin, int prec,
                                   void* stream);
 int64_t creste_conv_wino4_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int prec);
+/* Measurement aid: with the probe enabled every CRESTE_ALGO_WINOGRAD4 call records HIP events around its GEMM kernel on the
+ * call's stream; creste_conv_wino4_gemm_last_ms waits for the last one (bench.py: roofline.gemm_kernel). */
+int creste_conv_wino4_gemm_probe(int enable);
+int creste_conv_wino4_gemm_last_ms(float* ms);
 /* Size in BYTES of the packed weight for (Cout,Cin,KH,KW) at precision `prec`. */
 int64_t creste_conv_packed_weight_bytes(int Cout, int Cin, int KH, int KW, int prec);
 /* Pack a torch OIHW fp32 weight (device pointer, contiguous) into the GEMM layout, optionally
