@@ -203,12 +203,13 @@ WINOGRAD_MIN_C = 256
 # F(4x4,3x3) (csrc/conv_wino4.hip): 1.78x fewer products again and a GEMM loop that is LDS-DMA + MFMA only, for the price of
 # the transformed input / the products crossing HBM once each; preferred over F(2x2) where both apply
 WINOGRAD4 = True
-WINOGRAD4_MIN_CIN, WINOGRAD4_MIN_COUT = 256, 128
+WINOGRAD4_MIN_C, WINOGRAD4_MIN_CC = 128, 128 * 256     # both sides >= 128 channels, Cin * Cout >= 128 * 256 (128 -> 128 breaks even:
+# 1.48 vs 1.53 ms @256x256x16; 256 -> 128: 2.35 vs 2.71; 128 -> 256: 2.19 vs 2.81)
 
 
 def conv_algo(prec: int, k: int, stride: int, pad, cin: int, cout: int) -> int:
     if WINOGRAD4 and prec in (PREC_BF16X6, PREC_BF16X3) and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1) \
-            and cin >= WINOGRAD4_MIN_CIN and cout >= WINOGRAD4_MIN_COUT \
+            and min(cin, cout) >= WINOGRAD4_MIN_C and cin * cout >= WINOGRAD4_MIN_CC \
             and _lib.load().creste_conv_wino4_supported(prec, k, k, stride, cin, cout):
         return ALGO_WINOGRAD4
     if WINOGRAD and prec == PREC_BF16X6 and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1) \
