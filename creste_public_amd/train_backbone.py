@@ -120,7 +120,7 @@ class ConvG:
             gw, acc = _acc(grads, w)
             quads = (Cin % 4 == 0 and Cout % 4 == 0 and x.cs % 4 == 0 and gy.cs % 4 == 0 and x.co % 4 == 0 and gy.co % 4 == 0)
             if (WGRAD_WINOGRAD and hipnn._precision in (ops.PREC_BF16X6, ops.PREC_F16X3) and quads and self.pad[0] == 1 and self.pad[2] == 1
-                    and min(Cin, Cout) >= 128 and Cin * Cout >= WGRAD_WINOGRAD_MIN_C * 128
+                    and min(Cin, Cout) >= WGRAD_WINOGRAD_MIN_C
                     and lib.creste_conv_wgrad_wino4_supported(self.K, self.s, x.H, x.W, gy.H, gy.W, Cin, Cout)):
                 # wide 3x3 (bf16x6, and f16x3 -- at the wider bf16x6 grade): through the F(4x4,3x3) transform, 4x fewer
                 # matrix products (csrc/conv_wino4.hip)
