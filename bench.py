@@ -77,7 +77,7 @@ def kernel_symbol(pc, N, Ho, Wo):
     if getattr(pc, "algo", 0) == 2:             # Winograd F(4x4,3x3): input transform + GEMM over the 36 positions + output transform
         split = {2: 2, 3: 3}[pc.prec]
         return (PREC_NAME[pc.prec] + "+winograd4",
-                f"wino4_in_kernel<{split}> + wino4_gemm_kernel<{split}, {4 if pc.Cout > 128 else 2}> + wino4_out_kernel")
+                f"wino4_in_kernel<{split}, UP> + wino4_gemm_kernel<{split}, {4 if pc.Cout > 128 else 2}> + wino4_out_kernel")
     if pc.prec == 0:
         return ("f32", "conv_igemm_f32_kernel<2, 2, 2, 2>" if pc.Cout > 64 else
                 "conv_igemm_f32_kernel<2, 2, 2, 1>" if pc.Cout > 32 else "conv_igemm_f32_kernel<4, 1, 1, 1>")
@@ -642,7 +642,14 @@ def main():
             try:
                 # a Winograd call is several kernels ("a + b + c"): HBM bytes of one call = the sum over its kernels
                 cnt = json.load(open(pj))
-                parts = [cnt.get(k.strip(), {}).get("hbm_bytes_per_launch") for k in kname.split(" + ")]
+                def per_launch(k):
+                    if ", UP>" in k:      # the input transform has two instantiations (plain / fused upsample + concat input)
+                        es = [cnt.get(k.replace("UP", v)) for v in ("false", "true")]
+                        es = [e for e in es if e]
+                        n = sum(e["launches"] for e in es)
+                        return sum(e["hbm_bytes_per_launch"] * e["launches"] for e in es) / n if n else None
+                    return cnt.get(k, {}).get("hbm_bytes_per_launch")
+                parts = [per_launch(k.strip()) for k in kname.split(" + ")]
                 traffic = sum(parts) if all(v is not None for v in parts) else None
             except Exception:
                 traffic = None
