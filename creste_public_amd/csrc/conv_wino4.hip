@@ -253,7 +253,7 @@ __device__ __forceinline__ void w4_bt2(const w4f32x2 (&d)[6], w4f32x2 (&t)[6]) {
 // result is bit-identical to upsampling first.  Windows that touch the image border (clamped taps, zero padding) take
 // the generic per-pixel path.
 template <int SPLIT, bool UP>
-__global__ __launch_bounds__(256) void wino4_in_kernel(const Wino4InArgs p) {
+__global__ __launch_bounds__(256, 4) void wino4_in_kernel(const Wino4InArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned tbuf[W4_POS * 4 * 16 * 4];      // [pos][chunk half * 2 + octet][tile][4 pairs]
   const int t = threadIdx.x;
   // gridDim.x is a multiple of 16: workgroup (x, y) sits on XCD x % 8.  Every XCD gets a contiguous range of tile groups,
