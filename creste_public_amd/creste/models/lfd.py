@@ -40,9 +40,8 @@ class MaxEntIRL(nn.Module):
         self.action_horizon = _cfg_get(model_cfg, "action_horizon")
         self.solve_mdp = _cfg_get(model_cfg, "solve_mdp", False)
         self.zero_terminal_state = _cfg_get(model_cfg, "zero_terminal_state", False)
-        if self.policy_method != "pp":
-            raise NotImplementedError("policy_method 'fc' (iterative_policy_rollout) is not used by the "
-                                      "shipped configs; the HIP path implements 'pp'")
+        if self.policy_method not in ("pp", "fc"):
+            raise ValueError(f"Policy method {self.policy_method} not found.")
         self.register_buffer("dynamics", torch.tensor(_DYNAMICS, dtype=torch.long))
         H, W = self.map_size
         fov = tu.create_trapezoidal_fov_mask(H * 2, W, 70, 70, 0, 100).view(1, 1, H * 2, W)
@@ -64,6 +63,9 @@ class MaxEntIRL(nn.Module):
             raise NotImplementedError(self.traversability_head_cfg["value_iterator"])
         nk = self.traversability_head_cfg["net_kwargs"]
         self.traversability_head = VIN(nk["reward_cfg"], nk["qvalue_cfg"])
+        if self.policy_method == "fc":     # reference lfd.py:96-101 (the default when a config names no method)
+            self.fc = nn.Linear(nk["qvalue_cfg"]["dims"][-1], 8, bias=False)
+            self.sm = nn.Softmax(dim=1)
         self.freeze_backbone = _cfg_get(model_cfg, "freeze_backbone", True)
         self.freeze_head = _cfg_get(model_cfg, "freeze_head", False)
         self.load_strict = _cfg_get(model_cfg, "load_strict", True)
@@ -121,6 +123,27 @@ class MaxEntIRL(nn.Module):
             float(_cfg_get(self.policy_cfg, "temperature", 1.0)), method == "sharpen",
             bool(self.zero_terminal_state))
         return {"exp_svf": svf, "state_preds_grid": grid, "state_preds": states}
+
+    def iterative_policy_rollout(self, q, expert, T):
+        """policy_method 'fc' (reference lfd.py:279-312): the Q vectors at the expert's cells of steps 0..T-2 go through `fc`
+        + softmax in ONE batched product; only the greedy state walk is sequential (it clamps at the grid border).
+        q [B,l_q,H,W], expert [B,>=T-1,2] grid cells -> policy_fc [B,T,8] (row 0 zero), state_preds [B,T,2] (long)."""
+        B, lq, H, W = q.shape
+        cells = expert[:, :T - 1, :2].long()
+        bi = torch.arange(B, device=q.device).view(B, 1).expand(B, T - 1)
+        qv = q[bi, :, cells[..., 0], cells[..., 1]]                        # [B, T-1, l_q]
+        probs = self.sm(self.fc(qv.reshape(B * (T - 1), lq))).view(B, T - 1, 8)
+        policy = torch.zeros(B, T, 8, dtype=torch.float32, device=q.device)
+        policy[:, 1:] = probs
+        with torch.no_grad():
+            moves = self.dynamics[probs.argmax(dim=2)]                     # [B, T-1, 2]
+            lo = torch.zeros(2, dtype=torch.long, device=q.device)
+            hi = torch.tensor([H - 1, W - 1], dtype=torch.long, device=q.device)
+            states = torch.zeros(B, T, 2, dtype=torch.long, device=q.device)
+            states[:, 0] = expert[:, 0, :2].long()
+            for t in range(1, T):
+                states[:, t] = torch.minimum(torch.maximum(states[:, t - 1] + moves[:, t - 1], lo), hi)
+        return {"policy_fc": policy, "state_preds": states}
 
     # ---- frozen half of the forward (perception backbone -> BEV predictions -> pooled / cropped reward input): depends on
     # no trainable parameter, so in IRL training the NEXT batch's frozen half can run on a second stream while this
@@ -217,5 +240,8 @@ class MaxEntIRL(nn.Module):
             raise NotImplementedError("goal maps (goal_kwargs) are not used by the shipped configs")
         outputs.update(head.forward_from_view(view, Ho, Wo, S, solve_mdp=True))
         with torch.no_grad():
-            outputs.update(self.expected_state_visitation_frequency(outputs["policy"], expert))
+            if self.policy_method == "fc":         # reference lfd.py:357-360
+                outputs.update(self.iterative_policy_rollout(outputs["q_estimate"], S, self.action_horizon))
+            else:
+                outputs.update(self.expected_state_visitation_frequency(outputs["policy"], expert))
         return outputs

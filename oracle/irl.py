@@ -129,8 +129,10 @@ class MaxEntIRL(nn.Module):
         self.policy_cfg = _get(cfg, "policy_kwargs", {})
         self.map_size = list(_get(cfg, "map_size", [64, 128]))
         self.policy_method = _get(cfg, "policy_method", "fc")
-        if self.policy_method != "pp":
-            raise NotImplementedError("only policy_method='pp' is used by the shipped configs")
+        if self.policy_method not in ("pp", "fc"):
+            raise ValueError(f"Policy method {self.policy_method} not found.")
+        if self.policy_method == "fc":            # lfd.py:96-101: a linear read-out of the Q vector at the expert's cell
+            self.fc = nn.Linear(th["net_kwargs"]["qvalue_cfg"]["dims"][-1], 8, bias=False)
         self.action_horizon = cfg["action_horizon"]
         self.solve_mdp = _get(cfg, "solve_mdp", False)
         self.zero_terminal_state = _get(cfg, "zero_terminal_state", False)
@@ -190,6 +192,25 @@ class MaxEntIRL(nn.Module):
         assert torch.all(svf >= 0)
         return {"exp_svf": svf, "state_preds_grid": grid, "state_preds": states}
 
+    def iterative_policy_rollout(self, q, expert, T):
+        """policy_method 'fc' (lfd.py:279-312): at step t the Q vector at the expert's cell of step t-1 goes through `fc` and a
+        softmax; the greedy action moves the predicted state (clamped to the grid).  q [B,l_q,H,W], expert [B,>=T-1,2] grid
+        cells -> policy_fc [B,T,8] (row 0 zero), state_preds [B,T,2]."""
+        B, lq, H, W = q.shape
+        states = torch.zeros(B, T, 2, dtype=torch.long)
+        states[:, 0] = expert[:, 0, :2].long()
+        probs = torch.zeros(B, T, 8)
+        for t in range(1, T):
+            for b in range(B):
+                r, c = int(expert[b, t - 1, 0]), int(expert[b, t - 1, 1])
+                p = F.softmax(self.fc(q[b, :, r, c].view(1, lq)), dim=1)[0]
+                a = int(p.argmax())
+                nxt = states[b, t - 1] + self.dynamics[a]
+                states[b, t, 0] = int(nxt[0].clamp(0, H - 1))
+                states[b, t, 1] = int(nxt[1].clamp(0, W - 1))
+                probs[b, t] = p
+        return {"policy_fc": probs, "state_preds": states}
+
     def forward(self, inputs):
         image, p2p = inputs[0], inputs[1]
         out = self.backbone((image, p2p))
@@ -205,7 +226,10 @@ class MaxEntIRL(nn.Module):
         S[:, :, 1].clamp_(0, self.map_size[1] - 1)
         out.update(self.traversability_head(out, S, solve_mdp=True))
         with torch.no_grad():
-            out.update(self.expected_svf(out["policy"], expert))
+            if self.policy_method == "fc":        # lfd.py:357-360
+                out.update(self.iterative_policy_rollout(out["q_estimate"], S, self.action_horizon))
+            else:
+                out.update(self.expected_svf(out["policy"], expert))
         return out
 
 

@@ -335,6 +335,28 @@ def gen_vin_svf_loss():
     npz("expert_raster.npz", expert=experts, points=pts, counts=cnt)
 
 
+def gen_policy_fc():
+    """MaxEntIRL.iterative_policy_rollout (policy_method 'fc', lfd.py:279-312) on a seeded Q map."""
+    import torch.nn as nn
+    import creste.models.lfd as lfd
+    g = torch.Generator().manual_seed(2024)
+    B, lq, H, W, T = 3, 10, 24, 40, 50
+    q = torch.randn(B, lq, H, W, generator=g)
+    fc = nn.Linear(lq, 8, bias=False)
+    with torch.no_grad():
+        fc.weight.copy_(torch.randn(8, lq, generator=g))
+    tt = torch.linspace(0, 1, T).view(1, T, 1)
+    S = (torch.tensor([[[20.0, 20.0]], [[1.0, 2.0]], [[23.0, 39.0]]]) +
+         tt * torch.tensor([[[-18.0, 15.0]], [[0.0, 36.0]], [[-6.0, -38.0]]])).long()
+    S[:, :, 0].clamp_(0, H - 1)
+    S[:, :, 1].clamp_(0, W - 1)
+    dyn = torch.tensor([[-1, -1], [-1, 0], [-1, 1], [0, -1], [0, 1], [1, -1], [1, 0], [1, 1]], dtype=torch.long)
+    ns = SimpleNamespace(fc=fc, sm=nn.Softmax(dim=1), dynamics=dyn)
+    with torch.no_grad():
+        o = lfd.MaxEntIRL.iterative_policy_rollout(ns, q, S, T)
+    npz("policy_fc.npz", q=q, S=S, fc_weight=fc.weight.detach(), policy_fc=o["policy_fc"], state_preds=o["state_preds"])
+
+
 def gen_blocks_and_utils():
     from creste.models.blocks.conv import MultiLayerConv, ConvEncoder, MultiScaleFCN
     from creste.models.blocks.effnet import Up
@@ -503,6 +525,7 @@ if __name__ == "__main__":
     gen_splat_modes()
     gen_splat_mv()
     gen_vin_svf_loss()
+    gen_policy_fc()
     gen_blocks_and_utils()
     gen_distill_losses()
     gen_ssc_losses()

@@ -474,3 +474,38 @@ def test_irl_training_step_on_large_mdp_grids(variant):
             assert _rms(a - b) <= 2e-3 * max(_rms(b), 1e-8) + 1e-9, n
     finally:
         creste_public_amd.set_precision("f32")
+
+
+def test_policy_method_fc_forward(oracle_case):
+    """policy_method 'fc' -- the reference's default when a config names no method (lfd.py:31,96-101,279-312,357-360): same
+    parameter names as the oracle (`fc.weight`), and with the oracle's q map the rollout is reproduced exactly; end to end the
+    step-1 policy agrees to the costmap tolerance."""
+    import copy
+    import creste_public_amd
+    from creste_public_amd import MaxEntIRL
+    from oracle.irl import MaxEntIRL as OracleIRL
+    oracle_pp, _, (rgbd, p2p, expert) = oracle_case
+    cfg = copy.deepcopy(maxent_irl_cfg((H, W), solve_mdp=True))
+    cfg["policy_method"] = "fc"
+    torch.manual_seed(5)
+    oracle = OracleIRL(cfg)
+    sd = dict(oracle_pp.state_dict())
+    sd["fc.weight"] = oracle.fc.weight.detach().clone()
+    oracle.load_state_dict(sd, strict=True)
+    oracle.eval()
+    with torch.no_grad():
+        ref = oracle((rgbd, p2p, expert))
+    creste_public_amd.set_precision("f32")
+    model = MaxEntIRL(cfg)
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    model = model.cuda().eval()
+    with torch.no_grad():
+        got = model((rgbd.cuda(), p2p.cuda(), expert.cuda()))
+        S = (expert[:, :, :2, 2].long() // (256 // model.map_size[1]))
+        S[:, :, 0].clamp_(0, model.map_size[0] - 1); S[:, :, 1].clamp_(0, model.map_size[1] - 1)
+        same_q = model.iterative_policy_rollout(ref["q_estimate"].cuda(), S.cuda(), model.action_horizon)
+    assert set(k for k in ref if not k.startswith("_")) == set(got.keys())
+    assert "policy_fc" in got and "exp_svf" not in got
+    assert torch.equal(same_q["state_preds"].cpu(), ref["state_preds"])
+    assert float((same_q["policy_fc"].cpu() - ref["policy_fc"]).abs().max()) < 1e-5
+    assert float((got["policy_fc"][:, 1].cpu() - ref["policy_fc"][:, 1]).abs().max()) < 5e-3

@@ -273,3 +273,26 @@ def test_utils(golden):
     assert torch.equal(oi.trapezoid_fov_mask(128, 128, 70, 70, 0, 100), g.t("fov_128"))
     assert torch.equal(oi.trapezoid_fov_mask(40, 60), g.t("fov_default"))
     assert torch.equal(oi.resize_and_crop(g.t("rc_in"), (4, 4), (0, 2, 0, 4)), g.t("rc_out"))
+
+
+def test_policy_fc_rollout_matches_reference_golden():
+    """policy_method 'fc' (reference lfd.py:279-312, golden from make_golden.py::gen_policy_fc): the oracle's restatement
+    and the HIP package's batched form (host logic, runs on any device) reproduce the reference's outputs."""
+    import os
+    import numpy as np
+    import torch
+    from types import SimpleNamespace
+    from oracle.irl import MaxEntIRL as OracleIRL, DYNAMICS
+    from creste_public_amd.creste.models.lfd import MaxEntIRL as HipIRL
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "policy_fc.npz"))
+    q, S = torch.from_numpy(d["q"]), torch.from_numpy(d["S"])
+    T = S.shape[1]
+    fc = torch.nn.Linear(q.shape[1], 8, bias=False)
+    with torch.no_grad():
+        fc.weight.copy_(torch.from_numpy(d["fc_weight"]))
+    ns = SimpleNamespace(fc=fc, sm=torch.nn.Softmax(dim=1), dynamics=torch.tensor(DYNAMICS, dtype=torch.long))
+    for impl in (OracleIRL.iterative_policy_rollout, HipIRL.iterative_policy_rollout):
+        with torch.no_grad():
+            o = impl(ns, q, S, T)
+        assert torch.equal(o["state_preds"], torch.from_numpy(d["state_preds"]))
+        assert float((o["policy_fc"] - torch.from_numpy(d["policy_fc"])).abs().max()) < 1e-6
