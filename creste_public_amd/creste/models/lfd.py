@@ -155,14 +155,25 @@ class MaxEntIRL(nn.Module):
 
     def _frozen_half(self, image, p2p):
         head = self.traversability_head
-        keys = head.reward_cfg["input_keys"]
+        keys = list(head.reward_cfg["input_keys"])
         want = [f"{p}_preds" for p in self.backbone.bevclassifier.output_prefix]
-        if list(keys) != want:
-            raise NotImplementedError(f"reward input_keys {list(keys)} must be the BEV heads' preds {want}")
         r = self.backbone.forward_act(image, p2p)
         outputs = self.backbone.pack_outputs(r, image.shape[0])
-        view = head.input_view_act(r["preds_buf"])
-        return r, outputs, view
+        if keys == want:
+            # the shipped configs: the heads' 1x1 projections already wrote one channel-concatenated tensor (no copy)
+            src = r["preds_buf"]
+        else:
+            # any other selection of backbone outputs (reference vin.py:104-107: torch.cat over feat_map[key], dim=1)
+            missing = [k for k in keys if k not in outputs]
+            if missing:
+                raise KeyError(f"reward input_keys {missing} are not outputs of the backbone ({sorted(outputs)})")
+            cat = torch.cat([outputs[k].float() for k in keys], dim=1).contiguous()
+            if cat.shape[1] % 4:
+                raise NotImplementedError(f"reward input_keys select {cat.shape[1]} channels: the HIP path reads channel "
+                                          "quads (NHWC rows of 16 bytes)")
+            src = ops.nchw_to_nhwc(cat)
+        r["iv_hw"] = (src.H, src.W)
+        return r, outputs, head.input_view_act(src)
 
     def prefetch_backbone(self, inputs):
         """Enqueue the frozen half of `forward(inputs)` on a side stream; the next `forward` with the SAME input tensors
@@ -226,7 +237,7 @@ class MaxEntIRL(nn.Module):
         r, outputs, view = frozen if frozen is not None else self._frozen_half(inputs[0], inputs[1])
         outputs = dict(outputs)
         head = self.traversability_head
-        Ho, Wo = r["preds_buf"].H, r["preds_buf"].W
+        Ho, Wo = r["iv_hw"]
         if not self.solve_mdp:
             outputs.update(head.forward_from_view(view, Ho, Wo, None, False))
             return outputs
