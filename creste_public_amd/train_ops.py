@@ -88,6 +88,9 @@ def pointwise2(op: int, a: Act, b: Act | None, out: Act | None = None) -> Act:
 # pass).  Off by default: measured, the IRL step does not get faster (reference config 31.2 -> 31.9 ms, 256x256 MDP grid
 # 56.9 -> 56.1 ms: the reward network is launch- and BatchNorm-bound, not MFMA-bound), so it keeps exact fp32 products.
 REWARD_FOLLOWS_F16X3 = False
+# bf16x6 (fp32-equivalent products, no operand bounds to track): the reward network's forward / tangent / input-gradient
+# convs follow the backbone's mode -- its 5x5 convs run on the three-piece row kernel since round 3
+REWARD_FOLLOWS_BF16X6 = True
 
 
 class ConvT:
@@ -109,6 +112,8 @@ class ConvT:
         from . import hipnn
         if REWARD_FOLLOWS_F16X3 and hipnn._precision == ops.PREC_F16X3:
             return ops.conv_precision(ops.PREC_F16X3, self.K, 1, cin)
+        if REWARD_FOLLOWS_BF16X6 and hipnn._precision == ops.PREC_BF16X6:
+            return ops.conv_precision(ops.PREC_BF16X6, self.K, 1, cin)
         return ops.PREC_F32
 
     def _packed(self):
