@@ -399,7 +399,7 @@ struct Wino4OutArgs {
 // tile two output rows at a time so that the write side runs thread = (pixel, channel quad): 16 lanes write 256
 // contiguous bytes of one NHWC pixel and read bias / residual the same way.
 constexpr int W4O_TILES = 16, W4O_QUADS = 16, W4O_ROW = W4O_QUADS * 4 + 4;
-__global__ __launch_bounds__(256, 4) void wino4_out_kernel(const Wino4OutArgs p) {
+__global__ __launch_bounds__(256) void wino4_out_kernel(const Wino4OutArgs p) {
   __shared__ __attribute__((aligned(16))) float tilebuf[W4O_TILES * 8 * W4O_ROW];
   __shared__ float scratch[4];
   const int Q = p.Cout >> 2;
