@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libcreste_hip.so")
 
-ABI_VERSION = 6          # creste_abi_version() of the library this binding was written against
+ABI_VERSION = 7          # creste_abi_version() of the library this binding was written against
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
 
@@ -76,6 +76,7 @@ SIGNATURES = {
     "creste_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "creste_nhwc_to_nchw_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "creste_lidar_depth_image_f32": (_i, [_vp, _i, _vp, _i, _i, _i64, _i, _i, _i, C.c_double, _vp, _i64, _vp]),
+    "creste_lidar_pixels_to_depth_f64": (_i, [_vp, _i, _i, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "creste_depth_expectation_f32": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp]),
     "creste_pixel_geometry_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp,
                                         _vp, _i, _i, _vp]),
@@ -199,11 +200,15 @@ class _RecordingLib:
         return call
 
 
+# int-returning entry points whose trailing void* is NOT a stream (queries / probes): never recorded into a plan
+NOT_LAUNCHES = ("creste_conv_supported", "creste_se_partial_count", "creste_conv_wino4_gemm_last_ms")
+
+
 def is_launch(name: str) -> bool:
     """Entry points that launch work on a stream: int return and a trailing void* stream (csrc/plan_dispatch.inc)."""
     res, args = SIGNATURES[name]
     return (res is _i and bool(args) and args[-1] is _vp and not name.startswith("creste_hip_model")
-            and name not in ("creste_conv_supported", "creste_se_partial_count"))
+            and name not in NOT_LAUNCHES)
 
 
 def load(path: str | None = None):

@@ -582,6 +582,29 @@ def lidar_depth_image(points: torch.Tensor, lidar2cam: torch.Tensor, H: int, W: 
     return out
 
 
+def lidar_pixels_to_depth(points: torch.Tensor, lidar2cam: torch.Tensor, H: int, W: int, reduce: str = "max"):
+    """One scan through `creste_lidar_pixels_to_depth_f64`: points [NP,>=3] fp32 | float64 (CUDA), lidar2cam [3|4,4]
+    float64 -> (uv int32 [NP,2], mask bool [NP], reduced float64 [H,W], last_write fp32 [H,W])."""
+    lib = _lib.load()
+    if reduce not in ("max", "min"):
+        raise ValueError(f"Invalid depth_priority {reduce}")
+    if not points.is_cuda or points.dim() != 2 or points.shape[1] < 3 or points.dtype not in (torch.float32, torch.float64) \
+            or not points.is_contiguous():
+        raise HipLibraryError("lidar_pixels_to_depth: points must be a contiguous CUDA fp32 / float64 [NP,>=3] tensor")
+    _chk(lidar2cam, torch.float64, name="lidar2cam")
+    NP, dev = points.shape[0], points.device
+    uv = torch.empty((NP, 2), dtype=torch.int32, device=dev)
+    mask = torch.empty((NP,), dtype=torch.uint8, device=dev)
+    reduced = torch.empty((H, W), dtype=torch.float64, device=dev)
+    last = torch.empty((H, W), dtype=torch.float32, device=dev)
+    work = torch.empty((2 * H * W,), dtype=torch.int64, device=dev)
+    _lib.check(lib.creste_lidar_pixels_to_depth_f64(points.data_ptr(), int(points.dtype == torch.float64), points.shape[1],
+                                                    lidar2cam.data_ptr(), NP, H, W, int(reduce == "min"), uv.data_ptr(),
+                                                    mask.data_ptr(), reduced.data_ptr(), last.data_ptr(), work.data_ptr(),
+                                                    _stream()), "lidar_pixels_to_depth")
+    return uv, mask.bool(), reduced, last
+
+
 def depth_expectation(logits: Act, bin_values: torch.Tensor):
     lib = _lib.load()
     P = logits.N * logits.H * logits.W

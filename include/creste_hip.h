@@ -266,6 +266,16 @@ int creste_lidar_depth_image_f32(const float* points, int point_stride, const do
                                  int mat_stride, int B, int64_t NP, int H, int W, int reduce_min,
                                  double scale, float* depth, int64_t depth_batch_stride, void* stream);
 
+/* The whole of the reference's `pixels_to_depth` for one scan, in its float64 (creste/utils/projection.py:64-155, every
+ * `return_keys` entry :139-153): points [NP, point_stride>=3] fp32 or float64 (points_f64), lidar2cam row-major 3x4 / 4x4
+ * float64 -> uv [NP,2] int32 = trunc(clip(xy/z, int32 range)) of EVERY point (:90-95; may be null), mask [NP] bytes =
+ * z_cam > 0 and in-image (:97-104; may be null), reduced [H*W] float64 = max | min over the kept points of a pixel, 0 =
+ * empty (torch_scatter.scatter, :124-131), last_write [H*W] fp32 = depth of the LAST kept point on the pixel (numpy fancy
+ * assignment, :116-118; may be null).  work: 16*H*W bytes of scratch, 8-byte aligned. */
+int creste_lidar_pixels_to_depth_f64(const void* points, int points_f64, int point_stride, const double* lidar2cam,
+                                     int64_t NP, int H, int W, int reduce_min, int* uv, unsigned char* mask,
+                                     double* reduced, float* last_write, void* work, void* stream);
+
 /* Depth-bin logits -> metric depth + argmax bin.  reference depth.py:61-100,129-130 and
  * depth_utils.py:300-313: depth_m = sum_c softmax(logits)_c * bin_values[c] / 1000. */
 int creste_depth_expectation_f32(const float* logits, int cs, int64_t P, int nbins,

@@ -296,3 +296,36 @@ def test_policy_fc_rollout_matches_reference_golden():
             o = impl(ns, q, S, T)
         assert torch.equal(o["state_preds"], torch.from_numpy(d["state_preds"]))
         assert float((o["policy_fc"] - torch.from_numpy(d["policy_fc"])).abs().max()) < 1e-6
+
+
+def test_projection_matches_reference(golden):
+    """oracle/lidar.py and the host mirror's matrix builders against the reference's own `get_pixel2pts_transform`,
+    `get_pts2pixel_transform` and `pixels_to_depth` (projection.npz: creste/utils/projection.py run by make_golden.py)."""
+    from creste_public_amd.creste.utils import projection as mirror
+    from oracle import lidar as ol
+    g = golden("projection.npz")
+    for tag in "ab":
+        H, W = (int(v) for v in g[f"{tag}/hw"])
+        calib = dict(lidar2cam=g[f"{tag}/lidar2cam"], R=g[f"{tag}/R"], P=g[f"{tag}/P"])
+        for fn in (lambda: ol.pixel2pts_transform(calib["lidar2cam"], calib["R"], calib["P"]),
+                   lambda: mirror.get_pixel2pts_transform(calib)):
+            assert np.array_equal(fn(), g[f"{tag}/p2p"])
+        for fn in (lambda: ol.pts2pixel_transform(calib["lidar2cam"], calib["R"], calib["P"]),
+                   lambda: mirror.get_pts2pixel_transform(calib)):
+            assert np.array_equal(fn(), g[f"{tag}/pts2pix"])
+        pts, l2c = g[f"{tag}/points"], g[f"{tag}/lidar2camrect"]
+        for prio in ("max", "min"):
+            got = ol.pixels_to_depth(pts, l2c, H, W, reduce=prio)
+            for k, v in got.items():
+                ref = g[f"{tag}/{prio}/{k}"]
+                assert v.dtype == ref.dtype and np.array_equal(v, ref), (tag, prio, k)
+            # the image form the kernels are tested against (tests/test_lidar.py) is the same reduction
+            img = ol.depth_image(pts, l2c, H, W, reduce=prio)
+            ip = g[f"{tag}/{prio}/image_pts"]
+            assert np.array_equal(img[ip[:, 1], ip[:, 0]], g[f"{tag}/{prio}/image_depth"])
+            assert np.count_nonzero(img) == ip.shape[0]
+    # the cases the fixture is there for
+    m, uvb = g["b/max/pc_mask"], ol.project(g["b/points"], g["b/lidar2camrect"], 40, 64)[0]
+    assert (np.abs(uvb.astype(np.int64)) >= 2**31 - 1).any() and not m[(np.abs(uvb.astype(np.int64)) >= 2**31 - 1).any(1)].any()
+    assert g["a/max/pc_pts"].shape[0] > 1.5 * g["a/max/image_pts"].shape[0]          # duplicate pixels
+    assert (g["a/max/image_depth"] >= g["a/min/image_depth"]).all() and (g["a/max/image_depth"] > g["a/min/image_depth"]).any()
