@@ -23,6 +23,7 @@
 //                      workgroups, three LDS stages, every byte by LDS-DMA, one barrier per 16-channel chunk
 //   wino4_out_kernel   Y = A^T M A per (tile, channel quad) + the direct kernels' epilogue
 #include "common.h"
+#include <stdlib.h>
 
 namespace creste {
 
@@ -62,9 +63,16 @@ struct Wino4GemmArgs {
 // tile blocks; unit u goes to XCD u % 8 (workgroup b sits on XCD b % 8) and its 32 items to that XCD's workgroups, so a
 // weight panel streams through the XCD's L2 once for four tile blocks and a V tile once for its cout tiles.  Placement
 // is speed only.
-template <int SPLIT, int TN>
+//
+// AF32: the A operand (transformed input) arrives as fp32, [k-quad][256 rows][4 floats] per chunk (2/3 of the bytes of the
+// three bf16 pieces, in HBM and through the LDS-DMA), and every wave splits its own 64 rows into the bf16 pieces in
+// registers right after reading them -- the conversions / subtractions of wino4_in_kernel's piece loop, so the pieces
+// and therefore the products are bit-identical to the pre-split form (which the weight gradient keeps using).
+typedef float w4f32x8 __attribute__((ext_vector_type(8)));
+template <int SPLIT, int TN, bool AF32>
 __global__ __launch_bounds__(512, 2) void wino4_gemm_kernel(const Wino4GemmArgs p) {
-  constexpr int A_OCT = W4_M * 16, A_PLANE = 2 * A_OCT, A_BYTES = SPLIT * A_PLANE;       // [piece][k-octet][row][8 bf16]
+  constexpr int A_OCT = W4_M * 16, A_PLANE = 2 * A_OCT;                                  // [piece][k-octet][row][8 bf16]
+  constexpr int A_BYTES = AF32 ? 4 * W4_M * 16 : SPLIT * A_PLANE;                        // AF32: [k-quad][row][4 f32]
   constexpr int U_OCT = 64 * 16, U_PLANE = 2 * U_OCT, U_BYTES = SPLIT * U_PLANE;         // one 64-cout weight unit
   constexpr int B_BYTES = TN * U_BYTES;
   constexpr int STAGE = A_BYTES + B_BYTES, NS = 3;
@@ -82,7 +90,6 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_kernel(const Wino4GemmArgs 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 3, wn = wave >> 2;     // 4 row groups of 64 tiles x 2 channel halves
   const int li = lane & 31, lh = lane >> 5;
-  const int Q = p.Cout >> 2;
 
   const int cus = gridDim.x >> 3;
   const int xcd = blockIdx.x & 7, P = p.npos * p.tiles_n;
@@ -158,9 +165,20 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_kernel(const Wino4GemmArgs 
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       const int row = wm * 64 + mt * 32 + li;
+      if constexpr (AF32) {
+        const w4f32x4 q0 = *reinterpret_cast<const w4f32x4*>(A + (2 * lh) * A_OCT + row * 16);
+        const w4f32x4 q1 = *reinterpret_cast<const w4f32x4*>(A + (2 * lh + 1) * A_OCT + row * 16);
+        w4f32x8 x{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
 #pragma unroll
-      for (int pl = 0; pl < SPLIT; ++pl)
-        af[mt][pl] = *reinterpret_cast<const w4bf16x8*>(A + pl * A_PLANE + lh * A_OCT + row * 16);
+        for (int pl = 0; pl < SPLIT; ++pl) {
+          af[mt][pl] = __builtin_convertvector(x, w4bf16x8);
+          if (pl + 1 < SPLIT) x -= __builtin_convertvector(af[mt][pl], w4f32x8);
+        }
+      } else {
+#pragma unroll
+        for (int pl = 0; pl < SPLIT; ++pl)
+          af[mt][pl] = *reinterpret_cast<const w4bf16x8*>(A + pl * A_PLANE + lh * A_OCT + row * 16);
+      }
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -227,6 +245,7 @@ struct Wino4InArgs {
   int nchunk, m_blocks;
   const float* up_src;       // UP: channels >= Cin - up_C are the exact 2x bilinear upsample of up_src [N, H/2, W/2, up_cs]
   int up_C, up_cs;
+  int order, ncp;            // order 1: 1-D grid, channel-chunk pairs fastest inside an XCD's contiguous range of tile groups
 };
 
 // One workgroup = 16 tiles x 32 channels (two chunks), tile groups the fast grid dimension; thread = (tile, channel
@@ -252,13 +271,29 @@ __device__ __forceinline__ void w4_bt2(const w4f32x2 (&d)[6], w4f32x2 (&t)[6]) {
 // wy0 * (hx * v00 + lx * v01) + wy1 * (hx * v10 + lx * v11), horizontal sums shared by the rows that use them), so the
 // result is bit-identical to upsampling first.  Windows that touch the image border (clamped taps, zero padding) take
 // the generic per-pixel path.
-template <int SPLIT, bool UP>
+// F32V: V is written as fp32, [pos][tile block][chunk][k-quad][256 tiles][4] (the AF32 form of the GEMM): no pieces; the
+// pairs cross the LDS tile twelve positions at a time ([position][k-quad of the 32 channels][16 tiles][4 floats], rows padded
+// by 16 bytes) and leave as the same 256-byte runs.
+constexpr int W4I_ROW = 16 * 16 + 16;          // bytes of one (position, k-quad) row of the F32V tile
+template <int SPLIT, bool UP, bool F32V>
 __global__ __launch_bounds__(256, 4) void wino4_in_kernel(const Wino4InArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned tbuf[W4_POS * 4 * 16 * 4];      // [pos][chunk half * 2 + octet][tile][4 pairs]
+  static_assert(12 * 8 * W4I_ROW <= (int)sizeof(unsigned) * W4_POS * 4 * 16 * 4, "F32V tile");
   const int t = threadIdx.x;
   // gridDim.x is a multiple of 16: workgroup (x, y) sits on XCD x % 8.  Every XCD gets a contiguous range of tile groups,
   // so the 6x6 windows' shared pixels (2 of 6 columns / rows) are re-read from ITS L2 (round-robin: 2.4x the input fetched)
-  const int tg = xcd_remap(blockIdx.x, gridDim.x), chunk0 = blockIdx.y * 2;
+  int tg, chunk0;
+  if (p.order) {
+    // workgroup L sits on XCD L % 8.  Each XCD owns a contiguous range of tile groups and walks it with the channel-chunk
+    // pairs FASTEST: the workgroups in flight on an XCD cover every channel of a few tile groups, so a 128-byte line that
+    // two channel groups share (pixel stride 1984 B at 496 channels = 15.5 lines) and the rows / columns neighbouring
+    // windows share are fetched from HBM once and then served by that XCD's L2
+    const int L = blockIdx.x, xcd = L & 7, idx = L >> 3, q = (p.m_blocks * 16) >> 3;
+    const int tgl = idx / p.ncp;
+    tg = xcd * q + tgl; chunk0 = (idx - tgl * p.ncp) * 2;
+  } else {
+    tg = xcd_remap(blockIdx.x, gridDim.x); chunk0 = blockIdx.y * 2;
+  }
   const int tl = t >> 4, cp = t & 15;
   const int tile = tg * 16 + tl, ch = chunk0 * W4_CK + cp * 2;
   const int per = p.tiles_y * p.tiles_x;
@@ -358,6 +393,34 @@ __global__ __launch_bounds__(256, 4) void wino4_in_kernel(const Wino4InArgs p) {
     for (int j = 0; j < 6; ++j) u[i][j] = o[j];
   }
   const int mb = (tg * 16) >> 8, row0 = (tg * 16) & (W4_M - 1);
+  if constexpr (F32V) {
+    char* tb = reinterpret_cast<char*>(tbuf);
+    // write side: thread = (position parity, k-quad of the 32 channels, tile); its six units of a group are 2 positions apart
+    const int tlw = t & 15, kq8 = (t >> 4) & 7, pph = t >> 7;
+    const int chunk = chunk0 + (kq8 >> 2);
+    const size_t pos_stride = (size_t)p.m_blocks * p.nchunk * (size_t)(4 * W4_M * 16);
+    char* dst0 = p.V + (((size_t)mb * p.nchunk + chunk) * 4 + (kq8 & 3)) * (size_t)(W4_M * 16) + (size_t)(row0 + tlw) * 16 +
+                 pph * pos_stride;
+    const char* src0 = tb + (pph * 8 + kq8) * W4I_ROW + tlw * 16;
+    char* wr0 = tb + (cp >> 1) * W4I_ROW + tl * 16 + (cp & 1) * 8;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      if (g) __syncthreads();
+#pragma unroll
+      for (int pp = 0; pp < 12; ++pp) {
+        const int pos = g * 12 + pp;
+        *reinterpret_cast<w4f32x2*>(wr0 + pp * 8 * W4I_ROW) = u[pos / 6][pos % 6];
+      }
+      __syncthreads();
+      if (chunk < p.nchunk) {
+#pragma unroll
+        for (int it = 0; it < 6; ++it)
+          *reinterpret_cast<w4f32x4*>(dst0 + (size_t)(g * 12 + 2 * it) * pos_stride) =
+              *reinterpret_cast<const w4f32x4*>(src0 + 2 * it * 8 * W4I_ROW);
+      }
+    }
+    return;
+  }
   constexpr int UNITS = W4_POS * 4 * 16;       // 16-byte units of one piece: (position, chunk half * 2 + octet, tile)
 #pragma unroll
   for (int pl = 0; pl < SPLIT; ++pl) {
@@ -392,6 +455,7 @@ struct Wino4OutArgs {
   int N, Ho, Wo, Cout, out_cs, out_co, res_cs, act;
   int tiles_y, tiles_x, T;
   long mplane;
+  int order, ncg, ntg8;      // order 1: 1-D grid, cout groups fastest inside an XCD's range of ntg8 tile groups
 };
 
 // One workgroup = 16 consecutive tiles x 64 couts.  Read side: thread = (tile, channel quad), 36 x 16-byte loads streamed
@@ -404,7 +468,14 @@ __global__ __launch_bounds__(256) void wino4_out_kernel(const Wino4OutArgs p) {
   __shared__ float scratch[4];
   const int Q = p.Cout >> 2;
   const int t = threadIdx.x;
-  const int tile0 = blockIdx.x * W4O_TILES, quad0 = blockIdx.y * W4O_QUADS;
+  int tile0, quad0;
+  if (p.order) {
+    const int L = blockIdx.x, xcd = L & 7, idx = L >> 3, tgl = idx / p.ncg;
+    tile0 = (xcd * p.ntg8 + tgl) * W4O_TILES; quad0 = (idx - tgl * p.ncg) * W4O_QUADS;
+    if (tile0 >= p.T) return;
+  } else {
+    tile0 = blockIdx.x * W4O_TILES; quad0 = blockIdx.y * W4O_QUADS;
+  }
   const int tl = t & (W4O_TILES - 1), ql = t >> 4;
   w4f32x4 y[4][4];
 #pragma unroll
@@ -545,9 +616,11 @@ int conv_wino4_pack(const float* w, const float* scale, void* wpk, int Cout, int
 // < 3 %: the 36 streams do not alias in HBM)
 static inline long wino4_mplane(long T, int Cout) { return T * Cout; }
 
+// the larger of the two V forms (pre-split pieces; fp32 is 2/3 or 1/1 of it) so that either fits the workspace
 static inline long wino4_v_bytes(long T, int Cin, int prec) {
   const long m_blocks = (T + W4_M - 1) / W4_M, nchunk = (Cin + W4_CK - 1) / W4_CK;
-  return (long)W4_POS * m_blocks * nchunk * wino4_split(prec) * 2 * W4_M * 16;
+  const int sp = wino4_split(prec);
+  return (long)W4_POS * m_blocks * nchunk * (sp > 2 ? sp : 2) * 2 * W4_M * 16;
 }
 
 int64_t conv_wino4_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int prec) {
@@ -559,12 +632,12 @@ int64_t conv_wino4_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int
 static std::atomic<bool> g_w4_probe{false};
 static hipEvent_t g_w4_ev[2] = {nullptr, nullptr};
 
-template <int SPLIT, int TN>
+template <int SPLIT, int TN, bool AF32 = false>
 static int launch_wino4_gemm(const Wino4GemmArgs& a, hipStream_t s) {
-  constexpr int smem = 3 * (SPLIT * 2 * W4_M * 16 + TN * SPLIT * 2 * 64 * 16);
+  constexpr int smem = 3 * ((AF32 ? 4 : SPLIT * 2) * W4_M * 16 + TN * SPLIT * 2 * 64 * 16);
   static_assert(smem <= 160 * 1024, "Winograd GEMM stages do not fit the LDS");
   static std::atomic<uint64_t> attr_devs{0};
-  CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino4_gemm_kernel<SPLIT, TN>), smem, attr_devs));
+  CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino4_gemm_kernel<SPLIT, TN, AF32>), smem, attr_devs));
   int dev = 0, cus = 0;
   CRESTE_HIP(hipGetDevice(&dev));
   CRESTE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -572,7 +645,7 @@ static int launch_wino4_gemm(const Wino4GemmArgs& a, hipStream_t s) {
   long per_xcd = cus / 8 > 0 ? cus / 8 : 1;
   const long need = (items + 7) / 8;
   if (per_xcd > need) per_xcd = need;
-  wino4_gemm_kernel<SPLIT, TN><<<(unsigned)(per_xcd * 8), 512, smem, s>>>(a);
+  wino4_gemm_kernel<SPLIT, TN, AF32><<<(unsigned)(per_xcd * 8), 512, smem, s>>>(a);
   CRESTE_CHECK_LAUNCH("wino4_gemm");
   return CRESTE_OK;
 }
@@ -599,14 +672,22 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
   ia.up_src = d->up_src; ia.up_C = d->up_C; ia.up_cs = d->up_cs;
   CRESTE_REQUIRE((d->Cin & 3) == 0 && (!d->in || ((d->in_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(d->in) & 15) == 0)),
                  "conv2d: the F(4x4,3x3) input transform reads channel pairs (Cin / in_cs multiples of 4, as every NHWC conv here)");
-  const dim3 igrid((unsigned)(m_blocks * 16), (unsigned)((nchunk + 1) / 2));      // tile groups fast: m_blocks < 2^18
+  const char* ord_env = getenv("CRESTE_W4_ORDER");
+  const int order = ord_env ? atoi(ord_env) : 2;
+  ia.order = order & 1; ia.ncp = (nchunk + 1) / 2;
+  const dim3 igrid = ia.order ? dim3((unsigned)(m_blocks * 16 * ia.ncp)) : dim3((unsigned)(m_blocks * 16), (unsigned)((nchunk + 1) / 2));
+  const char* f32_env = getenv("CRESTE_W4_F32V");
+  const bool f32v = f32_env ? atoi(f32_env) != 0 : true;
   if (d->flags & CRESTE_CONV_V_VALID) {
     // the caller vouches that `work` holds V of this very input (creste_hip.h)
+  } else if (f32v) {
+    if (d->up_src) wino4_in_kernel<3, true, true><<<igrid, 256, 0, s>>>(ia);
+    else wino4_in_kernel<3, false, true><<<igrid, 256, 0, s>>>(ia);
   } else if (d->up_src) {
-    if (split == 3) wino4_in_kernel<3, true><<<igrid, 256, 0, s>>>(ia);
-    else wino4_in_kernel<2, true><<<igrid, 256, 0, s>>>(ia);
-  } else if (split == 3) wino4_in_kernel<3, false><<<igrid, 256, 0, s>>>(ia);
-  else wino4_in_kernel<2, false><<<igrid, 256, 0, s>>>(ia);
+    if (split == 3) wino4_in_kernel<3, true, false><<<igrid, 256, 0, s>>>(ia);
+    else wino4_in_kernel<2, true, false><<<igrid, 256, 0, s>>>(ia);
+  } else if (split == 3) wino4_in_kernel<3, false, false><<<igrid, 256, 0, s>>>(ia);
+  else wino4_in_kernel<2, false, false><<<igrid, 256, 0, s>>>(ia);
   CRESTE_CHECK_LAUNCH("wino4_in");
 
   Wino4GemmArgs a;
@@ -621,7 +702,10 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
     if (!g_w4_ev[0]) { CRESTE_HIP(hipEventCreate(&g_w4_ev[0])); CRESTE_HIP(hipEventCreate(&g_w4_ev[1])); }
     CRESTE_HIP(hipEventRecord(g_w4_ev[0], s));
   }
-  if (tn == 4) rc = split == 3 ? launch_wino4_gemm<3, 4>(a, s) : launch_wino4_gemm<2, 4>(a, s);
+  if (f32v) {
+    if (tn == 4) rc = split == 3 ? launch_wino4_gemm<3, 4, true>(a, s) : launch_wino4_gemm<2, 4, true>(a, s);
+    else rc = split == 3 ? launch_wino4_gemm<3, 2, true>(a, s) : launch_wino4_gemm<2, 2, true>(a, s);
+  } else if (tn == 4) rc = split == 3 ? launch_wino4_gemm<3, 4>(a, s) : launch_wino4_gemm<2, 4>(a, s);
   else rc = split == 3 ? launch_wino4_gemm<3, 2>(a, s) : launch_wino4_gemm<2, 2>(a, s);
   if (rc != CRESTE_OK) return rc;
   if (probe) CRESTE_HIP(hipEventRecord(g_w4_ev[1], s));
@@ -630,7 +714,10 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
   o.M = M; o.bias = d->bias; o.res = d->res; o.row_mask = d->row_mask; o.out = d->out; o.out_amax = d->out_amax;
   o.N = d->N; o.Ho = d->Ho; o.Wo = d->Wo; o.Cout = d->Cout; o.out_cs = d->out_cs; o.out_co = d->out_co; o.res_cs = d->res_cs;
   o.act = d->act; o.tiles_y = tiles_y; o.tiles_x = tiles_x; o.T = (int)T; o.mplane = a.mplane;
-  const dim3 ogrid((unsigned)((T + W4O_TILES - 1) / W4O_TILES), (unsigned)((d->Cout / 4 + W4O_QUADS - 1) / W4O_QUADS));
+  o.order = (order >> 1) & 1; o.ncg = (d->Cout / 4 + W4O_QUADS - 1) / W4O_QUADS;
+  o.ntg8 = (int)(((T + W4O_TILES - 1) / W4O_TILES + 7) / 8);
+  const dim3 ogrid = o.order ? dim3((unsigned)(o.ntg8 * 8 * o.ncg))
+                             : dim3((unsigned)((T + W4O_TILES - 1) / W4O_TILES), (unsigned)((d->Cout / 4 + W4O_QUADS - 1) / W4O_QUADS));
   wino4_out_kernel<<<ogrid, 256, 0, s>>>(o);
   CRESTE_CHECK_LAUNCH("wino4_out");
   return CRESTE_OK;
