@@ -77,7 +77,7 @@ def kernel_symbol(pc, N, Ho, Wo):
     if getattr(pc, "algo", 0) == 2:             # Winograd F(4x4,3x3): input transform + GEMM over the 36 positions + output transform
         split = {2: 2, 3: 3}[pc.prec]
         return (PREC_NAME[pc.prec] + "+winograd4",
-                f"wino4_in_kernel<{split}, UP> + wino4_gemm_kernel<{split}, {4 if pc.Cout > 128 else 2}> + wino4_out_kernel")
+                f"wino4_in_kernel<3, UP, true> + wino4_gemm32_kernel<{split}, {4 if pc.Cout > 128 else 2}> + wino4_out_kernel")
     if pc.prec == 0:
         return ("f32", "conv_igemm_f32_kernel<2, 2, 2, 2>" if pc.Cout > 64 else
                 "conv_igemm_f32_kernel<2, 2, 2, 1>" if pc.Cout > 32 else "conv_igemm_f32_kernel<4, 1, 1, 1>")
@@ -203,14 +203,14 @@ def gemm_kernel_probe(step):
         hipnn.ops.conv2d = orig
     if not calls:
         return None
-    return {"kernel": "wino4_gemm_kernel<SPLIT, TN> (the GEMM kernel of every F(4x4,3x3) conv call of one step)",
+    return {"kernel": "wino4_gemm32_kernel<SPLIT, TN> (the GEMM kernel of every F(4x4,3x3) conv call of one step)",
             "calls_per_step": calls, "ms_per_step": round(ms_tot, 3),
             "piece_products_pflops": round(raw / (ms_tot * 1e-3) / 1e15, 4),
             "mfma_issue_util": round(raw / (ms_tot * 1e-3) / 1e12 / 2500.0, 4),
             "algorithmic_tflops": round(alg / (ms_tot * 1e-3) / 1e12, 1),
             "note": "HIP events around the GEMM kernel alone (library probe), one untimed step after the timed ones; "
                     "piece products = 36 positions x padded tiles x padded Cin x padded Cout x 2 x pieces, issued on "
-                    "v_mfma_f32_32x32x16_bf16 (dense peak 2500 TFLOP/s); PMC of the same kernel: profiles/r03_pmc_wino4_496.txt"}
+                    "v_mfma_f32_32x32x16_bf16 (dense peak 2500 TFLOP/s); PMC of the pre-split form of this kernel: profiles/r03_pmc_wino4_496.txt"}
 
 
 def cpu_baseline(batches=(1, 16), runs=5, budget_s=210.0):
@@ -643,7 +643,7 @@ def main():
                 # a Winograd call is several kernels ("a + b + c"): HBM bytes of one call = the sum over its kernels
                 cnt = json.load(open(pj))
                 def per_launch(k):
-                    if ", UP>" in k:      # the input transform has two instantiations (plain / fused upsample + concat input)
+                    if ", UP" in k:       # the input transform has two instantiations (plain / fused upsample + concat input)
                         es = [cnt.get(k.replace("UP", v)) for v in ("false", "true")]
                         es = [e for e in es if e]
                         n = sum(e["launches"] for e in es)

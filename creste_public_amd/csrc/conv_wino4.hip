@@ -236,6 +236,199 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_kernel(const Wino4GemmArgs 
   }
 }
 
+// ---- the forward GEMM on fp32 V (the default): one continuous pipeline over the workgroup's whole item list
+// Per chunk c of the stream (stage s = c % 3), after ONE barrier: the LDS-DMA of A(c + 3) and B(c + 2) is issued -- across
+// item boundaries, so an item's first chunks are already there when its predecessor ends (the pre-split kernel above pays a
+// full memory latency at every item head) --, the MFMAs of chunk c run on the bf16 pieces of A(c) that were split one chunk
+// earlier, and between them the wave reads its 64 rows of A(c + 1) as fp32 and splits them (the conversions / subtractions
+// of wino4_in_kernel's piece loop: pieces and products bit-identical to the pre-split form).  A is consumed one chunk
+// ahead of B, so three stages of each suffice: 3 x (16 + 24) KiB.
+template <int SPLIT, int TN>
+__global__ __launch_bounds__(512, 2) void wino4_gemm32_kernel(const Wino4GemmArgs p) {
+  constexpr int A_QUAD = W4_M * 16, A_BYTES = 4 * A_QUAD;                                // [k-quad][row][4 f32]
+  constexpr int U_OCT = 64 * 16, U_PLANE = 2 * U_OCT, U_BYTES = SPLIT * U_PLANE;         // one 64-cout weight unit
+  constexpr int B_BYTES = TN * U_BYTES;
+  constexpr int NS = 3;
+  constexpr int A_INSTR = A_BYTES / 1024, B_INSTR = B_BYTES / 1024;
+  constexpr int kA = A_INSTR / 8, kBw = (B_INSTR + 7) / 8;     // 1 KiB DMA pieces EVERY wave issues per chunk
+  constexpr int kDma = kA + kBw;
+  constexpr int NT = TN;
+  constexpr int kStores = 2 * NT * 4;
+  static_assert(A_INSTR % 8 == 0 && B_BYTES % 1024 == 0, "tiles must be whole DMA pieces");
+  static_assert(kDma + kStores <= 63, "vmcnt is a 6-bit counter");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Ast = smem;
+  char* const Bst = smem + NS * A_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;     // 4 row groups of 64 tiles x 2 channel halves
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int cus = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, P = p.npos * p.tiles_n;
+  const int units_pg = (P + 7) >> 3, nunits = units_pg * ((p.m_blocks + W4_MBG - 1) / W4_MBG);
+  int slot = blockIdx.x >> 3;
+
+  struct Item { int mb, pos, tn; const char* a; const char* w; };
+  // -> true when `slot` names an item (advancing over the holes of ragged units), false at the end
+  auto setup = [&](Item& it) __attribute__((always_inline)) -> bool {
+    for (;; slot += cus) {
+      const int unit = (slot >> 5) * 8 + xcd, w = slot & 31;
+      if (unit >= nunits) return false;
+      const int mg = unit / units_pg, pg = unit - mg * units_pg;   // panel groups fastest: neighbouring XCDs share V tiles in the MALL
+      const int pnl = pg * 8 + (w & 7);
+      it.mb = mg * W4_MBG + (w >> 3);
+      if (pnl >= P || it.mb >= p.m_blocks) continue;
+      it.pos = pnl / p.tiles_n; it.tn = pnl - it.pos * p.tiles_n;
+      it.a = p.V + ((size_t)it.pos * p.m_blocks + it.mb) * p.nchunk * A_BYTES;
+      it.w = p.wpk + ((size_t)it.pos * p.units + (size_t)it.tn * TN) * p.nchunk * U_BYTES;
+      return true;
+    }
+  };
+  auto uniform = [](const char* q) __attribute__((always_inline)) -> const char* {
+    const size_t v = reinterpret_cast<size_t>(q);
+    return reinterpret_cast<const char*>(((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                                         (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+  };
+  auto dma_a = [&](const Item& it, int c, int st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int jj = 0; jj < kA; ++jj) {
+      const int i = wave + 8 * jj;
+      const char* src = uniform(it.a + (size_t)c * A_BYTES + i * 1024);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (unsigned)(lane * 16)),
+                                       (__attribute__((address_space(3))) void*)(Ast + st * A_BYTES + i * 1024), 16, 0, 0);
+    }
+  };
+  // a wave with no weight piece left re-copies its previous one (same bytes to the same place): every wave issues kBw
+  auto dma_b = [&](const Item& it, int c, int st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int jj = 0; jj < kBw; ++jj) {
+      int i = wave + 8 * jj;
+      if (i >= B_INSTR) i -= 8;
+      const int uu = i / (U_BYTES / 1024), r = i % (U_BYTES / 1024);
+      const char* src = uniform(it.w + ((size_t)uu * p.nchunk + c) * U_BYTES + r * 1024);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (unsigned)(lane * 16)),
+                                       (__attribute__((address_space(3))) void*)(Bst + st * B_BYTES + i * 1024), 16, 0, 0);
+    }
+  };
+
+  w4f32x16 acc[2][NT];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  w4bf16x8 af[2][SPLIT];
+  // this wave's rows of the A tile in stage `st`: fp32 -> bf16 pieces (lane = row li of the 32-row block, k-octet lh)
+  auto read_a = [&](int st, int mt, w4f32x4 (&q)[2]) __attribute__((always_inline)) {
+    const char* A = Ast + st * A_BYTES + (wm * 64 + mt * 32 + li) * 16;
+    q[0] = *reinterpret_cast<const w4f32x4*>(A + (2 * lh) * A_QUAD);
+    q[1] = *reinterpret_cast<const w4f32x4*>(A + (2 * lh + 1) * A_QUAD);
+  };
+  auto split_a = [&](const w4f32x4 (&q)[2], w4bf16x8 (&dst)[SPLIT]) __attribute__((always_inline)) {
+    w4f32x8 x{q[0][0], q[0][1], q[0][2], q[0][3], q[1][0], q[1][1], q[1][2], q[1][3]};
+#pragma unroll
+    for (int pl = 0; pl < SPLIT; ++pl) {
+      dst[pl] = __builtin_convertvector(x, w4bf16x8);
+      if (pl + 1 < SPLIT) x -= __builtin_convertvector(dst[pl], w4f32x8);
+    }
+  };
+  // MFMAs of the chunk in stage `st` (weights as the first operand: D = U * V^T, a lane owns one tile, its registers the
+  // couts) with the split of the NEXT chunk's rows (stage `stn`) between them
+  auto mfma_chunk = [&](int st, int stn) __attribute__((always_inline)) {
+    const char* B = Bst + st * B_BYTES;
+    w4bf16x8 bfr[2][SPLIT], afn[2][SPLIT];
+    w4f32x4 raw[2][2];
+    auto read_b = [&](int nt, w4bf16x8 (&dst)[SPLIT]) __attribute__((always_inline)) {
+      const int n = (wn * NT + nt) * 32 + li;
+#pragma unroll
+      for (int pl = 0; pl < SPLIT; ++pl)
+        dst[pl] = *reinterpret_cast<const w4bf16x8*>(B + (n >> 6) * U_BYTES + pl * U_PLANE + lh * U_OCT + (n & 63) * 16);
+    };
+    read_b(0, bfr[0]);
+    read_a(stn, 0, raw[0]);
+    read_a(stn, 1, raw[1]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (nt + 1 < NT) read_b(nt + 1, bfr[(nt + 1) & 1]);     // lands behind this tile's 4 * SPLIT MFMAs
+      w4_split_mfma2<SPLIT>(bfr[nt & 1], af[0], af[1], acc[0][nt], acc[1][nt]);
+      if (NT == 2) {
+        split_a(raw[nt], afn[nt]);
+      } else if (nt < 2) {
+        split_a(raw[nt], afn[nt]);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int pl = 0; pl < SPLIT; ++pl) af[mt][pl] = afn[mt][pl];
+  };
+
+  Item cur, nxt;
+  if (!setup(cur)) return;
+  slot += cus;
+  bool has_next = setup(nxt);
+  zero_acc();
+  // prologue: A(0..2), B(0..1) of the first item (nchunk >= 3)
+  dma_a(cur, 0, 0); dma_a(cur, 1, 1); dma_a(cur, 2, 2);
+  dma_b(cur, 0, 0); dma_b(cur, 1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  {
+    w4f32x4 raw[2];
+    read_a(0, 0, raw); split_a(raw, af[0]);
+    read_a(0, 1, raw); split_a(raw, af[1]);
+  }
+  int st = 0;                                   // stage of the current chunk = (chunks so far) % 3
+  for (;;) {
+    for (int c = 0; c < p.nchunk; ++c) {
+      // this wave's pieces of B(c) and A(c + 1) have landed: they were issued two chunks ago; younger operations are the
+      // kDma pieces of the previous chunk and, in the first two chunks of an item, the kStores product stores of the
+      // previous item issued between them.  At the very end of the list (no next item) batches thin out: wait for all
+      if (!has_next && c + 2 >= p.nchunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (c < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma + kStores) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma) : "memory");
+      // everybody's pieces are in, and everybody is done with chunk c - 1: with A(c) (stage st) and B(c - 1) (stage st + 2)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const int st1 = st == 2 ? 0 : st + 1, st2 = st == 0 ? 2 : st - 1;
+      if (c + 3 < p.nchunk) dma_a(cur, c + 3, st);
+      else if (has_next) dma_a(nxt, c + 3 - p.nchunk, st);
+      if (c + 2 < p.nchunk) dma_b(cur, c + 2, st2);
+      else if (has_next) dma_b(nxt, c + 2 - p.nchunk, st2);
+      mfma_chunk(st, st1);
+      st = st1;
+    }
+    // ---- item tail: products to M[pos][cout / 4][tile][4] (lane = tile, registers 4g..4g+3 = four consecutive couts:
+    // a half-wave writes 512 contiguous bytes per instruction).  ALL kStores stores are issued (rows past the last
+    // tile / couts past Cout go to a junk line behind the workspace) so that the next item's waits can count them
+    float* Mp = p.M + (size_t)cur.pos * p.mplane;
+    float* const junk = p.M + (size_t)p.npos * p.mplane + lane * 4;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int m = cur.mb * W4_M + wm * 64 + mt * 32 + li;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = cur.tn * (64 * TN) + (wn * NT + nt) * 32 + 8 * g + 4 * lh;
+          float* dst = (m < p.T && n < p.Cout) ? Mp + ((size_t)(n >> 2) * p.T + m) * 4 : junk;
+          *reinterpret_cast<w4f32x4*>(dst) =
+              w4f32x4{acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+        }
+    }
+    if (!has_next) break;
+    cur = nxt;
+    slot += cus;
+    has_next = setup(nxt);
+    zero_acc();
+  }
+}
+
 struct Wino4InArgs {
   const float* in;
   char* V;
@@ -276,7 +469,7 @@ __device__ __forceinline__ void w4_bt2(const w4f32x2 (&d)[6], w4f32x2 (&t)[6]) {
 // by 16 bytes) and leave as the same 256-byte runs.
 constexpr int W4I_ROW = 16 * 16 + 16;          // bytes of one (position, k-quad) row of the F32V tile
 template <int SPLIT, bool UP, bool F32V>
-__global__ __launch_bounds__(256, 4) void wino4_in_kernel(const Wino4InArgs p) {
+__global__ __launch_bounds__(256, (UP && F32V) ? 3 : 4) void wino4_in_kernel(const Wino4InArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned tbuf[W4_POS * 4 * 16 * 4];      // [pos][chunk half * 2 + octet][tile][4 pairs]
   static_assert(12 * 8 * W4I_ROW <= (int)sizeof(unsigned) * W4_POS * 4 * 16 * 4, "F32V tile");
   const int t = threadIdx.x;
@@ -309,50 +502,41 @@ __global__ __launch_bounds__(256, 4) void wino4_in_kernel(const Wino4InArgs p) {
     if (UP && ok && ch >= C2) {
       const int H1 = p.H >> 1, W1 = p.W >> 1;
       const float* src = p.up_src + (size_t)img * H1 * W1 * p.up_cs + (ch - C2);
-      const bool inner = p.pad_t == 1 && p.pad_l == 1 && y0 >= 0 && y0 + 5 < p.H && x0 >= 0 && x0 + 5 < p.W;
-      if (inner) {
-        // window rows y0 + i, i = 0..5 (y0 odd): source rows (2ty - 1 + (i >> 1), + 1), weight of the second 0.25 / 0.75
-        w4f32x2 P[4][4];
+      // ONE branch-free form for interior and border windows (a wave mixes both: the per-pixel border path this replaces
+      // ran on 15 % of the waves of a 64 x 64 tile grid at several times the cost).  Window pixel (oy, ox) = (y0 + i, x0 + j)
+      // takes PyTorch's taps ya = floor(sy), yb = min(ya + 1, H1 - 1), sy = max(0.5 (oy + 0.5) - 0.5, 0).  With pad 1, y0 is
+      // odd and ya = yb0 + (i >> 1) for yb0 = (y0 - 1) / 2 -- except at oy = 0, where the clamp makes sy = 0: there the
+      // weights are (1, 0) and the tap standing in for row -1 is the clamped load of row 0, so 1 * r0 + 0 * r0 = r0 as the
+      // stand-alone kernel forms it (csrc/pointwise.hip: upsample2x_concat_kernel).  Rows past H1 - 1 clamp likewise (the
+      // duplicate holds the tap's own data); window pixels outside the image are the conv's zero padding.
+      const int yb0 = 2 * ty - 1, xb0 = 2 * tx - 1;            // pad 1 (conv_wino4_run requires it with up_src): y0 = 4 ty - 1
+      w4f32x2 P[4][4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < 4; ++a) {
+        int ry = yb0 + a; ry = ry < 0 ? 0 : (ry > H1 - 1 ? H1 - 1 : ry);
 #pragma unroll
-          for (int b = 0; b < 4; ++b)
-            P[a][b] = *reinterpret_cast<const w4f32x2*>(src + ((size_t)(2 * ty - 1 + a) * W1 + (2 * tx - 1 + b)) * p.up_cs);
-        w4f32x2 hz[4][6];
+        for (int b = 0; b < 4; ++b) {
+          int rx = xb0 + b; rx = rx < 0 ? 0 : (rx > W1 - 1 ? W1 - 1 : rx);
+          P[a][b] = *reinterpret_cast<const w4f32x2*>(src + ((size_t)ry * W1 + rx) * p.up_cs);
+        }
+      }
+      w4f32x2 hz[4][6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int ox = x0 + j;
+        const float lx = ox == 0 ? 0.f : ((j & 1) ? 0.75f : 0.25f), hx = 1.f - lx;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) hz[a][j] = hx * P[a][j >> 1] + lx * P[a][(j >> 1) + 1];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int oy = y0 + i;
+        const float wy1 = oy == 0 ? 0.f : ((i & 1) ? 0.75f : 0.25f), wy0 = 1.f - wy1;
+        const bool yin = (unsigned)oy < (unsigned)p.H;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-          const float lx = (j & 1) ? 0.75f : 0.25f, hx = 1.f - lx;
-#pragma unroll
-          for (int a = 0; a < 4; ++a) hz[a][j] = hx * P[a][j >> 1] + lx * P[a][(j >> 1) + 1];
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const float wy1 = (i & 1) ? 0.75f : 0.25f, wy0 = 1.f - wy1;
-#pragma unroll
-          for (int j = 0; j < 6; ++j) d[i][j] = wy0 * hz[i >> 1][j] + wy1 * hz[(i >> 1) + 1][j];
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const int oy = y0 + i;
-          float sy = 0.5f * ((float)oy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
-          const int ya = (int)sy, yb = ya + (ya < H1 - 1 ? 1 : 0);
-          const float wy1 = sy - (float)ya, wy0 = 1.f - wy1;
-#pragma unroll
-          for (int j = 0; j < 6; ++j) {
-            const int ox = x0 + j;
-            const bool in = (unsigned)oy < (unsigned)p.H && (unsigned)ox < (unsigned)p.W;
-            float sx = 0.5f * ((float)ox + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
-            const int xa = (int)sx, xb = xa + (xa < W1 - 1 ? 1 : 0);
-            const float lx = sx - (float)xa, hx = 1.f - lx;
-            const int yac = in ? ya : 0, ybc = in ? yb : 0, xac = in ? xa : 0, xbc = in ? xb : 0;
-            const w4f32x2 v00 = *reinterpret_cast<const w4f32x2*>(src + ((size_t)yac * W1 + xac) * p.up_cs);
-            const w4f32x2 v01 = *reinterpret_cast<const w4f32x2*>(src + ((size_t)yac * W1 + xbc) * p.up_cs);
-            const w4f32x2 v10 = *reinterpret_cast<const w4f32x2*>(src + ((size_t)ybc * W1 + xac) * p.up_cs);
-            const w4f32x2 v11 = *reinterpret_cast<const w4f32x2*>(src + ((size_t)ybc * W1 + xbc) * p.up_cs);
-            const w4f32x2 v = wy0 * (hx * v00 + lx * v01) + wy1 * (hx * v10 + lx * v11);
-            d[i][j] = in ? v : w4f32x2{0.f, 0.f};
-          }
+          const w4f32x2 v = wy0 * hz[i >> 1][j] + wy1 * hz[(i >> 1) + 1][j];
+          d[i][j] = (yin && (unsigned)(x0 + j) < (unsigned)p.W) ? v : w4f32x2{0.f, 0.f};
         }
       }
     } else if (!ok) {                 // rows past the last tile / channels past Cin: zeros (p.in may be null with UP)
@@ -650,10 +834,30 @@ static int launch_wino4_gemm(const Wino4GemmArgs& a, hipStream_t s) {
   return CRESTE_OK;
 }
 
+template <int SPLIT, int TN>
+static int launch_wino4_gemm32(const Wino4GemmArgs& a, hipStream_t s) {
+  constexpr int smem = 3 * (4 * W4_M * 16 + TN * SPLIT * 2 * 64 * 16);
+  static_assert(smem <= 160 * 1024, "Winograd GEMM stages do not fit the LDS");
+  static std::atomic<uint64_t> attr_devs{0};
+  CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino4_gemm32_kernel<SPLIT, TN>), smem, attr_devs));
+  int dev = 0, cus = 0;
+  CRESTE_HIP(hipGetDevice(&dev));
+  CRESTE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const long items = (long)a.m_blocks * a.npos * a.tiles_n;
+  long per_xcd = cus / 8 > 0 ? cus / 8 : 1;
+  const long need = (items + 7) / 8;
+  if (per_xcd > need) per_xcd = need;
+  wino4_gemm32_kernel<SPLIT, TN><<<(unsigned)(per_xcd * 8), 512, smem, s>>>(a);
+  CRESTE_CHECK_LAUNCH("wino4_gemm32");
+  return CRESTE_OK;
+}
+
 int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
   CRESTE_REQUIRE(conv_wino4_supported(d->prec, d->KH, d->KW, d->stride, d->Cin, d->Cout),
                  "conv2d: the F(4x4,3x3) path is built for stride-1 3x3 convs in the bf16 split modes, Cout a multiple of 4");
   CRESTE_REQUIRE(d->work && !d->a_scale, "conv2d: the Winograd path needs its workspace and takes no per-sample input gate");
+  CRESTE_REQUIRE(!d->up_src || (d->pad_t == 1 && d->pad_l == 1 && d->H == 2 * d->up_H && d->W == 2 * d->up_W),
+                 "conv2d: the fused upsample of the F(4x4,3x3) input transform is the exact 2x one under pad 1");
   CRESTE_REQUIRE((d->out_cs & 3) == 0 && (d->out_co & 3) == 0 && (!d->res || (d->res_cs & 3) == 0) &&
                      (reinterpret_cast<uintptr_t>(d->out) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->work) & 15) == 0,
                  "conv2d: the Winograd path needs 16-byte aligned output / residual channel slices and workspace");
@@ -702,7 +906,11 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
     if (!g_w4_ev[0]) { CRESTE_HIP(hipEventCreate(&g_w4_ev[0])); CRESTE_HIP(hipEventCreate(&g_w4_ev[1])); }
     CRESTE_HIP(hipEventRecord(g_w4_ev[0], s));
   }
-  if (f32v) {
+  const bool stream = f32v && nchunk >= 3 && (f32_env ? atoi(f32_env) != 2 : true);
+  if (stream) {
+    if (tn == 4) rc = split == 3 ? launch_wino4_gemm32<3, 4>(a, s) : launch_wino4_gemm32<2, 4>(a, s);
+    else rc = split == 3 ? launch_wino4_gemm32<3, 2>(a, s) : launch_wino4_gemm32<2, 2>(a, s);
+  } else if (f32v) {
     if (tn == 4) rc = split == 3 ? launch_wino4_gemm<3, 4, true>(a, s) : launch_wino4_gemm<2, 4, true>(a, s);
     else rc = split == 3 ? launch_wino4_gemm<3, 2, true>(a, s) : launch_wino4_gemm<2, 2, true>(a, s);
   } else if (tn == 4) rc = split == 3 ? launch_wino4_gemm<3, 4>(a, s) : launch_wino4_gemm<2, 4>(a, s);

@@ -18,3 +18,9 @@ wall = int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])
 print(f"one step: {b - a} launches, GPU kernel time {T / 1e6:.2f} ms, wall {wall / 1e6:.2f} ms\n\n| kernel | calls | ms | % | avg us |\n|---|---|---|---|---|")
 for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:top]:
     print(f"| `{k[:70]}` | {cnt[k]} | {v / 1e6:.3f} | {100 * v / T:.1f} | {v / cnt[k] / 1e3:.1f} |")
+if len(sys.argv) > 4:      # every launch of the kernels whose name contains argv[4], in launch order (us, grid)
+    print()
+    for r in rows[a:b]:
+        if sys.argv[4] in r["Kernel_Name"]:
+            k = re.sub(r"^void\s+", "", r["Kernel_Name"]).replace("creste::", "").split("(")[0]
+            print(f"{k[:48]:48s} {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:9.1f} us  grid {r.get('Grid_Size_X', r.get('Grid_Size', '?'))}")

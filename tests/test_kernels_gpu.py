@@ -601,6 +601,42 @@ def test_conv_winograd4_fused_upsample_concat(ops, N, C1, C2, H1, W1, Cout):
     assert lazy._mat is not None and ops.conv2d(lazy, pcd).buf.shape == y.buf.shape
 
 
+@pytest.mark.parametrize("prec", ["bf16x6", "bf16x3"])
+@pytest.mark.parametrize("N,Cin,Cout,H,W,up", [
+    (2, 128, 256, 20, 28, False),      # 8 chunks, one ragged tile block
+    (1, 496, 496, 37, 41, False),      # 31 chunks, partial tiles in both directions, two cout tiles
+    (3, 144, 132, 16, 16, False),      # nchunk = 9 (odd), Cout tile of 128 (TN = 2), padded couts
+    (2, 256, 128, 24, 40, True),       # fused upsample form of the input transform
+])
+def test_conv_winograd4_fp32_transformed_input_is_bit_identical(ops, monkeypatch, prec, N, Cin, Cout, H, W, up):
+    """The default F(4x4,3x3) path keeps the transformed input V as fp32 and splits it into bf16 pieces inside the GEMM
+    (csrc/conv_wino4.hip: wino4_gemm32_kernel, the continuous pipeline; CRESTE_W4_F32V=2: the per-item kernel).  Both must
+    equal the pre-split form (V written as bf16 pieces by the input transform, CRESTE_W4_F32V=0) bit for bit: the same
+    conversions and subtractions produce the same pieces, the same MFMAs in the same order the same products."""
+    code = {"bf16x6": ops.PREC_BF16X6, "bf16x3": ops.PREC_BF16X3}[prec]
+    g = torch.Generator().manual_seed(Cin + H)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    pc = ops.pack_conv(dev(w), dev(b), None, 1, 1, ops.ACT_RELU, code, algo=ops.ALGO_WINOGRAD4)
+    if up:
+        x1 = to_act(ops, torch.randn(N, Cin - 64, H // 2, W // 2, generator=g))
+        skip = to_act(ops, torch.randn(N, 64, H, W, generator=g))
+        make = lambda: ops.upsample_concat_lazy(x1, skip, H, W, 0.5, 0.5)
+    else:
+        x = to_act(ops, torch.randn(N, Cin, H, W, generator=g))
+        make = lambda: x
+    outs = {}
+    for mode in ("0", "2", "1"):
+        monkeypatch.setenv("CRESTE_W4_F32V", mode)
+        for order in ("0", "3"):                       # workgroup orders of the transform kernels: placement only
+            monkeypatch.setenv("CRESTE_W4_ORDER", order)
+            outs[mode, order] = ops.conv2d(make(), pc).buf.clone()
+    ref = outs["0", "0"]
+    assert float(ref.abs().max()) > 0.1
+    for k, v in outs.items():
+        assert torch.equal(v, ref), k
+
+
 def test_conv_winograd4_shared_input_transform(ops):
     """three F(4x4,3x3) convs over ONE materialised upsample + concat (the BEV heads' first conv, inpainting.py:141-146):
     the input transform runs once (CRESTE_CONV_V_VALID) and every output equals the stand-alone conv bit for bit."""
