@@ -109,19 +109,28 @@ class ConvProfiler:
 
     def install(self):
         from creste_public_amd import ops
-        self._ops, self._orig, self._orig_splat = ops, ops.conv2d, ops.bev_splat
+        self._ops, self._orig = ops, ops.conv2d
+        self._orig_plan, self._orig_gather = ops.bev_splat_plan, ops.bev_splat_gather
         prof = self
 
-        def timed_splat(xyz, feats, off_xy, vox_xy, GH, GW, *a, **kw):
+        def timed_plan(xyz, *a, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            r = prof._orig_splat(xyz, feats, off_xy, vox_xy, GH, GW, *a, **kw)
+            plan = prof._orig_plan(xyz, *a, **kw)
             e1.record()
-            B, P, F = xyz.shape[0], xyz.shape[1], feats.C
+            plan._bench_ev = (e0, e1)
+            return plan
+
+        def timed_gather(plan, feats, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = prof._orig_gather(plan, feats, *a, **kw)
+            e1.record()
+            B, P, F, GH, GW = plan.B, plan.P, feats.C, plan.GH, plan.GW
             # 4 * (F*P + 2*P + F*G + G) bytes per frame -- features and xy read once, BEV map + densities written once
-            prof.splat.append((e0, e1, 4.0 * B * (F * P + 2 * P + F * GH * GW + GH * GW)))
+            prof.splat.append((plan._bench_ev, (e0, e1), 4.0 * B * (F * P + 2 * P + F * GH * GW + GH * GW)))
             return r
-        ops.bev_splat = timed_splat
+        ops.bev_splat_plan, ops.bev_splat_gather = timed_plan, timed_gather
 
         def timed(x, pc, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -137,22 +146,26 @@ class ConvProfiler:
 
     def uninstall(self):
         self._ops.conv2d = self._orig
-        self._ops.bev_splat = self._orig_splat
+        self._ops.bev_splat_plan, self._ops.bev_splat_gather = self._orig_plan, self._orig_gather
 
     def splat_roofline(self):
         if not self.splat:
             return None
-        ms = [e0.elapsed_time(e1) for e0, e1, _ in self.splat]
+        plan_ms = [p[0].elapsed_time(p[1]) for p, _, _ in self.splat]
+        gath_ms = [g[0].elapsed_time(g[1]) for _, g, _ in self.splat]
+        ms = [a + b for a, b in zip(plan_ms, gath_ms)]
         by = self.splat[0][2]
         avg = sum(ms) / len(ms)
-        return {"bound": "hbm", "kernel": "creste_bev_splat_mode_f32 (splat_key + splat_build_reg + splat_fill_rec + "
-                                          "splat_sort_rec + splat_gather8: the whole call)",
+        return {"bound": "hbm", "kernel": "creste_bev_splat_plan_f32 (splat_key + splat_build_reg + splat_fill_rec + "
+                                          "splat_sort_rec) + creste_bev_splat_gather_f32 (splat_gather8): every splat kernel of the step",
                 "achieved": round(by / (avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(by / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes": by, "avg_call_ms": round(avg, 4),
+                "plan_ms": round(sum(plan_ms) / len(plan_ms), 4), "gather_ms": round(sum(gath_ms) / len(gath_ms), 4),
                 "min_call_ms": round(min(ms), 4), "calls": len(ms), "traffic": None,
-                "note": "HIP events around every BEV splat call INSIDE the timed steps (the network's own predicted depths "
-                        "and fused features, batch 16); bytes = 4*(F*P + 2*P + F*G + G) per frame (SURVEY 8d: F=96, "
-                        "P=46208, G=65536), one read of the inputs and one write of the outputs"}
+                "note": "HIP events around the binning plan (enqueued right after the pixel geometry, ahead of the fusion "
+                        "conv) and around the gather, INSIDE the timed steps (the network's own predicted depths and fused "
+                        "features, batch 16); time = plan_ms + gather_ms; bytes = 4*(F*P + 2*P + F*G + G) per frame "
+                        "(SURVEY 8d: F=96, P=46208, G=65536), one read of the inputs and one write of the outputs"}
 
     def summary(self):
         by = {}
@@ -282,40 +295,47 @@ def _median_step_ms(fn, steps):
     return ts[len(ts) // 2], last
 
 
-def distill_extras(device, steps=5, B=8):
-    """BASELINE configs[3], per-GPU part: one stage-1 distillation training step (train_pefree.py) -- training-mode
-    forward, CrossEntropyDepth + SmoothL1Depth + MSELoss, backward to all 25.5 M encoder parameters into the flat
-    all-reduce arena, Adam -- batch 8 of 1216x608 on the HIP training kernels."""
+def _distill_setup(device, B=8, seed=0):
+    """-> (step_fn, describe_fn, trainer): one stage-1 distillation training step on `B` frames (see distill_extras)."""
     from creste_public_amd import harness, synth
     from creste_public_amd.creste.models.distillation import DistillationBackbone
     from creste_public_amd.creste.utils.loss_utils import LossManager
     cfg = harness.distillation_cfg((IMG_H, IMG_W))
     torch.cuda.empty_cache()                   # the inference / IRL runs before this leave a fragmented cache
-    torch.manual_seed(0)
+    torch.manual_seed(0)                       # identical replicas on every rank; the DATA differs by `seed`
     model = DistillationBackbone(cfg).to(device)
     synth.randomize_bn(model, seed=1)
-    rgbd, _ = synth.make_frames(B, IMG_H, IMG_W, seed=2)
-    g = torch.Generator().manual_seed(3)
+    rgbd, _ = synth.make_frames(B, IMG_H, IMG_W, seed=2 + 100 * seed)
+    g = torch.Generator().manual_seed(3 + 100 * seed)
     batch = {"image": rgbd.to(device),
              "depth_label": (torch.rand(B, 1, IMG_H // 4, IMG_W // 4, generator=g) * 26000.0).to(device),
              "fimg_label": torch.randn(B, 1, 128, IMG_H // 4, IMG_W // 4, generator=g).to(device)}
     tr = harness.DistillTrainer(model, LossManager(cfg), cfg)
-    tr.training_step(batch); tr.training_step(batch); torch.cuda.synchronize()
-    ms, logs = _median_step_ms(lambda: tr.training_step(batch), steps)
-    n = sum(p.numel() for p in model.parameters() if p.grad is not None)
-    del tr, model, batch
+
+    def describe(logs):
+        n = sum(p.numel() for p in model.parameters() if p.grad is not None)
+        return (f"batch {B}, {IMG_W}x{IMG_H}, EfficientNet-B0 U-Net + depth/DINO heads in training mode, "
+                f"{n} parameters with gradients, Adam; loss {float(logs['train/loss']):.3f}")
+    return (lambda: tr.training_step(batch)), describe, tr
+
+
+def distill_extras(device, steps=5, B=8):
+    """BASELINE configs[3], per-GPU part: one stage-1 distillation training step (train_pefree.py) -- training-mode
+    forward, CrossEntropyDepth + SmoothL1Depth + MSELoss, backward to all 25.5 M encoder parameters into the flat
+    all-reduce arena, Adam -- batch 8 of 1216x608 on the HIP training kernels."""
+    step, describe, tr = _distill_setup(device, B)
+    step(); step(); torch.cuda.synchronize()
+    ms, logs = _median_step_ms(step, steps)
+    cfg_s = describe(logs)
+    del tr, step, describe
     torch.cuda.empty_cache()
     import creste_public_amd as _cpa
     return {"distill_train_step_ms": round(ms, 1), "distill_frames_per_s": round(B / ms * 1e3, 1),
-            "operands": _cpa.get_precision(),
-            "distill_config": f"batch {B}, {IMG_W}x{IMG_H}, EfficientNet-B0 U-Net + depth/DINO heads in training mode, "
-                              f"{n} parameters with gradients, Adam; loss {float(logs['train/loss']):.3f}"}
+            "operands": _cpa.get_precision(), "distill_config": cfg_s}
 
 
-def ssc_extras(device, steps=5, B=8):
-    """BASELINE configs[3], second stage: one BEV-SSC training step (train_ssc.py) -- TerrainNet in training mode
-    (encoder + depth-guided splat + ResNet-18 BEV heads), the six SSC losses, backward through the splat into
-    features and depth, Adam -- batch 8 of 1216x608 -> 256x256 BEV on the HIP training kernels."""
+def _ssc_setup(device, B=8, seed=0):
+    """-> (step_fn, describe_fn, trainer): one BEV-SSC training step on `B` frames (see ssc_extras)."""
     from creste_public_amd import harness, synth
     from creste_public_amd.creste.models.terrainnet import TerrainNet
     from creste_public_amd.creste.utils.loss_utils import LossManager
@@ -324,8 +344,8 @@ def ssc_extras(device, steps=5, B=8):
     model = TerrainNet(cfg).to(device)
     synth.randomize_bn(model, seed=1)
     synth.peak_depth_head(model)                 # varied depths -> a populated BEV map (see synth.calibrate_bn_hip)
-    rgbd, p2p = synth.make_frames(B, IMG_H, IMG_W, seed=2)
-    g = torch.Generator().manual_seed(3)
+    rgbd, p2p = synth.make_frames(B, IMG_H, IMG_W, seed=2 + 100 * seed)
+    g = torch.Generator().manual_seed(3 + 100 * seed)
     G, Hs, Ws = 256, IMG_H // 4, IMG_W // 4
     data = {"image": rgbd, "p2p": p2p, "depth_label": torch.rand(B, 1, Hs, Ws, generator=g) * 26000.0,
             "fimg_label": torch.randn(B, 1, 128, Hs, Ws, generator=g),
@@ -336,17 +356,28 @@ def ssc_extras(device, steps=5, B=8):
             "fov_mask": torch.rand(B, G, G, generator=g) > 0.5, "elevation_label": torch.randn(B, 2, G, G, generator=g)}
     batch = {"joint": {k: v.to(device) for k, v in data.items()}}
     tr = harness.SSCTrainer(model, LossManager(cfg).to(device), cfg)
-    tr.training_step(batch); tr.training_step(batch); torch.cuda.synchronize()
-    ms, logs = _median_step_ms(lambda: tr.training_step(batch), steps)
-    n = sum(p.numel() for p in model.parameters() if p.grad is not None)
-    del tr, model, batch
+
+    def describe(logs):
+        n = sum(p.numel() for p in model.parameters() if p.grad is not None)
+        return (f"batch {B}, {IMG_W}x{IMG_H} -> 256x256 BEV, TerrainNet in training mode, SupPixelCon + CE + MSE + "
+                f"depth CE + depth SmoothL1 + elevation SmoothL1, {n} parameters with gradients, Adam; "
+                f"loss {float(logs['train/loss']):.3f}")
+    return (lambda: tr.training_step(batch)), describe, tr
+
+
+def ssc_extras(device, steps=5, B=8):
+    """BASELINE configs[3], second stage: one BEV-SSC training step (train_ssc.py) -- TerrainNet in training mode
+    (encoder + depth-guided splat + ResNet-18 BEV heads), the six SSC losses, backward through the splat into
+    features and depth, Adam -- batch 8 of 1216x608 -> 256x256 BEV on the HIP training kernels."""
+    step, describe, tr = _ssc_setup(device, B)
+    step(); step(); torch.cuda.synchronize()
+    ms, logs = _median_step_ms(step, steps)
+    cfg_s = describe(logs)
+    del tr, step, describe
     torch.cuda.empty_cache()
     import creste_public_amd as _cpa
     return {"ssc_train_step_ms": round(ms, 1), "ssc_frames_per_s": round(B / ms * 1e3, 1),
-            "operands": _cpa.get_precision(),
-            "ssc_config": f"batch {B}, {IMG_W}x{IMG_H} -> 256x256 BEV, TerrainNet in training mode, SupPixelCon + CE + MSE + "
-                          f"depth CE + depth SmoothL1 + elevation SmoothL1, {n} parameters with gradients, Adam; "
-                          f"loss {float(logs['train/loss']):.3f}"}
+            "operands": _cpa.get_precision(), "ssc_config": cfg_s}
 
 
 IRL_VARIANTS = {
@@ -437,6 +468,73 @@ def irl_step_bench(model_infer, device, variant, steps=5):
         creste_public_amd.set_precision(prev)
 
 
+def _irl_setup(model_infer, device, variant, seed=0):
+    """-> (step_fn, trainer): one IRL training step of `IRL_VARIANTS[variant]` through harness.IRLTrainer (manual
+    optimisation, look-ahead batch on the side stream, ONE flat gradient all-reduce: train_traversability.py:66-105)."""
+    import numpy as np
+    from creste_public_amd import LossManager, MaxEntIRL, harness, maxent_irl_cfg, synth
+    v = IRL_VARIANTS[variant]
+    B, (GH, GW) = v["B"], v["bev"]
+    cfg = maxent_irl_cfg((IMG_H, IMG_W), solve_mdp=True, map_size=v["map_size"], map_ds=v["map_ds"],
+                         point_cloud_range=v["pcr"], voxel_size=v["voxel"])
+    model = MaxEntIRL(cfg)
+    sd = {k: t for k, t in model_infer.state_dict().items() if ".cam2map." not in k or "z_proj" in k or "vision_fusion" in k}
+    model.load_state_dict(sd, strict=False)
+    with torch.no_grad():
+        model.traversability_head.r.postpool[0].norm.weight.mul_(0.01)
+        model.traversability_head.r.postpool[0].norm.bias.mul_(0.01)
+    model = model.to(device).train()
+    tr = harness.IRLTrainer(model, LossManager(cfg).to(device), cfg, graphs=True)
+    rgbd, p2p = synth.make_frames(B, IMG_H, IMG_W, seed=4242 + 100 * seed)
+    fov = torch.ones(B, max(GH, 2 * v["map_size"][0]), max(GW, 2 * v["map_size"][1]), dtype=torch.bool, device=device)
+    rng = np.random.RandomState(seed)
+    c0 = np.array([[GH / 2 - 28.0, GW / 2.0]])
+    cf = [dict(trajectories=(c0 + np.linspace(0, 1, 20)[None, :, None] *
+                             rng.uniform(-0.3 * GW, 0.3 * GW, size=(2, 1, 2))).astype(np.float32),
+               rank=np.array([0, 1])) for _ in range(B)]
+    batch = {"irl": {"image": rgbd.to(device), "p2p": p2p.to(device),
+                     "traversability_label": synth.make_experts(B, 50, (GH, GW), seed=5 + seed).to(device),
+                     "fov_mask": fov, "counterfactuals_label": cf}}
+    return (lambda: tr.training_step(batch, batch)), tr
+
+
+def train_dp_extras(model_infer, device, rank, steps=5):
+    """BASELINE configs[3] / [4]: the data-parallel training steps under the process group bench.py was launched with --
+    every rank a micro-batch of 8 frames of its own, synchronous SGD through harness.DistillTrainer / SSCTrainer /
+    IRLTrainer with the real gradient exchange (dist_utils.GradArena inside the encoder's backward, HookedArena on the
+    BEV heads, one flat all-reduce of the reward net; reference: Lightning DDP, train_pefree.py:261-288,
+    train_ssc.py:342-358, train_traversability.py:400-416).  Per leg: dist_utils.measure_dp_step."""
+    import creste_public_amd
+    from creste_public_amd import dist_utils
+    out = {"note": "per-rank micro-batch 8 x 1216x608; step_ms = max over ranks of the median step; allreduce_exposed_ms = "
+                   "step_ms - the same steps with the gradient collectives switched off (what the overlap did not hide); "
+                   "allreduce_bytes / collective_calls = payload this rank hands to RCCL per step; frames_per_s = whole job"}
+
+    def leg(name, setup):
+        torch.cuda.empty_cache()
+        objs = setup()
+        step = objs[0]
+        step(); torch.cuda.synchronize()                      # eager / graph-capturing first step
+        out[name] = dist_utils.measure_dp_step(step, steps, 8, device=device, warmup=1)
+        out[name]["operands"] = creste_public_amd.get_precision()
+        tr = objs[-1]
+        if getattr(tr, "model", None) is not None and hasattr(tr.model, "_prefetched"):
+            tr.model._prefetched = None
+        del objs, step, tr
+        torch.cuda.empty_cache()
+
+    leg("distill", lambda: _distill_setup(device, 8, seed=rank))
+    leg("ssc", lambda: _ssc_setup(device, 8, seed=rank))
+    leg("irl_reference", lambda: _irl_setup(model_infer, device, "reference", seed=rank))
+    prev = creste_public_amd.get_precision()
+    creste_public_amd.set_precision("bf16")                   # configs[4]: bf16 encoder + fp32 IRL sweep
+    try:
+        leg("irl_cf512", lambda: _irl_setup(model_infer, device, "cf512", seed=rank))
+    finally:
+        creste_public_amd.set_precision(prev)
+    return out
+
+
 def vi_kernel_bench(device, B, Hg, Wg):
     """The MDP kernels alone on r ~ U[0,1): value iteration (gamma 0.99, threshold 1e-3)."""
     from creste_public_amd import ops
@@ -499,6 +597,8 @@ def main():
     ap.add_argument("--no-irl", action="store_true", help="skip the IRL train-step timing")
     ap.add_argument("--no-modes", action="store_true", help="skip the short extra runs of the other precisions")
     ap.add_argument("--layers", default="", help="write a per-conv-shape timing table to this file")
+    ap.add_argument("--no-train-dp", action="store_true",
+                    help="under torch.distributed.run: skip the data-parallel training legs (configs[3]/[4])")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -721,6 +821,13 @@ def main():
             line["ssc"] = ssc_extras(device)
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+    train_dp = None
+    if dist is not None and not args.no_train_dp:
+        # every rank takes part (synchronous SGD); rank 0 reports
+        train_dp = train_dp_extras(model, device, rank)
+    if rank == 0:
+        if train_dp is not None:
+            line["train_dp"] = train_dp
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

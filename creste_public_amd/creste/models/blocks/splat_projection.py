@@ -98,18 +98,22 @@ class Camera2MapMulti(nn.Module):
         F = fbuf.cs - self.z_dim
         xyz, mask = ops.pixel_geometry(depth, p2p, g["bounds"], g["w1"], g["b1"], g["w2"], g["b2"],
                                        fbuf.slice(F, self.z_dim))
-        whole = Act(fbuf.buf, fbuf.cs, 0)
-        if feats_amax is not None and (ops.TRACK_AMAX or hipnn_precision() == "f16x3"):
-            whole.amax = ops.max2(feats_amax, ops.absmax(fbuf.slice(F, self.z_dim)))
-        fused = self.vision_fusion.forward_act(whole, row_mask=mask)
         gh, gw = g["grid"]
         # NC cameras per frame: views (b, s, c) are consecutive, so the reference's concatenation of the cameras'
         # points ([B*NS, NC*H*W, .], :227-234) is a reshape of the per-view buffers
         BN = xyz.shape[0]
         assert BN % self.NC == 0, f"Number of frames must be divisible by {self.NC}"
-        pts = xyz.reshape(BN // self.NC, -1, 3)
+        if self.scatter_mode not in ops.SPLAT_MODES:
+            raise Exception("Unknown splat scatter mode:", self.scatter_mode)
+        # the binning plan needs the points only: enqueued here, ahead of the fusion conv whose output the gather reads
+        plan = ops.bev_splat_plan(xyz.reshape(BN // self.NC, -1, 3), g["off"], g["vox"], gh, gw)
+        whole = Act(fbuf.buf, fbuf.cs, 0)
+        if feats_amax is not None and (ops.TRACK_AMAX or hipnn_precision() == "f16x3"):
+            whole.amax = ops.max2(feats_amax, ops.absmax(fbuf.slice(F, self.z_dim)))
+        fused = self.vision_fusion.forward_act(whole, row_mask=mask)
         fl = Act(fused.buf.view(BN // self.NC, self.NC * fused.H, fused.W, fused.cs), fused.C, fused.co, fused.amax)
-        coords, bev, dens = ops.bev_splat(pts, fl, g["off"], g["vox"], gh, gw, self.min_weight, self.scatter_mode)
+        bev, dens = ops.bev_splat_gather(plan, fl, self.min_weight, self.scatter_mode)
+        coords = plan.coords
         return dict(bev=bev, dens=dens, coords=coords, xyz=xyz, mask=mask, fused=fused, fused_in=whole)
 
     def forward(self, x):

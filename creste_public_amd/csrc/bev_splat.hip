@@ -501,17 +501,12 @@ extern "C" int64_t creste_bev_splat_workspace_bytes(int B, int P, int GH, int GW
   return (int64_t)(2 * align256((size_t)B * P * 4) + align256((size_t)B * (E + 1) * 4) + 2 * align256((size_t)B * P * 16));
 }
 
-extern "C" int creste_bev_splat_mode_f32(const float* xyz, const float* feats, int feats_cs, int B, int P,
-                                         int F, float off_x, float off_y, float vox_x, float vox_y, int GH,
-                                         int GW, float min_weight, int mode, float* coords, float* bev,
-                                         float* dens, void* work, void* stream) {
-  CRESTE_REQUIRE(xyz && feats && coords && bev && dens && work, "bev_splat: null pointer");
-  CRESTE_REQUIRE(mode == CRESTE_SPLAT_MEAN || mode == CRESTE_SPLAT_SUM || mode == CRESTE_SPLAT_MAX,
-                 "bev_splat: unknown scatter mode %d", mode);
-  CRESTE_REQUIRE(B > 0 && P > 0 && F > 0 && F % 4 == 0 && F <= 256 && feats_cs % 4 == 0 && feats_cs >= F,
-                 "bev_splat: F must be a multiple of 4 and <= 256");
-  CRESTE_REQUIRE(GH > 0 && GW > 0 && vox_x > 0.f && vox_y > 0.f, "bev_splat: bad grid");
-  CRESTE_REQUIRE((long)P * feats_cs < (1L << 31), "bev_splat: P * feature stride overflows the 32-bit point offset");
+// Binning plan of one batch of points: needs ONLY xyz (reference splat_projection.py:185-187 + the index half of :293-333),
+// so the model enqueues it right behind the pixel geometry, ahead of the 288 -> 96 fusion conv that produces the features.
+extern "C" int creste_bev_splat_plan_f32(const float* xyz, int B, int P, float off_x, float off_y, float vox_x, float vox_y,
+                                         int GH, int GW, float* coords, void* work, void* stream) {
+  CRESTE_REQUIRE(xyz && coords && work, "bev_splat_plan: null pointer");
+  CRESTE_REQUIRE(B > 0 && P > 0 && GH > 0 && GW > 0 && vox_x > 0.f && vox_y > 0.f, "bev_splat_plan: bad dims / grid");
   const int E = (GH + 1) * (GW + 1);
   const long BP = (long)B * P;
   hipStream_t s = (hipStream_t)stream;
@@ -547,6 +542,23 @@ extern "C" int creste_bev_splat_mode_f32(const float* xyz, const float* feats, i
   }
   splat_sort_rec_kernel<<<dim3((E + SORT_CELLS - 1) / SORT_CELLS, B), 256, 0, s>>>(w.offset, w.recu, w.rec, P, E);
   CRESTE_CHECK_LAUNCH("splat_sort_rec");
+  return CRESTE_OK;
+}
+
+// The gather over a plan (creste_bev_splat_plan_f32 of the same B, P, GH, GW into the same `work`): every BEV cell's F
+// channels written once (reference splat_projection.py:320-352).
+extern "C" int creste_bev_splat_gather_f32(const float* feats, int feats_cs, int B, int P, int F, int GH, int GW,
+                                           float min_weight, int mode, float* bev, float* dens, void* work, void* stream) {
+  CRESTE_REQUIRE(feats && bev && dens && work, "bev_splat_gather: null pointer");
+  CRESTE_REQUIRE(mode == CRESTE_SPLAT_MEAN || mode == CRESTE_SPLAT_SUM || mode == CRESTE_SPLAT_MAX,
+                 "bev_splat: unknown scatter mode %d", mode);
+  CRESTE_REQUIRE(B > 0 && P > 0 && F > 0 && F % 4 == 0 && F <= 256 && feats_cs % 4 == 0 && feats_cs >= F,
+                 "bev_splat: F must be a multiple of 4 and <= 256");
+  CRESTE_REQUIRE(GH > 0 && GW > 0, "bev_splat: bad grid");
+  CRESTE_REQUIRE((long)P * feats_cs < (1L << 31), "bev_splat: P * feature stride overflows the 32-bit point offset");
+  const int E = (GH + 1) * (GW + 1);
+  hipStream_t s = (hipStream_t)stream;
+  SplatWork w = carve(work, B, P, E);
   const long ncell = (long)B * GH * GW;
   const int fq = F / 4;
   if (F % 32 == 0 && F <= 128 && (long)B * GH < (1L << 30) && (feats_cs % 4) == 0) {      // row-per-workgroup fast path
@@ -588,6 +600,21 @@ extern "C" int creste_bev_splat_mode_f32(const float* xyz, const float* feats, i
 #undef CRESTE_SPLAT_GATHER
   CRESTE_CHECK_LAUNCH("splat_gather");
   return CRESTE_OK;
+}
+
+
+extern "C" int creste_bev_splat_mode_f32(const float* xyz, const float* feats, int feats_cs, int B, int P,
+                                         int F, float off_x, float off_y, float vox_x, float vox_y, int GH,
+                                         int GW, float min_weight, int mode, float* coords, float* bev,
+                                         float* dens, void* work, void* stream) {
+  CRESTE_REQUIRE(xyz && feats && coords && bev && dens && work, "bev_splat: null pointer");
+  CRESTE_REQUIRE(mode == CRESTE_SPLAT_MEAN || mode == CRESTE_SPLAT_SUM || mode == CRESTE_SPLAT_MAX,
+                 "bev_splat: unknown scatter mode %d", mode);
+  CRESTE_REQUIRE(B > 0 && P > 0 && F > 0 && F % 4 == 0 && F <= 256 && feats_cs % 4 == 0 && feats_cs >= F,
+                 "bev_splat: F must be a multiple of 4 and <= 256");
+  const int rc = creste_bev_splat_plan_f32(xyz, B, P, off_x, off_y, vox_x, vox_y, GH, GW, coords, work, stream);
+  if (rc != CRESTE_OK) return rc;
+  return creste_bev_splat_gather_f32(feats, feats_cs, B, P, F, GH, GW, min_weight, mode, bev, dens, work, stream);
 }
 
 extern "C" int creste_bev_splat_f32(const float* xyz, const float* feats, int feats_cs, int B, int P,

@@ -14,8 +14,41 @@ import torch
 import torch.distributed as dist
 
 
+_collectives_enabled = True
+STATS = {"bytes": 0, "calls": 0}      # payload bytes / calls of the gradient + feature collectives since reset_stats()
+
+
 def is_dist() -> bool:
-    return dist.is_available() and dist.is_initialized()
+    return _collectives_enabled and dist.is_available() and dist.is_initialized()
+
+
+def reset_stats():
+    STATS["bytes"], STATS["calls"] = 0, 0
+
+
+def _count(t: torch.Tensor):
+    STATS["bytes"] += t.numel() * t.element_size()
+    STATS["calls"] += 1
+
+
+class collectives:
+    """`with collectives(False):` -- every data-path collective of this module (gradient all-reduces, the contrastive
+    loss's all-gather) becomes the one-process no-op, under an initialised process group.  bench.py times a training step
+    with and without its exchange this way (the difference = the exposed, i.e. not overlapped, communication time); the
+    ranks' parameters diverge under it, so it is a measurement device only."""
+
+    def __init__(self, enabled: bool):
+        self.enabled = enabled
+
+    def __enter__(self):
+        global _collectives_enabled
+        self.prev, _collectives_enabled = _collectives_enabled, self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        global _collectives_enabled
+        _collectives_enabled = self.prev
+        return False
 
 
 def shard_range(total: int, rank: int, world: int):
@@ -25,8 +58,12 @@ def shard_range(total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _pg() -> bool:       # bench bookkeeping reduces over ranks whether or not the data-path collectives are switched off
+    return dist.is_available() and dist.is_initialized()
+
+
 def max_over_ranks(value: float, device=None) -> float:
-    if not is_dist():
+    if not _pg():
         return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -34,7 +71,7 @@ def max_over_ranks(value: float, device=None) -> float:
 
 
 def sum_over_ranks(value: float, device=None) -> float:
-    if not is_dist():
+    if not _pg():
         return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -54,9 +91,9 @@ def allreduce_mean_grads(params) -> int:
     dev, dt = params[0].device, params[0].dtype
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(dt)
                       for p in params])
-    if is_dist():
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat /= dist.get_world_size()
+    _count(flat)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
     off = 0
     for p in params:
         n = p.numel()
@@ -108,6 +145,7 @@ class GradArena(dict):
 
     def _send(self, upto):
         if upto > self.sent and is_dist():
+            _count(self.flat[self.sent:upto])
             self.handles.append(dist.all_reduce(self.flat[self.sent:upto], op=dist.ReduceOp.SUM, async_op=True))
         self.sent = max(self.sent, upto)
 
@@ -177,6 +215,7 @@ class HookedArena:
 
     def _send(self, upto):
         if upto > self.sent and is_dist():
+            _count(self.flat[self.sent:upto])
             self.handles.append(dist.all_reduce(self.flat[self.sent:upto], op=dist.ReduceOp.SUM, async_op=True))
         self.sent = max(self.sent, upto)
 
@@ -232,9 +271,52 @@ def gather_varlen(feats: torch.Tensor, labels: torch.Tensor):
     pad = n_max - feats.shape[0]
     f = torch.nn.functional.pad(feats, (0, 0, 0, pad)) if pad else feats
     l = torch.nn.functional.pad(labels, (0, pad), value=-1) if pad else labels
+    _count(f); _count(l)
     parts = all_gather_with_grad(f.contiguous())
     lab_parts = [torch.empty_like(l) for _ in range(world)]
     dist.all_gather(lab_parts, l.contiguous())
     all_feats = torch.cat([p_[:c] for p_, c in zip(parts, counts)], dim=0)
     all_labels = torch.cat([p_[:c] for p_, c in zip(lab_parts, counts)], dim=0)
     return all_feats, all_labels, sum(counts[:rank])
+
+
+def measure_dp_step(step_fn, steps: int, frames_per_rank: int, device=None, warmup: int = 1) -> dict:
+    """Bookkeeping of bench.py's data-parallel training legs: `step_fn()` = one synchronous-SGD step of THIS rank (its
+    own micro-batch; the gradient exchange inside).  Every rank times `steps` steps with the exchange and `steps` without
+    (`collectives(False)`), each as the median of per-step wall times bracketed by a device synchronisation; the job's
+    step time is the MAX over ranks.  -> step_ms, step_ms_no_collective, allreduce_exposed_ms (their difference: what the
+    overlap did not hide), allreduce_bytes / collective_calls per step (payload handed to the collectives by this rank),
+    frames_per_s = world x frames_per_rank / step_ms."""
+    import time
+    world = dist.get_world_size() if _pg() else 1
+
+    def sync():
+        if device is not None and torch.device(device).type == "cuda":
+            torch.cuda.synchronize(device)
+
+    def timed(n):
+        ts = []
+        for _ in range(n):
+            if _pg():
+                dist.barrier()
+            sync()
+            t0 = time.perf_counter()
+            step_fn()
+            sync()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        ts.sort()
+        return ts[len(ts) // 2]
+
+    for _ in range(warmup):
+        step_fn()
+    reset_stats()
+    with_ms = max_over_ranks(timed(steps), device)
+    by, calls = STATS["bytes"] // max(steps, 1), STATS["calls"] / max(steps, 1)
+    with collectives(False):
+        for _ in range(warmup):
+            step_fn()
+        without_ms = max_over_ranks(timed(steps), device)
+    return {"world": world, "step_ms": round(with_ms, 3), "step_ms_no_collective": round(without_ms, 3),
+            "allreduce_exposed_ms": round(with_ms - without_ms, 3), "allreduce_bytes": int(by),
+            "collective_calls": round(calls, 2), "frames_per_rank": frames_per_rank,
+            "frames_per_s": round(world * frames_per_rank / with_ms * 1e3, 2)}

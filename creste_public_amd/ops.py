@@ -635,29 +635,55 @@ def pixel_geometry(depth, p2p, bounds6, w1, b1, w2, b2, zfeat: Act):
 SPLAT_MODES = {"mean": 0, "sum": 1, "max": 2}
 
 
-def bev_splat(xyz, feats: Act, off_xy, vox_xy, GH, GW, min_weight=1.0, scatter_mode="mean"):
-    """xyz [B,P,3], feats Act viewed as [B,P,F] -> (coords [B,P,2], bev Act [B,GH,GW,F], dens [B,GH,GW]).
-    scatter_mode: the reference's 'mean' | 'sum' | 'max' (splat_projection.py:334-352)."""
+class SplatPlan:
+    """Binning plan of one batch of points (creste_bev_splat_plan_f32): bev_coords + the workspace the gather reads."""
+
+    def __init__(self, coords, work, B, P, GH, GW):
+        self.coords, self.work, self.B, self.P, self.GH, self.GW = coords, work, B, P, GH, GW
+
+
+def bev_splat_plan(xyz, off_xy, vox_xy, GH, GW) -> SplatPlan:
+    """xyz [B,P,3] -> SplatPlan.  Needs only the points: the model enqueues it right after `pixel_geometry`, ahead of the
+    fusion conv that produces the features (reference splat_projection.py:185-187 and the index half of :293-333)."""
+    lib = _lib.load()
+    B, P, _ = xyz.shape
+    dev = xyz.device
+    coords = torch.empty((B, P, 2), dtype=torch.float32, device=dev)
+    work = torch.empty(lib.creste_bev_splat_workspace_bytes(B, P, GH, GW), dtype=torch.uint8, device=dev)
+    _lib.check(lib.creste_bev_splat_plan_f32(_chk(xyz).data_ptr(), B, P, float(off_xy[0]), float(off_xy[1]),
+                                             float(vox_xy[0]), float(vox_xy[1]), GH, GW, coords.data_ptr(),
+                                             work.data_ptr(), _stream()), "bev_splat_plan")
+    return SplatPlan(coords, work, B, P, GH, GW)
+
+
+def bev_splat_gather(plan: SplatPlan, feats: Act, min_weight=1.0, scatter_mode="mean"):
+    """plan + feats Act viewed as [B,P,F] -> (bev Act [B,GH,GW,F], dens [B,GH,GW]); same stream as the plan."""
     lib = _lib.load()
     if scatter_mode not in SPLAT_MODES:
         raise Exception("Unknown splat scatter mode:", scatter_mode)
-    B, P, _ = xyz.shape
-    F = feats.C
-    dev = xyz.device
-    coords = torch.empty((B, P, 2), dtype=torch.float32, device=dev)
+    B, P, GH, GW, F, dev = plan.B, plan.P, plan.GH, plan.GW, feats.C, plan.coords.device
+    if feats.N * feats.H * feats.W != B * P:
+        raise HipLibraryError(f"bev_splat_gather: {feats.N * feats.H * feats.W} feature rows for a plan of {B * P} points")
     bev = Act.empty(B, GH, GW, F, dev)
     dens = torch.empty((B, GH, GW), dtype=torch.float32, device=dev)
-    work = torch.empty(lib.creste_bev_splat_workspace_bytes(B, P, GH, GW), dtype=torch.uint8, device=dev)
-    _lib.check(lib.creste_bev_splat_mode_f32(_chk(xyz).data_ptr(), feats.ptr, feats.cs, B, P, F,
-                                             float(off_xy[0]), float(off_xy[1]), float(vox_xy[0]),
-                                             float(vox_xy[1]), GH, GW, float(min_weight),
-                                             SPLAT_MODES[scatter_mode], coords.data_ptr(),
-                                             bev.ptr, dens.data_ptr(), work.data_ptr(), _stream()), "bev_splat")
+    _lib.check(lib.creste_bev_splat_gather_f32(feats.ptr, feats.cs, B, P, F, GH, GW, float(min_weight),
+                                               SPLAT_MODES[scatter_mode], bev.ptr, dens.data_ptr(), plan.work.data_ptr(),
+                                               _stream()), "bev_splat_gather")
     # |bev| <= max|feats|: 'mean' divides the tap-weighted sum by max(sum of weights, min_weight >= 1), 'max' takes
     # w * f with w <= 1 -- the consumer's operand bound needs no pass over the 25 MB/frame map
     if scatter_mode in ("mean", "max") and min_weight >= 1.0 and feats.amax is not None:
         bev.amax = feats.amax
-    return coords, bev, dens
+    return bev, dens
+
+
+def bev_splat(xyz, feats: Act, off_xy, vox_xy, GH, GW, min_weight=1.0, scatter_mode="mean"):
+    """xyz [B,P,3], feats Act viewed as [B,P,F] -> (coords [B,P,2], bev Act [B,GH,GW,F], dens [B,GH,GW]).
+    scatter_mode: the reference's 'mean' | 'sum' | 'max' (splat_projection.py:334-352).  Plan + gather back to back."""
+    if scatter_mode not in SPLAT_MODES:
+        raise Exception("Unknown splat scatter mode:", scatter_mode)
+    plan = bev_splat_plan(xyz, off_xy, vox_xy, GH, GW)
+    bev, dens = bev_splat_gather(plan, feats, min_weight, scatter_mode)
+    return plan.coords, bev, dens
 
 
 def bev_splat_bwd(coords, feats: Act, g_bev: Act, g_dens, bev: Act, dens, vox_xy, min_weight=1.0, scatter_mode="mean"):

@@ -318,6 +318,15 @@ int creste_bev_splat_mode_f32(const float* xyz, const float* feats, int feats_cs
                               float min_weight, int mode, float* coords, float* bev, float* dens, void* work,
                               void* stream);
 
+/* creste_bev_splat_mode_f32 in its two halves.  The binning PLAN (voxel coordinates, base-cell keys, CSR of the cells,
+ * per-cell records sorted by point id) depends on xyz alone (splat_projection.py:185-187 and the index half of :293-333), so
+ * the model enqueues it right after the pixel geometry, ahead of the 288 -> 96 fusion conv that produces the features; the
+ * GATHER then reads the plan from the same `work` (same B, P, GH, GW, same stream order) and writes bev / dens once. */
+int creste_bev_splat_plan_f32(const float* xyz, int B, int P, float off_x, float off_y, float vox_x, float vox_y, int GH,
+                              int GW, float* coords, void* work, void* stream);
+int creste_bev_splat_gather_f32(const float* feats, int feats_cs, int B, int P, int F, int GH, int GW, float min_weight,
+                                int mode, float* bev, float* dens, void* work, void* stream);
+
 /* Value iteration on the 8-connected grid MDP.  reference vin.py:36-46 (transition kernel),
  * :48-80 (Jacobi sweeps, hard-max backup, batch-global convergence test, final q + softmax).
  *   r [B,H,W] -> v [B,H,W], q [B,8,H,W], policy [B,8,H,W]; *sweeps_out (device int) = sweep count.

@@ -305,3 +305,65 @@ def test_two_rank_gloo_varlen_contrastive_loss_value():
         assert p.exitcode == 0
     for rank, loss, ref in res:
         assert abs(loss - ref) < 1e-5 * max(1.0, abs(ref)), (rank, loss, ref)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# bench.py's data-parallel training legs: dist_utils.measure_dp_step (with / without the exchange, max over ranks,
+# payload accounting) on the SSC stand-in, 2 ranks.
+def _dp_measure_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        from creste_public_amd import harness
+        from creste_public_amd.creste.utils.loss_utils import LossManager
+        torch.manual_seed(0)
+        model = _StandInTerrainNet()
+        cfg = _ssc_cfg()
+        tr = harness.SSCTrainer(model, LossManager(cfg), cfg)
+        batch = _ssc_batch(rank)
+        nparam = sum(p.numel() for p in model.parameters())
+        calls = []
+
+        def step():
+            torch.manual_seed(100 + rank)
+            calls.append(du.is_dist())
+            if rank == 1:
+                time.sleep(0.02)                      # the slower rank sets the job's step time
+            tr.training_step(batch)
+        res = du.measure_dp_step(step, steps=3, frames_per_rank=batch["joint"]["image"].shape[0], warmup=1)
+        # after the measurement the collectives are back on and a step re-synchronises nothing by itself: the replicas
+        # diverged under collectives(False) (documented) -- but the group still works
+        assert du.is_dist()
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        q.put((rank, res, nparam, calls, float(t)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_measure_dp_step_bookkeeping():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_measure_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, r0, nparam, calls0, s0), (_, r1, _, calls1, s1) = res
+    assert s0 == s1 == 1.0
+    # 1 warm-up + 3 timed steps with the exchange, then 1 + 3 without
+    assert calls0 == calls1 == [True] * 4 + [False] * 4
+    for r in (r0, r1):
+        assert r["world"] == 2 and r["step_ms"] >= 20.0 and r["step_ms_no_collective"] >= 20.0      # max over ranks: rank 1 sleeps
+        assert abs(r["allreduce_exposed_ms"] - (r["step_ms"] - r["step_ms_no_collective"])) < 2e-3
+        assert r["frames_per_s"] == round(2 * r["frames_per_rank"] / r["step_ms"] * 1e3, 2)
+        # payload per step: every gradient once (fp32) + the contrastive loss's padded feature / label all-gather
+        assert r["allreduce_bytes"] >= 4 * nparam and r["collective_calls"] >= 3
+    assert r0["step_ms"] == r1["step_ms"] and r0["step_ms_no_collective"] == r1["step_ms_no_collective"]
+    # one process: the same function is a plain timer
+    one = du.measure_dp_step(lambda: None, steps=2, frames_per_rank=8)
+    assert one["world"] == 1 and one["allreduce_bytes"] == 0 and one["collective_calls"] == 0
