@@ -13,6 +13,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace creste {
@@ -191,6 +193,8 @@ __global__ __launch_bounds__(VM_THREADS) void vi_multi_kernel(const float* __res
 // Tiles: 32 x 32 (+8) for the large grids (512 workgroups at 8 x 256 x 256), 16 x 16 (+8) when that leaves CUs idle
 // (256 workgroups at the reference's 8 x 64 x 128, which the tile-per-sample form ran on 8).
 constexpr int VI_MAXW = 16;        // waves per workgroup of the persistent solver (<= 1024 threads)
+constexpr unsigned VI_ABORT = 0xffffffffu;          // verdict word: a workgroup gave up waiting (launch not co-resident)
+constexpr int VI_SPIN_LIMIT = 1 << 21;              // polls (~0.1 ... 1 us each) before a waiter declares the launch stuck
 struct ViPArgs {
   const float* r;
   float* vbuf0;
@@ -211,18 +215,27 @@ struct ViPArgs {
 // side (~15 us and ~25 us per chunk).  Instead every workgroup STORES its S deltas and an arrival flag; workgroup 0
 // polls the flags (one coalesced load per pass), reduces the deltas, applies the convergence test and publishes the
 // verdict in the word everyone else polls.
+// Every wait is bounded: a waiter that has polled VI_SPIN_LIMIT times publishes VI_ABORT in the verdict word and everybody
+// leaves (-> -2; the launch was not co-resident, e.g. two solves on two streams or a graph replay next to a full-chip
+// kernel that never drains; *sweeps_out becomes INT32_MIN).  Floor of the protocol, measured with empty chunks
+// (profiles/r04_value_iteration.md): ~6 us at 256 workgroups, ~10 us at 512 -- four dependent trips to the coherence point.
 template <int S>
 __device__ __forceinline__ int vi_rendezvous(const ViPArgs& p, int chunk, float* red, int* s_first) {
   const int tid = threadIdx.x, nt = blockDim.x;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's sc1 stores have reached the coherence point
   __syncthreads();
   if (tid == 0) __hip_atomic_store(p.arrive + blockIdx.x, (unsigned)(chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool stuck = false;
   if (blockIdx.x == 0) {
-    for (;;) {
+    for (int spin = 0;; ++spin) {
       int ok = 1;
       for (int i = tid; i < p.nwg; i += nt)
         ok &= __hip_atomic_load(p.arrive + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(chunk + 1);
-      if (__syncthreads_and(ok)) break;
+      // (spin is uniform; the other waiters' abort word is looked at once per 1024 passes, by every thread alike)
+      if ((spin & 1023) == 1023 && __hip_atomic_load(p.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == VI_ABORT) ok = -1;
+      const int all = __syncthreads_and(ok == 1), any_abort = __syncthreads_or(ok < 0);
+      if (all) break;
+      if (any_abort || spin > VI_SPIN_LIMIT) { stuck = true; break; }
     }
     float m[S];
 #pragma unroll
@@ -245,21 +258,34 @@ __device__ __forceinline__ int vi_rendezvous(const ViPArgs& p, int chunk, float*
         for (int w = 0; w < (nt + 63) / 64; ++w) mm = fmaxf(mm, red[j * VI_MAXW + w]);
         if (!(mm > p.thr)) first = j;
       }
-      __hip_atomic_store(p.go, ((unsigned)(chunk + 1) << 8) | (unsigned)(first + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.go, stuck ? VI_ABORT : (((unsigned)(chunk + 1) << 8) | (unsigned)(first + 1)), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (tid == 0) {
     unsigned g;
-    while (((g = __hip_atomic_load(p.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 8) != (unsigned)(chunk + 1))
+    int spin = 0;
+    while (((g = __hip_atomic_load(p.go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 8) != (unsigned)(chunk + 1) && g != VI_ABORT) {
+      if (++spin > VI_SPIN_LIMIT) {
+        __hip_atomic_store(p.go, VI_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g = VI_ABORT;
+        break;
+      }
       __builtin_amdgcn_s_sleep(1);
-    *s_first = (int)(g & 255u) - 1;
+    }
+    *s_first = g == VI_ABORT ? -2 : (int)(g & 255u) - 1;
   }
   __syncthreads();
   return *s_first;
 }
 
+#ifdef VI_TRACE
+__device__ long long g_vi_trace[8];      // {chunks, sweeps + store, rendezvous, halo} cycles per chunk of workgroups 0 and 100
+#endif
+// (launch bounds: 6 waves per SIMD = at most 80 registers, so that two 9-wave workgroups fit a CU even when both put three
+// waves on the same SIMD -- see the residency note at the launch.)
 template <int NSTRIP>
-__global__ __launch_bounds__(NSTRIP == 1 ? 576 : 256) void vi_persist_kernel(const ViPArgs p) {
+__global__ __launch_bounds__(NSTRIP == 1 ? 576 : 256, NSTRIP == 1 ? 6 : 4) void vi_persist_kernel(const ViPArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int s_first;
   const int S = p.S, RH = p.TH + 2 * S, RW = p.TW + 2 * S, LW = RW + 8, SW = RW >> 2, nstr = RH * SW;
@@ -400,10 +426,15 @@ __global__ __launch_bounds__(NSTRIP == 1 ? 576 : 256) void vi_persist_kernel(con
 #ifdef VI_TRACE
     tC = __builtin_readcyclecounter();
     t_sw += tB - tA; t_rv += tC - tB;
-    if (first >= 0 && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
-      printf("wg %d chunks %d: sweeps+store %lld rendezvous %lld halo %lld cycles per chunk\n", (int)blockIdx.x, chunk + 1,
-             t_sw / (chunk + 1), t_rv / (chunk + 1), t_halo / (chunk + 1));
+    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {      // (no printf: its host service would wait on this
+      long long* o = g_vi_trace + (blockIdx.x ? 4 : 0);              //  spinning kernel)
+      o[0] = chunk + 1; o[1] = t_sw / (chunk + 1); o[2] = t_rv / (chunk + 1); o[3] = t_halo / (chunk + 1);
+    }
 #endif
+    if (first == -2) {                   // somebody gave up waiting: the launch is not co-resident
+      if (blockIdx.x == 0 && tid == 0) p.st->done = -1;
+      return;
+    }
     if (first >= 0) {
       // the test failed first at sweep `first` of this chunk: the answer is the chunk-start state advanced first+1 sweeps
 #pragma unroll
@@ -445,12 +476,13 @@ __global__ __launch_bounds__(256) void vi_final2_kernel(const float* __restrict_
                                                         float* __restrict__ v_out, float* __restrict__ q_out,
                                                         float* __restrict__ pi_out, int32_t* sweeps_out) {
   __shared__ float xs[TH + 2][TW + 2];
-  const bool done = st->done != 0;
+  const bool aborted = st->done < 0;          // the persistent solver gave up waiting for workgroups that never became resident
+  const bool done = st->done > 0;
   const float* v = (done ? st->final_buf : last_buf) ? buf1 : buf0;
   const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
   const long plane = (long)b * H * W;
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
-    *sweeps_out = done ? st->converged_at : -sweeps_run;
+    *sweeps_out = aborted ? INT32_MIN : (done ? st->converged_at : -sweeps_run);
   load_x_tile(xs, r + plane, v + plane, H, W, y0, x0, gamma);
   __syncthreads();
   const int lx = threadIdx.x & 63, lyb = threadIdx.x >> 6;
@@ -522,9 +554,35 @@ extern "C" int creste_value_iteration_f32(const float* r, int B, int H, int W, f
     int per_cu = 0;
     const void* fn = reinterpret_cast<const void*>(vi_persist_kernel<1>);
     CRESTE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, psmem));
+    {
+      // The occupancy query assumes the best placement of a workgroup's waves; the hardware deals them to the four SIMDs
+      // round-robin from a varying start, so ceil(waves / 4) of them can land on one SIMD for every workgroup of the CU.
+      // Size the launch with that worst case (measured: a 93-register build of this kernel, 5 waves per SIMD, query
+      // answer 2 per CU, left the second 9-wave workgroup of some CUs waiting for ever).
+      hipFuncAttributes fa;
+      CRESTE_HIP(hipFuncGetAttributes(&fa, fn));
+      const int alloc = (fa.numRegs + 7) / 8 * 8, wps = alloc > 0 ? (512 / alloc > 8 ? 8 : 512 / alloc) : 8;
+      const int wg_waves = (threads + 63) / 64, worst = wps / ((wg_waves + 3) / 4);
+      if (per_cu > worst) per_cu = worst;
+    }
     const char* force_multi = getenv("CRESTE_VI_MULTI");
     if (nwg <= (long)per_cu * cus && !(force_multi && force_multi[0] == '1')) {
       const int max_chunks = (max_sweeps + PS - 1) / PS;
+      // Two solves at once (two streams of this process) could each end up partially resident and wait for each other
+      // until the bounded spins give up: launches of the persistent solver are chained through one event per device, so
+      // the second one starts behind the first whatever stream it is on.  (Not inside a stream capture: a captured launch
+      // cannot wait on an event of another stream; graph replays rely on the bounded spin alone.)
+      static std::mutex mu;
+      static hipEvent_t chain[64] = {};
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      CRESTE_HIP(hipStreamIsCapturing(s, &cap));
+      const bool chained = cap == hipStreamCaptureStatusNone && dev < 64;
+      std::unique_lock<std::mutex> lock(mu, std::defer_lock);
+      if (chained) {
+        lock.lock();
+        if (!chain[dev]) CRESTE_HIP(hipEventCreateWithFlags(&chain[dev], hipEventDisableTiming));
+        else CRESTE_HIP(hipStreamWaitEvent(s, chain[dev], 0));
+      }
       CRESTE_HIP(hipMemsetAsync(buf0, 0, (size_t)B * H * W * 4, s));
       CRESTE_HIP(hipMemsetAsync(st, 0, sizeof(VmState) + 4u * (size_t)((nwg + 63) / 64 * 64 + 64 + 2 * nwg * PS), s));
       // rendezvous area (inside the memset above): arrival flags, the verdict word on its own line, per-workgroup deltas
@@ -536,8 +594,9 @@ extern "C" int creste_value_iteration_f32(const float* r, int B, int H, int W, f
       vi_persist_kernel<1><<<(unsigned)nwg, threads, psmem, s>>>(a);
       (void)nstrip;
       CRESTE_CHECK_LAUNCH("vi_persist");
+      if (chained) CRESTE_HIP(hipEventRecord(chain[dev], s));
       // without convergence the last chunk wrote plane max_chunks & 1; *sweeps_out < 0 reports it (the call itself stays
-      // asynchronous: a non-converged solve is a negative sweep count, not an error code)
+      // asynchronous: a non-converged solve is a negative sweep count, INT32_MIN a launch that was not co-resident)
       vi_final2_kernel<<<fgrid, 256, 0, s>>>(r, buf0, buf1, st, max_chunks & 1, max_chunks * PS, H, W, discount, v, q, policy,
                                              sweeps_out);
       CRESTE_CHECK_LAUNCH("vi_final");
@@ -578,3 +637,9 @@ extern "C" int creste_value_iteration_f32(const float* r, int B, int H, int W, f
   }
   return CRESTE_OK;
 }
+
+#ifdef VI_TRACE
+extern "C" int creste_vi_trace_read(long long* out8) {
+  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(creste::g_vi_trace), 64) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -262,3 +262,26 @@ def test_value_iteration_is_stream_asynchronous_and_graph_capturable(ops):
     # a solve that cannot converge in max_sweeps reports a negative sweep count instead of blocking the host
     v, q, pi, sw = ops.value_iteration(r, 0.99, 1e-3, max_sweeps=16)
     assert int(sw) == -16 and torch.isfinite(v).all()
+
+
+def test_value_iteration_two_streams_at_once(ops):
+    """Two solves enqueued on two streams with no dependency between them: each persistent launch needs most of the chip
+    resident, so the library chains them through a per-device event (csrc/value_iteration.hip) instead of letting both
+    end up half resident -- both must finish, with the results of solves run one after the other.  (Every device-side
+    wait is bounded as well: a launch that cannot become co-resident reports INT32_MIN sweeps instead of hanging.)"""
+    B, H, W = 8, 256, 256                      # 512 workgroups each: two of them cannot share the device
+    g = torch.Generator().manual_seed(5)
+    ra, rb = torch.rand(B, H, W, generator=g).cuda(), (torch.rand(B, H, W, generator=g) * 2.0).cuda()
+    ref_a, ref_b = ops.value_iteration(ra, 0.99, 1e-3), ops.value_iteration(rb, 0.99, 1e-3)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = {}
+    for _ in range(3):
+        with torch.cuda.stream(sa):
+            outs["a"] = ops.value_iteration(ra, 0.99, 1e-3)
+        with torch.cuda.stream(sb):
+            outs["b"] = ops.value_iteration(rb, 0.99, 1e-3)
+    sa.synchronize(); sb.synchronize()
+    for out, ref in ((outs["a"], ref_a), (outs["b"], ref_b)):
+        assert int(out[3]) == int(ref[3]) > 0
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[2], ref[2])
