@@ -44,8 +44,19 @@ class VIN(nn.Module):
         if self.w.shape[0] != 8:
             raise NotImplementedError("HIP value iteration is built for the 8-connected action set")
         v, q, pi, sweeps = ops.value_iteration(r.detach()[:, 0].contiguous().float(), discount, threshold)
-        self.last_sweeps = sweeps
+        self._last_sweeps = sweeps
         return v.unsqueeze(1), pi, q
+
+    @property
+    def last_sweeps(self):
+        """Sweep count of the last solve (device int32 tensor).  The solve is asynchronous, so a failure cannot raise where
+        it happens: it is reported in the sign (ops.value_iteration) -- reading this property is the checkpoint (one host
+        synchronisation; the trainers read it when they log, every step under CRESTE_CHECK_VI=1): a negative count
+        raises, as the reference's loop would have spun / the launch-per-chunk form returned CRESTE_ERR_NOCONV."""
+        s = getattr(self, "_last_sweeps", None)
+        if s is not None:
+            ops.check_vi_sweeps(s)
+        return s
 
     def input_view_act(self, preds: Act) -> Act:
         """cat(input_keys) -> max_pool2d(ds) -> front half rows (vin.py:104-109), one kernel pass."""

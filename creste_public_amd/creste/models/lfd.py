@@ -27,7 +27,11 @@ class MaxEntIRL(nn.Module):
     def __init__(self, model_cfg):
         super().__init__()
         # checkpoint loaders that write through `.data` do not bump tensor versions: drop derived-weight caches
-        self.register_load_state_dict_post_hook(lambda m, keys: _hipnn.invalidate_caches())
+        # ... and a frozen half prefetched with the OLD weights must not be picked up by the next forward
+        def _after_load(m, keys):
+            _hipnn.invalidate_caches()
+            m._prefetched = None
+        self.register_load_state_dict_post_hook(_after_load)
         self.model_cfg = model_cfg
         self.backbone_cfg = model_cfg["vision_backbone"]
         self.traversability_head_cfg = model_cfg["traversability_head"]
@@ -151,7 +155,13 @@ class MaxEntIRL(nn.Module):
     # runs them back to back, 24 of the 46 ms of a step at BASELINE configs[2])
     @staticmethod
     def _input_key(inputs):
-        return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in inputs[:2])
+        """(tensor, version) of image and p2p.  The TENSORS are held (and compared by identity): a key of addresses alone
+        would match a new batch that the allocator placed in a dropped batch's block."""
+        return tuple((t, t._version) for t in inputs[:2])
+
+    @staticmethod
+    def _same_inputs(key, inputs):
+        return len(key) == 2 and all(k[0] is t and k[1] == t._version for k, t in zip(key, inputs[:2]))
 
     def _frozen_half(self, image, p2p):
         head = self.traversability_head
@@ -200,7 +210,7 @@ class MaxEntIRL(nn.Module):
 
     def _take_prefetched(self, inputs):
         pf, self._prefetched = self._prefetched, None
-        if pf is None or pf[0] != self._input_key(inputs):
+        if pf is None or not self._same_inputs(pf[0], inputs):
             return None
         _, r, outputs, view, done = pf
         main = torch.cuda.current_stream(inputs[0].device)

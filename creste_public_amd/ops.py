@@ -6,6 +6,8 @@ Every wrapper validates device/dtype/contiguity and raises; nothing here compute
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from dataclasses import dataclass
 
@@ -46,7 +48,11 @@ class _AmaxPool:
 
     @classmethod
     def slot(cls, device) -> torch.Tensor:
-        key = (device.type, device.index)
+        # one block per (device, STREAM): a block is zero-filled on the stream that creates it, and its slots are raised by
+        # atomics of kernels on the stream that takes them -- a slot handed to another stream could be raised before the
+        # fill has run there (the frozen half of the IRL step runs on a side stream), and the block's memory would belong
+        # to the other stream's allocator pool
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
         blk = cls._blocks.get(key)
         if blk is None or blk[1] >= blk[0].numel():
             blk = [fill_(torch.empty(1024, dtype=torch.float32, device=device), 0.0), 0]
@@ -716,8 +722,26 @@ def depth_expectation_bwd(logits: Act, bin_values, g_depth, g_logits: Act | None
     return g_logits
 
 
+def check_vi_sweeps(sweeps: torch.Tensor) -> int:
+    """The contract of `value_iteration`'s asynchronous sweep count, checked on the host (synchronises): > 0 converged
+    after that many sweeps; -n: NOT converged within n sweeps (v / q / policy are the state after n sweeps: discount >= 1,
+    diverging rewards, max_sweeps too small); INT32_MIN: the persistent solver's workgroups were not all resident and gave
+    up waiting (another full-chip kernel or a second solve shared the device) -- the outputs are unusable."""
+    n = int(sweeps.item())
+    if n == -2 ** 31:
+        raise HipLibraryError("value_iteration: the persistent solver could not get all of its workgroups resident "
+                              "(another kernel held the device); outputs are invalid -- run the solve alone on the device "
+                              "or set CRESTE_VI_MULTI=1")
+    if n <= 0:
+        raise HipLibraryError(f"value_iteration: no convergence within {-n} sweeps (reference vin.py:68-74 would still be "
+                              "iterating): check the discount (< 1) and the reward scale")
+    return n
+
+
 def value_iteration(r: torch.Tensor, discount: float, threshold: float = 1e-3, max_sweeps: int = 100000):
-    """r [B,H,W] -> v [B,H,W], q [B,8,H,W], policy [B,8,H,W], sweeps (device int32 tensor)."""
+    """r [B,H,W] -> v [B,H,W], q [B,8,H,W], policy [B,8,H,W], sweeps (device int32 tensor).  The call is asynchronous:
+    failures are reported in the SIGN of `sweeps` (see `check_vi_sweeps`), which the caller checks off the hot path --
+    `VIN.last_sweeps` does, and every call does under CRESTE_CHECK_VI=1 (debugging: one host sync per solve)."""
     lib = _lib.load()
     B, H, W = r.shape
     dev = r.device
@@ -730,6 +754,8 @@ def value_iteration(r: torch.Tensor, discount: float, threshold: float = 1e-3, m
                                               float(threshold), int(max_sweeps), v.data_ptr(),
                                               q.data_ptr(), pi.data_ptr(), sweeps.data_ptr(),
                                               work.data_ptr(), _stream()), "value_iteration")
+    if os.environ.get("CRESTE_CHECK_VI") == "1":
+        check_vi_sweeps(sweeps)
     return v, q, pi, sweeps
 
 

@@ -243,3 +243,26 @@ def test_ssc_losses_match_reference_golden(tmp_path):
         torch.testing.assert_close(preds[k].grad, t(gk), rtol=1e-4, atol=1e-7)
     nan_ok = torch.isnan(elev_label) == torch.isnan(t("elev_label"))       # the caller's label tensor is not rewritten
     assert nan_ok.all() and torch.equal(torch.nan_to_num(elev_label), torch.nan_to_num(t("elev_label")))
+
+
+def test_value_iteration_sweep_count_contract_and_prefetch_key():
+    """Host-side contracts that need no GPU: the sign convention of the asynchronous sweep count (ops.check_vi_sweeps) and
+    the identity-based key of MaxEntIRL's prefetched frozen half (a key of addresses alone matched a NEW batch allocated in
+    a dropped batch's block)."""
+    import pytest
+    import torch
+    from creste_public_amd import ops
+    from creste_public_amd._lib import HipLibraryError
+    from creste_public_amd.creste.models.lfd import MaxEntIRL
+    assert ops.check_vi_sweeps(torch.tensor([690], dtype=torch.int32)) == 690
+    with pytest.raises(HipLibraryError, match="no convergence within 16 sweeps"):
+        ops.check_vi_sweeps(torch.tensor([-16], dtype=torch.int32))
+    with pytest.raises(HipLibraryError, match="resident"):
+        ops.check_vi_sweeps(torch.tensor([-2 ** 31], dtype=torch.int32))
+    a, p = torch.zeros(2, 3), torch.zeros(2, 4, 4)
+    key = MaxEntIRL._input_key((a, p))
+    assert MaxEntIRL._same_inputs(key, (a, p))
+    b = torch.zeros(2, 3)                          # same shape / dtype / (possibly) address, another tensor
+    assert not MaxEntIRL._same_inputs(key, (b, p))
+    a.add_(1.0)                                    # same tensor, written since the prefetch
+    assert not MaxEntIRL._same_inputs(key, (a, p))
