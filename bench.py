@@ -560,6 +560,7 @@ def irl_extras(model_infer, device, steps=5):
     for name in IRL_VARIANTS:
         out[name] = irl_step_bench(model_infer, device, name, steps)
     out["irl_train_step_ms"] = out["reference"]["train_step_ms"]
+    out["vi_8x64x128"] = vi_kernel_bench(device, 8, 64, 128)
     out["vi_8x256x256"] = vi_kernel_bench(device, 8, 256, 256)
     out["vi_8x512x512"] = vi_kernel_bench(device, 8, 512, 512)
     return out
@@ -817,6 +818,9 @@ def main():
                                    "note": "r ~ U[0,1) [8,256,256], gamma 0.99, threshold 1e-3; bytes = B*H*W*(12*sweeps + 72) "
                                            "(SURVEY 8d: the HBM-streaming figure of a sweep-per-launch solver; the state is "
                                            "LDS / L2 resident here, so the fraction may exceed 1)"}
+            vr = line["irl"]["vi_8x64x128"]
+            line["roofline_vi"]["reference_grid_8x64x128"] = {"achieved": vr["algorithmic_GBps"], "frac": vr["frac_of_hbm_peak"],
+                                                              "ms": vr["ms"], "sweeps": vr["sweeps"]}
             line["distill"] = distill_extras(device)
             line["ssc"] = ssc_extras(device)
         if args.gpus == 1 and not args.no_cpu_baseline:

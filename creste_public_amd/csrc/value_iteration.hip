@@ -469,6 +469,308 @@ __global__ __launch_bounds__(NSTRIP == 1 ? 576 : 256, NSTRIP == 1 ? 6 : 4) void 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The persistent solver WITHOUT a barrier (the default).  vi_persist_kernel above spends 43-55 % of a solve in its
+// rendezvous (profiles/r04_value_iteration.md: four dependent trips to the coherence point per chunk, ~10 us at 512
+// workgroups even with nothing to wait for).  Here nothing waits for a global decision:
+//   * after its 8 sweeps of chunk c a workgroup publishes its tile's interior as 8-byte {value, c + 1} granules
+//     (write-through 16-byte stores, two granules each) and its 8 per-sweep interior deltas as {delta, c + 1} granules;
+//   * it then polls ONLY the granules of its halo ring (its <= 8 neighbours' interiors) until they carry this chunk's
+//     tag -- the tag travels with the data, so there is no flag to order behind the payload and no fence -- and goes on
+//     with chunk c + 1 SPECULATIVELY;
+//   * the batch-global convergence test of chunk c - 1 is evaluated one chunk late, by every workgroup for itself: the
+//     loads of all workgroups' delta granules of chunk c - 1 (published at least a chunk ago) are issued before the halo
+//     polling and consumed after it, i.e. their latency hides behind the neighbour exchange.  If the test failed first at
+//     sweep j of chunk c - 1, the workgroup drops what it did since, restores the state it had at the start of chunk
+//     c - 1 (a two-deep register snapshot), redoes exactly j + 1 sweeps and writes the final values.
+// Same arithmetic, same sweep count as sweep-per-launch execution (tests: ..._persistent_equals_chunk_per_launch);
+// at most two chunks (16 of ~690 sweeps) of discarded work at the end.  The exchange planes are double-buffered by chunk
+// parity: a workgroup can only be one chunk ahead of a NEIGHBOUR (it needs the neighbour's previous chunk to proceed).
+// The delta records are read by everybody, one chunk late: a workgroup enters chunk c once all have finished the sweeps of
+// c - 2, while a slow one may still have to read the records of c - 3 -- four slots (chunk & 3).  (With two, a fast
+// workgroup overwrote a record a slow one was still polling for: found as an INT32_MIN abort at 512 workgroups.)
+// Every poll is bounded (abort word, INT32_MIN sweeps) as above.
+struct ViSArgs {
+  const float* r;
+  unsigned long long* vex;       // [2][B*H*W] {v bits, chunk + 1}: tile interiors after that chunk
+  float* vfinal;                 // [B*H*W] the answer (plain stores; read by vi_final2_kernel after the kernel boundary)
+  VmState* st;
+  unsigned* abort_word;
+  unsigned* rec;                 // [4][nwg] (chunk + 1) << 8 | bit j: the tile's interior moved by more than thr in sweep j
+  int B, H, W, TH, TW, S, tiles_x, tiles_y, nwg, max_chunks, vec;
+  float gamma, thr;
+};
+
+typedef unsigned long long vi_u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void vi_store16_sc1(void* p, vi_u64x2 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+// two 16-byte loads in flight together (32 bytes = the four granules of a strip), one wait
+__device__ __forceinline__ void vi_load32_sc1(const void* p, vi_u64x2& a, vi_u64x2& b) {
+  asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
+}
+
+// MAXT: 576 threads (32 x 32 and 16 x 16 tiles: regions of 48 x 48 / 32 x 32 cells; 6 waves per SIMD so that two such
+// workgroups fit a CU whatever the wave placement) or 960 (32 x 64 tiles, region 48 x 80: ONE workgroup per CU).
+template <int MAXT>
+__global__ __launch_bounds__(MAXT, MAXT == 576 ? 6 : 4) void vi_spec_kernel(const ViSArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ int s_flag[2];
+  constexpr int SS = 8;
+  const int S = p.S, RH = p.TH + 2 * S, RW = p.TW + 2 * S, LW = RW + 8, SW = RW >> 2, nstr = RH * SW;
+  const int plane = (RH + 2) * LW;
+  float* const xb[2] = {lds, lds + plane};
+  unsigned* const smask = reinterpret_cast<unsigned*>(lds + 2 * plane);      // [2][VI_MAXW] per-wave ORs: own chunk / everybody's
+  const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6;
+  int id = blockIdx.x;
+  const int tx = id % p.tiles_x; id /= p.tiles_x;
+  const int ty = id % p.tiles_y;
+  const int b = id / p.tiles_y;
+  const int gy0 = ty * p.TH - S, gx0 = tx * p.TW - S;
+  const long pl = (long)b * p.H * p.W, BHW = (long)p.B * p.H * p.W;
+
+  float rr[4], vv[4], s0[4], s1[4];      // s1: state at the start of the current chunk, s0: of the one before
+  int li = -1, gofs = 0;
+  unsigned inb = 0, inner = 0;           // 4-bit masks: cell inside the grid / inside this workgroup's tile
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { rr[e] = 0.f; vv[e] = 0.f; s0[e] = 0.f; s1[e] = 0.f; }
+  if (tid < nstr) {
+    const int row = tid / SW, c0 = (tid - row * SW) * 4;
+    const int gy = gy0 + row, gx = gx0 + c0;
+    li = (row + 1) * LW + 4 + c0;
+    gofs = gy * p.W + gx;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool in = (unsigned)gy < (unsigned)p.H && (unsigned)(gx + e) < (unsigned)p.W;
+      if (in) { inb |= 1u << e; rr[e] = p.r[pl + gofs + e]; }
+      if (in && row >= S && row < S + p.TH && c0 + e >= S && c0 + e < S + p.TW) inner |= 1u << e;
+    }
+  }
+  const unsigned ring = inb & ~inner;
+  const bool vec = (p.vec & 1) && inb == 15u;          // a whole strip, 32-byte aligned granules: 16-byte loads
+  // ... 16-byte stores (CRESTE_VI_VEC=3, NOT the default): a 16-byte `sc0 sc1` store is not atomic per 8-byte granule --
+  // readers on other CUs saw a fresh tag next to a stale value (160+ wrong cells after two chunks once two workgroups
+  // share a CU; 8 x 160 x 256, scripts/vi_dbg.py).  Granules are therefore published with one 8-byte atomic store each.
+  const bool vecs = (p.vec & 2) && inb == 15u;
+  for (int i = tid; i < 2 * plane; i += nt) lds[i] = 0.f;     // zero frames (and out-of-grid cells) of both planes
+  __syncthreads();
+
+  auto put_x = [&](float* dst) __attribute__((always_inline)) {
+    if (li >= 0) {
+      float4 x;
+      x.x = (inb & 1) ? __fadd_rn(rr[0], __fmul_rn(vv[0], p.gamma)) : 0.f;
+      x.y = (inb & 2) ? __fadd_rn(rr[1], __fmul_rn(vv[1], p.gamma)) : 0.f;
+      x.z = (inb & 4) ? __fadd_rn(rr[2], __fmul_rn(vv[2], p.gamma)) : 0.f;
+      x.w = (inb & 8) ? __fadd_rn(rr[3], __fmul_rn(vv[3], p.gamma)) : 0.f;
+      *reinterpret_cast<float4*>(dst + li) = x;
+    }
+  };
+  // one Jacobi sweep of the whole region: plane `src` -> registers + plane `dst`; returns this thread's interior delta
+  auto sweep = [&](const float* src, float* dst) __attribute__((always_inline)) -> float {
+    float dmax = 0.f;
+    if (li < 0) return dmax;
+    float w[3][6];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const float* row = src + li + (dy - 1) * LW;
+      const float4 c = *reinterpret_cast<const float4*>(row);
+      w[dy][0] = row[-1]; w[dy][1] = c.x; w[dy][2] = c.y; w[dy][3] = c.z; w[dy][4] = c.w; w[dy][5] = row[4];
+    }
+    float mx[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      float sacc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          sacc[e] = __fmaf_rn(kTaps[a][t].w, w[1 + kTaps[a][t].dy][e + 1 + kTaps[a][t].dx], sacc[e]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mx[e] = fmaxf(mx[e], sacc[e]);
+    }
+    float xn[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float m = mx[e];
+      if (inner & (1u << e)) dmax = fmaxf(dmax, fabsf(__fsub_rn(m, vv[e])));
+      vv[e] = m;
+      xn[e] = (inb & (1u << e)) ? __fadd_rn(rr[e], __fmul_rn(m, p.gamma)) : 0.f;
+    }
+    *reinterpret_cast<float4*>(dst + li) = make_float4(xn[0], xn[1], xn[2], xn[3]);
+    return dmax;
+  };
+  auto gran = [](float v, unsigned tag) __attribute__((always_inline)) -> unsigned long long {
+    return ((unsigned long long)tag << 32) | __float_as_uint(v);
+  };
+  auto finish = [&]() __attribute__((always_inline)) {      // the answer, plain stores (visible after the kernel boundary)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (inner & (1u << e)) p.vfinal[pl + gofs + e] = vv[e];
+  };
+
+#ifdef VI_TRACE
+  long long t_sw = 0, t_pub = 0, t_halo = 0, t_ver = 0, tA, tB, tC, tD, tE;
+  int npoll = 0;
+#endif
+  for (int chunk = 0; chunk <= p.max_chunks; ++chunk) {
+    const unsigned tag = (unsigned)(chunk + 1);
+    const bool work = chunk < p.max_chunks;
+#ifdef VI_TRACE
+    tA = __builtin_readcyclecounter();
+#endif
+    unsigned long long* const ex = p.vex + (size_t)(chunk & 1) * BHW + pl + gofs;
+    if (work) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s0[e] = s1[e]; s1[e] = vv[e]; }
+      put_x(xb[0]);
+      __syncthreads();
+      float dm[SS];
+#pragma unroll
+      for (int j = 0; j < SS; ++j) {
+        dm[j] = sweep(xb[j & 1], xb[(j + 1) & 1]);
+        __syncthreads();
+      }
+#ifdef VI_TRACE
+      tB = __builtin_readcyclecounter();
+#endif
+      // publish the interior (the neighbours' halo for chunk + 1) first, then the deltas
+      if (inner) {
+        if (vecs && inner == 15u) {
+          vi_store16_sc1(ex, vi_u64x2{gran(vv[0], tag), gran(vv[1], tag)});
+          vi_store16_sc1(ex + 2, vi_u64x2{gran(vv[2], tag), gran(vv[3], tag)});
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (inner & (1u << e)) __hip_atomic_store(ex + e, gran(vv[e], tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      // the batch-global test `max |v' - v| > thr` of sweep j is an OR over cells: one bit per sweep and workgroup
+      unsigned mask = 0;
+#pragma unroll
+      for (int j = 0; j < SS; ++j) mask |= (dm[j] > p.thr ? 1u : 0u) << j;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mask |= (unsigned)__shfl_xor((int)mask, o);
+      if ((tid & 63) == 0) smask[wave] = mask;
+      __syncthreads();
+      if (tid == 0) {
+        unsigned m = 0;
+        for (int w = 0; w < (nt + 63) / 64; ++w) m |= smask[w];
+        __hip_atomic_store(p.rec + (size_t)(chunk & 3) * p.nwg + blockIdx.x, (tag << 8) | m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+#ifdef VI_TRACE
+    tC = __builtin_readcyclecounter();
+#endif
+    // ---- the verdict words of chunk - 1, of every workgroup: loads first (they are old: one trip, hidden behind the halo polls)
+    int fail = 0;
+    const unsigned* rbase = p.rec + (size_t)((chunk - 1) & 3) * p.nwg;
+    unsigned g0 = 0;
+    const bool have_rec = chunk >= 1 && tid < p.nwg;
+    if (have_rec) g0 = __hip_atomic_load(rbase + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- halo ring <- the neighbours' interiors of this chunk
+    if (work && ring) {
+      for (int spin = 0;; ++spin) {
+        bool ok = true;
+        if (vec && ring == 15u) {
+          vi_u64x2 a, c;
+          vi_load32_sc1(ex, a, c);
+          ok = (unsigned)(a[0] >> 32) == tag && (unsigned)(a[1] >> 32) == tag && (unsigned)(c[0] >> 32) == tag &&
+               (unsigned)(c[1] >> 32) == tag;
+          if (ok) {
+            vv[0] = __uint_as_float((unsigned)a[0]); vv[1] = __uint_as_float((unsigned)a[1]);
+            vv[2] = __uint_as_float((unsigned)c[0]); vv[3] = __uint_as_float((unsigned)c[1]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (ring & (1u << e)) {
+              const unsigned long long g = __hip_atomic_load(ex + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if ((unsigned)(g >> 32) == tag) vv[e] = __uint_as_float((unsigned)g); else ok = false;
+            }
+        }
+        if (ok) break;
+        if ((spin & 255) == 255 && __hip_atomic_load(p.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { fail = 1; break; }
+        if (spin > VI_SPIN_LIMIT) {
+          __hip_atomic_store(p.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          fail = 1;
+          break;
+        }
+      }
+    }
+#ifdef VI_TRACE
+    __syncthreads();
+    tD = __builtin_readcyclecounter();
+#endif
+    // ---- verdict of chunk - 1 (every workgroup computes the same one)
+    int first = -1;
+    if (chunk >= 1) {
+      unsigned any = 0;
+      for (int i = tid; i < p.nwg; i += nt) {
+        unsigned g = g0;
+        for (int spin = 0;; ++spin) {
+          if (!(i == tid && spin == 0)) g = __hip_atomic_load(rbase + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((g >> 8) == (unsigned)chunk) break;
+          if ((spin & 255) == 255 && __hip_atomic_load(p.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { fail = 1; break; }
+          if (spin > VI_SPIN_LIMIT) {
+            __hip_atomic_store(p.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fail = 1;
+            break;
+          }
+        }
+        any |= g & 255u;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) any |= (unsigned)__shfl_xor((int)any, o);
+      if ((tid & 63) == 0) smask[VI_MAXW + wave] = any;
+    }
+    if (tid == 0) s_flag[0] = 0;
+    __syncthreads();
+    if (fail) s_flag[0] = 1;
+    if (chunk >= 1 && tid == 0) {
+      unsigned m = 0;
+      for (int w = 0; w < (nt + 63) / 64; ++w) m |= smask[VI_MAXW + w];
+      const unsigned quiet = ~m & 255u;                  // sweeps in which nobody moved by more than thr
+      s_flag[1] = quiet ? __builtin_ctz(quiet) : -1;     // the first of them ends the iteration (vin.py:68-74)
+    }
+    __syncthreads();
+#ifdef VI_TRACE
+    tE = __builtin_readcyclecounter();
+    if (work) { t_sw += tB - tA; t_pub += tC - tB; t_halo += tD - tC; t_ver += tE - tD; }
+    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && chunk >= 1) {
+      long long* o = g_vi_trace + (blockIdx.x ? 4 : 0);
+      o[0] = t_sw / chunk; o[1] = t_pub / chunk; o[2] = t_halo / chunk; o[3] = t_ver / chunk;
+    }
+#endif
+    if (s_flag[0]) {                     // somebody gave up waiting: the launch is not co-resident
+      if (blockIdx.x == 0 && tid == 0) p.st->done = -1;
+      return;
+    }
+    if (chunk >= 1) first = s_flag[1];
+    if (first >= 0) {
+      // the test failed first at sweep `first` of chunk - 1: the answer is that chunk's start state advanced first + 1 sweeps
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vv[e] = work ? s0[e] : s1[e];
+      put_x(xb[0]);
+      __syncthreads();
+      for (int j = 0; j <= first; ++j) {
+        (void)sweep(xb[j & 1], xb[(j + 1) & 1]);
+        __syncthreads();
+      }
+      finish();
+      if (blockIdx.x == 0 && tid == 0) {
+        p.st->converged_at = (chunk - 1) * S + first + 1;
+        p.st->final_buf = 0;
+        __threadfence();
+        p.st->done = chunk;
+      }
+      return;
+    }
+    __syncthreads();                     // s_flag / red are rewritten by the next chunk
+  }
+  finish();                              // no convergence within max_chunks chunks: the state after the last one
+}
+
 __global__ __launch_bounds__(256) void vi_final2_kernel(const float* __restrict__ r,
                                                         const float* __restrict__ buf0,
                                                         const float* __restrict__ buf1, const VmState* st,
@@ -517,8 +819,10 @@ static inline size_t vi_align(size_t x) { return (x + 255) / 256 * 256; }
 
 extern "C" int64_t creste_value_iteration_workspace_bytes(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return -1;
-  // two v buffers + state header + one delta word per sweep (bounded by 1<<20 sweeps, + one chunk)
-  return (int64_t)(2 * vi_align((size_t)B * H * W * 4) + vi_align(sizeof(VmState) + 4u * ((1u << 20) + 256)));
+  // two exchange buffers of 8-byte {value, tag} granules (the launch-per-chunk fallback uses the same memory as two fp32
+  // planes) + the answer + state header + one delta word per sweep (bounded by 1<<20 sweeps, + one chunk)
+  return (int64_t)(2 * vi_align((size_t)B * H * W * 8) + vi_align((size_t)B * H * W * 4) +
+                   vi_align(sizeof(VmState) + 4u * ((1u << 20) + 256)));
 }
 
 extern "C" int creste_value_iteration_f32(const float* r, int B, int H, int W, float discount,
@@ -531,7 +835,9 @@ extern "C" int creste_value_iteration_f32(const float* r, int B, int H, int W, f
   char* wp = (char*)work;
   float* buf0 = (float*)wp;
   float* buf1 = (float*)(wp + vi_align((size_t)B * H * W * 4));
-  VmState* st = (VmState*)(wp + 2 * vi_align((size_t)B * H * W * 4));
+  unsigned long long* vex = (unsigned long long*)wp;                          // [2][B*H*W] granules (barrier-free solver)
+  float* vfinal = (float*)(wp + 2 * vi_align((size_t)B * H * W * 8));
+  VmState* st = (VmState*)(wp + 2 * vi_align((size_t)B * H * W * 8) + vi_align((size_t)B * H * W * 4));
   unsigned* delta = (unsigned*)(st + 1);
 
   const dim3 fgrid((W + TW - 1) / TW, (H + TH - 1) / TH, B);
@@ -542,17 +848,24 @@ extern "C" int creste_value_iteration_f32(const float* r, int B, int H, int W, f
     int dev = 0, cus = 0;
     CRESTE_HIP(hipGetDevice(&dev));
     CRESTE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    int T = 32;
-    if ((long)B * ((H + 31) / 32) * ((W + 31) / 32) < cus) T = 16;
-    const int tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
+    const char* sync_env = getenv("CRESTE_VI_SYNC");
+    const bool spec = !(sync_env && sync_env[0] == '1');           // the barrier-free solver (default) / the rendezvous form
+    int T = 32, TWd = 32;
+    if ((long)B * ((H + 31) / 32) * ((W + 31) / 32) < cus) T = TWd = 16;
+    // more 32 x 32 tiles than CUs: two 9-wave workgroups per CU get in each other's way (a polling workgroup takes issue
+    // slots from its computing CU-mate: 8 x 256 x 256 spent 25 k of 56 k cycles per chunk waiting).  32 x 64 tiles, one
+    // 15-wave workgroup per CU, when that covers the grid: 17 % fewer halo cells as well
+    else if (spec && (long)B * ((H + 31) / 32) * ((W + 31) / 32) > cus && (long)B * ((H + 31) / 32) * ((W + 63) / 64) <= cus) TWd = 64;
+    const int tiles_x = (W + TWd - 1) / TWd, tiles_y = (H + T - 1) / T;
     const long nwg = (long)B * tiles_x * tiles_y;
-    const int RH = T + 2 * PS, RW = T + 2 * PS, nstr = RH * (RW / 4);
+    const int RH = T + 2 * PS, RW = TWd + 2 * PS, nstr = RH * (RW / 4);
     // one 1 x 4 strip per thread (576 threads for the 48 x 48 region, 256 for 32 x 32): many light waves per SIMD -- with 3
     // strips per thread and 1.5 waves per SIMD every LDS / barrier / dependent-issue latency was exposed (4.2 us per sweep)
     const int threads = nstr, nstrip = 1;
-    const size_t psmem = (size_t)(2 * (RH + 2) * (RW + 8) + PS * VI_MAXW) * sizeof(float);
+    const size_t psmem = (size_t)(2 * (RH + 2) * (RW + 8) + 2 * PS * VI_MAXW) * sizeof(float);
     int per_cu = 0;
-    const void* fn = reinterpret_cast<const void*>(vi_persist_kernel<1>);
+    const void* fn = !spec ? reinterpret_cast<const void*>(vi_persist_kernel<1>)
+                           : (threads > 576 ? reinterpret_cast<const void*>(vi_spec_kernel<960>) : reinterpret_cast<const void*>(vi_spec_kernel<576>));
     CRESTE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, psmem));
     {
       // The occupancy query assumes the best placement of a workgroup's waves; the hardware deals them to the four SIMDs
@@ -582,6 +895,24 @@ extern "C" int creste_value_iteration_f32(const float* r, int B, int H, int W, f
         lock.lock();
         if (!chain[dev]) CRESTE_HIP(hipEventCreateWithFlags(&chain[dev], hipEventDisableTiming));
         else CRESTE_HIP(hipStreamWaitEvent(s, chain[dev], 0));
+      }
+      if (spec) {
+        const long rec_words = 64 + 4 * nwg;                // abort word on its own line + [4][nwg] verdict words
+        CRESTE_REQUIRE(rec_words <= (1L << 20) && (threads >= nwg || true), "value_iteration: workspace too small for the delta records");
+        CRESTE_HIP(hipMemsetAsync(vex, 0, 2 * vi_align((size_t)B * H * W * 8), s));          // tags 0 = nothing published
+        CRESTE_HIP(hipMemsetAsync(st, 0, sizeof(VmState) + 4u * (size_t)rec_words, s));
+        const char* vec_env = getenv("CRESTE_VI_VEC");
+        const int vec = (W % 4 == 0 && T % 4 == 0 && PS % 4 == 0) ? (vec_env ? atoi(vec_env) : 1) : 0;
+        ViSArgs a{r, vex, vfinal, st, delta, delta + 64, B, H, W, T, TWd, PS, tiles_x,
+                  tiles_y, (int)nwg, max_chunks, vec, discount, threshold};
+        // second exchange plane starts B*H*W granules after the first (the kernel indexes [parity][B*H*W])
+        if (threads > 576) vi_spec_kernel<960><<<(unsigned)nwg, threads, psmem, s>>>(a);
+        else vi_spec_kernel<576><<<(unsigned)nwg, threads, psmem, s>>>(a);
+        CRESTE_CHECK_LAUNCH("vi_spec");
+        if (chained) CRESTE_HIP(hipEventRecord(chain[dev], s));
+        vi_final2_kernel<<<fgrid, 256, 0, s>>>(r, vfinal, vfinal, st, 0, max_chunks * PS, H, W, discount, v, q, policy, sweeps_out);
+        CRESTE_CHECK_LAUNCH("vi_final");
+        return CRESTE_OK;
       }
       CRESTE_HIP(hipMemsetAsync(buf0, 0, (size_t)B * H * W * 4, s));
       CRESTE_HIP(hipMemsetAsync(st, 0, sizeof(VmState) + 4u * (size_t)((nwg + 63) / 64 * 64 + 64 + 2 * nwg * PS), s));
