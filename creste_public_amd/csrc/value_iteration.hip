@@ -511,18 +511,30 @@ __device__ __forceinline__ void vi_load32_sc1(const void* p, vi_u64x2& a, vi_u64
                : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
 }
 
-// MAXT: 576 threads (32 x 32 and 16 x 16 tiles: regions of 48 x 48 / 32 x 32 cells; 6 waves per SIMD so that two such
-// workgroups fit a CU whatever the wave placement) or 960 (32 x 64 tiles, region 48 x 80: ONE workgroup per CU).
+// Thread mapping: a wave holds WHOLE rows of 1 x 4 strips (64 / SW rows; a few tail lanes idle), so a strip's left / right
+// neighbour cells are its neighbour LANES' values: they come by DPP (v_mov_b32_dpp wave_shr / wave_shl), the strip's own
+// row stays in registers from the sweep before, and a sweep touches the LDS with two 16-byte reads (rows above / below)
+// and one 16-byte write -- round 3's form read three rows as nine ds_read2_b32 (the sweeps wait on LDS latency; the VALU
+// work is free: profiles/r04_value_iteration.md).
+// MAXT: 640 threads (32 x 32 tiles: 48 x 48 region = 10 waves of 5 rows; 16 x 16: 32 x 32 = 4 waves of 8 rows) or 1024
+// (32 x 64 tiles, 48 x 80 = 16 waves of 3 rows).  ONE workgroup per CU in every case (the launch is refused otherwise: two
+// workgroups per CU only get in each other's way, see the tile choice at the launch).
+__device__ __forceinline__ float vi_lane_below(float v) {      // value of lane - 1 (0 for lane 0)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float vi_lane_above(float v) {      // value of lane + 1 (0 for lane 63)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
 template <int MAXT>
-__global__ __launch_bounds__(MAXT, MAXT == 576 ? 6 : 4) void vi_spec_kernel(const ViSArgs p) {
+__global__ __launch_bounds__(MAXT, MAXT == 640 ? 3 : 4) void vi_spec_kernel(const ViSArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int s_flag[2];
   constexpr int SS = 8;
-  const int S = p.S, RH = p.TH + 2 * S, RW = p.TW + 2 * S, LW = RW + 8, SW = RW >> 2, nstr = RH * SW;
+  const int S = p.S, RH = p.TH + 2 * S, RW = p.TW + 2 * S, LW = RW + 8, SW = RW >> 2, RPW = 64 / SW;
   const int plane = (RH + 2) * LW;
   float* const xb[2] = {lds, lds + plane};
   unsigned* const smask = reinterpret_cast<unsigned*>(lds + 2 * plane);      // [2][VI_MAXW] per-wave ORs: own chunk / everybody's
-  const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6;
+  const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63;
   int id = blockIdx.x;
   const int tx = id % p.tiles_x; id /= p.tiles_x;
   const int ty = id % p.tiles_y;
@@ -531,12 +543,15 @@ __global__ __launch_bounds__(MAXT, MAXT == 576 ? 6 : 4) void vi_spec_kernel(cons
   const long pl = (long)b * p.H * p.W, BHW = (long)p.B * p.H * p.W;
 
   float rr[4], vv[4], s0[4], s1[4];      // s1: state at the start of the current chunk, s0: of the one before
+  float own[4] = {0.f, 0.f, 0.f, 0.f};   // x = r + gamma v of this strip (what the LDS plane holds for it)
   int li = -1, gofs = 0;
   unsigned inb = 0, inner = 0;           // 4-bit masks: cell inside the grid / inside this workgroup's tile
 #pragma unroll
   for (int e = 0; e < 4; ++e) { rr[e] = 0.f; vv[e] = 0.f; s0[e] = 0.f; s1[e] = 0.f; }
-  if (tid < nstr) {
-    const int row = tid / SW, c0 = (tid - row * SW) * 4;
+  const int lrow = lane / SW, cs = lane - lrow * SW, srow = wave * RPW + lrow;
+  const bool first_cs = cs == 0, last_cs = cs == SW - 1;
+  if (lrow < RPW && srow < RH) {
+    const int row = srow, c0 = cs * 4;
     const int gy = gy0 + row, gx = gx0 + c0;
     li = (row + 1) * LW + 4 + c0;
     gofs = gy * p.W + gx;
@@ -556,26 +571,27 @@ __global__ __launch_bounds__(MAXT, MAXT == 576 ? 6 : 4) void vi_spec_kernel(cons
   for (int i = tid; i < 2 * plane; i += nt) lds[i] = 0.f;     // zero frames (and out-of-grid cells) of both planes
   __syncthreads();
 
+  const int lis = li >= 0 ? li : LW + 4;               // idle lanes read (never write) a valid slot: every lane runs the DPP
   auto put_x = [&](float* dst) __attribute__((always_inline)) {
-    if (li >= 0) {
-      float4 x;
-      x.x = (inb & 1) ? __fadd_rn(rr[0], __fmul_rn(vv[0], p.gamma)) : 0.f;
-      x.y = (inb & 2) ? __fadd_rn(rr[1], __fmul_rn(vv[1], p.gamma)) : 0.f;
-      x.z = (inb & 4) ? __fadd_rn(rr[2], __fmul_rn(vv[2], p.gamma)) : 0.f;
-      x.w = (inb & 8) ? __fadd_rn(rr[3], __fmul_rn(vv[3], p.gamma)) : 0.f;
-      *reinterpret_cast<float4*>(dst + li) = x;
-    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) own[e] = (inb & (1u << e)) ? __fadd_rn(rr[e], __fmul_rn(vv[e], p.gamma)) : 0.f;
+    if (li >= 0) *reinterpret_cast<float4*>(__builtin_assume_aligned(dst + li, 16)) = make_float4(own[0], own[1], own[2], own[3]);
   };
-  // one Jacobi sweep of the whole region: plane `src` -> registers + plane `dst`; returns this thread's interior delta
+  // one Jacobi sweep of the whole region: plane `src` -> registers + plane `dst`; returns this thread's interior delta.
+  // No lane leaves early: the neighbour lanes' values are read by DPP.
   auto sweep = [&](const float* src, float* dst) __attribute__((always_inline)) -> float {
     float dmax = 0.f;
-    if (li < 0) return dmax;
     float w[3][6];
+    const float4 up = *reinterpret_cast<const float4*>(__builtin_assume_aligned(src + lis - LW, 16));
+    const float4 dn = *reinterpret_cast<const float4*>(__builtin_assume_aligned(src + lis + LW, 16));
+    w[0][1] = up.x; w[0][2] = up.y; w[0][3] = up.z; w[0][4] = up.w;
+    w[1][1] = own[0]; w[1][2] = own[1]; w[1][3] = own[2]; w[1][4] = own[3];
+    w[2][1] = dn.x; w[2][2] = dn.y; w[2][3] = dn.z; w[2][4] = dn.w;
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
-      const float* row = src + li + (dy - 1) * LW;
-      const float4 c = *reinterpret_cast<const float4*>(row);
-      w[dy][0] = row[-1]; w[dy][1] = c.x; w[dy][2] = c.y; w[dy][3] = c.z; w[dy][4] = c.w; w[dy][5] = row[4];
+      const float l = vi_lane_below(w[dy][4]), r = vi_lane_above(w[dy][1]);
+      w[dy][0] = first_cs ? 0.f : l;          // beyond the region's edge: the zero frame
+      w[dy][5] = last_cs ? 0.f : r;
     }
     float mx[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
@@ -596,8 +612,9 @@ __global__ __launch_bounds__(MAXT, MAXT == 576 ? 6 : 4) void vi_spec_kernel(cons
       if (inner & (1u << e)) dmax = fmaxf(dmax, fabsf(__fsub_rn(m, vv[e])));
       vv[e] = m;
       xn[e] = (inb & (1u << e)) ? __fadd_rn(rr[e], __fmul_rn(m, p.gamma)) : 0.f;
+      own[e] = xn[e];
     }
-    *reinterpret_cast<float4*>(dst + li) = make_float4(xn[0], xn[1], xn[2], xn[3]);
+    if (li >= 0) *reinterpret_cast<float4*>(__builtin_assume_aligned(dst + li, 16)) = make_float4(xn[0], xn[1], xn[2], xn[3]);
     return dmax;
   };
   auto gran = [](float v, unsigned tag) __attribute__((always_inline)) -> unsigned long long {
@@ -858,14 +875,16 @@ extern "C" int creste_value_iteration_f32(const float* r, int B, int H, int W, f
     else if (spec && (long)B * ((H + 31) / 32) * ((W + 31) / 32) > cus && (long)B * ((H + 31) / 32) * ((W + 63) / 64) <= cus) TWd = 64;
     const int tiles_x = (W + TWd - 1) / TWd, tiles_y = (H + T - 1) / T;
     const long nwg = (long)B * tiles_x * tiles_y;
-    const int RH = T + 2 * PS, RW = TWd + 2 * PS, nstr = RH * (RW / 4);
+    const int RH = T + 2 * PS, RW = TWd + 2 * PS;
+    const int nstr = spec ? (RH + 64 / (RW / 4) - 1) / (64 / (RW / 4)) * 64        // whole rows of strips per wave
+                          : RH * (RW / 4);
     // one 1 x 4 strip per thread (576 threads for the 48 x 48 region, 256 for 32 x 32): many light waves per SIMD -- with 3
     // strips per thread and 1.5 waves per SIMD every LDS / barrier / dependent-issue latency was exposed (4.2 us per sweep)
     const int threads = nstr, nstrip = 1;
     const size_t psmem = (size_t)(2 * (RH + 2) * (RW + 8) + 2 * PS * VI_MAXW) * sizeof(float);
     int per_cu = 0;
     const void* fn = !spec ? reinterpret_cast<const void*>(vi_persist_kernel<1>)
-                           : (threads > 576 ? reinterpret_cast<const void*>(vi_spec_kernel<960>) : reinterpret_cast<const void*>(vi_spec_kernel<576>));
+                           : (threads > 640 ? reinterpret_cast<const void*>(vi_spec_kernel<1024>) : reinterpret_cast<const void*>(vi_spec_kernel<640>));
     CRESTE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, psmem));
     {
       // The occupancy query assumes the best placement of a workgroup's waves; the hardware deals them to the four SIMDs
@@ -877,6 +896,7 @@ extern "C" int creste_value_iteration_f32(const float* r, int B, int H, int W, f
       const int alloc = (fa.numRegs + 7) / 8 * 8, wps = alloc > 0 ? (512 / alloc > 8 ? 8 : 512 / alloc) : 8;
       const int wg_waves = (threads + 63) / 64, worst = wps / ((wg_waves + 3) / 4);
       if (per_cu > worst) per_cu = worst;
+      if (spec && per_cu > 1) per_cu = 1;          // the barrier-free solver is built and tuned for one workgroup per CU
     }
     const char* force_multi = getenv("CRESTE_VI_MULTI");
     if (nwg <= (long)per_cu * cus && !(force_multi && force_multi[0] == '1')) {
@@ -906,8 +926,8 @@ extern "C" int creste_value_iteration_f32(const float* r, int B, int H, int W, f
         ViSArgs a{r, vex, vfinal, st, delta, delta + 64, B, H, W, T, TWd, PS, tiles_x,
                   tiles_y, (int)nwg, max_chunks, vec, discount, threshold};
         // second exchange plane starts B*H*W granules after the first (the kernel indexes [parity][B*H*W])
-        if (threads > 576) vi_spec_kernel<960><<<(unsigned)nwg, threads, psmem, s>>>(a);
-        else vi_spec_kernel<576><<<(unsigned)nwg, threads, psmem, s>>>(a);
+        if (threads > 640) vi_spec_kernel<1024><<<(unsigned)nwg, threads, psmem, s>>>(a);
+        else vi_spec_kernel<640><<<(unsigned)nwg, threads, psmem, s>>>(a);
         CRESTE_CHECK_LAUNCH("vi_spec");
         if (chained) CRESTE_HIP(hipEventRecord(chain[dev], s));
         vi_final2_kernel<<<fgrid, 256, 0, s>>>(r, vfinal, vfinal, st, 0, max_chunks * PS, H, W, discount, v, q, policy, sweeps_out);

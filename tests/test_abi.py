@@ -115,10 +115,9 @@ def test_hot_kernels_stay_out_of_scratch():
         "conv_patch_row_kernelILi7E": 48,
         "wgrad_rows_kernelILi5ELi25E": 40,            # 100 accumulators at 3 waves/SIMD: the row-prefetch registers spill
                                                       # around the matrix loop (3 scratch ops per row, none inside it)
-        # the persistent MDP solvers are built for 6 waves per SIMD (80 registers) so that two 9-wave workgroups fit a CU
-        # under any wave placement (csrc/value_iteration.hip); what spills sits at the chunk head / in the redo path, the
-        # eight sweeps between the barriers are scratch-free (checked in the ISA)
-        "vi_spec_kernelILi576E": 16,
+        # the rendezvous form of the persistent MDP solver (CRESTE_VI_SYNC=1) is built for 6 waves per SIMD (80 registers) so
+        # that two 9-wave workgroups fit a CU under any wave placement (csrc/value_iteration.hip); what spills sits at the
+        # chunk head / in the redo path, the eight sweeps between the barriers are scratch-free (checked in the ISA)
         "vi_persist_kernelILi1E": 12,
     }
     bad = []

@@ -533,6 +533,26 @@ def test_pixel_geometry_and_splat(ops, golden, name):
     torch.testing.assert_close(bev.buf.abs().sum().cpu(), g.t("bev_features_abs_sum"), rtol=1e-5, atol=0)
 
 
+def test_splat_plan_is_reusable_and_independent_of_the_features(ops, golden):
+    """creste_bev_splat_plan_f32 needs only the points (the model enqueues it ahead of the fusion conv): ONE plan serves
+    any number of gathers, each equal to the one-call splat of the same features, bit for bit, in every scatter mode."""
+    g, sd = _splat_inputs(golden, "splat_wide.npz")
+    xyz = dev(g.t("xyz")[:, 0].permute(0, 2, 3, 1).reshape(g.t("xyz").shape[0], -1, 3).contiguous())
+    off, vox = (12.8, 12.8), (np.float32(0.1), np.float32(0.1))
+    plan = ops.bev_splat_plan(xyz, off, vox, 256, 256)
+    assert torch.equal(plan.coords.cpu(), g.t("bev_coords"))
+    gen = torch.Generator().manual_seed(9)
+    fa = to_act(ops, (g.t("fused") * g.t("mask"))[:, 0])
+    fb = to_act(ops, torch.randn(g.t("fused")[:, 0].shape, generator=gen))
+    for feats in (fa, fb, fa):
+        for mode in ("mean", "sum", "max"):
+            bev, dens = ops.bev_splat_gather(plan, feats, 1.0, mode)
+            c1, b1, d1 = ops.bev_splat(xyz, feats, off, vox, 256, 256, 1.0, mode)
+            assert torch.equal(bev.buf, b1.buf) and torch.equal(dens, d1) and torch.equal(plan.coords, c1)
+    with pytest.raises(Exception):
+        ops.bev_splat_gather(plan, to_act(ops, torch.randn(1, 96, 3, 5)), 1.0, "mean")      # rows != points of the plan
+
+
 @pytest.mark.parametrize("name", ["vi_a.npz", "vi_b.npz"])
 def test_value_iteration(ops, golden, name):
     g = golden(name)

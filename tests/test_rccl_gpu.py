@@ -149,6 +149,17 @@ def _child(port, q):
             say(f"{kind} step under nccl: loss {float(logs['train/loss']):.6f} (stand-alone {ref_loss:.6f}), max |param "
                 f"difference| {res[kind][0]:.3e}" + (f", {launched} bucket all-reduces during the backward" if launched is not None else ""))
             del m, tr
+        # --- bench.py's data-parallel leg bookkeeping on a real step under the group (dist_utils.measure_dp_step)
+        m, tr = distill(3)
+        torch.manual_seed(50)
+        rec = dist_utils.measure_dp_step(lambda: tr.training_step(batches["distill"]), steps=2, frames_per_rank=2,
+                                         device=torch.device("cuda", 0), warmup=1)
+        nparam = sum(p.numel() for p in m.parameters())
+        res["dp_leg"] = rec
+        res["dp_leg_ok"] = bool(rec["world"] == 1 and 0 < rec["allreduce_bytes"] <= 4 * nparam and rec["collective_calls"] >= 1 and
+                                rec["step_ms"] > 0 and rec["step_ms_no_collective"] > 0 and dist_utils.is_dist())
+        say(f"measure_dp_step (distillation step): {rec}")
+        del m, tr
         dist.barrier()
         dist.destroy_process_group()
         say("process group destroyed cleanly")
@@ -171,6 +182,7 @@ def test_rccl_one_rank_runs_every_collective_call_site():
         f.write(log + ("" if status == "ok" else "\nFAILED: " + str(res)))
     assert status == "ok", res
     assert p.exitcode == 0
+    assert res["dp_leg_ok"], res["dp_leg"]
     assert res["grad_arena_ok"] and res["grad_arena_async_buckets"] >= 1
     assert res["hooked_arena_ok"] and res["hooked_arena_async_buckets"] >= 1
     assert res["gather_varlen_ok"] and res["flat_allreduce_ok"] and res["max_over_ranks"] == 1.25
