@@ -26,6 +26,14 @@ SOURCES = ["error.cpp", "plan_runtime.cpp", "conv_igemm.hip", "conv_patch.hip", 
 EXTRA_FLAGS = {"conv_wino.hip": ["-fno-slp-vectorize"], "conv_wino4.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}",
          "-Wall", "-Wno-unused-function"]
+# NO packed-fp32 VALU anywhere (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): on gfx950 a wave's packed-fp32 result is
+# occasionally WRONG -- one component of 16 consecutive lanes of one instruction -- while waves of ANOTHER kernel issue MFMAs
+# on the same CU (found when the inference forward started to run two half-batches on two streams: the fused MBConv kernels
+# beside the 1x1 conv kernel, 3-8 corrupted steps of 12; none of 120 with scalar v_fma_f32; scripts/concurrency_bisect.py,
+# profiles/r04_pipeline_notes.md).  One stream never shows it (kernels of one stream do not share a CU), any second stream
+# can (pipelined inference, the IRL step's prefetch of the frozen half).  Speed: neutral (39.8 -> 39.4 ms for the step).
+NO_PK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+FLAGS += NO_PK
 
 
 def _hipcc() -> str:
@@ -56,7 +64,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 print("[creste build]", " ".join(cmd), flush=True)
             r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
             remarks = [ln for ln in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" in ln]
-            other = [ln for ln in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in ln]
+            other = [ln for ln in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in ln
+                     and "is not a recognized feature for this target" not in ln]     # (the host half ignores NO_PK)
             if r.returncode or any("warning:" in ln or "error:" in ln for ln in other):   # (else: the remarks' source context)
                 print("\n".join(other), file=sys.stderr, flush=True)
             if r.returncode:

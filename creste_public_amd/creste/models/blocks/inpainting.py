@@ -93,7 +93,8 @@ class DeconvHead(nn.Module):
         c3, proj = self._units()
         sf, (rh, rw) = up_scales(self.up2[0].scale_factor)
         Ho, Wo = up_out_size(h.H, h.W, sf)
-        feat = c3(ops.upsample_concat_lazy(h, None, Ho, Wo, rh, rw))
+        with ops.shared_rows():
+            feat = c3(ops.upsample_concat_lazy(h, None, Ho, Wo, rh, rw))
         return proj(feat, out=pred_out), feat
 
     def from_concat_act(self, cat: Act, pred_out: Act = None):

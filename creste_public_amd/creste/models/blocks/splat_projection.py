@@ -106,13 +106,15 @@ class Camera2MapMulti(nn.Module):
         if self.scatter_mode not in ops.SPLAT_MODES:
             raise Exception("Unknown splat scatter mode:", self.scatter_mode)
         # the binning plan needs the points only: enqueued here, ahead of the fusion conv whose output the gather reads
-        plan = ops.bev_splat_plan(xyz.reshape(BN // self.NC, -1, 3), g["off"], g["vox"], gh, gw)
+        with ops.shared_rows():
+            plan = ops.bev_splat_plan(xyz.reshape(BN // self.NC, -1, 3), g["off"], g["vox"], gh, gw)
         whole = Act(fbuf.buf, fbuf.cs, 0)
         if feats_amax is not None and (ops.TRACK_AMAX or hipnn_precision() == "f16x3"):
             whole.amax = ops.max2(feats_amax, ops.absmax(fbuf.slice(F, self.z_dim)))
         fused = self.vision_fusion.forward_act(whole, row_mask=mask)
         fl = Act(fused.buf.view(BN // self.NC, self.NC * fused.H, fused.W, fused.cs), fused.C, fused.co, fused.amax)
-        bev, dens = ops.bev_splat_gather(plan, fl, self.min_weight, self.scatter_mode)
+        with ops.shared_rows():
+            bev, dens = ops.bev_splat_gather(plan, fl, self.min_weight, self.scatter_mode)
         coords = plan.coords
         return dict(bev=bev, dens=dens, coords=coords, xyz=xyz, mask=mask, fused=fused, fused_in=whole)
 

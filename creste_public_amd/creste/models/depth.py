@@ -43,13 +43,15 @@ class DepthCompletion(nn.Module):
         if d["mode"] != "UD":
             raise NotImplementedError("softmax-expectation depth uses uniform bins (mode 'UD')")
         if self._bins is None or self._bins.device != device:
+            ops.note_cache_build()
             self._bins = torch.linspace(d["depth_min"], d["depth_max"], d["num_bins"], device=device)
         return self._bins
 
     def forward_act(self, x: Act, feats_out: Act = None):
         feats = self.vision_backbone.forward_act(x, out=feats_out)
-        logits = self.depth_head.forward_act(feats)
-        depth, bins = ops.depth_expectation(logits, self._bin_values(x.buf.device))
+        with ops.shared_rows():
+            logits = self.depth_head.forward_act(feats)
+            depth, bins = ops.depth_expectation(logits, self._bin_values(x.buf.device))
         return dict(logits=logits, depth=depth, bins=bins, feats=feats)
 
     def _pack_outputs(self, r):

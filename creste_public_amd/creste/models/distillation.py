@@ -62,7 +62,8 @@ class DistillationBackbone(nn.Module):
 
     def forward_act(self, x: Act, feats_out: Act = None):
         r = self.depthcomp.forward_act(x, feats_out=feats_out)
-        r["dino"] = self.dino_head.forward_act(r["feats"])
+        with ops.shared_rows():
+            r["dino"] = self.dino_head.forward_act(r["feats"])
         return r
 
     def pack_outputs(self, r, B):

@@ -78,6 +78,7 @@ class MaxEntIRL(nn.Module):
         self.backbone.eval()
         self._fov_u8 = None
         self._side_stream, self._prefetched = None, None
+        self._part_streams, self._parts_warm = [], False
         if self.weights_path and os.path.isfile(self.weights_path) and not os.path.isfile(self.ckpt_path or ""):
             self.load_weights(self.weights_path)
 
@@ -183,7 +184,73 @@ class MaxEntIRL(nn.Module):
                                           "quads (NHWC rows of 16 bytes)")
             src = ops.nchw_to_nhwc(cat)
         r["iv_hw"] = (src.H, src.W)
-        return r, outputs, head.input_view_act(src)
+        with ops.shared_rows():
+            view = head.input_view_act(src)
+        return r, outputs, view
+
+    # ---- pipelined inference.  The frozen half of an eval forward is 46 % matrix-bound GEMM kernels (persistent, one
+    # workgroup per CU) and 40 % bandwidth-bound transform / elementwise kernels that alternate on ONE stream.  Run as
+    # `inference_parts` forwards of B / parts frames on as many streams, issued one after the other by this thread, part
+    # k + 1 trails part k by the host's issue time and its bandwidth-bound kernels fill in beside / between the other
+    # part's GEMMs (measured: batch 16, 39.8 -> 37.9 ms with two parts; four parts lose, profiles/r04_pipeline_notes.md).
+    # Each part is exactly `_frozen_half` of its frames (bit-identical to calling the model on those frames); the parts
+    # write their rows of shared whole-batch output buffers (ops.PartContext), nothing is concatenated.
+    inference_parts = 2            # 0 / 1: off
+    inference_part_rows = 4        # smallest part worth a stream of its own
+
+    def _parts_for(self, B):
+        from ... import _lib
+        n = int(self.inference_parts or 1)
+        if (n < 2 or torch.is_grad_enabled() or _lib._recorder is not None or B % n or B // n < self.inference_part_rows
+                or os.environ.get("CRESTE_INFER_PARTS", "") in ("0", "1")):
+            return 1                                   # (the plan recorder of deploy.export_plan traces ONE stream)
+        return n
+
+    def _frozen_parts(self, image, p2p, parts):
+        dev = image.device
+        main = torch.cuda.current_stream(dev)
+        if len(self._part_streams) < parts - 1 or any(s.device != dev for s in self._part_streams):
+            self._part_streams = [torch.cuda.Stream(device=dev) for _ in range(parts - 1)]
+        n = image.shape[0] // parts
+        fork = torch.cuda.Event()
+        fork.record(main)                              # the inputs are ready once a stream gets here
+        ctx, res = ops.PartContext(parts), []
+        prev, ops._PART.ctx = ops._PART.ctx, ctx
+        builds = ops.CACHE_BUILDS
+        try:
+            for i in range(parts):
+                st = main if i == 0 else self._part_streams[i - 1]
+                ctx.begin(i)
+                if i:
+                    st.wait_event(fork)
+                with torch.cuda.stream(st):
+                    res.append(self._frozen_half(image[i * n:(i + 1) * n], p2p[i * n:(i + 1) * n]))
+                if i == 0 and (ops.CACHE_BUILDS != builds or not self._parts_warm):
+                    # part 0 (re)built caches -- packed weights, folded BatchNorm, constants -- by launches on ITS stream (always
+                    # assumed of a model's first pipelined forward): the other parts read them only behind part 0
+                    fork = torch.cuda.Event()
+                    fork.record(main)
+                    self._parts_warm = True
+            ctx.begin(parts)                           # (checks that the last part took every shared buffer)
+        finally:
+            ops._PART.ctx = prev
+        for st in self._part_streams[:parts - 1]:
+            main.wait_stream(st)
+
+        def cat(ts):                                   # an output that no shared buffer holds (none in the shipped configs)
+            for t in ts[1:]:
+                t.record_stream(main)
+            return torch.cat(ts)
+        r0, out0, view0 = res[0]
+        outputs = {}
+        for k, v in out0.items():
+            w = ctx.whole(v)
+            outputs[k] = w if w is not None else cat([r[1][k] for r in res])
+        view = ctx.whole_act(view0)
+        if view is None:
+            view = ops.Act(cat([r[2].buf for r in res]), view0.C, view0.co)
+        r = {"iv_hw": r0["iv_hw"], "parts": [x[0] for x in res]}
+        return r, outputs, view
 
     def prefetch_backbone(self, inputs):
         """Enqueue the frozen half of `forward(inputs)` on a side stream; the next `forward` with the SAME input tensors
@@ -240,7 +307,10 @@ class MaxEntIRL(nn.Module):
         require_hip(image, "MaxEntIRL")
         B = image.shape[0]
         got = self._take_prefetched(inputs)
-        return self._forward_trainable(inputs, got if got is not None else self._frozen_half(image, p2p))
+        if got is None:
+            parts = self._parts_for(B)
+            got = self._frozen_parts(image, p2p, parts) if parts > 1 else self._frozen_half(image, p2p)
+        return self._forward_trainable(inputs, got)
 
     def _forward_trainable(self, inputs, frozen):
         """the rest of `forward` given the frozen half's results (r, outputs, view)"""

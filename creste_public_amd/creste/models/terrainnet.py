@@ -128,7 +128,8 @@ class TerrainNet(nn.Module):
         ds = self.vision_cfg["effnet_cfgs"]["downsample"]
         F = self.vision_cfg["effnet_cfgs"]["out_channels"]
         assert H % ds == 0 and W % ds == 0, "image size must be a multiple of the encoder downsample"
-        fbuf = self.cam2map.fusion_buffer(B * N, H // ds, W // ds, F, rgbd.device)
+        with ops.shared_rows():                  # outputs (`depth_preds_feats`, the heads' predictions): see ops.PartContext
+            fbuf = self.cam2map.fusion_buffer(B * N, H // ds, W // ds, F, rgbd.device)
         fslice = fbuf.slice(0, F)                # the encoder's last conv leaves max|features| on this slice
         r = self.depthcomp.forward_act(x, feats_out=fslice)
         sp = self.cam2map.forward_act(r["depth"], fbuf, p2p.reshape(B * N, 4, 4).contiguous().float(),
@@ -136,8 +137,9 @@ class TerrainNet(nn.Module):
         r.update(sp)
         if self.bevclassifier is not None:
             nc = self.bevclassifier.num_classes
-            pb = Act.empty(B, sp["bev"].H, sp["bev"].W, sum(nc), rgbd.device) \
-                if preds_buf_channels is None else preds_buf_channels
+            with ops.shared_rows():
+                pb = Act.empty(B, sp["bev"].H, sp["bev"].W, sum(nc), rgbd.device) \
+                    if preds_buf_channels is None else preds_buf_channels
             r["heads"] = self.bevclassifier.forward_act(sp["bev"], preds_buf=pb)
             r["preds_buf"] = pb
         return r

@@ -834,6 +834,30 @@ static int launch_wino4_gemm(const Wino4GemmArgs& a, hipStream_t s) {
   return CRESTE_OK;
 }
 
+// experiment knobs (scripts/wino_overlap_micro.py, profiles/r04_pipeline_notes.md): CRESTE_W4_GEMM_WGS = persistent GEMM
+// workgroups per XCD (default: one per CU), CRESTE_W4_CHAIN = 1 runs the GEMM kernels of ALL streams of a device in host
+// issue order (one event per device)
+static int w4_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+static hipEvent_t g_w4_chain_ev[16] = {};
+static int w4_chain_wait(hipStream_t s) {
+  if (!w4_env_int("CRESTE_W4_CHAIN", 0)) return CRESTE_OK;
+  int dev = 0;
+  CRESTE_HIP(hipGetDevice(&dev));
+  if (g_w4_chain_ev[dev & 15]) CRESTE_HIP(hipStreamWaitEvent(s, g_w4_chain_ev[dev & 15], 0));
+  return CRESTE_OK;
+}
+static int w4_chain_record(hipStream_t s) {
+  if (!w4_env_int("CRESTE_W4_CHAIN", 0)) return CRESTE_OK;
+  int dev = 0;
+  CRESTE_HIP(hipGetDevice(&dev));
+  if (!g_w4_chain_ev[dev & 15]) CRESTE_HIP(hipEventCreateWithFlags(&g_w4_chain_ev[dev & 15], hipEventDisableTiming));
+  CRESTE_HIP(hipEventRecord(g_w4_chain_ev[dev & 15], s));
+  return CRESTE_OK;
+}
+
 template <int SPLIT, int TN>
 static int launch_wino4_gemm32(const Wino4GemmArgs& a, hipStream_t s) {
   constexpr int smem = 3 * (4 * W4_M * 16 + TN * SPLIT * 2 * 64 * 16);
@@ -845,11 +869,14 @@ static int launch_wino4_gemm32(const Wino4GemmArgs& a, hipStream_t s) {
   CRESTE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const long items = (long)a.m_blocks * a.npos * a.tiles_n;
   long per_xcd = cus / 8 > 0 ? cus / 8 : 1;
+  const int lim = w4_env_int("CRESTE_W4_GEMM_WGS", 0);
+  if (lim > 0 && lim < per_xcd) per_xcd = lim;
   const long need = (items + 7) / 8;
   if (per_xcd > need) per_xcd = need;
+  { const int rc = w4_chain_wait(s); if (rc != CRESTE_OK) return rc; }
   wino4_gemm32_kernel<SPLIT, TN><<<(unsigned)(per_xcd * 8), 512, smem, s>>>(a);
   CRESTE_CHECK_LAUNCH("wino4_gemm32");
-  return CRESTE_OK;
+  return w4_chain_record(s);
 }
 
 int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {

@@ -144,6 +144,7 @@ class Cached:
             for t in src:
                 if t is not None:
                     require_hip(t, "parameter")
+            ops.note_cache_build()
             self._val, self._key = self.build(), key
         return self._val
 

@@ -7,6 +7,7 @@ Every wrapper validates device/dtype/contiguity and raises; nothing here compute
 from __future__ import annotations
 
 import os
+import threading
 
 import ctypes as C
 from dataclasses import dataclass
@@ -25,6 +26,16 @@ TRACK_AMAX = False
 # Bumped by hipnn.invalidate_caches(): part of the key of every cache of tensors derived from module parameters
 # (packed / flipped weights, folded BatchNorm), for updates that do not bump `tensor._version` (writes through `.data`).
 CACHE_EPOCH = 0
+
+# Counts the (re)builds of such caches (packed weights, folded BatchNorm, geometry constants ...).  A cache is filled by
+# launches on the stream of whoever misses first; a pipelined forward (MaxEntIRL._frozen_parts) whose part 0 built anything
+# makes the later parts' streams wait for part 0 before they read it.
+CACHE_BUILDS = 0
+
+
+def note_cache_build():
+    global CACHE_BUILDS
+    CACHE_BUILDS += 1
 
 
 def _stream() -> int:
@@ -85,6 +96,78 @@ def reset_amax_pool():
     _AmaxPool._blocks.clear()
 
 
+# ---- pipelined inference: one batch as PARTS forwards on PARTS streams (creste/models/lfd.py: MaxEntIRL._frozen_parts)
+# Inside `shared_rows()` regions of such a forward, every buffer with the batch as its leading dimension is rows
+# [i * n, (i + 1) * n) of ONE buffer of parts * n rows that all parts write: the k-th such allocation of part i is the k-th of
+# part 0 (same code path, same shapes), so the whole-batch outputs exist without a concatenation (4.6 GB at batch 16).
+class PartContext:
+    def __init__(self, parts: int):
+        self.parts, self.index, self.pos, self.depth = int(parts), 0, 0, 0
+        self.log = []                       # the shared buffers in allocation order (allocated by part 0 on ITS stream)
+        self.storages = set()
+
+    def begin(self, index: int):
+        if index and self.pos not in (0, len(self.log)):
+            raise HipLibraryError("pipelined forward: a part made fewer shared allocations than part 0")
+        self.index, self.pos = index, 0
+
+    def whole(self, t: torch.Tensor):
+        """part 0's view [n, ...] of a shared buffer -> the view of all parts * n rows (None if `t` is not such a view)."""
+        if (not torch.is_tensor(t) or not t.is_cuda or t.dim() == 0
+                or t.untyped_storage().data_ptr() not in self.storages or t.stride(0) == 0):
+            return None
+        return torch.as_strided(t, (t.shape[0] * self.parts,) + tuple(t.shape[1:]), t.stride(), t.storage_offset())
+
+    def whole_act(self, a):
+        b = self.whole(a.buf)
+        return None if b is None else Act(b, a.C, a.co)
+
+
+class _PartState(threading.local):
+    ctx = None
+
+
+_PART = _PartState()
+
+
+class shared_rows:
+    """`with shared_rows():` -- batch-leading buffers allocated inside come from the parts' shared whole-batch buffers when a
+    pipelined forward is running (no effect otherwise).  Put around the producers of a forward's OUTPUTS."""
+
+    def __enter__(self):
+        if _PART.ctx is not None:
+            _PART.ctx.depth += 1
+
+    def __exit__(self, *exc):
+        if _PART.ctx is not None:
+            _PART.ctx.depth -= 1
+        return False
+
+
+def rows_empty(shape, dtype, device) -> torch.Tensor:
+    """torch.empty(shape) whose dim 0 is the batch; inside a `shared_rows()` region of a pipelined forward: this part's rows
+    of the shared whole-batch buffer."""
+    c = _PART.ctx
+    if c is None or c.depth == 0:
+        return torch.empty(shape, dtype=dtype, device=device)
+    n = int(shape[0])
+    full_shape = (n * c.parts,) + tuple(int(v) for v in shape[1:])
+    if c.index == 0:
+        full = torch.empty(full_shape, dtype=dtype, device=device)
+        c.log.append(full)
+        c.storages.add(full.untyped_storage().data_ptr())
+    else:
+        if c.pos >= len(c.log):
+            raise HipLibraryError("pipelined forward: a part made more shared allocations than part 0")
+        full = c.log[c.pos]
+        if tuple(full.shape) != full_shape or full.dtype != dtype:
+            raise HipLibraryError(f"pipelined forward: shared allocation {c.pos} is {tuple(full.shape)} {full.dtype} in part 0 "
+                                  f"and {full_shape} {dtype} in part {c.index}")
+        full.record_stream(torch.cuda.current_stream(full.device))     # allocated on part 0's stream, written on this one
+    c.pos += 1
+    return full[c.index * n:(c.index + 1) * n]
+
+
 @dataclass
 class Act:
     buf: torch.Tensor      # [N,H,W,cs] contiguous fp32
@@ -105,7 +188,7 @@ class Act:
 
     @staticmethod
     def empty(N, H, W, C, device, cs=None):
-        return Act(torch.empty((N, H, W, cs or C), dtype=torch.float32, device=device), C, 0)
+        return Act(rows_empty((N, H, W, cs or C), torch.float32, device), C, 0)
 
     def slice(self, co, C):
         assert co + C <= self.cs
@@ -228,6 +311,7 @@ def pack_conv(weight: torch.Tensor, bias, bn, stride, pad, act, prec=PREC_F32, a
     """weight OIHW (CUDA fp32); bn = None or (gamma, beta, mean, var, eps) -> folded eval-mode BN.
     pad = int | (pad_t, pad_b, pad_l, pad_r).  algo: None = the policy of `conv_algo`, or ALGO_DIRECT / ALGO_WINOGRAD."""
     lib = _lib.load()
+    note_cache_build()
     w = _chk(weight.detach().contiguous(), name="conv weight")
     Cout, Cin, KH, KW = w.shape
     scale = None
@@ -614,8 +698,8 @@ def lidar_pixels_to_depth(points: torch.Tensor, lidar2cam: torch.Tensor, H: int,
 def depth_expectation(logits: Act, bin_values: torch.Tensor):
     lib = _lib.load()
     P = logits.N * logits.H * logits.W
-    depth = torch.empty((logits.N, logits.H, logits.W), dtype=torch.float32, device=logits.buf.device)
-    bins = torch.empty((logits.N, logits.H, logits.W), dtype=torch.int64, device=logits.buf.device)
+    depth = rows_empty((logits.N, logits.H, logits.W), torch.float32, logits.buf.device)
+    bins = rows_empty((logits.N, logits.H, logits.W), torch.int64, logits.buf.device)
     _lib.check(lib.creste_depth_expectation_f32(logits.ptr, logits.cs, P, logits.C,
                                                 _chk(bin_values).data_ptr(), depth.data_ptr(),
                                                 bins.data_ptr(), _stream()), "depth_expectation")
@@ -654,7 +738,7 @@ def bev_splat_plan(xyz, off_xy, vox_xy, GH, GW) -> SplatPlan:
     lib = _lib.load()
     B, P, _ = xyz.shape
     dev = xyz.device
-    coords = torch.empty((B, P, 2), dtype=torch.float32, device=dev)
+    coords = rows_empty((B, P, 2), torch.float32, dev)
     work = torch.empty(lib.creste_bev_splat_workspace_bytes(B, P, GH, GW), dtype=torch.uint8, device=dev)
     _lib.check(lib.creste_bev_splat_plan_f32(_chk(xyz).data_ptr(), B, P, float(off_xy[0]), float(off_xy[1]),
                                              float(vox_xy[0]), float(vox_xy[1]), GH, GW, coords.data_ptr(),
@@ -671,7 +755,7 @@ def bev_splat_gather(plan: SplatPlan, feats: Act, min_weight=1.0, scatter_mode="
     if feats.N * feats.H * feats.W != B * P:
         raise HipLibraryError(f"bev_splat_gather: {feats.N * feats.H * feats.W} feature rows for a plan of {B * P} points")
     bev = Act.empty(B, GH, GW, F, dev)
-    dens = torch.empty((B, GH, GW), dtype=torch.float32, device=dev)
+    dens = rows_empty((B, GH, GW), torch.float32, dev)
     _lib.check(lib.creste_bev_splat_gather_f32(feats.ptr, feats.cs, B, P, F, GH, GW, float(min_weight),
                                                SPLAT_MODES[scatter_mode], bev.ptr, dens.data_ptr(), plan.work.data_ptr(),
                                                _stream()), "bev_splat_gather")
