@@ -9,11 +9,12 @@ cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 PREC=${3:-bf16x6}
-CMD="python bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-modes --no-irl --precision $PREC"
+EXTRA=${4:-}      # e.g. "--parts 1": one forward on one stream (stand-alone kernel durations)
+CMD="python bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-modes --no-irl --precision $PREC $EXTRA"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 grep '^{' $OUT/trace.log > $OUT/bench_under_trace.json
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 1200 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-modes --no-irl --precision $PREC > $OUT/pmc_$C.log 2>&1
+  timeout 1200 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-modes --no-irl --no-host-fed --parts 1 --precision $PREC > $OUT/pmc_$C.log 2>&1
 done
 find $OUT -type f | head -50
 # keep the merge small: drop the big per-dispatch traces except the stats/counter CSVs
