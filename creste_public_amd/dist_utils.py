@@ -145,6 +145,8 @@ class GradArena(dict):
 
     def _send(self, upto):
         if upto > self.sent and is_dist():
+            from . import ops
+            ops.wgrad_join(self.flat.device)        # weight gradients written on the side stream: ordered before the collective
             _count(self.flat[self.sent:upto])
             self.handles.append(dist.all_reduce(self.flat[self.sent:upto], op=dist.ReduceOp.SUM, async_op=True))
         self.sent = max(self.sent, upto)
@@ -215,6 +217,8 @@ class HookedArena:
 
     def _send(self, upto):
         if upto > self.sent and is_dist():
+            from . import ops
+            ops.wgrad_join(self.flat.device)        # weight gradients written on the side stream: ordered before the collective
             _count(self.flat[self.sent:upto])
             self.handles.append(dist.all_reduce(self.flat[self.sent:upto], op=dist.ReduceOp.SUM, async_op=True))
         self.sent = max(self.sent, upto)

@@ -33,6 +33,30 @@ CACHE_EPOCH = 0
 CACHE_BUILDS = 0
 
 
+# ---- weight gradients on a side stream (train_backbone.ConvG.bwd): a conv's weight gradient needs the layer's output gradient
+# and its saved input but nothing downstream needs IT before the optimiser (or the gradient exchange): it leaves the
+# backward's critical path and its matrix-bound kernels overlap the bandwidth-bound BatchNorm / transform kernels of the
+# input-gradient chain.  `wgrad_join()` = "every weight gradient issued so far is ordered before what this stream does next".
+WGRAD_STREAM = os.environ.get("CRESTE_WGRAD_STREAM", "1") != "0"
+_wgrad_streams: dict = {}
+
+
+def wgrad_stream(device):
+    if not WGRAD_STREAM:
+        return None
+    s = _wgrad_streams.get(device.index)
+    if s is None:
+        s = _wgrad_streams[device.index] = [torch.cuda.Stream(device=device), False]
+    return s
+
+
+def wgrad_join(device=None):
+    for idx, s in _wgrad_streams.items():
+        if s[1] and (device is None or device.index == idx):
+            torch.cuda.current_stream(s[0].device).wait_stream(s[0])
+            s[1] = False
+
+
 def note_cache_build():
     global CACHE_BUILDS
     CACHE_BUILDS += 1

@@ -15,6 +15,8 @@ drop-connect, autograd bookkeeping).
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 from torch import nn
 
@@ -68,6 +70,9 @@ def add(a: Act | None, b: Act | None) -> Act | None:
     return pointwise2(2, a, b)
 
 
+WGRAD_STREAM_MIN = 1 << 22          # pixels x channels below which a weight gradient stays on the backward's stream
+
+
 class ConvG:
     """dense conv, any stride / static padding, optional bias (forward: conv engine; dgrad: stride 1 only)."""
 
@@ -118,35 +123,44 @@ class ConvG:
         x = self.x
         if grads is not None:
             gw, acc = _acc(grads, w)
-            quads = (Cin % 4 == 0 and Cout % 4 == 0 and x.cs % 4 == 0 and gy.cs % 4 == 0 and x.co % 4 == 0 and gy.co % 4 == 0)
-            if (WGRAD_WINOGRAD and hipnn._precision in (ops.PREC_BF16X6, ops.PREC_F16X3) and quads and self.pad[0] == 1 and self.pad[2] == 1
-                    and min(Cin, Cout) >= WGRAD_WINOGRAD_MIN_C
-                    and lib.creste_conv_wgrad_wino4_supported(self.K, self.s, x.H, x.W, gy.H, gy.W, Cin, Cout)):
-                # wide 3x3 (bf16x6, and f16x3 -- at the wider bf16x6 grade): through the F(4x4,3x3) transform, 4x fewer
-                # matrix products (csrc/conv_wino4.hip)
-                work = torch.empty(lib.creste_conv_wgrad_wino4_workspace_bytes(x.N, x.H, x.W, Cin, Cout), dtype=torch.uint8,
-                                   device=w.device)
-                _lib.check(lib.creste_conv_wgrad_wino4(x.ptr, x.cs, gy.ptr, gy.cs, gw.data_ptr(), x.N, x.H, x.W, Cin, Cout,
-                                                       self.pad[0], self.pad[2], acc, work.data_ptr(), _stream()),
-                           "conv_wgrad_wino4")
-            else:
-                work = torch.empty(lib.creste_conv_wgrad_strided_workspace_bytes(gy.N, gy.H, gy.W, Cin, Cout, self.K),
-                                   dtype=torch.uint8, device=w.device)
-                if (hipnn._precision == ops.PREC_F16X3 and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 8 and Cout >= 8
-                        and x.cs % 4 == 0 and gy.cs % 4 == 0 and x.co % 4 == 0 and gy.co % 4 == 0):
-                    # f16x3 wgrad: fp16 hi+lo operands from the tensors' |max| bounds, fp32 accumulation
-                    _lib.check(lib.creste_conv_wgrad_f16x3(x.ptr, x.cs, gy.ptr, gy.cs, gw.data_ptr(),
-                                                           ops.absmax(x).data_ptr(), ops.absmax(gy).data_ptr(), x.N, x.H,
-                                                           x.W, gy.H, gy.W, Cin, Cout, self.K, self.s, self.pad[0],
-                                                           self.pad[2], acc, work.data_ptr(), _stream()), "conv_wgrad_f16x3")
+            side = ops.wgrad_stream(w.device) if x.N * x.H * x.W * max(Cin, Cout) >= WGRAD_STREAM_MIN else None
+            if side is not None:
+                # the weight gradient reads gy and the saved x and nothing of this backward reads IT: on the side stream,
+                # behind everything issued so far, while this stream goes on with the input gradient
+                side[0].wait_stream(torch.cuda.current_stream(w.device))
+                side[1] = True
+                for t in (gy.buf, x.buf, gw):
+                    t.record_stream(side[0])
+            with (torch.cuda.stream(side[0]) if side is not None else contextlib.nullcontext()):
+                quads = (Cin % 4 == 0 and Cout % 4 == 0 and x.cs % 4 == 0 and gy.cs % 4 == 0 and x.co % 4 == 0 and gy.co % 4 == 0)
+                if (WGRAD_WINOGRAD and hipnn._precision in (ops.PREC_BF16X6, ops.PREC_F16X3) and quads and self.pad[0] == 1 and self.pad[2] == 1
+                        and min(Cin, Cout) >= WGRAD_WINOGRAD_MIN_C
+                        and lib.creste_conv_wgrad_wino4_supported(self.K, self.s, x.H, x.W, gy.H, gy.W, Cin, Cout)):
+                    # wide 3x3 (bf16x6, and f16x3 -- at the wider bf16x6 grade): through the F(4x4,3x3) transform, 4x fewer
+                    # matrix products (csrc/conv_wino4.hip)
+                    work = torch.empty(lib.creste_conv_wgrad_wino4_workspace_bytes(x.N, x.H, x.W, Cin, Cout), dtype=torch.uint8,
+                                       device=w.device)
+                    _lib.check(lib.creste_conv_wgrad_wino4(x.ptr, x.cs, gy.ptr, gy.cs, gw.data_ptr(), x.N, x.H, x.W, Cin, Cout,
+                                                           self.pad[0], self.pad[2], acc, work.data_ptr(), _stream()),
+                               "conv_wgrad_wino4")
                 else:
-                    # bf16x6: the wide 3x3 convs at the forward's operand grade (six bf16 piece products), the rest exact fp32
-                    fn = lib.creste_conv_wgrad_bf16x6 if hipnn._precision == ops.PREC_BF16X6 else lib.creste_conv_wgrad_strided_f32
-                    _lib.check(fn(x.ptr, x.cs, gy.ptr, gy.cs, gw.data_ptr(), x.N, x.H, x.W,
-                                  gy.H, gy.W, Cin, Cout, self.K, self.s, self.pad[0],
-                                  self.pad[2], acc, work.data_ptr(), _stream()),
-                               "conv_wgrad_strided")
-            if self.conv.bias is not None:
+                    work = torch.empty(lib.creste_conv_wgrad_strided_workspace_bytes(gy.N, gy.H, gy.W, Cin, Cout, self.K),
+                                       dtype=torch.uint8, device=w.device)
+                    if (hipnn._precision == ops.PREC_F16X3 and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 8 and Cout >= 8
+                            and x.cs % 4 == 0 and gy.cs % 4 == 0 and x.co % 4 == 0 and gy.co % 4 == 0):
+                        # f16x3 wgrad: fp16 hi+lo operands from the tensors' |max| bounds, fp32 accumulation
+                        _lib.check(lib.creste_conv_wgrad_f16x3(x.ptr, x.cs, gy.ptr, gy.cs, gw.data_ptr(),
+                                                               ops.absmax(x).data_ptr(), ops.absmax(gy).data_ptr(), x.N, x.H,
+                                                               x.W, gy.H, gy.W, Cin, Cout, self.K, self.s, self.pad[0],
+                                                               self.pad[2], acc, work.data_ptr(), _stream()), "conv_wgrad_f16x3")
+                    else:
+                        # bf16x6: the wide 3x3 convs at the forward's operand grade (six bf16 piece products), the rest exact fp32
+                        fn = lib.creste_conv_wgrad_bf16x6 if hipnn._precision == ops.PREC_BF16X6 else lib.creste_conv_wgrad_strided_f32
+                        _lib.check(fn(x.ptr, x.cs, gy.ptr, gy.cs, gw.data_ptr(), x.N, x.H, x.W,
+                                      gy.H, gy.W, Cin, Cout, self.K, self.s, self.pad[0],
+                                      self.pad[2], acc, work.data_ptr(), _stream()),
+                                   "conv_wgrad_strided")
+            if self.conv.bias is not None:               # (a small reduction: stays on the backward's stream)
                 gb, accb = _acc(grads, self.conv.bias)
                 s = sample_reduce(gy, None, 1.0, per_sample=False).view(-1)
                 if accb:
@@ -541,6 +555,7 @@ class BackboneFn(torch.autograd.Function):
             gl = ops.depth_expectation_bwd(ctx.logits, eng.model.depthcomp._bin_values(ctx.logits.buf.device),
                                            _gd.detach().float().contiguous(), g_logits=gl)
         eng.backward(gl, a(g_feats), a(g_dino), grads)
+        ops.wgrad_join(ctx.logits.buf.device)
         if hasattr(grads, "finish"):
             grads.finish()                                        # tail bucket, wait, average over ranks
         return (None, None, *(grads.get(id(p)) for p in eng.params()))

@@ -164,6 +164,7 @@ class BevHeadFn(torch.autograd.Function):
         pairs = [(a(gouts[2 * i]), a(gouts[2 * i + 1])) for i in range(len(eng.heads))]
         grads = eng.new_grad_store()
         g_in = eng.backward(pairs, grads, need_input=ctx.needs_input_grad[1])
+        ops.wgrad_join()                                  # weight gradients issued on the side stream (train_backbone.ConvG.bwd)
         if hasattr(grads, "finish"):
             grads.finish()
         return (None, g_in.nchw() if g_in is not None else None, *(grads.get(id(p)) for p in eng.params()))

@@ -126,6 +126,7 @@ class SplatFn(torch.autograd.Function):
         gd = g_dens.detach().float().reshape(eng.saved["dens"].shape).contiguous() if g_dens is not None else None
         grads = {}
         g_depth, g_feats = eng.backward(gb, gd, grads)
+        ops.wgrad_join()
         return (None, g_depth, g_feats.nchw(), None, None, *(grads.get(id(p)) for p in eng.params()))
 
 

@@ -506,3 +506,46 @@ def test_conv_wgrad_winograd(N, Cin, H, W, Cout, acc):
                                            work.data_ptr(), torch.cuda.current_stream().cuda_stream), "conv_wgrad_wino4")
     ref = w.grad + (0.5 if acc else 0.0)
     assert _rel(gw, ref) < 1e-5
+
+
+def test_weight_gradients_on_the_side_stream_are_the_same_gradients(monkeypatch):
+    """ConvG.bwd issues the conv weight gradients on a side stream (ops.wgrad_stream) while the backward's stream goes on with
+    the input-gradient chain: every parameter gradient equals the one-stream backward's bit for bit -- per-tensor store and
+    flat arena, several back-to-back steps without a host synchronisation (the allocator recycles the cotangents' blocks)."""
+    from creste_public_amd import harness, ops, train_backbone
+    from creste_public_amd.creste.models.distillation import DistillationBackbone
+    from creste_public_amd.creste.utils.loss_utils import LossManager
+    H, W, B = 128, 192, 4
+    harness.seed_everything(5)
+    cfg = harness.distillation_cfg((H, W))
+    model = DistillationBackbone(cfg).cuda()
+    batch = _distill_batch(B, H, W, seed=4)
+    lm = LossManager(cfg)
+
+    def run(side, arena, steps=3):
+        monkeypatch.setattr(ops, "WGRAD_STREAM", side)
+        monkeypatch.setattr(train_backbone, "WGRAD_STREAM_MIN", 0)             # every conv of this small model
+        got = []
+        for _ in range(steps):
+            torch.manual_seed(11)
+            model.train()
+            model.zero_grad(set_to_none=True)
+            out = model(batch["image"])
+            model._train_engine.arena = arena
+            td = {f"outputs/{k}": v for k, v in out.items()}
+            td.update({f"inputs/{k}": v for k, v in batch.items()})
+            td["task"] = None
+            ld, _ = lm(td)
+            sum(w * v for w, v in ld.values()).backward()
+            got.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+        torch.cuda.synchronize()
+        return got
+
+    ref = run(False, False, steps=1)[0]
+    assert len(ref) > 200
+    for arena in (False, True):
+        for i, g in enumerate(run(True, arena)):
+            assert ops._wgrad_streams, "the side stream was never used"
+            assert g.keys() == ref.keys()
+            for n in ref:
+                assert torch.equal(g[n], ref[n]), f"{n} (arena {arena}, step {i})"
