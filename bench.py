@@ -32,6 +32,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")        # before the HIP runtime starts (see creste_public_amd/__init__.py)
 
 IMG_H, IMG_W, BATCH = 608, 1216, 16
 # TFLOP/s dense (MI355X_MICROARCH.md): the peak of the MFMA instruction each mode ISSUES -- v_mfma_f32_32x32x2_f32

@@ -8,7 +8,13 @@ All arithmetic of the path runs in libcreste_hip.so (include/creste_hip.h); ther
 stock-PyTorch fallback -- ops raise `HipLibraryError` when the library or a GPU tensor is missing.
 """
 import importlib
+import os
 import sys
+
+# More hardware queues for this process's streams (read by the HIP runtime when it starts; default 4): the side streams of the
+# pipelined inference / the weight gradients / the IRL prefetch only help on a queue of their own (ops.concurrent_stream
+# measures whether they got one).  Only takes effect when the package is imported before the first GPU call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from .config import Cfg, as_cfg, maxent_irl_cfg, terrainnet_cfg  # noqa: F401
 from ._lib import HipLibraryError  # noqa: F401

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libcreste_hip.so")
 
-ABI_VERSION = 7          # creste_abi_version() of the library this binding was written against
+ABI_VERSION = 8          # creste_abi_version() of the library this binding was written against
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
 
@@ -70,6 +70,7 @@ SIGNATURES = {
     "creste_maxpool2_nhwc_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "creste_maxpool_nhwc_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "creste_fill_u32": (_i, [_vp, C.c_uint32, _i64, _vp]),
+    "creste_spin_us": (_i, [C.c_int, C.c_int, _vp]),
     "creste_max2_f32": (_i, [_vp, _vp, _vp, _vp]),
     "creste_affine_act_nhwc_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
     "creste_resize_plane_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _f, _f, _vp]),

@@ -190,7 +190,8 @@ class MaxEntIRL(nn.Module):
 
     # ---- pipelined inference.  The frozen half of an eval forward is 46 % matrix-bound GEMM kernels (persistent, one
     # workgroup per CU) and 40 % bandwidth-bound transform / elementwise kernels that alternate on ONE stream.  Run as
-    # `inference_parts` forwards of B / parts frames on as many streams, issued one after the other by this thread, part
+    # `inference_parts` forwards of B / parts frames on as many streams (a side stream PROBED to run beside the caller's:
+    # ops.concurrent_stream), issued one after the other by this thread, part
     # k + 1 trails part k by the host's issue time and its bandwidth-bound kernels fill in beside / between the other
     # part's GEMMs (measured: batch 16, 39.8 -> 37.9 ms with two parts; four parts lose, profiles/r04_pipeline_notes.md).
     # Each part is exactly `_frozen_half` of its frames (bit-identical to calling the model on those frames); the parts
@@ -198,19 +199,24 @@ class MaxEntIRL(nn.Module):
     inference_parts = 2            # 0 / 1: off
     inference_part_rows = 4        # smallest part worth a stream of its own
 
-    def _parts_for(self, B):
+    def _parts_for(self, B, device=None):
         from ... import _lib
         n = int(self.inference_parts or 1)
         if (n < 2 or torch.is_grad_enabled() or _lib._recorder is not None or B % n or B // n < self.inference_part_rows
                 or os.environ.get("CRESTE_INFER_PARTS", "") in ("0", "1")):
             return 1                                   # (the plan recorder of deploy.export_plan traces ONE stream)
+        if n == 2 and ops.concurrent_stream(device or torch.device("cuda", torch.cuda.current_device()), "parts") is None:
+            return 1                                   # no stream that really runs beside this one: two parts would only be slower
         return n
 
     def _frozen_parts(self, image, p2p, parts):
         dev = image.device
         main = torch.cuda.current_stream(dev)
-        if len(self._part_streams) < parts - 1 or any(s.device != dev for s in self._part_streams):
-            self._part_streams = [torch.cuda.Stream(device=dev) for _ in range(parts - 1)]
+        if parts != 2:
+            if len(self._part_streams) < parts - 1 or any(s.device != dev for s in self._part_streams):
+                self._part_streams = [torch.cuda.Stream(device=dev) for _ in range(parts - 1)]     # (experiments only)
+        else:
+            self._part_streams = [ops.concurrent_stream(dev, "parts")]
         n = image.shape[0] // parts
         fork = torch.cuda.Event()
         fork.record(main)                              # the inputs are ready once a stream gets here
@@ -263,8 +269,8 @@ class MaxEntIRL(nn.Module):
         if self._side_stream is None or self._side_stream.device != image.device:
             # LOWEST priority: the frozen half is throughput work (full-chip MFMA kernels); the trainable half on the
             # caller's stream is a latency chain of ~600 small kernels that must not queue behind it
-            lo = max(torch.cuda.Stream.priority_range())
-            self._side_stream = torch.cuda.Stream(device=image.device, priority=lo)
+            # (a stream probed to run beside the caller's -- ops.concurrent_stream; any stream keeps the results right)
+            self._side_stream = ops.concurrent_stream(image.device, "prefetch") or torch.cuda.Stream(device=image.device)
         side = self._side_stream
         side.wait_stream(main)                       # the inputs are ready once the main stream gets here
         with torch.cuda.stream(side), torch.no_grad():
@@ -308,7 +314,7 @@ class MaxEntIRL(nn.Module):
         B = image.shape[0]
         got = self._take_prefetched(inputs)
         if got is None:
-            parts = self._parts_for(B)
+            parts = self._parts_for(B, image.device)
             got = self._frozen_parts(image, p2p, parts) if parts > 1 else self._frozen_half(image, p2p)
         return self._forward_trainable(inputs, got)
 

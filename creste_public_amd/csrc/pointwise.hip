@@ -899,6 +899,19 @@ __global__ void fill_u32_kernel(uint32_t* __restrict__ p, uint32_t v, long n) {
 }
 __global__ void max2_f32_kernel(const float* a, const float* b, float* out) { *out = fmaxf(*a, *b); }
 
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+extern "C" int creste_spin_us(int microseconds, int workgroups, void* stream) {
+  CRESTE_REQUIRE(microseconds >= 0 && microseconds <= 100000 && workgroups >= 1 && workgroups <= 1000000,
+                 "spin_us: 0 .. 100000 microseconds, 1 .. 1000000 workgroups");
+  spin_kernel<<<(unsigned)workgroups, 64, 0, (hipStream_t)stream>>>((long long)microseconds * 100);
+  CRESTE_CHECK_LAUNCH("spin");
+  return CRESTE_OK;
+}
+
 extern "C" int creste_fill_u32(void* dst, uint32_t value, int64_t n, void* stream) {
   CRESTE_REQUIRE(dst && n >= 0 && (reinterpret_cast<uintptr_t>(dst) & 3) == 0, "fill_u32: bad args");
   if (n == 0) return CRESTE_OK;

@@ -33,6 +33,68 @@ CACHE_EPOCH = 0
 CACHE_BUILDS = 0
 
 
+# ---- side streams that REALLY run beside the caller's.  HIP maps a process's streams onto a few hardware queues
+# (GPU_MAX_HW_QUEUES, default 4) in creation order; two streams that land on one queue run their kernels in issue order --
+# and worse than that: the pipelined inference step measured 38.2 ms on a concurrent side stream, 43.0 ms (= two half-batch
+# forwards back to back) or 57 ms on a side stream that shared the caller's queue, and which of the two a process gets
+# depends on how many streams anything (torch's pool, RCCL, a copy stream) created before.  Two queues of one dispatch PIPE
+# are no better for full-chip kernels: the second kernel waits until the first has handed out its whole grid (two tiny
+# kernels run side by side there, so the probe must use a large grid).  So a side stream is PROBED (_runs_beside).
+_side_streams: dict = {}
+_probe_log: list = []
+
+
+def _runs_beside(main: torch.cuda.Stream, cand: torch.cuda.Stream) -> bool:
+    """Does a kernel on `main` get onto the device while `cand` is still handing out the workgroups of a large grid (and
+    the other way round)?  A 60000-workgroup do-nothing kernel (~3 waves of residents of 40 us) on one stream, a
+    one-workgroup 10 us kernel on the other, issued right behind it: beside each other the small one is done in tens of
+    microseconds; on one hardware queue, or on two queues of one dispatch pipe, only after the large one (~340 us; threshold 150)."""
+    lib = _lib.load()
+    dev = main.device
+    worst = 0.0
+    for big, small in ((cand, main), (main, cand)):
+        best = 1e9
+        for _ in range(2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            e0.record(big)
+            small.wait_event(e0)
+            _lib.check(lib.creste_spin_us(40, 60000, big.cuda_stream), "spin_us")
+            _lib.check(lib.creste_spin_us(10, 1, small.cuda_stream), "spin_us")
+            e1.record(small)
+            torch.cuda.synchronize(dev)
+            best = min(best, e0.elapsed_time(e1))
+        worst = max(worst, best)
+    _probe_log.append(round(worst * 1e3, 1))           # microseconds (diagnostics: scripts/host_issue_time.py)
+    return worst < 0.150
+
+
+def concurrent_stream(device, role: str, tries: int = 12):
+    """A stream of `device` for `role` ('parts', 'wgrad', 'prefetch': one stream each, cached) that was measured to run
+    beside the CURRENT stream and beside the other roles' streams; None when no such stream can be had (the caller then stays
+    on one stream).  CRESTE_SIDE_STREAMS=0 turns every side stream off."""
+    if os.environ.get("CRESTE_SIDE_STREAMS", "1") == "0":
+        return None
+    main = torch.cuda.current_stream(device)
+    key = (device.index, role, main.cuda_stream)
+    if key in _side_streams:
+        return _side_streams[key]
+    if _lib._recorder is not None or torch.cuda.is_current_stream_capturing():
+        return None                                   # (never probe inside a plan trace / graph capture)
+    others = [s for (d, r, m), s in _side_streams.items() if d == device.index and s is not None]
+    found, rejected = None, []
+    for _ in range(tries):
+        cand = torch.cuda.Stream(device=device)
+        if any(cand.cuda_stream == s.cuda_stream for s in others + rejected + [main]):
+            continue
+        if _runs_beside(main, cand) and all(_runs_beside(o, cand) for o in others):
+            found = cand
+            break
+        rejected.append(cand)                         # (kept alive: torch hands its pool out round-robin)
+    _side_streams[key] = found
+    return found
+
+
 # ---- weight gradients on a side stream (train_backbone.ConvG.bwd): a conv's weight gradient needs the layer's output gradient
 # and its saved input but nothing downstream needs IT before the optimiser (or the gradient exchange): it leaves the
 # backward's critical path and its matrix-bound kernels overlap the bandwidth-bound BatchNorm / transform kernels of the
@@ -42,17 +104,20 @@ _wgrad_streams: dict = {}
 
 
 def wgrad_stream(device):
+    """[stream, used-since-the-last-join] -- or None: off, or no stream that runs beside the current one"""
     if not WGRAD_STREAM:
         return None
-    s = _wgrad_streams.get(device.index)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    s = _wgrad_streams.get(key)
     if s is None:
-        s = _wgrad_streams[device.index] = [torch.cuda.Stream(device=device), False]
-    return s
+        st = concurrent_stream(device, "wgrad")
+        s = _wgrad_streams[key] = [st, False] if st is not None else False
+    return s or None
 
 
 def wgrad_join(device=None):
-    for idx, s in _wgrad_streams.items():
-        if s[1] and (device is None or device.index == idx):
+    for (idx, _), s in _wgrad_streams.items():
+        if s and s[1] and (device is None or device.index == idx):
             torch.cuda.current_stream(s[0].device).wait_stream(s[0])
             s[1] = False
 

@@ -239,6 +239,14 @@ int creste_maxpool_nhwc_f32(const float* in, int N, int H, int W, int C, int in_
 int creste_fill_u32(void* dst, uint32_t value, int64_t n, void* stream);
 int creste_max2_f32(const float* a, const float* b, float* out, void* stream);
 
+/* `workgroups` single-wavefront workgroups that each do nothing for `microseconds` of the device's constant 100 MHz clock
+ * (at most 100 000 us, 1 .. 1 000 000 workgroups): the probe with which the host finds out whether two of its streams
+ * really run side by side -- HIP maps streams onto a few hardware queues (two streams on one queue run their kernels in
+ * issue order) and the queues onto fewer dispatch pipes (a kernel waits while another queue of its pipe is still handing
+ * out the workgroups of a large grid); creste_public_amd/ops.py: concurrent_stream.  The reference has no counterpart: it
+ * runs one stream. */
+int creste_spin_us(int microseconds, int workgroups, void* stream);
+
 /* y = act(x*scale[c] + shift[c]): an eval-mode BatchNorm that FOLLOWS a ReLU (MultiScaleFCN trunk,
  * reference conv.py:118-128: conv -> ReLU -> BN -> ReLU) and so cannot be folded into the conv. */
 int creste_affine_act_nhwc_f32(const float* x, int x_cs, const float* scale, const float* shift,
