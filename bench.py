@@ -727,12 +727,23 @@ def main():
         out_h = host_fed_steps(args.steps)
         fence()
         el_h = dist_utils.max_over_ranks(time.perf_counter() - t1, device)
-        assert torch.equal(out_h["traversability_preds"], out["traversability_preds"])
+        # the host-fed steps must reproduce the resident ones bit for bit; a mismatch is REPORTED in the line (with the frames
+        # that differ) rather than raised, so that one bad step cannot take the whole measurement down
+        same_as_resident, mismatch = torch.equal(out_h["traversability_preds"], out["traversability_preds"]), None
+        if not same_as_resident:
+            again = step()
+            rows = lambda a, b: torch.nonzero((a != b).reshape(a.shape[0], -1).any(1)).flatten().tolist()   # noqa: E731
+            mismatch = {k: {"host_fed_vs_timed": rows(out_h[k], out[k]), "fresh_vs_timed": rows(again[k], out[k]),
+                            "fresh_vs_host_fed": rows(again[k], out_h[k])} for k in out if out[k].is_floating_point()}
+            print(f"[bench] WARNING: host-fed step differs from the resident one: {mismatch}", file=sys.stderr, flush=True)
         host_fed = {"value": round(args.batch * args.gpus * args.steps / el_h, 3), "ms_per_step": round(el_h / args.steps * 1e3, 3),
                     "h2d_bytes_per_step": int(h_rgbd.numel() * 4 + h_scan.numel() * 4),
                     "note": "pinned host batch (RGB-D frames + LiDAR scan) -> device on a copy stream, two device buffers: "
                             "the copy of batch k+1 overlaps the compute of batch k; the first copy of the timed region "
-                            "is exposed; outputs bit-identical to the resident run"}
+                            "is exposed; `equals_resident`: the last host-fed step's costmap == the resident run's, bit for bit",
+                    "equals_resident": bool(same_as_resident)}
+        if mismatch is not None:
+            host_fed["mismatch_frames"] = mismatch
         del bufs, h_rgbd, h_scan
 
     modes = {}
