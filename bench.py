@@ -616,7 +616,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from creste_public_amd import dist_utils as _du
+        _du.init_rccl(torch.device("cuda", local_rank))       # (collectives on a high-priority stream: see its docstring)
     elif args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one rank per GPU)")
     device = torch.device("cuda", local_rank)

@@ -20,6 +20,21 @@ _collectives_enabled = True
 STATS = {"bytes": 0, "calls": 0}      # payload bytes / calls of the gradient + feature collectives since reset_stats()
 
 
+def init_rccl(device, **kw):
+    """dist.init_process_group("nccl") with the collectives on a HIGH-PRIORITY stream.  Not for their latency: torch takes
+    the process group's stream from its pool of default-priority streams otherwise, HIP maps that pool onto the same few
+    hardware queues as everybody else's streams, and a collective that shares a queue with the backward's stream sits in
+    FRONT of the backward's later kernels while it waits for the weight-gradient stream (measured on one rank: 12-22 ms per
+    distillation / BEV-SSC step, depending only on how many streams had been created before).  High-priority streams have
+    hardware queues of their own."""
+    opts = None
+    try:
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    except Exception:                                      # (a torch without the option: default stream choice)
+        opts = None
+    return dist.init_process_group("nccl", device_id=device, **({"pg_options": opts} if opts is not None else {}), **kw)
+
+
 def is_dist() -> bool:
     return _collectives_enabled and dist.is_available() and dist.is_initialized()
 
@@ -108,9 +123,6 @@ def allreduce_mean_grads(params) -> int:
     return int(flat.numel())
 
 
-_ISSUE_STREAMS: dict = {}
-
-
 def _send_slice(arena, upto):
     """Hand flat[sent:upto] to the collective.  The conv weight gradients of the slice are written on the weight-gradient
     side stream (ops.wgrad_stream), which runs BEHIND the backward's stream, and torch's process group orders a collective
@@ -129,12 +141,12 @@ def _send_slice(arena, upto):
             main = torch.cuda.current_stream(dev)
             s = ops._wgrad_streams.get((dev.index, main.cuda_stream))
             if s and s[1]:
-                if os.environ.get("CRESTE_COLL_ISSUE", "third") == "join":
+                # the third stream is PROBED like every side stream: on the hardware queue of the backward's stream its wait
+                # for the weight-gradient stream would sit in front of the backward's later kernels (measured: 5 / 13 ms)
+                c = None if os.environ.get("CRESTE_COLL_ISSUE", "third") == "join" else ops.concurrent_stream(dev, "issue")
+                if c is None:
                     ops.wgrad_join(dev)
                 else:
-                    c = _ISSUE_STREAMS.get(dev.index)
-                    if c is None:
-                        c = _ISSUE_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
                     c.wait_stream(main)
                     c.wait_stream(s[0])
                     ctx = torch.cuda.stream(c)
