@@ -14,11 +14,11 @@ from creste_public_amd import synth, ops
 device = torch.device("cuda", 0)
 creste_public_amd.set_precision("bf16x6")
 model = bench.build_model(device)
-B, H, W = 16, bench.IMG_H, bench.IMG_W
+B, H, W = int(os.environ.get("B", "16")), bench.IMG_H, bench.IMG_W
 rgbd, p2p = synth.make_frames(B, H, W, seed=3)
 rgbd, p2p = rgbd.to(device), p2p.to(device)
 for parts in (0, 2):
-    model.inference_parts = parts
+    model.inference_parts = parts; model.inference_part_rows = 1
     with torch.no_grad():
         for _ in range(3):
             model((rgbd, p2p))

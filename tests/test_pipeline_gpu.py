@@ -25,6 +25,7 @@ def _model(solve_mdp=False, seed=7):
     model = model.cuda().eval()
     rgbd, p2p = synth.make_frames(2, H, W, seed=seed + 1)
     synth.calibrate_bn_hip(model, rgbd.cuda(), p2p.cuda())
+    model.inference_part_rows = 4          # (the default, 6, is a speed threshold measured at 1216x608: these are correctness tests)
     return model
 
 
@@ -82,6 +83,10 @@ def test_first_pipelined_forward_builds_the_caches_for_every_part():
 def test_pipelining_is_off_where_it_must_be():
     model = _model()
     assert model._parts_for(2) == 1 and model._parts_for(7) == 1           # too small / not divisible
+    del model.inference_part_rows
+    with torch.no_grad():
+        assert model._parts_for(8) == 1 and model._parts_for(12) == 2      # the shipped threshold: parts of >= 6 frames
+    model.inference_part_rows = 4
     with torch.enable_grad():
         assert model._parts_for(16) == 1                                   # autograd is recording
     with torch.no_grad():
