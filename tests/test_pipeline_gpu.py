@@ -149,3 +149,19 @@ def test_back_to_back_pipelined_steps_are_reproducible_at_full_size():
         for k, v in o.items():
             assert torch.equal(v, ref[k]), f"step {i}: {k}"
     assert float((ref["bev_densities"] > 0).float().mean()) > 0.05
+
+
+def test_side_stream_probe_tells_one_queue_from_two():
+    """ops.concurrent_stream hands out only streams that were MEASURED to run beside the caller's (creste_spin_us): a stream
+    probed against itself is the one-queue case and must fail; whatever the probe accepts must pass it again, and the roles'
+    streams are distinct."""
+    dev = torch.device("cuda", 0)
+    main = torch.cuda.current_stream(dev)
+    assert not ops._runs_beside(main, main)                       # one queue: the small kernel waits for the large grid
+    got = {role: ops.concurrent_stream(dev, role) for role in ("parts", "wgrad", "prefetch")}
+    assert all(s is None or isinstance(s, torch.cuda.Stream) for s in got.values())
+    live = [s for s in got.values() if s is not None]
+    assert len({s.cuda_stream for s in live}) == len(live) and all(s.cuda_stream != main.cuda_stream for s in live)
+    for s in live:
+        assert ops._runs_beside(main, s)
+    assert ops.concurrent_stream(dev, "parts") is got["parts"]    # cached per (device, role, caller's stream)
