@@ -402,7 +402,7 @@ def test_512_grid_bf16_encoder_pipeline():
     assert float(X.max()) > 300                       # coordinates in 5 cm cells
 
 
-@pytest.mark.parametrize("variant", ["cf512", "mdp256"])
+@pytest.mark.parametrize("variant", ["cf512", "mdp256", "mdp256-bf16x6"])
 def test_irl_training_step_on_large_mdp_grids(variant):
     """BASELINE configs[4] (counterfactual IRL, 512x512 BEV grid at 5 cm -> 128x256 MDP grid, bf16 encoder operands,
     fp32 reward net / value iteration / SVF) and configs[2] (256x256 MDP grid = front half of a 512x256 BEV map,
@@ -415,12 +415,13 @@ def test_irl_training_step_on_large_mdp_grids(variant):
     from creste_public_amd import LossManager, MaxEntIRL
     from oracle import irl as oirl
     Hh, Ww, Bb = 128, 192, 2
+    variant, _, operands = variant.partition("-")          # "-bf16x6": the headline operand mode (bench.py's irl.mdp256 leg)
     if variant == "cf512":
         kw = dict(map_size=(128, 256), map_ds=2, voxel_size=[0.05, 0.05, 3])
         bev, prec = (512, 512), "bf16"
     else:
         kw = dict(map_size=(256, 256), map_ds=1, point_cloud_range=[-25.6, -12.8, -2, 25.6, 12.8, 1])
-        bev, prec = (512, 256), "f16x3"
+        bev, prec = (512, 256), operands or "f16x3"
     cfg = maxent_irl_cfg((Hh, Ww), solve_mdp=True, **kw)
     torch.manual_seed(77)
     oracle = oirl.MaxEntIRL(cfg)
