@@ -204,8 +204,9 @@ class MaxEntIRL(nn.Module):
         from ... import _lib
         n = int(self.inference_parts or 1)
         if (n < 2 or torch.is_grad_enabled() or _lib._recorder is not None or B % n or B // n < self.inference_part_rows
-                or os.environ.get("CRESTE_INFER_PARTS", "") in ("0", "1")):
-            return 1                                   # (the plan recorder of deploy.export_plan traces ONE stream)
+                or os.environ.get("CRESTE_INFER_PARTS", "") in ("0", "1") or torch.cuda.is_current_stream_capturing()):
+            return 1                                   # (the plan recorder of deploy.export_plan traces ONE stream; a hipGraph
+                                                       #  capture keeps the one-stream forward it was written for)
         if n == 2 and ops.concurrent_stream(device or torch.device("cuda", torch.cuda.current_device()), "parts") is None:
             return 1                                   # no stream that really runs beside this one: two parts would only be slower
         return n
