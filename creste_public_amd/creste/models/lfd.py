@@ -78,7 +78,7 @@ class MaxEntIRL(nn.Module):
         self.backbone.eval()
         self._fov_u8 = None
         self._side_stream, self._prefetched = None, None
-        self._part_streams, self._parts_warm = [], False
+        self._parts_warm = False
         if self.weights_path and os.path.isfile(self.weights_path) and not os.path.isfile(self.ckpt_path or ""):
             self.load_weights(self.weights_path)
 
@@ -201,64 +201,20 @@ class MaxEntIRL(nn.Module):
                                    # and a lone step gets 1.4 ms slower; 12 as 2 x 6: -3 %, 16: -4 %, 32: -4.4 %)
 
     def _parts_for(self, B, device=None):
-        from ... import _lib
-        n = int(self.inference_parts or 1)
-        if (n < 2 or torch.is_grad_enabled() or _lib._recorder is not None or B % n or B // n < self.inference_part_rows
-                or os.environ.get("CRESTE_INFER_PARTS", "") in ("0", "1") or torch.cuda.is_current_stream_capturing()):
-            return 1                                   # (the plan recorder of deploy.export_plan traces ONE stream; a hipGraph
-                                                       #  capture keeps the one-stream forward it was written for)
-        if n == 2 and ops.concurrent_stream(device or torch.device("cuda", torch.cuda.current_device()), "parts") is None:
-            return 1                                   # no stream that really runs beside this one: two parts would only be slower
-        return n
+        return ops.parts_for(B, device or torch.device("cuda", torch.cuda.current_device()), self.inference_parts,
+                             self.inference_part_rows)
 
     def _frozen_parts(self, image, p2p, parts):
-        dev = image.device
-        main = torch.cuda.current_stream(dev)
-        if parts != 2:
-            if len(self._part_streams) < parts - 1 or any(s.device != dev for s in self._part_streams):
-                self._part_streams = [torch.cuda.Stream(device=dev) for _ in range(parts - 1)]     # (experiments only)
-        else:
-            self._part_streams = [ops.concurrent_stream(dev, "parts")]
-        n = image.shape[0] // parts
-        fork = torch.cuda.Event()
-        fork.record(main)                              # the inputs are ready once a stream gets here
-        ctx, res = ops.PartContext(parts), []
-        prev, ops._PART.ctx = ops._PART.ctx, ctx
-        builds = ops.CACHE_BUILDS
-        try:
-            for i in range(parts):
-                st = main if i == 0 else self._part_streams[i - 1]
-                ctx.begin(i)
-                if i:
-                    st.wait_event(fork)
-                with torch.cuda.stream(st):
-                    res.append(self._frozen_half(image[i * n:(i + 1) * n], p2p[i * n:(i + 1) * n]))
-                if i == 0 and (ops.CACHE_BUILDS != builds or not self._parts_warm):
-                    # part 0 (re)built caches -- packed weights, folded BatchNorm, constants -- by launches on ITS stream (always
-                    # assumed of a model's first pipelined forward): the other parts read them only behind part 0
-                    fork = torch.cuda.Event()
-                    fork.record(main)
-                    self._parts_warm = True
-            ctx.begin(parts)                           # (checks that the last part took every shared buffer)
-        finally:
-            ops._PART.ctx = prev
-        for st in self._part_streams[:parts - 1]:
-            main.wait_stream(st)
-
-        def cat(ts):                                   # an output that no shared buffer holds (none in the shipped configs)
-            for t in ts[1:]:
-                t.record_stream(main)
-            return torch.cat(ts)
-        r0, out0, view0 = res[0]
-        outputs = {}
-        for k, v in out0.items():
-            w = ctx.whole(v)
-            outputs[k] = w if w is not None else cat([r[1][k] for r in res])
+        ctx, res = ops.forward_in_parts(self._frozen_half, (image, p2p), parts, owner=self)
+        outputs = ops.whole_outputs(ctx, [r[1] for r in res])
+        view0 = res[0][2]
         view = ctx.whole_act(view0)
-        if view is None:
-            view = ops.Act(cat([r[2].buf for r in res]), view0.C, view0.co)
-        r = {"iv_hw": r0["iv_hw"], "parts": [x[0] for x in res]}
-        return r, outputs, view
+        if view is None:                               # (not in the shipped configs: the input view is a shared buffer)
+            bufs = [r[2].buf for r in res]
+            for t in bufs[1:]:
+                t.record_stream(torch.cuda.current_stream(image.device))
+            view = ops.Act(torch.cat(bufs), view0.C, view0.co)
+        return {"iv_hw": res[0][0]["iv_hw"], "parts": [x[0] for x in res]}, outputs, view
 
     def prefetch_backbone(self, inputs):
         """Enqueue the frozen half of `forward(inputs)` on a side stream; the next `forward` with the SAME input tensors

@@ -162,4 +162,12 @@ class TerrainNet(nn.Module):
             from ...train_terrain import terrainnet_forward_train
             mv = x[2] if self.use_movability and len(x) > 2 else None     # immovable mask [B,N,Hs,Ws] (:317-320)
             return terrainnet_forward_train(self, rgbd, p2p, mv)
+        parts = ops.parts_for(rgbd.shape[0], rgbd.device, self.inference_parts, self.inference_part_rows)
+        if parts > 1:                                  # pipelined like MaxEntIRL's frozen half (lfd.py: inference_parts)
+            ctx, res = ops.forward_in_parts(lambda a, b: self.pack_outputs(self.forward_act(a, b), a.shape[0]),
+                                            (rgbd, p2p), parts, owner=self)
+            return ops.whole_outputs(ctx, res)
         return self.pack_outputs(self.forward_act(rgbd, p2p), rgbd.shape[0])
+
+    inference_parts = 2            # batches of >= 2 x inference_part_rows frames run as two forwards on two streams
+    inference_part_rows = 6

@@ -95,6 +95,76 @@ def concurrent_stream(device, role: str, tries: int = 12):
     return found
 
 
+# ---- the generic half of a pipelined forward (MaxEntIRL._frozen_parts, TerrainNet / DistillationBackbone.forward in eval mode)
+def parts_for(B: int, device, want: int = 2, min_rows: int = 6) -> int:
+    """How many parts an eval forward of B frames runs in: `want` when pipelining is allowed here (no autograd, no plan
+    trace, no stream capture, B divisible, parts of >= min_rows frames, a probed side stream available), else 1."""
+    n = int(want or 1)
+    if (n < 2 or torch.is_grad_enabled() or _lib._recorder is not None or B % n or B // n < min_rows
+            or os.environ.get("CRESTE_INFER_PARTS", "") in ("0", "1") or _PART.ctx is not None
+            or torch.cuda.is_current_stream_capturing()):
+        return 1
+    if n == 2 and concurrent_stream(device, "parts") is None:
+        return 1
+    return n
+
+
+def forward_in_parts(fn, batch_tensors, parts: int, owner=None):
+    """fn(*slices) for each of `parts` equal slices of the batch-leading `batch_tensors`, part 0 on the caller's stream, the
+    others on side streams (two parts: the probed 'parts' stream), joined before returning -> (PartContext, [results]).
+    Inside, `shared_rows()` allocations are rows of shared whole-batch buffers (PartContext.whole gives the whole-batch view of
+    part 0's result).  `owner`: any object; its `_parts_warm` attribute records that its lazily built caches exist (a part
+    that (re)builds caches makes the later parts start behind it)."""
+    dev = batch_tensors[0].device
+    main = torch.cuda.current_stream(dev)
+    streams = [concurrent_stream(dev, "parts")] if parts == 2 else [torch.cuda.Stream(device=dev) for _ in range(parts - 1)]
+    if any(s is None for s in streams):
+        raise HipLibraryError("forward_in_parts: no side stream (ask parts_for first)")
+    n = batch_tensors[0].shape[0] // parts
+    fork = torch.cuda.Event()
+    fork.record(main)                                  # the inputs are ready once a stream gets here
+    ctx, res = PartContext(parts), []
+    prev, _PART.ctx = _PART.ctx, ctx
+    builds = CACHE_BUILDS
+    try:
+        for i in range(parts):
+            st = main if i == 0 else streams[i - 1]
+            ctx.begin(i)
+            if i:
+                st.wait_event(fork)
+            with torch.cuda.stream(st):
+                res.append(fn(*(t[i * n:(i + 1) * n] for t in batch_tensors)))
+            if i == 0 and (CACHE_BUILDS != builds or not getattr(owner, "_parts_warm", False)):
+                # part 0 (re)built caches -- packed weights, folded BatchNorm, constants -- by launches on ITS stream (always
+                # assumed of an owner's first pipelined forward): the other parts read them only behind part 0
+                fork = torch.cuda.Event()
+                fork.record(main)
+                if owner is not None:
+                    owner._parts_warm = True
+        ctx.begin(parts)                               # (checks that the last part took every shared buffer)
+    finally:
+        _PART.ctx = prev
+    for st in streams:
+        main.wait_stream(st)
+    return ctx, res
+
+
+def whole_outputs(ctx: PartContext, dicts) -> dict:
+    """the whole-batch output dict of a pipelined forward from its parts' dicts: views of the shared buffers, a concatenation
+    only for a tensor no shared buffer holds"""
+    main = torch.cuda.current_stream()
+    out = {}
+    for k, v in dicts[0].items():
+        w = ctx.whole(v)
+        if w is None:
+            ts = [d[k] for d in dicts]
+            for t in ts[1:]:
+                t.record_stream(main)
+            w = torch.cat(ts)
+        out[k] = w
+    return out
+
+
 # ---- weight gradients on a side stream (train_backbone.ConvG.bwd): a conv's weight gradient needs the layer's output gradient
 # and its saved input but nothing downstream needs IT before the optimiser (or the gradient exchange): it leaves the
 # backward's critical path and its matrix-bound kernels overlap the bandwidth-bound BatchNorm / transform kernels of the

@@ -165,3 +165,30 @@ def test_side_stream_probe_tells_one_queue_from_two():
     for s in live:
         assert ops._runs_beside(main, s)
     assert ops.concurrent_stream(dev, "parts") is got["parts"]    # cached per (device, role, caller's stream)
+
+
+def test_terrainnet_eval_forward_is_pipelined_the_same_way():
+    """TerrainNet.forward in eval mode (SSC validation, the deployment script's model) runs batches of >= 12 frames as two
+    forwards on two streams too: equal to the plain forwards of its halves, bit for bit, outputs in shared buffers."""
+    from creste_public_amd import TerrainNet, terrainnet_cfg
+    torch.manual_seed(5)
+    creste_public_amd.set_precision("bf16x6")
+    net = TerrainNet(terrainnet_cfg((H, W)))
+    synth.randomize_bn(net, seed=5)
+    net = net.cuda().eval()
+    B = 12
+    rgbd, p2p = synth.make_frames(B, H, W, seed=77)
+    rgbd, p2p = rgbd.cuda(), p2p.cuda()
+    with torch.no_grad():
+        net.inference_parts = 0
+        want = [{k: v.clone() for k, v in net((rgbd[i * 6:(i + 1) * 6].contiguous(), p2p[i * 6:(i + 1) * 6].contiguous())).items()}
+                for i in range(2)]
+        del net.inference_parts
+        assert ops.parts_for(B, rgbd.device, net.inference_parts, net.inference_part_rows) == 2
+        for rep in range(2):
+            got = net((rgbd, p2p))
+            torch.cuda.synchronize()
+            assert set(got) == set(want[0])
+            for k, v in got.items():
+                assert torch.equal(v, torch.cat([w[k] for w in want])), f"{k} (repeat {rep})"
+    assert got["bev_features"][:6].untyped_storage().data_ptr() == got["bev_features"][6:].untyped_storage().data_ptr()
