@@ -585,6 +585,57 @@ def latency_extras(model, device, iters=30):
             "note": "eager launches through the C ABI, inputs resident in HBM; not the headline workload"}
 
 
+def self_launch(n: int, argv=None) -> int:
+    """Re-run this script as `n` ranks: `python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1
+    --master-port <free> bench.py <same arguments>` (what the driver runs for N > 1; CRESTE_BENCH_FORCE_LAUNCH=1 takes this
+    path for N = 1 too).  The children inherit stdout / stderr: rank 0's JSON line is this command's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CRESTE_BENCH_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))     # (the launcher's default of 1 would
+    #                                                                                throttle the rank-0 CPU baseline)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args) -> int:
+    """The launcher + timing bookkeeping of `main` with nothing to run on: process group on gloo, a step = a sleep of 2 ms x
+    (rank + 1), barrier + max over ranks around exactly K steps, ONE line from rank 0.  For the CPU test of `--gpus N`."""
+    import torch.distributed as dist
+    from creste_public_amd import dist_utils
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    for _ in range(args.warmup):
+        time.sleep(0.002)
+    if dist.is_initialized():
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (rank + 1))
+    if dist.is_initialized():
+        dist.barrier()
+    el = dist_utils.max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({"metric": "frames/sec (RGB+LiDAR->BEV costmap)", "value": round(args.batch * world * args.steps / el, 3),
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "data": "dry-run", "launched_by": "self" if os.environ.get("CRESTE_BENCH_LAUNCHED") else "external",
+                          "note": "NOT a measurement: launcher check, a step is a sleep"}), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -604,7 +655,17 @@ def main():
     ap.add_argument("--layers", default="", help="write a per-conv-shape timing table to this file")
     ap.add_argument("--no-train-dp", action="store_true",
                     help="under torch.distributed.run: skip the data-parallel training legs (configs[3]/[4])")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / bookkeeping check without a GPU (tests/test_dist_cpu.py): gloo, a sleep for a step; "
+                         "the line says data = 'dry-run' and is NOT a measurement")
     args = ap.parse_args()
+
+    if (args.gpus > 1 or os.environ.get("CRESTE_BENCH_FORCE_LAUNCH") == "1") and "RANK" not in os.environ:
+        # `python bench.py --gpus N` as the driver calls it: become N ranks, one per GPU, under torch.distributed.run on this
+        # node; rank 0 of the children prints the single JSON line, this process only passes output and exit code through
+        raise SystemExit(self_launch(args.gpus))
+    if args.dry_run:
+        raise SystemExit(dry_run(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -618,8 +679,6 @@ def main():
         torch.cuda.set_device(local_rank)
         from creste_public_amd import dist_utils as _du
         _du.init_rccl(torch.device("cuda", local_rank))       # (collectives on a high-priority stream: see its docstring)
-    elif args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one rank per GPU)")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -728,23 +787,23 @@ def main():
         out_h = host_fed_steps(args.steps)
         fence()
         el_h = dist_utils.max_over_ranks(time.perf_counter() - t1, device)
-        # the host-fed steps must reproduce the resident ones bit for bit; a mismatch is REPORTED in the line (with the frames
-        # that differ) rather than raised, so that one bad step cannot take the whole measurement down
-        same_as_resident, mismatch = torch.equal(out_h["traversability_preds"], out["traversability_preds"]), None
+        # the host-fed steps must reproduce the resident ones bit for bit: a mismatch means frames were corrupted somewhere in
+        # the timed steps, and a throughput of wrong frames is not a measurement -- the run FAILS, after saying
+        # which frames differ and whether a fresh step sides with the resident or the host-fed result
+        same_as_resident = torch.equal(out_h["traversability_preds"], out["traversability_preds"])
         if not same_as_resident:
             again = step()
             rows = lambda a, b: torch.nonzero((a != b).reshape(a.shape[0], -1).any(1)).flatten().tolist()   # noqa: E731
             mismatch = {k: {"host_fed_vs_timed": rows(out_h[k], out[k]), "fresh_vs_timed": rows(again[k], out[k]),
                             "fresh_vs_host_fed": rows(again[k], out_h[k])} for k in out if out[k].is_floating_point()}
-            print(f"[bench] WARNING: host-fed step differs from the resident one: {mismatch}", file=sys.stderr, flush=True)
+            print(f"[bench] FAILED: the host-fed step differs from the resident one: {mismatch}", file=sys.stderr, flush=True)
+            raise SystemExit(3)
         host_fed = {"value": round(args.batch * args.gpus * args.steps / el_h, 3), "ms_per_step": round(el_h / args.steps * 1e3, 3),
                     "h2d_bytes_per_step": int(h_rgbd.numel() * 4 + h_scan.numel() * 4),
                     "note": "pinned host batch (RGB-D frames + LiDAR scan) -> device on a copy stream, two device buffers: "
                             "the copy of batch k+1 overlaps the compute of batch k; the first copy of the timed region "
                             "is exposed; `equals_resident`: the last host-fed step's costmap == the resident run's, bit for bit",
                     "equals_resident": bool(same_as_resident)}
-        if mismatch is not None:
-            host_fed["mismatch_frames"] = mismatch
         del bufs, h_rgbd, h_scan
 
     modes = {}
@@ -888,17 +947,24 @@ def main():
                                                               "ms": vr["ms"], "sweeps": vr["sweeps"]}
             line["distill"] = distill_extras(device)
             line["ssc"] = ssc_extras(device)
-        if args.gpus == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
     train_dp = None
     if dist is not None and not args.no_train_dp:
         # every rank takes part (synchronous SGD); rank 0 reports
         train_dp = train_dp_extras(model, device, rank)
+    if dist is not None:
+        torch.cuda.synchronize()
+        host_group = dist.new_group(backend="gloo") if world > 1 else None
     if rank == 0:
         if train_dp is not None:
             line["train_dp"] = train_dp
+        if not args.no_cpu_baseline:
+            # rank 0 only, at every N, after all GPU work: the other ranks wait on the HOST (a gloo barrier: no collective
+            # kernel spins on their GPUs meanwhile); `cores` says how many host threads the baseline used
+            line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if dist is not None:
+        if host_group is not None:
+            dist.barrier(group=host_group)
         dist.barrier()
         dist.destroy_process_group()
 

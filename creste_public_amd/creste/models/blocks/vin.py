@@ -50,9 +50,10 @@ class VIN(nn.Module):
     @property
     def last_sweeps(self):
         """Sweep count of the last solve (device int32 tensor).  The solve is asynchronous, so a failure cannot raise where
-        it happens: it is reported in the sign (ops.value_iteration) -- reading this property is the checkpoint (one host
-        synchronisation; the trainers read it when they log, every step under CRESTE_CHECK_VI=1): a negative count
-        raises, as the reference's loop would have spun / the launch-per-chunk form returned CRESTE_ERR_NOCONV."""
+        it happens: it is reported in the sign (ops.value_iteration).  It is checked without anybody asking: at the head
+        of the next solve and by IRLTrainer before every optimiser step (ops.vi_check: a 4-byte copy behind each solve);
+        reading this property checks NOW (one host synchronisation): a negative count raises, as the reference's loop
+        would have spun / the launch-per-chunk form returned CRESTE_ERR_NOCONV."""
         s = getattr(self, "_last_sweeps", None)
         if s is not None:
             ops.check_vi_sweeps(s)

@@ -247,23 +247,7 @@ class MaxEntIRL(nn.Module):
         main = torch.cuda.current_stream(inputs[0].device)
         main.wait_event(done)
         # the tensors were allocated on the side stream's pool: tell the allocator the main stream uses them too
-        seen = set()
-
-        def mark(o):
-            if torch.is_tensor(o):
-                if o.is_cuda and o.data_ptr() not in seen:
-                    seen.add(o.data_ptr())
-                    o.record_stream(main)
-            elif hasattr(o, "buf"):
-                mark(o.buf)
-                mark(getattr(o, "amax", None))
-            elif isinstance(o, dict):
-                for v in o.values():
-                    mark(v)
-            elif isinstance(o, (list, tuple)):
-                for v in o:
-                    mark(v)
-        mark(r); mark(outputs); mark(view)
+        ops.mark_stream((r, outputs, view), main)
         return r, outputs, view
 
     def forward(self, inputs):

@@ -18,7 +18,7 @@ import random
 import numpy as np
 import torch
 
-from . import dist_utils
+from . import dist_utils, ops
 from .creste.utils import train_utils as tu
 
 
@@ -97,15 +97,19 @@ class IRLTrainer:
                 self.model.prefetch_backbone((nxt["image"], nxt["p2p"]))
             else:
                 outputs = self.model(inputs)
-            with torch.no_grad():
-                merged = tu.merge_dict(("inputs", data), ("outputs", outputs))
-                merged["task"] = task
-            # tensors that carry the autograd graph must not be detached by the merge above
-            merged["outputs/traversability_preds"] = outputs["traversability_preds"]
-            merged["outputs/input_view"] = outputs["input_view"]
-            loss_dict, meta = self.loss(merged)
-            loss = sum(w * v for w, v in loss_dict.values())
-            loss.backward()
+            loss_dict, meta, loss = self._loss_and_backward(task, data, outputs)
+            # the MDP solve of this step reports failure in its sweep count, asynchronously: look at it before the
+            # gradients are used (waits for the solve's event only; loss / backward are still queued behind it).  A solve
+            # that was ABORTED (its workgroups were not all resident: another stream's kernels held the device) is redone
+            # in the launch-per-chunk form; no convergence raises.
+            if any(n == ops.VI_ABORTED for n in self._vi_counts()):
+                self.optimizer.zero_grad()
+                with ops.vi_launch_per_chunk():
+                    outputs = self.model._forward_trainable(inputs, None) if hasattr(self.model, "_forward_trainable") \
+                        else self.model(inputs)
+                loss_dict, meta, loss = self._loss_and_backward(task, data, outputs)
+                self._vi_counts()
+                self.vi_retries += 1
             dist_utils.allreduce_mean_grads(self.params)          # one flat all-reduce (no-op on 1 GPU)
             self.optimizer.step()
             total = total + loss.detach()
@@ -114,6 +118,29 @@ class IRLTrainer:
         logs["train/loss"] = total
         self.global_step += 1
         return logs
+
+    vi_retries = 0
+
+    def _loss_and_backward(self, task, data, outputs):
+        with torch.no_grad():
+            merged = tu.merge_dict(("inputs", data), ("outputs", outputs))
+            merged["task"] = task
+        # tensors that carry the autograd graph must not be detached by the merge above
+        merged["outputs/traversability_preds"] = outputs["traversability_preds"]
+        merged["outputs/input_view"] = outputs["input_view"]
+        loss_dict, meta = self.loss(merged)
+        loss = sum(w * v for w, v in loss_dict.values())
+        loss.backward()
+        return loss_dict, meta, loss
+
+    @staticmethod
+    def _vi_counts() -> list:
+        """sweep counts of the solves issued since the last look; raises on a solve that did not converge"""
+        counts = ops.vi_poll(wait=True)
+        for n in counts:
+            if n != ops.VI_ABORTED:
+                ops.check_vi_sweeps(torch.tensor([n], dtype=torch.int32))
+        return counts
 
     def on_train_epoch_end(self):
         self.scheduler.step()

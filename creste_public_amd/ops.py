@@ -109,21 +109,50 @@ def parts_for(B: int, device, want: int = 2, min_rows: int = 6) -> int:
     return n
 
 
+def mark_stream(obj, stream, _seen=None):
+    """record_stream(stream) on every CUDA tensor reachable from `obj` (tensors, Acts, dicts, lists / tuples): memory that
+    was allocated on one stream's pool and is about to be used on `stream`."""
+    seen = set() if _seen is None else _seen
+    if torch.is_tensor(obj):
+        if obj.is_cuda and obj.data_ptr() not in seen:
+            seen.add(obj.data_ptr())
+            obj.record_stream(stream)
+    elif hasattr(obj, "buf"):
+        mark_stream(obj.buf, stream, seen)
+        mark_stream(getattr(obj, "amax", None), stream, seen)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            mark_stream(v, stream, seen)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            mark_stream(v, stream, seen)
+
+
 def forward_in_parts(fn, batch_tensors, parts: int, owner=None):
     """fn(*slices) for each of `parts` equal slices of the batch-leading `batch_tensors`, part 0 on the caller's stream, the
     others on side streams (two parts: the probed 'parts' stream), joined before returning -> (PartContext, [results]).
     Inside, `shared_rows()` allocations are rows of shared whole-batch buffers (PartContext.whole gives the whole-batch view of
     part 0's result).  `owner`: any object; its `_parts_warm` attribute records that its lazily built caches exist (a part
-    that (re)builds caches makes the later parts start behind it)."""
+    that (re)builds caches makes the later parts start behind it), its `_parts_shapes` the shared buffers of earlier calls.
+
+    Ordering of the shared buffers: a buffer that another stream writes must not be a block that kernels still
+    queued on the caller's stream are using.  The shared buffers an owner asked for the last time it ran these input shapes
+    are therefore allocated BEFORE the fork event (everything queued on the caller's stream before it is complete when a
+    side stream starts); a buffer allocated by part 0 in mid-forward (first call, changed shapes) carries an event recorded
+    right behind the allocation, and the other parts wait for it before they touch the buffer (rows_empty)."""
     dev = batch_tensors[0].device
     main = torch.cuda.current_stream(dev)
     streams = [concurrent_stream(dev, "parts")] if parts == 2 else [torch.cuda.Stream(device=dev) for _ in range(parts - 1)]
     if any(s is None for s in streams):
         raise HipLibraryError("forward_in_parts: no side stream (ask parts_for first)")
     n = batch_tensors[0].shape[0] // parts
-    fork = torch.cuda.Event()
-    fork.record(main)                                  # the inputs are ready once a stream gets here
     ctx, res = PartContext(parts), []
+    skey = (parts, dev.index) + tuple((tuple(t.shape), t.dtype) for t in batch_tensors)
+    known = getattr(owner, "_parts_shapes", None)
+    if PREALLOCATE_SHARED and isinstance(known, dict) and skey in known:
+        ctx.prealloc = [torch.empty(shape, dtype=dtype, device=dev) for shape, dtype in known[skey]]
+    fork = torch.cuda.Event()
+    fork.record(main)                                  # the inputs (and the preallocated buffers) are ready once a stream gets here
     prev, _PART.ctx = _PART.ctx, ctx
     builds = CACHE_BUILDS
     try:
@@ -142,11 +171,20 @@ def forward_in_parts(fn, batch_tensors, parts: int, owner=None):
                 if owner is not None:
                     owner._parts_warm = True
         ctx.begin(parts)                               # (checks that the last part took every shared buffer)
+        if owner is not None:
+            if not isinstance(known, dict):
+                known = owner._parts_shapes = {}
+            known[skey] = [(tuple(t.shape), t.dtype) for t in ctx.log]
     finally:
         _PART.ctx = prev
-    for st in streams:
-        main.wait_stream(st)
+        for st in streams:                             # (also when a part raised: nothing stays un-joined)
+            main.wait_stream(st)
+    # what a later part returned outside the shared buffers lives in ITS stream's pool and is read on the caller's from here on
+    mark_stream(res[1:], main)
     return ctx, res
+
+
+PREALLOCATE_SHARED = True       # (tests switch it off to exercise the event-ordered form of every call)
 
 
 def whole_outputs(ctx: PartContext, dicts) -> dict:
@@ -263,6 +301,8 @@ class PartContext:
     def __init__(self, parts: int):
         self.parts, self.index, self.pos, self.depth = int(parts), 0, 0, 0
         self.log = []                       # the shared buffers in allocation order (allocated by part 0 on ITS stream)
+        self.events = []                    # per buffer: None (allocated before the fork) or the event behind its allocation
+        self.prealloc = []                  # buffers of the shapes the owner's last call asked for, allocated before the fork
         self.storages = set()
 
     def begin(self, index: int):
@@ -312,8 +352,18 @@ def rows_empty(shape, dtype, device) -> torch.Tensor:
     n = int(shape[0])
     full_shape = (n * c.parts,) + tuple(int(v) for v in shape[1:])
     if c.index == 0:
-        full = torch.empty(full_shape, dtype=dtype, device=device)
+        k = len(c.log)
+        if k < len(c.prealloc) and tuple(c.prealloc[k].shape) == full_shape and c.prealloc[k].dtype == dtype:
+            full, ev = c.prealloc[k], None
+        else:
+            # a block that part 0's stream freed a moment ago may still be in use by kernels queued there: the other parts'
+            # streams (which waited for the fork only) may write it once THIS point of part 0's stream has been reached
+            c.prealloc = c.prealloc[:k]
+            full = torch.empty(full_shape, dtype=dtype, device=device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(full.device))
         c.log.append(full)
+        c.events.append(ev)
         c.storages.add(full.untyped_storage().data_ptr())
     else:
         if c.pos >= len(c.log):
@@ -322,7 +372,10 @@ def rows_empty(shape, dtype, device) -> torch.Tensor:
         if tuple(full.shape) != full_shape or full.dtype != dtype:
             raise HipLibraryError(f"pipelined forward: shared allocation {c.pos} is {tuple(full.shape)} {full.dtype} in part 0 "
                                   f"and {full_shape} {dtype} in part {c.index}")
-        full.record_stream(torch.cuda.current_stream(full.device))     # allocated on part 0's stream, written on this one
+        here = torch.cuda.current_stream(full.device)
+        full.record_stream(here)                       # allocated on part 0's stream, written on this one
+        if c.events[c.pos] is not None:
+            here.wait_event(c.events[c.pos])
     c.pos += 1
     return full[c.index * n:(c.index + 1) * n]
 
@@ -981,25 +1034,91 @@ def check_vi_sweeps(sweeps: torch.Tensor) -> int:
     return n
 
 
+VI_ABORTED = -2 ** 31
+_vi_pending: list = []          # [(event, pinned int32[1])] of solves whose sweep count has not been looked at yet
+
+
+def _vi_note(sweeps: torch.Tensor):
+    """queue the asynchronous look at a solve's sweep count: a 4-byte copy into pinned memory behind the solve + an event"""
+    if _lib._recorder is not None or torch.cuda.is_current_stream_capturing():
+        return
+    host = torch.empty(1, dtype=torch.int32).pin_memory()
+    host.copy_(sweeps, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(sweeps.device))
+    _vi_pending.append((ev, host))
+
+
+def vi_poll(wait: bool = True) -> list:
+    """The sweep counts of the solves issued since the last poll whose result has arrived (all of them with wait=True: waits
+    for the LAST SOLVE's event, not for the stream -- work queued behind the solves keeps the device busy; wait=False
+    waits only while more than four solves are unlooked-at).  The caller decides what a negative count means for it;
+    `vi_check()` raises."""
+    out = []
+    while _vi_pending and (wait or len(_vi_pending) > 4 or _vi_pending[0][0].query()):
+        ev, host = _vi_pending.pop(0)
+        ev.synchronize()
+        out.append(int(host[0]))
+    return out
+
+
+def vi_check(wait: bool = True):
+    """Raise if a solve issued since the last poll failed (see check_vi_sweeps).  Runs by itself at the head of every
+    `value_iteration` (wait=False there: back-to-back solves stay asynchronous, at most four behind) and, waiting, in
+    IRLTrainer before every optimiser step."""
+    for n in vi_poll(wait):
+        check_vi_sweeps(torch.tensor([n], dtype=torch.int32))
+
+
 def value_iteration(r: torch.Tensor, discount: float, threshold: float = 1e-3, max_sweeps: int = 100000):
     """r [B,H,W] -> v [B,H,W], q [B,8,H,W], policy [B,8,H,W], sweeps (device int32 tensor).  The call is asynchronous:
-    failures are reported in the SIGN of `sweeps` (see `check_vi_sweeps`), which the caller checks off the hot path --
-    `VIN.last_sweeps` does, and every call does under CRESTE_CHECK_VI=1 (debugging: one host sync per solve)."""
+    failures are reported in the SIGN of `sweeps` (see `check_vi_sweeps`).  Nobody has to remember to look: every solve's
+    count is copied to pinned memory behind it and checked at the head of a later solve (`vi_check`; IRLTrainer checks
+    before each optimiser step and redoes a step whose solve was aborted through the launch-per-chunk form); `VIN.last_sweeps`
+    checks on demand; under CRESTE_CHECK_VI=1 every call checks at once (one host sync per solve) and an aborted persistent
+    solve is redone in the launch-per-chunk form before returning."""
     lib = _lib.load()
     B, H, W = r.shape
     dev = r.device
+    eager = _lib._recorder is None and not torch.cuda.is_current_stream_capturing()
+    if eager:
+        vi_check(wait=False)
     v = torch.empty((B, H, W), dtype=torch.float32, device=dev)
     q = torch.empty((B, 8, H, W), dtype=torch.float32, device=dev)
     pi = torch.empty((B, 8, H, W), dtype=torch.float32, device=dev)
     sweeps = torch.zeros(1, dtype=torch.int32, device=dev)
     work = torch.empty(lib.creste_value_iteration_workspace_bytes(B, H, W), dtype=torch.uint8, device=dev)
-    _lib.check(lib.creste_value_iteration_f32(_chk(r).data_ptr(), B, H, W, float(discount),
-                                              float(threshold), int(max_sweeps), v.data_ptr(),
-                                              q.data_ptr(), pi.data_ptr(), sweeps.data_ptr(),
-                                              work.data_ptr(), _stream()), "value_iteration")
-    if os.environ.get("CRESTE_CHECK_VI") == "1":
+
+    def solve():
+        _lib.check(lib.creste_value_iteration_f32(_chk(r).data_ptr(), B, H, W, float(discount),
+                                                  float(threshold), int(max_sweeps), v.data_ptr(),
+                                                  q.data_ptr(), pi.data_ptr(), sweeps.data_ptr(),
+                                                  work.data_ptr(), _stream()), "value_iteration")
+    solve()
+    if eager and os.environ.get("CRESTE_CHECK_VI") == "1":
+        if int(sweeps.item()) == VI_ABORTED:
+            with vi_launch_per_chunk():
+                solve()
         check_vi_sweeps(sweeps)
+    elif eager:
+        _vi_note(sweeps)
     return v, q, pi, sweeps
+
+
+class vi_launch_per_chunk:
+    """`with vi_launch_per_chunk():` -- solves inside take the launch-per-chunk form (host-synchronous, needs no co-residency):
+    the retry path of a persistent solve that reported VI_ABORTED."""
+
+    def __enter__(self):
+        self.prev = os.environ.get("CRESTE_VI_MULTI")
+        os.environ["CRESTE_VI_MULTI"] = "1"
+
+    def __exit__(self, *exc):
+        if self.prev is None:
+            os.environ.pop("CRESTE_VI_MULTI", None)
+        else:
+            os.environ["CRESTE_VI_MULTI"] = self.prev
+        return False
 
 
 def expected_svf(policy, expert_xy, fov_u8, T, ds, temperature, sharpen=True, zero_terminal=False):

@@ -124,6 +124,10 @@ class ConvG:
         if grads is not None:
             gw, acc = _acc(grads, w)
             side = ops.wgrad_stream(w.device) if x.N * x.H * x.W * max(Cin, Cout) >= WGRAD_STREAM_MIN else None
+            if side is not None and hipnn._precision == ops.PREC_F16X3:
+                # the |max| bounds are CACHED on the Acts and read again by this stream's input-gradient conv: they are
+                # made here, on the backward's stream (the side stream waits for it below), never on the side stream
+                ops.absmax(x), ops.absmax(gy)
             if side is not None:
                 # the weight gradient reads gy and the saved x and nothing of this backward reads IT: on the side stream,
                 # behind everything issued so far, while this stream goes on with the input gradient

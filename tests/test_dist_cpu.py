@@ -367,3 +367,29 @@ def test_two_rank_gloo_measure_dp_step_bookkeeping():
     # one process: the same function is a plain timer
     one = du.measure_dp_step(lambda: None, steps=2, frames_per_rank=8)
     assert one["world"] == 1 and one["allreduce_bytes"] == 0 and one["collective_calls"] == 0
+
+
+def test_bench_launches_itself_for_more_than_one_gpu():
+    """`python bench.py --gpus 2` with no RANK in the environment (how the driver calls it) must become two ranks under
+    torch.distributed.run and print ONE JSON line from rank 0.  `--dry-run`: gloo, a step is a sleep --
+    the launcher, rendezvous, barrier / max-over-ranks bookkeeping and exit code, nothing else."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["launched_by"] == "self" and line["data"] == "dry-run"
+    # the slowest rank's step (2 ms x 2) bounds the step time: max over ranks, not rank 0's own clock
+    assert line["ms_per_step"] >= 4.0
+    assert abs(line["value"] - 16 * 2 * 4 / (line["ms_per_step"] * 4e-3)) < 0.05 * line["value"]
+    # a failing rank must fail the command (WORLD_SIZE / --gpus disagreement is checked by every rank)
+    bad = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0
