@@ -78,7 +78,7 @@ def kernel_symbol(pc, N, Ho, Wo):
     if getattr(pc, "algo", 0) == 2:             # Winograd F(4x4,3x3): input transform + GEMM over the 36 positions + output transform
         split = {2: 2, 3: 3}[pc.prec]
         return (PREC_NAME[pc.prec] + "+winograd4",
-                f"wino4_in_kernel<3, UP, true> + wino4_gemm32_kernel<{split}, {4 if pc.Cout > 128 else 2}> + wino4_out_kernel")
+                f"wino4_in1_kernel<UP> + wino4_gemm32_kernel<{split}, {4 if pc.Cout > 128 else 2}> + wino4_out2_kernel")
     if pc.prec == 0:
         return ("f32", "conv_igemm_f32_kernel<2, 2, 2, 2>" if pc.Cout > 64 else
                 "conv_igemm_f32_kernel<2, 2, 2, 1>" if pc.Cout > 32 else "conv_igemm_f32_kernel<4, 1, 1, 1>")
@@ -164,8 +164,8 @@ class ConvProfiler:
                 "plan_ms": round(sum(plan_ms) / len(plan_ms), 4), "gather_ms": round(sum(gath_ms) / len(gath_ms), 4),
                 "min_call_ms": round(min(ms), 4), "calls": len(ms), "traffic": None,
                 "note": "HIP events around the binning plan (enqueued right after the pixel geometry, ahead of the fusion "
-                        "conv) and around the gather, INSIDE the timed steps (the network's own predicted depths and fused "
-                        "features, batch 16); time = plan_ms + gather_ms; bytes = 4*(F*P + 2*P + F*G + G) per frame "
+                        "conv) and around the gather, inside the one-stream steps run right after the timed region (the "
+                        "network's own predicted depths and fused features, batch 16); time = plan_ms + gather_ms; bytes = 4*(F*P + 2*P + F*G + G) per frame "
                         "(SURVEY 8d: F=96, P=46208, G=65536), one read of the inputs and one write of the outputs"}
 
     def summary(self):
@@ -705,8 +705,15 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
+    with torch.no_grad():
+        parts_used = model._parts_for(args.batch)
+    # The timed region of a pipelined run carries NO instrumentation: per-kernel event pairs there (two per conv launch and
+    # part, ~400 timing events per step on two streams) are not a property of the kernels (they span the other part's
+    # kernels) and were seen to disturb the very steps they sit in (single runs of 42-57 ms per step on boxes whose host-fed
+    # loop -- same steps, no events -- read 38-39).  Per-kernel numbers come from the one-stream steps right behind it.
     prof = ConvProfiler()
-    prof.install()
+    if parts_used == 1:
+        prof.install()
 
     def fence():
         torch.cuda.synchronize()
@@ -720,17 +727,16 @@ def main():
         out = step()
     fence()
     elapsed = time.perf_counter() - t0
-    prof.uninstall()
+    if parts_used == 1:
+        prof.uninstall()
     assert torch.isfinite(out["traversability_preds"]).all()
     # Per-KERNEL numbers (roofline, roofline_splat, the GEMM probe, --layers) come from the same number of steps run as ONE
     # forward on ONE stream right after the timed region: inside the pipelined steps the parts' kernels share the device, an
     # event pair around a launch also spans the other part's kernels, and a per-launch duration is not a property of that
-    # kernel any more (the pipelined steps' own event times are kept as `in_pipelined_steps`)
-    with torch.no_grad():
-        parts_used = model._parts_for(args.batch)
-    prof_pipe, serial_ms = None, None
+    # kernel any more
+    serial_ms = None
     if parts_used > 1:
-        prof_pipe, keep = prof, model.inference_parts
+        keep = model.inference_parts
         model.inference_parts = 0
         step()
         prof = ConvProfiler()
@@ -894,24 +900,12 @@ def main():
         sr = prof.splat_roofline()
         if sr is not None:
             line["roofline_splat"] = sr
-        if prof_pipe is not None:
-            # what the same event pairs read inside the pipelined (timed) steps, where the parts' kernels overlap
-            bp = prof_pipe.summary()
-            dp = bp.get(dom) or max(bp.values(), key=lambda v: v["ms"])
-            ach_p = dp["flops"] / (dp["ms"] * 1e-3) / 1e12
+        if serial_ms is not None:
             line["ms_per_step_one_stream"] = round(serial_ms, 3)
             line["roofline"]["measured_over"] = (f"{args.steps} steps run as one forward on one stream ({serial_ms:.2f} ms / step) "
                                                  "right after the timed region -- stand-alone launch durations, the ones "
-                                                 "`rocprofv3 --kernel-trace` of `bench.py --parts 1` shows")
-            line["roofline"]["in_pipelined_steps"] = {
-                "achieved": round(ach_p, 2), "frac": round(ach_p / PEAK[dprec], 4), "launches": dp["n"],
-                "avg_launch_ms": round(dp["ms"] / dp["n"], 4),
-                "note": "the same event pairs inside the timed (pipelined) steps: a launch's interval also holds the other part's "
-                        "kernels, so the durations of concurrent launches add up to more than the step"}
-            sp = prof_pipe.splat_roofline()
-            if sr is not None and sp is not None:
-                line["roofline_splat"]["in_pipelined_steps"] = {k: sp[k] for k in ("achieved", "frac", "avg_call_ms", "plan_ms",
-                                                                                 "gather_ms", "calls")}
+                                                 "`rocprofv3 --kernel-trace` of `bench.py --parts 1` shows; the timed "
+                                                 "(pipelined) steps themselves carry no event pairs")
         if host_fed is not None:
             line["value_host_fed"] = host_fed["value"]
             line["host_fed"] = host_fed

@@ -17,11 +17,14 @@
 // Relative rms error against float64 on the 496-channel layers: 1.3e-6 (direct fp32 accumulation: 1.8e-7, F(2x2): 1.1e-6).
 //
 //   wino4_pack_kernel  U = G g G^T per (cout, cin), 36 positions, the GEMM's weight-tile LDS image (pack time)
-//   wino4_in_kernel    V = B^T d B per (tile, cin): 6x6 window at stride 4, split into bf16 pieces, written as
-//                      V[pos][tile block][chunk][piece][k-octet][256 tiles][8]  (= the GEMM's A-operand LDS image)
-//   wino4_gemm_kernel  36 independent GEMMs M_p[tile, cout] = sum_cin V_p[tile, cin] U_p[cout, cin]; persistent
-//                      workgroups, three LDS stages, every byte by LDS-DMA, one barrier per 16-channel chunk
-//   wino4_out_kernel   Y = A^T M A per (tile, channel quad) + the direct kernels' epilogue
+//   wino4_in1_kernel   V = B^T d B per (tile, cin): 6x6 window at stride 4, written as fp32
+//                      V[pos][tile block][chunk][k-quad][256 tiles][4]  (= the GEMM's A-operand LDS image; round 3 wrote it
+//                      as bf16 pieces: wino4_in_kernel, kept as the bit-exact reference and for the weight gradient)
+//   wino4_gemm32_kernel 36 independent GEMMs M_p[tile, cout] = sum_cin V_p[tile, cin] U_p[cout, cin]; persistent
+//                      workgroups, three LDS stages, every byte by LDS-DMA, one barrier per 16-channel chunk, A split into
+//                      its bf16 pieces in registers
+//   wino4_out2_kernel  Y = A^T M A per (tile, channel pair) + the direct kernels' epilogue
+// Both transforms are sized to fit BESIDE a GEMM workgroup of another stream on the same CU (<= 112 VGPRs, <= 40 KiB LDS)
 #include "common.h"
 #include <stdlib.h>
 
@@ -464,14 +467,11 @@ __device__ __forceinline__ void w4_bt2(const w4f32x2 (&d)[6], w4f32x2 (&t)[6]) {
 // wy0 * (hx * v00 + lx * v01) + wy1 * (hx * v10 + lx * v11), horizontal sums shared by the rows that use them), so the
 // result is bit-identical to upsampling first.  Windows that touch the image border (clamped taps, zero padding) take
 // the generic per-pixel path.
-// F32V: V is written as fp32, [pos][tile block][chunk][k-quad][256 tiles][4] (the AF32 form of the GEMM): no pieces; the
-// pairs cross the LDS tile twelve positions at a time ([position][k-quad of the 32 channels][16 tiles][4 floats], rows padded
-// by 16 bytes) and leave as the same 256-byte runs.
-constexpr int W4I_ROW = 16 * 16 + 16;          // bytes of one (position, k-quad) row of the F32V tile
-template <int SPLIT, bool UP, bool F32V>
-__global__ __launch_bounds__(256, (UP && F32V) ? 3 : 4) void wino4_in_kernel(const Wino4InArgs p) {
+// (This is the PRE-SPLIT form, V as bf16 pieces: the reference the fp32-V path is checked against bit for bit, CRESTE_W4_F32V=0,
+// and the form whose pieces the weight gradient's GEMM consumes.  The forward's default is wino4_in1_kernel below: V as fp32.)
+template <int SPLIT, bool UP>
+__global__ __launch_bounds__(256, 4) void wino4_in_kernel(const Wino4InArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned tbuf[W4_POS * 4 * 16 * 4];      // [pos][chunk half * 2 + octet][tile][4 pairs]
-  static_assert(12 * 8 * W4I_ROW <= (int)sizeof(unsigned) * W4_POS * 4 * 16 * 4, "F32V tile");
   const int t = threadIdx.x;
   // gridDim.x is a multiple of 16: workgroup (x, y) sits on XCD x % 8.  Every XCD gets a contiguous range of tile groups,
   // so the 6x6 windows' shared pixels (2 of 6 columns / rows) are re-read from ITS L2 (round-robin: 2.4x the input fetched)
@@ -577,34 +577,6 @@ __global__ __launch_bounds__(256, (UP && F32V) ? 3 : 4) void wino4_in_kernel(con
     for (int j = 0; j < 6; ++j) u[i][j] = o[j];
   }
   const int mb = (tg * 16) >> 8, row0 = (tg * 16) & (W4_M - 1);
-  if constexpr (F32V) {
-    char* tb = reinterpret_cast<char*>(tbuf);
-    // write side: thread = (position parity, k-quad of the 32 channels, tile); its six units of a group are 2 positions apart
-    const int tlw = t & 15, kq8 = (t >> 4) & 7, pph = t >> 7;
-    const int chunk = chunk0 + (kq8 >> 2);
-    const size_t pos_stride = (size_t)p.m_blocks * p.nchunk * (size_t)(4 * W4_M * 16);
-    char* dst0 = p.V + (((size_t)mb * p.nchunk + chunk) * 4 + (kq8 & 3)) * (size_t)(W4_M * 16) + (size_t)(row0 + tlw) * 16 +
-                 pph * pos_stride;
-    const char* src0 = tb + (pph * 8 + kq8) * W4I_ROW + tlw * 16;
-    char* wr0 = tb + (cp >> 1) * W4I_ROW + tl * 16 + (cp & 1) * 8;
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-      if (g) __syncthreads();
-#pragma unroll
-      for (int pp = 0; pp < 12; ++pp) {
-        const int pos = g * 12 + pp;
-        *reinterpret_cast<w4f32x2*>(wr0 + pp * 8 * W4I_ROW) = u[pos / 6][pos % 6];
-      }
-      __syncthreads();
-      if (chunk < p.nchunk) {
-#pragma unroll
-        for (int it = 0; it < 6; ++it)
-          *reinterpret_cast<w4f32x4*>(dst0 + (size_t)(g * 12 + 2 * it) * pos_stride) =
-              *reinterpret_cast<const w4f32x4*>(src0 + 2 * it * 8 * W4I_ROW);
-      }
-    }
-    return;
-  }
   constexpr int UNITS = W4_POS * 4 * 16;       // 16-byte units of one piece: (position, chunk half * 2 + octet, tile)
 #pragma unroll
   for (int pl = 0; pl < SPLIT; ++pl) {
@@ -629,6 +601,149 @@ __global__ __launch_bounds__(256, (UP && F32V) ? 3 : 4) void wino4_in_kernel(con
   }
 }
 
+__device__ __forceinline__ void w4_bt1(const float (&d)[6], float (&t)[6]) {
+  const float a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1], c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+  t[0] = (4.f * d[0] - 5.f * d[2]) + d[4];
+  t[1] = a + b;
+  t[2] = a - b;
+  t[3] = c + e;
+  t[4] = c - e;
+  t[5] = (4.f * d[1] - 5.f * d[3]) + d[5];
+}
+
+// ---- the transforms that FIT BESIDE the GEMM (round 5).  The persistent GEMM workgroup holds 2 x 200 of a SIMD's 512 VGPRs
+// and 120 of the CU's 160 KiB of LDS: a kernel of another stream whose waves need <= 112 VGPRs and whose workgroup needs
+// <= 40 KiB of LDS is dispatched onto the SAME CUs and streams while the matrix pipe works (scripts/coresidency_probe.py: a
+// copy kernel of that size moves 2.4-3.2 TB/s beside the GEMM, which then runs 1.2-1.4 x longer: 20-25 % less time for the
+// pair than one after the other).  The pair / quad transforms above need 128-150 VGPRs and only run on CUs the GEMM does
+// not hold.  Same arithmetic, expression for expression: V, M and the outputs are bit-identical to theirs.
+//
+// Input transform: one workgroup = 8 tiles x 32 channels (two chunks); thread = (tile, channel): 36 4-byte loads (a wave
+// reads the 128 contiguous bytes of two pixels per instruction), B^T d B in place, the fp32 values cross an LDS tile twelve
+// positions at a time ([position][k-quad of the 32 channels][8 tiles][4 floats], rows padded by 16 bytes) and leave as
+// 128-byte runs of V (8 consecutive tiles of one k-quad).
+constexpr int W4S_ROW = 8 * 16 + 16;
+template <bool UP>
+__global__ __launch_bounds__(256) void wino4_in1_kernel(const Wino4InArgs p) {
+  __shared__ __attribute__((aligned(16))) char tb[12 * 8 * W4S_ROW];
+  const int t = threadIdx.x;
+  int tg, chunk0;
+  if (p.order) {
+    // as wino4_in_kernel: an XCD owns a contiguous range of tile groups and walks it with the channel-chunk pairs fastest
+    const int L = blockIdx.x, xcd = L & 7, idx = L >> 3, q = (p.m_blocks * 32) >> 3;
+    const int tgl = idx / p.ncp;
+    tg = xcd * q + tgl; chunk0 = (idx - tgl * p.ncp) * 2;
+  } else {
+    tg = xcd_remap(blockIdx.x, gridDim.x); chunk0 = blockIdx.y * 2;
+  }
+  const int tl = t >> 5, c = t & 31;
+  const int tile = tg * 8 + tl, ch = chunk0 * W4_CK + c;
+  const int per = p.tiles_y * p.tiles_x;
+  float d[6][6];
+  {
+    const bool ok = tile < p.T && ch < p.Cin;
+    const int tcl = ok ? tile : 0;
+    const int img = tcl / per, rem = tcl - img * per;
+    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    const int y0 = 4 * ty - p.pad_t, x0 = 4 * tx - p.pad_l;
+    const int C2 = UP ? p.Cin - p.up_C : p.Cin;
+    if (UP && ok && ch >= C2) {
+      // the exact 2x bilinear upsample of up_src formed from the 4x4 source patch of the window (see wino4_in_kernel)
+      const int H1 = p.H >> 1, W1 = p.W >> 1;
+      const float* src = p.up_src + (size_t)img * H1 * W1 * p.up_cs + (ch - C2);
+      const int yb0 = 2 * ty - 1, xb0 = 2 * tx - 1;
+      float hz[4][6];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        int ry = yb0 + a; ry = ry < 0 ? 0 : (ry > H1 - 1 ? H1 - 1 : ry);
+        float P[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          int rx = xb0 + b; rx = rx < 0 ? 0 : (rx > W1 - 1 ? W1 - 1 : rx);
+          P[b] = src[((size_t)ry * W1 + rx) * p.up_cs];
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int ox = x0 + j;
+          const float lx = ox == 0 ? 0.f : ((j & 1) ? 0.75f : 0.25f), hx = 1.f - lx;
+          hz[a][j] = hx * P[j >> 1] + lx * P[(j >> 1) + 1];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int oy = y0 + i;
+        const float wy1 = oy == 0 ? 0.f : ((i & 1) ? 0.75f : 0.25f), wy0 = 1.f - wy1;
+        const bool yin = (unsigned)oy < (unsigned)p.H;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const float v = wy0 * hz[i >> 1][j] + wy1 * hz[(i >> 1) + 1][j];
+          d[i][j] = (yin && (unsigned)(x0 + j) < (unsigned)p.W) ? v : 0.f;
+        }
+      }
+    } else if (!ok) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d[i][j] = 0.f;
+    } else {
+      const float* base = p.in + ch;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int yy = y0 + i;
+        const bool yok = (unsigned)yy < (unsigned)p.H;
+        const size_t rowoff = ((size_t)img * p.H + (yok ? yy : 0)) * p.W;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int xx = x0 + j;
+          const bool in = yok && (unsigned)xx < (unsigned)p.W;
+          const float v = base[(rowoff + (in ? xx : 0)) * p.in_cs];
+          d[i][j] = in ? v : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+      float o[6];
+      w4_bt1(col, o);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) d[i][j] = o[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float o[6];
+    w4_bt1(d[i], o);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) d[i][j] = o[j];
+  }
+  const int mb = (tg * 8) >> 8, row0 = (tg * 8) & (W4_M - 1);
+  // write side: thread = (position mod 4, k-quad of the 32 channels, tile)
+  const int tlw = t & 7, kq8 = (t >> 3) & 7, p4 = t >> 6;
+  const int chunk = chunk0 + (kq8 >> 2);
+  const size_t pos_stride = (size_t)p.m_blocks * p.nchunk * (size_t)(4 * W4_M * 16);
+  char* dst0 = p.V + (((size_t)mb * p.nchunk + chunk) * 4 + (kq8 & 3)) * (size_t)(W4_M * 16) + (size_t)(row0 + tlw) * 16 +
+               p4 * pos_stride;
+  const char* src0 = tb + (p4 * 8 + kq8) * W4S_ROW + tlw * 16;
+  char* wr0 = tb + (c >> 2) * W4S_ROW + tl * 16 + (c & 3) * 4;
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    if (g) __syncthreads();
+#pragma unroll
+    for (int pp = 0; pp < 12; ++pp) {
+      const int pos = g * 12 + pp;
+      *reinterpret_cast<float*>(wr0 + pp * 8 * W4S_ROW) = d[pos / 6][pos % 6];
+    }
+    __syncthreads();
+    if (chunk < p.nchunk) {
+#pragma unroll
+      for (int it = 0; it < 3; ++it)
+        *reinterpret_cast<w4f32x4*>(dst0 + (size_t)(g * 12 + 4 * it) * pos_stride) =
+            *reinterpret_cast<const w4f32x4*>(src0 + 4 * it * 8 * W4S_ROW);
+    }
+  }
+}
+
 struct Wino4OutArgs {
   const float* M;
   const float* bias;
@@ -642,44 +757,45 @@ struct Wino4OutArgs {
   int order, ncg, ntg8;      // order 1: 1-D grid, cout groups fastest inside an XCD's range of ntg8 tile groups
 };
 
-// One workgroup = 16 consecutive tiles x 64 couts.  Read side: thread = (tile, channel quad), 36 x 16-byte loads streamed
-// row by row of the 6x6 product tile (the 16 tiles of a quad are 256 contiguous bytes of M).  The 4x4 outputs cross an LDS
-// tile two output rows at a time so that the write side runs thread = (pixel, channel quad): 16 lanes write 256
-// contiguous bytes of one NHWC pixel and read bias / residual the same way.
-constexpr int W4O_TILES = 16, W4O_QUADS = 16, W4O_ROW = W4O_QUADS * 4 + 4;
-__global__ __launch_bounds__(256) void wino4_out_kernel(const Wino4OutArgs p) {
-  __shared__ __attribute__((aligned(16))) float tilebuf[W4O_TILES * 8 * W4O_ROW];
+constexpr int W4O_TILES = 16;
+
+// Output transform that fits beside the GEMM: one workgroup = 16 consecutive tiles x 32 couts.  Read side: thread = (tile,
+// channel PAIR), 36 x 8-byte loads row by row of the 6x6 product tile (two lanes share a quad's 16 bytes, the 16 tiles of a
+// quad are 256 contiguous bytes of M); all 16 output pixels of the tile cross ONE LDS tile; write side: thread = (pixel,
+// channel quad): 8 lanes write the 128 contiguous bytes of one NHWC pixel and read bias / residual the same way.
+constexpr int W4O2_QUADS = 8, W4O2_ROW = W4O2_QUADS * 4 + 4;
+__global__ __launch_bounds__(256) void wino4_out2_kernel(const Wino4OutArgs p) {
+  __shared__ __attribute__((aligned(16))) float tilebuf[W4O_TILES * 16 * W4O2_ROW];
   __shared__ float scratch[4];
   const int Q = p.Cout >> 2;
   const int t = threadIdx.x;
   int tile0, quad0;
   if (p.order) {
     const int L = blockIdx.x, xcd = L & 7, idx = L >> 3, tgl = idx / p.ncg;
-    tile0 = (xcd * p.ntg8 + tgl) * W4O_TILES; quad0 = (idx - tgl * p.ncg) * W4O_QUADS;
+    tile0 = (xcd * p.ntg8 + tgl) * W4O_TILES; quad0 = (idx - tgl * p.ncg) * W4O2_QUADS;
     if (tile0 >= p.T) return;
   } else {
-    tile0 = blockIdx.x * W4O_TILES; quad0 = blockIdx.y * W4O_QUADS;
+    tile0 = blockIdx.x * W4O_TILES; quad0 = blockIdx.y * W4O2_QUADS;
   }
-  const int tl = t & (W4O_TILES - 1), ql = t >> 4;
-  w4f32x4 y[4][4];
+  const int tl = t & (W4O_TILES - 1), pr = t >> 4;
+  w4f32x2 y[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) y[a][b] = w4f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < 4; ++b) y[a][b] = w4f32x2{0.f, 0.f};
   {
-    const int tile = tile0 + tl, quad = quad0 + ql;
+    const int tile = tile0 + tl, quad = quad0 + (pr >> 1);
     if (tile < p.T && quad < Q) {
-      const float* src = p.M + ((size_t)quad * p.T + tile) * 4;
+      const float* src = p.M + ((size_t)quad * p.T + tile) * 4 + (pr & 1) * 2;
       const size_t plane = (size_t)p.mplane;
-      // rows of A^T by column i: y[a][.] += AT[a][i] * r_i[.]
       constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        w4f32x4 m[6];
+        w4f32x2 m[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) m[j] = __builtin_nontemporal_load(reinterpret_cast<const w4f32x4*>(src + (i * 6 + j) * plane));
-        const w4f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-        const w4f32x4 r[4] = {(m[0] + s12) + s34, d12 + 2.f * d34, s12 + 4.f * s34, (d12 + 8.f * d34) + m[5]};
+        for (int j = 0; j < 6; ++j) m[j] = __builtin_nontemporal_load(reinterpret_cast<const w4f32x2*>(src + (i * 6 + j) * plane));
+        const w4f32x2 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+        const w4f32x2 r[4] = {(m[0] + s12) + s34, d12 + 2.f * d34, s12 + 4.f * s34, (d12 + 8.f * d34) + m[5]};
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           if (AT[a][i] == 0.f) continue;
@@ -689,41 +805,37 @@ __global__ __launch_bounds__(256) void wino4_out_kernel(const Wino4OutArgs p) {
       }
     }
   }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      *reinterpret_cast<w4f32x2*>(tilebuf + (tl * 16 + a * 4 + b) * W4O2_ROW + pr * 2) = y[a][b];
+  __syncthreads();
   float vmax = 0.f;
-  const int cq = t & 15, n = (quad0 + cq) * 4;
+  const int cq = t & 7, n = (quad0 + cq) * 4;
   const int per = p.tiles_y * p.tiles_x;
   const bool nok = quad0 + cq < Q;
   const w4f32x4 bs = (nok && p.bias) ? *reinterpret_cast<const w4f32x4*>(p.bias + n) : w4f32x4{0.f, 0.f, 0.f, 0.f};
+  if (nok) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    if (h) __syncthreads();
+    for (int pass = 0; pass < 8; ++pass) {
+      const int pl = pass * 32 + (t >> 3);            // pixel slot: tile pl / 16, output row (pl / 4) % 4, column pl % 4
+      const int tile = tile0 + (pl >> 4);
+      if (tile >= p.T) continue;
+      const int img = tile / per, rem = tile - img * per;
+      const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+      const int oy = 4 * ty + ((pl >> 2) & 3), ox = 4 * tx + (pl & 3);
+      if (oy >= p.Ho || ox >= p.Wo) continue;
+      const long mrow = ((long)img * p.Ho + oy) * p.Wo + ox;
+      w4f32x4 v = *reinterpret_cast<const w4f32x4*>(tilebuf + pl * W4O2_ROW + cq * 4) + bs;
+      if (p.res) v += *reinterpret_cast<const w4f32x4*>(p.res + mrow * p.res_cs + n);
+      const float rmask = p.row_mask ? p.row_mask[mrow] : 1.f;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-        *reinterpret_cast<w4f32x4*>(tilebuf + (tl * 8 + a * 4 + b) * W4O_ROW + ql * 4) = y[2 * h + a][b];
-    __syncthreads();
-    if (nok) {
-#pragma unroll
-      for (int pass = 0; pass < 8; ++pass) {
-        const int pl = pass * 16 + (t >> 4);          // pixel slot: tile pl / 8, output row 2h + (pl / 4) % 2, column pl % 4
-        const int tile = tile0 + (pl >> 3);
-        if (tile >= p.T) continue;
-        const int img = tile / per, rem = tile - img * per;
-        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-        const int oy = 4 * ty + 2 * h + ((pl >> 2) & 1), ox = 4 * tx + (pl & 3);
-        if (oy >= p.Ho || ox >= p.Wo) continue;
-        const long mrow = ((long)img * p.Ho + oy) * p.Wo + ox;
-        w4f32x4 v = *reinterpret_cast<const w4f32x4*>(tilebuf + pl * W4O_ROW + cq * 4) + bs;
-        if (p.res) v += *reinterpret_cast<const w4f32x4*>(p.res + mrow * p.res_cs + n);
-        const float rmask = p.row_mask ? p.row_mask[mrow] : 1.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = act_apply(v[e], p.act) * rmask;
-          vmax = fmaxf(vmax, fabsf(v[e]));
-        }
-        *reinterpret_cast<w4f32x4*>(p.out + mrow * p.out_cs + p.out_co + n) = v;
+      for (int e = 0; e < 4; ++e) {
+        v[e] = act_apply(v[e], p.act) * rmask;
+        vmax = fmaxf(vmax, fabsf(v[e]));
       }
+      *reinterpret_cast<w4f32x4*>(p.out + mrow * p.out_cs + p.out_co + n) = v;
     }
   }
   if (p.out_amax) block_amax_update(vmax, p.out_amax, scratch);
@@ -907,18 +1019,22 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
   const int order = ord_env ? atoi(ord_env) : 2;
   ia.order = order & 1; ia.ncp = (nchunk + 1) / 2;
   const dim3 igrid = ia.order ? dim3((unsigned)(m_blocks * 16 * ia.ncp)) : dim3((unsigned)(m_blocks * 16), (unsigned)((nchunk + 1) / 2));
+  const dim3 igrid1 = ia.order ? dim3((unsigned)(m_blocks * 32 * ia.ncp)) : dim3((unsigned)(m_blocks * 32), (unsigned)((nchunk + 1) / 2));
   const char* f32_env = getenv("CRESTE_W4_F32V");
   const bool f32v = f32_env ? atoi(f32_env) != 0 : true;
-  if (d->flags & CRESTE_CONV_V_VALID) {
+  // experiment knob (scripts/coresidency_probe.py): CRESTE_W4_ONLY = bit mask of the kernels of the call that run
+  // (1 input transform, 2 GEMM, 4 output transform); results are only meaningful with all three
+  const int only = w4_env_int("CRESTE_W4_ONLY", 7);
+  if ((d->flags & CRESTE_CONV_V_VALID) || !(only & 1)) {
     // the caller vouches that `work` holds V of this very input (creste_hip.h)
   } else if (f32v) {
-    if (d->up_src) wino4_in_kernel<3, true, true><<<igrid, 256, 0, s>>>(ia);
-    else wino4_in_kernel<3, false, true><<<igrid, 256, 0, s>>>(ia);
+    if (d->up_src) wino4_in1_kernel<true><<<igrid1, 256, 0, s>>>(ia);
+    else wino4_in1_kernel<false><<<igrid1, 256, 0, s>>>(ia);
   } else if (d->up_src) {
-    if (split == 3) wino4_in_kernel<3, true, false><<<igrid, 256, 0, s>>>(ia);
-    else wino4_in_kernel<2, true, false><<<igrid, 256, 0, s>>>(ia);
-  } else if (split == 3) wino4_in_kernel<3, false, false><<<igrid, 256, 0, s>>>(ia);
-  else wino4_in_kernel<2, false, false><<<igrid, 256, 0, s>>>(ia);
+    if (split == 3) wino4_in_kernel<3, true><<<igrid, 256, 0, s>>>(ia);
+    else wino4_in_kernel<2, true><<<igrid, 256, 0, s>>>(ia);
+  } else if (split == 3) wino4_in_kernel<3, false><<<igrid, 256, 0, s>>>(ia);
+  else wino4_in_kernel<2, false><<<igrid, 256, 0, s>>>(ia);
   CRESTE_CHECK_LAUNCH("wino4_in");
 
   Wino4GemmArgs a;
@@ -934,7 +1050,8 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
     CRESTE_HIP(hipEventRecord(g_w4_ev[0], s));
   }
   const bool stream = f32v && nchunk >= 3 && (f32_env ? atoi(f32_env) != 2 : true);
-  if (stream) {
+  if (!(only & 2)) rc = CRESTE_OK;
+  else if (stream) {
     if (tn == 4) rc = split == 3 ? launch_wino4_gemm32<3, 4>(a, s) : launch_wino4_gemm32<2, 4>(a, s);
     else rc = split == 3 ? launch_wino4_gemm32<3, 2>(a, s) : launch_wino4_gemm32<2, 2>(a, s);
   } else if (f32v) {
@@ -949,11 +1066,11 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
   o.M = M; o.bias = d->bias; o.res = d->res; o.row_mask = d->row_mask; o.out = d->out; o.out_amax = d->out_amax;
   o.N = d->N; o.Ho = d->Ho; o.Wo = d->Wo; o.Cout = d->Cout; o.out_cs = d->out_cs; o.out_co = d->out_co; o.res_cs = d->res_cs;
   o.act = d->act; o.tiles_y = tiles_y; o.tiles_x = tiles_x; o.T = (int)T; o.mplane = a.mplane;
-  o.order = (order >> 1) & 1; o.ncg = (d->Cout / 4 + W4O_QUADS - 1) / W4O_QUADS;
+  o.order = (order >> 1) & 1; o.ncg = (d->Cout / 4 + W4O2_QUADS - 1) / W4O2_QUADS;
   o.ntg8 = (int)(((T + W4O_TILES - 1) / W4O_TILES + 7) / 8);
   const dim3 ogrid = o.order ? dim3((unsigned)(o.ntg8 * 8 * o.ncg))
-                             : dim3((unsigned)((T + W4O_TILES - 1) / W4O_TILES), (unsigned)((d->Cout / 4 + W4O_QUADS - 1) / W4O_QUADS));
-  wino4_out_kernel<<<ogrid, 256, 0, s>>>(o);
+                             : dim3((unsigned)((T + W4O_TILES - 1) / W4O_TILES), (unsigned)o.ncg);
+  if (only & 4) wino4_out2_kernel<<<ogrid, 256, 0, s>>>(o);
   CRESTE_CHECK_LAUNCH("wino4_out");
   return CRESTE_OK;
 }
@@ -986,15 +1103,6 @@ __device__ __forceinline__ void w4_a(const float (&v)[4], float (&t)[6]) {
   t[4] = (v[0] - 2.f * v[1]) + (4.f * v[2] - 8.f * v[3]);
   t[5] = v[3];
   (void)s01; (void)d01;
-}
-__device__ __forceinline__ void w4_bt1(const float (&d)[6], float (&t)[6]) {
-  const float a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1], c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
-  t[0] = (4.f * d[0] - 5.f * d[2]) + d[4];
-  t[1] = a + b;
-  t[2] = a - b;
-  t[3] = c + e;
-  t[4] = c - e;
-  t[5] = (4.f * d[1] - 5.f * d[3]) + d[5];
 }
 
 // Workgroup = 16 consecutive tiles (= one K chunk) x 32 channels; thread = (tile PAIR, channel): scalar loads with the

@@ -119,10 +119,6 @@ def test_hot_kernels_stay_out_of_scratch():
         # that two 9-wave workgroups fit a CU under any wave placement (csrc/value_iteration.hip); what spills sits at the
         # chunk head / in the redo path, the eight sweeps between the barriers are scratch-free (checked in the ISA)
         "vi_persist_kernelILi1E": 12,
-        # without packed-fp32 VALU (build.py NO_PK) the channel-PAIR arithmetic of the plain F(4x4) input transform needs five
-        # more registers than its four-workgroups-per-CU budget of 128: 20 bytes per lane, outside the load / store loops;
-        # measured 252 us per launch against 259 with v_pk_* and no scratch (profiles/r04p1_kernel_stats.csv, r04_step_table.md)
-        "wino4_in_kernelILi3ELb0ELb1EE": 20,
     }
     bad = []
     for name, u in usage.items():
