@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libcreste_hip.so")
 
-ABI_VERSION = 8          # creste_abi_version() of the library this binding was written against
+ABI_VERSION = 9          # creste_abi_version() of the library this binding was written against
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
 
@@ -156,6 +156,7 @@ SIGNATURES = {
     "creste_hip_model_info": (C.c_char_p, [_vp]),
     "creste_hip_model_num_inputs": (_i, [_vp]),
     "creste_hip_model_num_outputs": (_i, [_vp]),
+    "creste_hip_model_num_streams": (_i, [_vp]),
     "creste_hip_model_input": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i),
                                     C.POINTER(_i64), C.POINTER(_i64)]),
     "creste_hip_model_output": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i),
@@ -165,7 +166,43 @@ SIGNATURES = {
 }
 
 _lib = None
-_recorder = None          # a list while deploy.export_plan traces a forward: (name, args) of every launching call
+_recorder = None          # a PlanRecorder while deploy.export_plan traces a forward: every launching call and stream-order edge
+
+
+class PlanRecorder(list):
+    """(name, args, stream handle) of every launching call of a traced forward, in host issue order; stream-order edges as
+    the pseudo calls ("__record__" | "__wait__", [("i", event id)], stream handle).  `pipelined`: the traced forward may run
+    in parts on several streams (ops.forward_in_parts); otherwise it is kept on one stream."""
+
+    def __init__(self, pipelined: bool = False):
+        super().__init__()
+        self.pipelined = bool(pipelined)
+        self._events = {}
+
+    def event_id(self, ev) -> int:
+        return self._events.setdefault(id(ev), len(self._events))
+
+
+def event_record(ev, stream):
+    """ev.record(stream) -- and, while a plan is traced, the edge's first half (the C runtime replays it with an event of its own)"""
+    ev.record(stream)
+    if _recorder is not None:
+        _recorder.append(("__record__", [("i", _recorder.event_id(ev))], int(stream.cuda_stream)))
+
+
+def event_wait(stream, ev):
+    """stream.wait_event(ev) -- recorded like event_record"""
+    stream.wait_event(ev)
+    if _recorder is not None:
+        _recorder.append(("__wait__", [("i", _recorder.event_id(ev))], int(stream.cuda_stream)))
+
+
+def stream_wait_stream(dst, src):
+    """dst.wait_stream(src): everything issued on `src` so far is ordered before what `dst` does next"""
+    import torch
+    ev = torch.cuda.Event()
+    event_record(ev, src)
+    event_wait(dst, ev)
 
 
 class _RecordingLib:
@@ -198,7 +235,7 @@ class _RecordingLib:
                     saved.append(("d", float(a)))
                 else:                                   # byref(ConvDesc)
                     saved.append(("desc", bytes(a._obj)))
-            rec.append((name, saved))
+            rec.append((name, saved, int(args[-1] or 0)))
             return fn(*args)
         return call
 

@@ -54,7 +54,9 @@ struct Tensor {
   int64_t shape[6], stride[6];
 };
 struct Call {
-  const PlanFn* fn;
+  const PlanFn* fn;                // nullptr: a stream-order edge (op = 1 record / 2 wait, args[0].i = event index)
+  int op = 0;
+  uint32_t stream = 0;             // 0 = the caller's stream, k > 0 = the runtime's own side stream k - 1
   std::vector<PlanArg> args;
 };
 struct Model {
@@ -67,6 +69,8 @@ struct Model {
   int flags = 0;
   hipGraphExec_t graph = nullptr;
   hipStream_t graph_stream = nullptr;
+  std::vector<hipStream_t> side;   // the streams a pipelined plan's parts run on (the Python path's side streams)
+  std::vector<hipEvent_t> events;  // one per recorded fork / join / buffer-ordering edge
   int device = 0;
 };
 
@@ -104,6 +108,10 @@ void destroy(Model* m) {
   if (!m) return;
   if (m->graph) (void)hipGraphExecDestroy(m->graph);
   if (m->graph_stream) (void)hipStreamDestroy(m->graph_stream);
+  for (hipStream_t st : m->side)
+    if (st) (void)hipStreamDestroy(st);
+  for (hipEvent_t ev : m->events)
+    if (ev) (void)hipEventDestroy(ev);
   for (void* p : m->segs)
     if (p) (void)hipFree(p);
   delete m;
@@ -115,10 +123,23 @@ const PlanFn* find_fn(const std::string& name) {
   return nullptr;
 }
 
+// Replay: every launch on the stream it was recorded on (stream 0 = `s`), the recorded edges as event record / wait pairs.
+// A plan traced on one stream has no edges; a pipelined plan (deploy.export_plan of a forward that ran as parts on several
+// streams) forks behind the input copies on `s` and joins back onto `s` before its last call returns.
 int run_calls(Model* m, hipStream_t s) {
   for (const Call& c : m->calls) {
-    const int rc = c.fn->call(c.args.data(), (void*)s);
-    if (rc != 0) return rc;                           // the entry point has set the error string
+    hipStream_t st = c.stream == 0 ? s : m->side[c.stream - 1];
+    if (c.fn) {
+      const int rc = c.fn->call(c.args.data(), (void*)st);
+      if (rc != 0) return rc;                         // the entry point has set the error string
+      continue;
+    }
+    hipEvent_t ev = m->events[c.args[0].i];
+    const hipError_t e = c.op == 1 ? hipEventRecord(ev, st) : hipStreamWaitEvent(st, ev, 0);
+    if (e != hipSuccess) {
+      ::creste::set_error("model_infer: stream-order edge failed: %s", hipGetErrorString(e));
+      return -2;
+    }
   }
   return 0;
 }
@@ -138,7 +159,7 @@ extern "C" int creste_hip_model_load(const char* path, int flags, void** handle)
   r.bytes(magic, 12);
   if (!r.ok || memcmp(magic, "CRESTEPLAN\0\0", 12) != 0) PLAN_FAIL("model_load: %s is not a creste plan file", path);
   const uint32_t version = r.get<uint32_t>(), desc_size = r.get<uint32_t>();
-  if (version != 2) PLAN_FAIL("model_load: plan format version %u, this library reads 2", version);
+  if (version != 3) PLAN_FAIL("model_load: plan format version %u, this library reads 3", version);
   // the recorded arguments are only meaningful to the library generation that recorded them: same C ABI, same
   // descriptor layout (a plan from another ABI would hand creste_conv2d_nhwc a short or mis-laid-out descriptor)
   const uint32_t abi = r.get<uint32_t>();
@@ -209,21 +230,38 @@ extern "C" int creste_hip_model_load(const char* path, int flags, void** handle)
   const uint32_t nfn = r.get<uint32_t>();
   if (!r.ok || nfn > 1024) PLAN_FAIL("model_load: corrupt function table");
   std::vector<const PlanFn*> fns(nfn);
+  std::vector<int> edge_op(nfn, 0);
+  uint32_t nstreams = 1, nevents = 0;
   for (uint32_t i = 0; i < nfn; ++i) {
     const std::string name = r.str();
     fns[i] = find_fn(name);
-    if (!r.ok || !fns[i]) PLAN_FAIL("model_load: the plan calls %s, which this library does not export", name.c_str());
+    if (name == "__record__") edge_op[i] = 1;
+    else if (name == "__wait__") edge_op[i] = 2;
+    if (!r.ok || (!fns[i] && !edge_op[i])) PLAN_FAIL("model_load: the plan calls %s, which this library does not export", name.c_str());
   }
   const uint32_t ncall = r.get<uint32_t>();
   if (!r.ok || ncall > (1u << 20)) PLAN_FAIL("model_load: corrupt call table");
   m->calls.resize(ncall);
   m->descs.reserve(ncall);
   for (uint32_t c = 0; c < ncall; ++c) {
-    const uint32_t fi = r.get<uint32_t>(), na = r.get<uint32_t>();
-    if (!r.ok || fi >= nfn || (int)na != fns[fi]->nargs) PLAN_FAIL("model_load: call %u does not match its entry point", c);
+    const uint32_t fi = r.get<uint32_t>(), sid = r.get<uint32_t>(), na = r.get<uint32_t>();
+    if (!r.ok || fi >= nfn || sid >= 16 || (int)na != (fns[fi] ? fns[fi]->nargs : 1))
+      PLAN_FAIL("model_load: call %u does not match its entry point", c);
     Call& call = m->calls[c];
     call.fn = fns[fi];
+    call.op = edge_op[fi];
+    call.stream = sid;
+    if (sid + 1 > nstreams) nstreams = sid + 1;
     call.args.resize(na);
+    if (!call.fn) {                                   // stream-order edge: one int argument, the event index
+      const uint32_t kind = r.get<uint32_t>();
+      const int32_t ev = r.get<int32_t>();
+      if (!r.ok || kind != K_I32 || ev < 0 || ev >= 4096) PLAN_FAIL("model_load: corrupt stream-order edge in call %u", c);
+      call.args[0].l = 0;
+      call.args[0].i = ev;
+      if ((uint32_t)ev + 1 > nevents) nevents = (uint32_t)ev + 1;
+      continue;
+    }
     for (uint32_t a = 0; a < na; ++a) {
       const uint32_t kind = r.get<uint32_t>();
       static const char kKindChar[] = {'i', 'l', 'f', 'd', 'p', 'D'};
@@ -261,10 +299,18 @@ extern "C" int creste_hip_model_load(const char* path, int flags, void** handle)
     }
   }
   if (!r.ok) PLAN_FAIL("model_load: truncated file");
+  m->side.assign(nstreams - 1, nullptr);
+  for (hipStream_t& st : m->side)
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; PLAN_FAIL("model_load: cannot create a side stream"); }
+  m->events.assign(nevents, nullptr);
+  for (hipEvent_t& ev : m->events)
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ev = nullptr; PLAN_FAIL("model_load: cannot create an event"); }
   fclose(f);
   *handle = m;
   return 0;
 }
+
+extern "C" int creste_hip_model_num_streams(void* handle) { return handle ? 1 + (int)((Model*)handle)->side.size() : -1; }
 
 extern "C" int creste_hip_model_free(void* handle) {
   destroy((Model*)handle);

@@ -128,9 +128,14 @@ def _snapshot(device):
     return sorted(segs)
 
 
-def export_plan(model: torch.nn.Module, example_inputs, path: str, warmup: int = 2) -> dict:
+def export_plan(model: torch.nn.Module, example_inputs, path: str, warmup: int = 2, pipelined: bool = True) -> dict:
     """Trace ONE eval-mode forward of `model` (MaxEntIRL with solve_mdp=False, or TerrainNet) on `example_inputs` =
     (rgbd [B,1,4,H,W], p2p [B,1,4,4]) and write the plan file `path`:
+
+      * `pipelined` (default): a forward that the model runs as parts on several streams (batches of >= 12 frames:
+        ops.forward_in_parts) is recorded AS SUCH -- every call carries its stream, the fork / join / buffer-ordering edges
+        are recorded as event record / wait pairs, and the C runtime replays them on streams of its own: the Python-free
+        artefact pipelines exactly as the Python path does (False: the forward is traced on one stream);
 
       * every launching C-ABI call of the forward, in order (entry-point name, scalars, conv descriptors);
       * the allocator segments those calls address (the arena) -- each pointer becomes (segment, offset);
@@ -163,7 +168,8 @@ def export_plan(model: torch.nn.Module, example_inputs, path: str, warmup: int =
         gc.collect()
         before = _snapshot(dev)                               # persistent state: parameters, packed weights, inputs
         ops.reset_amax_pool()                                 # |max| slot blocks are filled INSIDE the traced forward
-        rec = []
+        rec = _lib.PlanRecorder(pipelined)
+        main_handle = int(torch.cuda.current_stream(dev).cuda_stream)
         _lib._recorder = rec
         try:
             out = model(static_in)
@@ -195,8 +201,10 @@ def export_plan(model: torch.nn.Module, example_inputs, path: str, warmup: int =
         return si, p - after[i][0]
 
     calls, fn_ids = [], {}
-    for name, args in rec:
+    stream_ids = {main_handle: 0}                      # stream 0 = the stream the caller hands to creste_hip_model_infer
+    for name, args, handle in rec:
         fid = fn_ids.setdefault(name, len(fn_ids))
+        sid = stream_ids.setdefault(handle, len(stream_ids))
         enc = []
         for kind, v in args:
             if kind == "p":
@@ -211,7 +219,7 @@ def export_plan(model: torch.nn.Module, example_inputs, path: str, warmup: int =
                 enc.append((5, (v, rel)))
             else:
                 enc.append(({"i": 0, "l": 1, "f": 2, "d": 3}[kind], v))
-        calls.append((fid, enc))
+        calls.append((fid, sid, enc))
 
     def tensor_entry(name, t):
         if t.dtype not in _DTYPES or t.dim() > 6:
@@ -236,11 +244,11 @@ def export_plan(model: torch.nn.Module, example_inputs, path: str, warmup: int =
         return struct.pack("<I", len(b)) + b
 
     info = (f"{type(model).__name__} precision={hipnn.get_precision()} inputs="
-            f"{[tuple(t.shape) for t in static_in]} calls={len(calls)} abi={_lib.ABI_VERSION}").encode()
+            f"{[tuple(t.shape) for t in static_in]} calls={len(calls)} streams={len(stream_ids)} abi={_lib.ABI_VERSION}").encode()
     seg_sizes = [None] * len(used_segments)
     for i, si in used_segments.items():
         seg_sizes[si] = after[i][1]
-    blob = [PLAN_MAGIC, struct.pack("<III", 2, C.sizeof(_lib.ConvDesc), _lib.ABI_VERSION), s_(info), struct.pack("<I", len(seg_sizes))]
+    blob = [PLAN_MAGIC, struct.pack("<III", 3, C.sizeof(_lib.ConvDesc), _lib.ABI_VERSION), s_(info), struct.pack("<I", len(seg_sizes))]
     blob += [struct.pack("<Q", sz) for sz in seg_sizes]
     for group in (inputs, outputs):
         blob.append(struct.pack("<I", len(group)))
@@ -254,8 +262,8 @@ def export_plan(model: torch.nn.Module, example_inputs, path: str, warmup: int =
     blob.append(struct.pack("<I", len(names)))
     blob += [s_(n.encode()) for n in names]
     blob.append(struct.pack("<I", len(calls)))
-    for fid, enc in calls:
-        blob.append(struct.pack("<II", fid, len(enc)))
+    for fid, sid, enc in calls:
+        blob.append(struct.pack("<III", fid, sid, len(enc)))
         for kind, v in enc:
             blob.append(struct.pack("<I", kind))
             if kind == 0:
@@ -275,7 +283,9 @@ def export_plan(model: torch.nn.Module, example_inputs, path: str, warmup: int =
     with open(path, "wb") as f:
         for b in blob:
             f.write(b)
-    return {"calls": len(calls), "entry_points": names, "segments": len(seg_sizes), "arena_bytes": sum(seg_sizes),
+    launches = [n for n in names if not n.startswith("__")]
+    return {"calls": sum(1 for c in calls if not names[c[0]].startswith("__")), "entry_points": launches,
+            "streams": len(stream_ids), "events": len(rec._events), "segments": len(seg_sizes), "arena_bytes": sum(seg_sizes),
             "constant_bytes": sum(len(c[2]) for c in consts), "outputs": [o[0] for o in outputs]}
 
 
@@ -292,6 +302,7 @@ class PlanModel:
         _lib.check(self._lib.creste_hip_model_load(path.encode(), int(bool(graph)), C.byref(h)), "model_load")
         self._h = h
         self.info = self._lib.creste_hip_model_info(h).decode()
+        self.num_streams = self._lib.creste_hip_model_num_streams(h)      # > 1: a pipelined plan (side streams inside the runtime)
         self.inputs = [self._describe(self._lib.creste_hip_model_input, i)
                        for i in range(self._lib.creste_hip_model_num_inputs(h))]
         self.outputs = [self._describe(self._lib.creste_hip_model_output, i)

@@ -100,7 +100,7 @@ def parts_for(B: int, device, want: int = 2, min_rows: int = 6) -> int:
     """How many parts an eval forward of B frames runs in: `want` when pipelining is allowed here (no autograd, no plan
     trace, no stream capture, B divisible, parts of >= min_rows frames, a probed side stream available), else 1."""
     n = int(want or 1)
-    if (n < 2 or torch.is_grad_enabled() or _lib._recorder is not None or B % n or B // n < min_rows
+    if (n < 2 or torch.is_grad_enabled() or (_lib._recorder is not None and not _lib._recorder.pipelined) or B % n or B // n < min_rows
             or os.environ.get("CRESTE_INFER_PARTS", "") in ("0", "1") or _PART.ctx is not None
             or torch.cuda.is_current_stream_capturing()):
         return 1
@@ -152,7 +152,7 @@ def forward_in_parts(fn, batch_tensors, parts: int, owner=None):
     if PREALLOCATE_SHARED and isinstance(known, dict) and skey in known:
         ctx.prealloc = [torch.empty(shape, dtype=dtype, device=dev) for shape, dtype in known[skey]]
     fork = torch.cuda.Event()
-    fork.record(main)                                  # the inputs (and the preallocated buffers) are ready once a stream gets here
+    _lib.event_record(fork, main)                      # the inputs (and the preallocated buffers) are ready once a stream gets here
     prev, _PART.ctx = _PART.ctx, ctx
     builds = CACHE_BUILDS
     try:
@@ -160,14 +160,14 @@ def forward_in_parts(fn, batch_tensors, parts: int, owner=None):
             st = main if i == 0 else streams[i - 1]
             ctx.begin(i)
             if i:
-                st.wait_event(fork)
+                _lib.event_wait(st, fork)
             with torch.cuda.stream(st):
                 res.append(fn(*(t[i * n:(i + 1) * n] for t in batch_tensors)))
             if i == 0 and (CACHE_BUILDS != builds or not getattr(owner, "_parts_warm", False)):
                 # part 0 (re)built caches -- packed weights, folded BatchNorm, constants -- by launches on ITS stream (always
                 # assumed of an owner's first pipelined forward): the other parts read them only behind part 0
                 fork = torch.cuda.Event()
-                fork.record(main)
+                _lib.event_record(fork, main)
                 if owner is not None:
                     owner._parts_warm = True
         ctx.begin(parts)                               # (checks that the last part took every shared buffer)
@@ -178,7 +178,7 @@ def forward_in_parts(fn, batch_tensors, parts: int, owner=None):
     finally:
         _PART.ctx = prev
         for st in streams:                             # (also when a part raised: nothing stays un-joined)
-            main.wait_stream(st)
+            _lib.stream_wait_stream(main, st)
     # what a later part returned outside the shared buffers lives in ITS stream's pool and is read on the caller's from here on
     mark_stream(res[1:], main)
     return ctx, res
@@ -361,7 +361,7 @@ def rows_empty(shape, dtype, device) -> torch.Tensor:
             c.prealloc = c.prealloc[:k]
             full = torch.empty(full_shape, dtype=dtype, device=device)
             ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(full.device))
+            _lib.event_record(ev, torch.cuda.current_stream(full.device))
         c.log.append(full)
         c.events.append(ev)
         c.storages.add(full.untyped_storage().data_ptr())
@@ -375,7 +375,7 @@ def rows_empty(shape, dtype, device) -> torch.Tensor:
         here = torch.cuda.current_stream(full.device)
         full.record_stream(here)                       # allocated on part 0's stream, written on this one
         if c.events[c.pos] is not None:
-            here.wait_event(c.events[c.pos])
+            _lib.event_wait(here, c.events[c.pos])
     c.pos += 1
     return full[c.index * n:(c.index + 1) * n]
 

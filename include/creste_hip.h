@@ -636,12 +636,17 @@ int creste_irl_visitation_mix_f32(const float* exp_svf_raw, const uint8_t* fov, 
  *   output : index -> name (the reference's output-dict key, terrainnet.py:272-350 / vin.py:119-133), device pointer
  *            into the arena, dtype (0 = f32, 1 = i64, 2 = u8/bool), rank, shape[6], stride[6] in ELEMENTS; valid after
  *            the stream drained, overwritten by the next infer.
+ *   streams: a plan of a forward that the Python path pipelines (batches of >= 12 frames run as two half-batch forwards
+ *            on two streams) carries every call's stream and the fork / join / buffer-ordering edges; the runtime replays
+ *            them on side streams of its own (num_streams - 1 of them) behind `stream`, joined back before infer's last
+ *            call is issued -- the caller still synchronises `stream` only.
  * Results are bit-identical to the Python host path (the same launches on the same arena layout). */
 int creste_hip_model_load(const char* path, int flags, void** handle);
 int creste_hip_model_free(void* handle);
 const char* creste_hip_model_info(void* handle);
 int creste_hip_model_num_inputs(void* handle);
 int creste_hip_model_num_outputs(void* handle);
+int creste_hip_model_num_streams(void* handle);
 int creste_hip_model_input(void* handle, int index, const char** name, void** ptr, int* dtype, int* ndim,
                            int64_t* shape, int64_t* stride);
 int creste_hip_model_output(void* handle, int index, const char** name, void** ptr, int* dtype, int* ndim,

@@ -142,11 +142,11 @@ def test_plan_loader_rejects_foreign_abi_and_descriptor_layout(tmp_path):
         rc = handle.creste_hip_model_load(str(p).encode(), 0, ctypes.byref(h))
         return rc, handle.creste_last_error().decode()
 
-    rc, msg = try_load(1, desc, _lib.ABI_VERSION)
+    rc, msg = try_load(2, desc, _lib.ABI_VERSION)        # round 4's format: calls without a stream, no stream-order edges
     assert rc != 0 and "format version" in msg
-    rc, msg = try_load(2, desc, _lib.ABI_VERSION - 1)
+    rc, msg = try_load(3, desc, _lib.ABI_VERSION - 1)
     assert rc != 0 and "C-ABI version" in msg
-    rc, msg = try_load(2, desc - 8, _lib.ABI_VERSION)
+    rc, msg = try_load(3, desc - 8, _lib.ABI_VERSION)
     assert rc != 0 and "descriptor" in msg
     # the per-argument kind signatures the loader validates against are generated with the thunks
     inc = open(os.path.join(ROOT, "creste_public_amd", "csrc", "plan_dispatch.inc")).read()

@@ -101,3 +101,64 @@ def test_c_program_runs_the_plan_without_python(exported, tmp_path):
             assert torch.equal(got, ref[d["name"]].to(got.dtype)), d["name"]
     finally:
         pm.close()
+
+
+# ---- the pipelined plan: a forward that the Python path runs as two half-batch forwards on two
+# streams is exported with its streams and stream-order edges, and the C runtime replays it on streams of its own
+@pytest.fixture(scope="module")
+def exported_pipelined(tmp_path_factory):
+    creste_public_amd.set_precision("bf16x6")
+    torch.manual_seed(8)
+    model = MaxEntIRL(maxent_irl_cfg((H, W), solve_mdp=False))
+    synth.randomize_bn(model, seed=9)
+    model = model.cuda().eval()
+    model.inference_part_rows = 4                    # 8 frames = 2 parts of 4 (the shipped threshold is a speed threshold)
+    rgbd, p2p = synth.make_frames(8, H, W, seed=6)
+    rgbd, p2p = rgbd.cuda(), p2p.cuda()
+    synth.calibrate_bn_hip(model, rgbd[:2], p2p[:2])
+    with torch.no_grad():
+        assert model._parts_for(8) == 2, "no probed side stream on this box: the pipelined plan cannot be traced"
+    d = tmp_path_factory.mktemp("plan_pipe")
+    path, path1 = str(d / "irl_pipe.plan"), str(d / "irl_one_stream.plan")
+    summary = deploy.export_plan(model, (rgbd, p2p), path)
+    summary1 = deploy.export_plan(model, (rgbd, p2p), path1, pipelined=False)
+    yield model, path, summary, (rgbd, p2p), path1, summary1
+    creste_public_amd.set_precision("f32")
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_pipelined_plan_replays_the_two_stream_forward_bit_for_bit(exported_pipelined, graph):
+    model, path, summary, inputs, path1, summary1 = exported_pipelined
+    assert summary["streams"] == 2 and summary["events"] >= 2          # fork + join (+ buffer-ordering edges)
+    assert summary1["streams"] == 1 and summary1["events"] == 0
+    assert summary["calls"] > summary1["calls"]                         # two half-batch forwards launch more kernels
+    ref = _eager(model, inputs)                                          # the Python path: pipelined as well
+    pm = deploy.PlanModel(path, graph=graph)
+    try:
+        assert pm.num_streams == 2
+        for rep in range(3):
+            got = pm(inputs)
+            for k in ref:
+                assert torch.equal(got[k], ref[k].to(got[k].dtype)), f"{k} (replay {rep})"
+        rgbd2, p2p2 = synth.make_frames(8, H, W, seed=123)
+        ref2 = _eager(model, (rgbd2.cuda(), p2p2.cuda()))
+        got2 = pm((rgbd2.cuda(), p2p2.cuda()))
+        for k in ref2:
+            assert torch.equal(got2[k], ref2[k].to(got2[k].dtype)), k
+    finally:
+        pm.close()
+    # the one-stream plan of the same model computes the WHOLE batch in one forward: equal to the Python path with
+    # pipelining off (a half-batch forward differs from the whole-batch one at float-noise level: the SE pooling's partition)
+    model.inference_parts = 0
+    try:
+        ref1 = _eager(model, inputs)
+    finally:
+        del model.inference_parts
+    pm1 = deploy.PlanModel(path1)
+    try:
+        assert pm1.num_streams == 1
+        got1 = pm1(inputs)
+        for k in ref1:
+            assert torch.equal(got1[k], ref1[k].to(got1[k].dtype)), k
+    finally:
+        pm1.close()

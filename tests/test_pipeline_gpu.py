@@ -92,7 +92,7 @@ def test_pipelining_is_off_where_it_must_be():
     with torch.no_grad():
         assert model._parts_for(16) == 2
         from creste_public_amd import _lib
-        _lib._recorder = []
+        _lib._recorder = _lib.PlanRecorder()
         try:
             assert model._parts_for(16) == 1                               # deploy.export_plan traces one stream
         finally:
