@@ -52,6 +52,19 @@ __device__ __forceinline__ void w4_split_mfma2(const w4bf16x8 (&a)[SPLIT], const
     }
 }
 
+// the same for ONE row fragment and two weight tiles (the row-split wave layout: a wave owns 32 tiles x all couts)
+template <int SPLIT>
+__device__ __forceinline__ void w4_split_mfma2w(const w4bf16x8 (&w0)[SPLIT], const w4bf16x8 (&w1)[SPLIT],
+                                                const w4bf16x8 (&v)[SPLIT], w4f32x16& c0, w4f32x16& c1) {
+#pragma unroll
+  for (int order = SPLIT - 1; order >= 0; --order)
+#pragma unroll
+    for (int pa = order; pa >= 0; --pa) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[pa], v[order - pa], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[pa], v[order - pa], c1, 0, 0, 0);
+    }
+}
+
 struct Wino4GemmArgs {
   const char* V;             // [36][m_blocks][nchunk][SPLIT][2][256][8] bf16
   const char* wpk;           // [36][units][nchunk][SPLIT][2][64][8] bf16
@@ -246,7 +259,12 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_kernel(const Wino4GemmArgs 
 // earlier, and between them the wave reads its 64 rows of A(c + 1) as fp32 and splits them (the conversions / subtractions
 // of wino4_in_kernel's piece loop: pieces and products bit-identical to the pre-split form).  A is consumed one chunk
 // ahead of B, so three stages of each suffice: 3 x (16 + 24) KiB.
-template <int SPLIT, int TN>
+// RS (row split): the 8 waves are 8 row groups of 32 tiles, each against ALL 64 * TN couts (MT = 1, NT = 2 * TN weight tiles),
+// instead of 4 row groups of 64 tiles x 2 cout halves: every row of A is split into its bf16 pieces by ONE wave, not by two
+// (half the split's VALU work per chunk: the split is 9 % of the kernel, profiles/r05_gemm_notes.md), for twice the B-fragment
+// LDS reads.  Same products in the same order per accumulator: bit-identical.
+// EXP != 0: timing experiments only (WRONG results), see launch_wino4_gemm32.
+template <int SPLIT, int TN, int EXP = 0, bool RS = false>
 __global__ __launch_bounds__(512, 2) void wino4_gemm32_kernel(const Wino4GemmArgs p) {
   constexpr int A_QUAD = W4_M * 16, A_BYTES = 4 * A_QUAD;                                // [k-quad][row][4 f32]
   constexpr int U_OCT = 64 * 16, U_PLANE = 2 * U_OCT, U_BYTES = SPLIT * U_PLANE;         // one 64-cout weight unit
@@ -255,8 +273,8 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm32_kernel(const Wino4GemmArg
   constexpr int A_INSTR = A_BYTES / 1024, B_INSTR = B_BYTES / 1024;
   constexpr int kA = A_INSTR / 8, kBw = (B_INSTR + 7) / 8;     // 1 KiB DMA pieces EVERY wave issues per chunk
   constexpr int kDma = kA + kBw;
-  constexpr int NT = TN;
-  constexpr int kStores = 2 * NT * 4;
+  constexpr int MT = RS ? 1 : 2, NT = RS ? 2 * TN : TN;
+  constexpr int kStores = MT * NT * 4;
   static_assert(A_INSTR % 8 == 0 && B_BYTES % 1024 == 0, "tiles must be whole DMA pieces");
   static_assert(kDma + kStores <= 63, "vmcnt is a 6-bit counter");
 
@@ -266,7 +284,8 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm32_kernel(const Wino4GemmArg
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 3, wn = wave >> 2;     // 4 row groups of 64 tiles x 2 channel halves
+  const int wm = RS ? wave : wave & 3, wn = RS ? 0 : wave >> 2;     // 4 row groups of 64 tiles x 2 channel halves (RS: 8 x 1)
+  const int row0 = RS ? wm * 32 : wm * 64;
   const int li = lane & 31, lh = lane >> 5;
 
   const int cus = gridDim.x >> 3;
@@ -317,24 +336,29 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm32_kernel(const Wino4GemmArg
     }
   };
 
-  w4f32x16 acc[2][NT];
+  w4f32x16 acc[MT][NT];
   auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   };
-  w4bf16x8 af[2][SPLIT];
+  w4bf16x8 af[MT][SPLIT];
   // this wave's rows of the A tile in stage `st`: fp32 -> bf16 pieces (lane = row li of the 32-row block, k-octet lh)
   auto read_a = [&](int st, int mt, w4f32x4 (&q)[2]) __attribute__((always_inline)) {
-    const char* A = Ast + st * A_BYTES + (wm * 64 + mt * 32 + li) * 16;
+    const char* A = Ast + st * A_BYTES + (row0 + mt * 32 + li) * 16;
     q[0] = *reinterpret_cast<const w4f32x4*>(A + (2 * lh) * A_QUAD);
     q[1] = *reinterpret_cast<const w4f32x4*>(A + (2 * lh + 1) * A_QUAD);
   };
   auto split_a = [&](const w4f32x4 (&q)[2], w4bf16x8 (&dst)[SPLIT]) __attribute__((always_inline)) {
     w4f32x8 x{q[0][0], q[0][1], q[0][2], q[0][3], q[1][0], q[1][1], q[1][2], q[1][3]};
+    if (EXP == 1) {                     // no split arithmetic: the raw bits as "pieces"
+#pragma unroll
+      for (int pl = 0; pl < SPLIT; ++pl) dst[pl] = __builtin_bit_cast(w4bf16x8, q[pl & 1]);
+      return;
+    }
 #pragma unroll
     for (int pl = 0; pl < SPLIT; ++pl) {
       dst[pl] = __builtin_convertvector(x, w4bf16x8);
@@ -345,29 +369,40 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm32_kernel(const Wino4GemmArg
   // couts) with the split of the NEXT chunk's rows (stage `stn`) between them
   auto mfma_chunk = [&](int st, int stn) __attribute__((always_inline)) {
     const char* B = Bst + st * B_BYTES;
-    w4bf16x8 bfr[2][SPLIT], afn[2][SPLIT];
-    w4f32x4 raw[2][2];
+    w4bf16x8 afn[MT][SPLIT];
+    w4f32x4 raw[MT][2];
     auto read_b = [&](int nt, w4bf16x8 (&dst)[SPLIT]) __attribute__((always_inline)) {
       const int n = (wn * NT + nt) * 32 + li;
 #pragma unroll
       for (int pl = 0; pl < SPLIT; ++pl)
         dst[pl] = *reinterpret_cast<const w4bf16x8*>(B + (n >> 6) * U_BYTES + pl * U_PLANE + lh * U_OCT + (n & 63) * 16);
     };
-    read_b(0, bfr[0]);
-    read_a(stn, 0, raw[0]);
-    read_a(stn, 1, raw[1]);
+    if constexpr (RS) {
+      // weight tiles two at a time against the wave's one row fragment; the next pair's fragments land behind this pair's
+      // 4 * SPLIT MFMAs; the split of the next chunk's rows sits behind the first pair
+      w4bf16x8 bfr[2][2][SPLIT];
+      read_b(0, bfr[0][0]); read_b(1, bfr[0][1]);
+      read_a(stn, 0, raw[0]);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      if (nt + 1 < NT) read_b(nt + 1, bfr[(nt + 1) & 1]);     // lands behind this tile's 4 * SPLIT MFMAs
-      w4_split_mfma2<SPLIT>(bfr[nt & 1], af[0], af[1], acc[0][nt], acc[1][nt]);
-      if (NT == 2) {
-        split_a(raw[nt], afn[nt]);
-      } else if (nt < 2) {
-        split_a(raw[nt], afn[nt]);
+      for (int np = 0; np < NT / 2; ++np) {
+        if (np + 1 < NT / 2) { read_b(2 * np + 2, bfr[(np + 1) & 1][0]); read_b(2 * np + 3, bfr[(np + 1) & 1][1]); }
+        w4_split_mfma2w<SPLIT>(bfr[np & 1][0], bfr[np & 1][1], af[0], acc[0][2 * np], acc[0][2 * np + 1]);
+        if (np == 0) split_a(raw[0], afn[0]);
+      }
+    } else {
+      w4bf16x8 bfr[2][SPLIT];
+      read_b(0, bfr[0]);
+      read_a(stn, 0, raw[0]);
+      read_a(stn, MT - 1, raw[MT - 1]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (nt + 1 < NT) read_b(nt + 1, bfr[(nt + 1) & 1]);     // lands behind this tile's 4 * SPLIT MFMAs
+        w4_split_mfma2<SPLIT>(bfr[nt & 1], af[0], af[MT - 1], acc[0][nt], acc[MT - 1][nt]);
+        if (nt < MT) split_a(raw[nt < MT ? nt : 0], afn[nt < MT ? nt : 0]);
       }
     }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int pl = 0; pl < SPLIT; ++pl) af[mt][pl] = afn[mt][pl];
   };
@@ -384,8 +419,8 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm32_kernel(const Wino4GemmArg
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   {
     w4f32x4 raw[2];
-    read_a(0, 0, raw); split_a(raw, af[0]);
-    read_a(0, 1, raw); split_a(raw, af[1]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { read_a(0, mt, raw); split_a(raw, af[mt]); }
   }
   int st = 0;                                   // stage of the current chunk = (chunks so far) % 3
   for (;;) {
@@ -393,16 +428,21 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm32_kernel(const Wino4GemmArg
       // this wave's pieces of B(c) and A(c + 1) have landed: they were issued two chunks ago; younger operations are the
       // kDma pieces of the previous chunk and, in the first two chunks of an item, the kStores product stores of the
       // previous item issued between them.  At the very end of the list (no next item) batches thin out: wait for all
-      if (!has_next && c + 2 >= p.nchunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (EXP == 2) {                   // no wait for the DMA pieces
+      } else if (!has_next && c + 2 >= p.nchunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (c < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma + kStores) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma) : "memory");
       // everybody's pieces are in, and everybody is done with chunk c - 1: with A(c) (stage st) and B(c - 1) (stage st + 2)
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (EXP == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // no barrier
+      else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       const int st1 = st == 2 ? 0 : st + 1, st2 = st == 0 ? 2 : st - 1;
-      if (c + 3 < p.nchunk) dma_a(cur, c + 3, st);
-      else if (has_next) dma_a(nxt, c + 3 - p.nchunk, st);
-      if (c + 2 < p.nchunk) dma_b(cur, c + 2, st2);
-      else if (has_next) dma_b(nxt, c + 2 - p.nchunk, st2);
+      if (EXP == 4) {                   // no LDS-DMA at all (the stages keep the prologue's data)
+      } else {
+        if (c + 3 < p.nchunk) dma_a(cur, c + 3, st);
+        else if (has_next) dma_a(nxt, c + 3 - p.nchunk, st);
+        if (c + 2 < p.nchunk) dma_b(cur, c + 2, st2);
+        else if (has_next) dma_b(nxt, c + 2 - p.nchunk, st2);
+      }
       mfma_chunk(st, st1);
       st = st1;
     }
@@ -412,8 +452,8 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm32_kernel(const Wino4GemmArg
     float* Mp = p.M + (size_t)cur.pos * p.mplane;
     float* const junk = p.M + (size_t)p.npos * p.mplane + lane * 4;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int m = cur.mb * W4_M + wm * 64 + mt * 32 + li;
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = cur.mb * W4_M + row0 + mt * 32 + li;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -986,7 +1026,26 @@ static int launch_wino4_gemm32(const Wino4GemmArgs& a, hipStream_t s) {
   const long need = (items + 7) / 8;
   if (per_xcd > need) per_xcd = need;
   { const int rc = w4_chain_wait(s); if (rc != CRESTE_OK) return rc; }
-  wino4_gemm32_kernel<SPLIT, TN><<<(unsigned)(per_xcd * 8), 512, smem, s>>>(a);
+#ifdef CRESTE_W4_EXPERIMENTS
+  // timing experiments (WRONG results): CRESTE_W4_EXP = 1 no split arithmetic, 2 no vmcnt waits, 3 no barrier, 4 no LDS-DMA
+  if (const int ex = w4_env_int("CRESTE_W4_EXP", 0)) {
+    static std::atomic<uint64_t> ad1{0}, ad2{0}, ad3{0}, ad4{0};
+    const unsigned grid = (unsigned)(per_xcd * 8);
+    if (ex == 1) { CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino4_gemm32_kernel<SPLIT, TN, 1>), smem, ad1)); wino4_gemm32_kernel<SPLIT, TN, 1><<<grid, 512, smem, s>>>(a); }
+    if (ex == 2) { CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino4_gemm32_kernel<SPLIT, TN, 2>), smem, ad2)); wino4_gemm32_kernel<SPLIT, TN, 2><<<grid, 512, smem, s>>>(a); }
+    if (ex == 3) { CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino4_gemm32_kernel<SPLIT, TN, 3>), smem, ad3)); wino4_gemm32_kernel<SPLIT, TN, 3><<<grid, 512, smem, s>>>(a); }
+    if (ex == 4) { CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino4_gemm32_kernel<SPLIT, TN, 4>), smem, ad4)); wino4_gemm32_kernel<SPLIT, TN, 4><<<grid, 512, smem, s>>>(a); }
+    CRESTE_CHECK_LAUNCH("wino4_gemm32 (experiment)");
+    return CRESTE_OK;
+  }
+#endif
+  if (w4_env_int("CRESTE_W4_RS", 1)) {      // the row-split wave layout (default; 0: round 4's 4 x 2 layout, kept as the bit-exact twin)
+    static std::atomic<uint64_t> attr_rs{0};
+    CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino4_gemm32_kernel<SPLIT, TN, 0, true>), smem, attr_rs));
+    wino4_gemm32_kernel<SPLIT, TN, 0, true><<<(unsigned)(per_xcd * 8), 512, smem, s>>>(a);
+  } else {
+    wino4_gemm32_kernel<SPLIT, TN><<<(unsigned)(per_xcd * 8), 512, smem, s>>>(a);
+  }
   CRESTE_CHECK_LAUNCH("wino4_gemm32");
   return w4_chain_record(s);
 }

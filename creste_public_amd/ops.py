@@ -145,6 +145,15 @@ def forward_in_parts(fn, batch_tensors, parts: int, owner=None):
     streams = [concurrent_stream(dev, "parts")] if parts == 2 else [torch.cuda.Stream(device=dev) for _ in range(parts - 1)]
     if any(s is None for s in streams):
         raise HipLibraryError("forward_in_parts: no side stream (ask parts_for first)")
+    # The host never runs more than MAX_INFLIGHT pipelined forwards ahead of the device.  A buffer that two streams used goes
+    # back to the caching allocator only when the other stream's event has COMPLETED (record_stream): a host that enqueues
+    # forward after forward without looking back finds none of them reusable and grows the pool by a whole set of outputs
+    # (4.6 GB at batch 16) per forward -- hipMalloc stalls in the middle of the steps (measured: single runs of 42-85 ms per
+    # step where the same steps read 37.5 once the pool had grown).  Two forwards in flight keep the device fed.
+    q = _inflight.setdefault((dev.index, main.cuda_stream), [])
+    if _lib._recorder is None and not torch.cuda.is_current_stream_capturing():
+        while len(q) >= MAX_INFLIGHT:
+            q.pop(0).synchronize()
     n = batch_tensors[0].shape[0] // parts
     ctx, res = PartContext(parts), []
     skey = (parts, dev.index) + tuple((tuple(t.shape), t.dtype) for t in batch_tensors)
@@ -181,10 +190,16 @@ def forward_in_parts(fn, batch_tensors, parts: int, owner=None):
             _lib.stream_wait_stream(main, st)
     # what a later part returned outside the shared buffers lives in ITS stream's pool and is read on the caller's from here on
     mark_stream(res[1:], main)
+    if _lib._recorder is None and not torch.cuda.is_current_stream_capturing():
+        done = torch.cuda.Event()
+        done.record(main)
+        q.append(done)
     return ctx, res
 
 
 PREALLOCATE_SHARED = True       # (tests switch it off to exercise the event-ordered form of every call)
+MAX_INFLIGHT = 2                # pipelined forwards the host may have enqueued and not yet seen finished
+_inflight: dict = {}
 
 
 def whole_outputs(ctx: PartContext, dicts) -> dict:

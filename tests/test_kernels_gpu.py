@@ -650,8 +650,10 @@ def test_conv_winograd4_fp32_transformed_input_is_bit_identical(ops, monkeypatch
         monkeypatch.setenv("CRESTE_W4_F32V", mode)
         for order in ("0", "3"):                       # workgroup orders of the transform kernels: placement only
             monkeypatch.setenv("CRESTE_W4_ORDER", order)
-            outs[mode, order] = ops.conv2d(make(), pc).buf.clone()
-    ref = outs["0", "0"]
+            for rs in ("0", "1"):                      # wave layout of the streaming GEMM (row split): same products, same order
+                monkeypatch.setenv("CRESTE_W4_RS", rs)
+                outs[mode, order, rs] = ops.conv2d(make(), pc).buf.clone()
+    ref = outs["0", "0", "0"]
     assert float(ref.abs().max()) > 0.1
     for k, v in outs.items():
         assert torch.equal(v, ref), k
