@@ -314,26 +314,28 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm32_kernel(const Wino4GemmArg
     return reinterpret_cast<const char*>(((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
                                          (unsigned)__builtin_amdgcn_readfirstlane((int)v));
   };
+  auto dma_a1 = [&](const Item& it, int c, int st, int jj) __attribute__((always_inline)) {
+    const int i = wave + 8 * jj;
+    const char* src = uniform(it.a + (size_t)c * A_BYTES + i * 1024);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (unsigned)(lane * 16)),
+                                     (__attribute__((address_space(3))) void*)(Ast + st * A_BYTES + i * 1024), 16, 0, 0);
+  };
   auto dma_a = [&](const Item& it, int c, int st) __attribute__((always_inline)) {
 #pragma unroll
-    for (int jj = 0; jj < kA; ++jj) {
-      const int i = wave + 8 * jj;
-      const char* src = uniform(it.a + (size_t)c * A_BYTES + i * 1024);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (unsigned)(lane * 16)),
-                                       (__attribute__((address_space(3))) void*)(Ast + st * A_BYTES + i * 1024), 16, 0, 0);
-    }
+    for (int jj = 0; jj < kA; ++jj) dma_a1(it, c, st, jj);
   };
   // a wave with no weight piece left re-copies its previous one (same bytes to the same place): every wave issues kBw
+  auto dma_b1 = [&](const Item& it, int c, int st, int jj) __attribute__((always_inline)) {
+    int i = wave + 8 * jj;
+    if (i >= B_INSTR) i -= 8;
+    const int uu = i / (U_BYTES / 1024), r = i % (U_BYTES / 1024);
+    const char* src = uniform(it.w + ((size_t)uu * p.nchunk + c) * U_BYTES + r * 1024);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (unsigned)(lane * 16)),
+                                     (__attribute__((address_space(3))) void*)(Bst + st * B_BYTES + i * 1024), 16, 0, 0);
+  };
   auto dma_b = [&](const Item& it, int c, int st) __attribute__((always_inline)) {
 #pragma unroll
-    for (int jj = 0; jj < kBw; ++jj) {
-      int i = wave + 8 * jj;
-      if (i >= B_INSTR) i -= 8;
-      const int uu = i / (U_BYTES / 1024), r = i % (U_BYTES / 1024);
-      const char* src = uniform(it.w + ((size_t)uu * p.nchunk + c) * U_BYTES + r * 1024);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (unsigned)(lane * 16)),
-                                       (__attribute__((address_space(3))) void*)(Bst + st * B_BYTES + i * 1024), 16, 0, 0);
-    }
+    for (int jj = 0; jj < kBw; ++jj) dma_b1(it, c, st, jj);
   };
 
   w4f32x16 acc[MT][NT];
@@ -367,7 +369,9 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm32_kernel(const Wino4GemmArg
   };
   // MFMAs of the chunk in stage `st` (weights as the first operand: D = U * V^T, a lane owns one tile, its registers the
   // couts) with the split of the NEXT chunk's rows (stage `stn`) between them
-  auto mfma_chunk = [&](int st, int stn) __attribute__((always_inline)) {
+  // `piece(k)`, k < kDma: issues the k-th LDS-DMA piece of this chunk's prefetch -- between the MFMA groups, behind the
+  // chunk's own ds_reads (EXP 5; the guide prices a piece at 100-185 cycles in a phase that carries ds_reads, 25-60 later)
+  auto mfma_chunk = [&](int st, int stn, auto&& piece) __attribute__((always_inline)) {
     const char* B = Bst + st * B_BYTES;
     w4bf16x8 afn[MT][SPLIT];
     w4f32x4 raw[MT][2];
@@ -383,11 +387,14 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm32_kernel(const Wino4GemmArg
       w4bf16x8 bfr[2][2][SPLIT];
       read_b(0, bfr[0][0]); read_b(1, bfr[0][1]);
       read_a(stn, 0, raw[0]);
+      constexpr int NG = NT / 2, PPG = (kDma + NG - 1) / NG;
 #pragma unroll
-      for (int np = 0; np < NT / 2; ++np) {
-        if (np + 1 < NT / 2) { read_b(2 * np + 2, bfr[(np + 1) & 1][0]); read_b(2 * np + 3, bfr[(np + 1) & 1][1]); }
+      for (int np = 0; np < NG; ++np) {
+        if (np + 1 < NG) { read_b(2 * np + 2, bfr[(np + 1) & 1][0]); read_b(2 * np + 3, bfr[(np + 1) & 1][1]); }
         w4_split_mfma2w<SPLIT>(bfr[np & 1][0], bfr[np & 1][1], af[0], acc[0][2 * np], acc[0][2 * np + 1]);
         if (np == 0) split_a(raw[0], afn[0]);
+#pragma unroll
+        for (int k = np * PPG; k < (np + 1) * PPG && k < kDma; ++k) piece(k);
       }
     } else {
       w4bf16x8 bfr[2][SPLIT];
@@ -400,6 +407,8 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm32_kernel(const Wino4GemmArg
         w4_split_mfma2<SPLIT>(bfr[nt & 1], af[0], af[MT - 1], acc[0][nt], acc[MT - 1][nt]);
         if (nt < MT) split_a(raw[nt < MT ? nt : 0], afn[nt < MT ? nt : 0]);
       }
+#pragma unroll
+      for (int k = 0; k < kDma; ++k) piece(k);
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -436,14 +445,27 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm32_kernel(const Wino4GemmArg
       if (EXP == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // no barrier
       else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       const int st1 = st == 2 ? 0 : st + 1, st2 = st == 0 ? 2 : st - 1;
-      if (EXP == 4) {                   // no LDS-DMA at all (the stages keep the prologue's data)
+      if (EXP == 5) {                   // the prefetch's pieces between the MFMA groups (B first: it is needed first)
+        const bool a_cur = c + 3 < p.nchunk, b_cur = c + 2 < p.nchunk;
+        mfma_chunk(st, st1, [&](int k) __attribute__((always_inline)) {
+          if (k < kBw) {
+            if (b_cur) dma_b1(cur, c + 2, st2, k);
+            else if (has_next) dma_b1(nxt, c + 2 - p.nchunk, st2, k);
+          } else {
+            if (a_cur) dma_a1(cur, c + 3, st, k - kBw);
+            else if (has_next) dma_a1(nxt, c + 3 - p.nchunk, st, k - kBw);
+          }
+        });
       } else {
-        if (c + 3 < p.nchunk) dma_a(cur, c + 3, st);
-        else if (has_next) dma_a(nxt, c + 3 - p.nchunk, st);
-        if (c + 2 < p.nchunk) dma_b(cur, c + 2, st2);
-        else if (has_next) dma_b(nxt, c + 2 - p.nchunk, st2);
+        if (EXP == 4) {                 // no LDS-DMA at all (the stages keep the prologue's data)
+        } else {
+          if (c + 3 < p.nchunk) dma_a(cur, c + 3, st);
+          else if (has_next) dma_a(nxt, c + 3 - p.nchunk, st);
+          if (c + 2 < p.nchunk) dma_b(cur, c + 2, st2);
+          else if (has_next) dma_b(nxt, c + 2 - p.nchunk, st2);
+        }
+        mfma_chunk(st, st1, [](int) {});
       }
-      mfma_chunk(st, st1);
       st = st1;
     }
     // ---- item tail: products to M[pos][cout / 4][tile][4] (lane = tile, registers 4g..4g+3 = four consecutive couts:
@@ -1027,14 +1049,16 @@ static int launch_wino4_gemm32(const Wino4GemmArgs& a, hipStream_t s) {
   if (per_xcd > need) per_xcd = need;
   { const int rc = w4_chain_wait(s); if (rc != CRESTE_OK) return rc; }
 #ifdef CRESTE_W4_EXPERIMENTS
-  // timing experiments (WRONG results): CRESTE_W4_EXP = 1 no split arithmetic, 2 no vmcnt waits, 3 no barrier, 4 no LDS-DMA
+  // experiments on the row-split layout: CRESTE_W4_EXP = 1 no split arithmetic, 2 no vmcnt waits, 3 no barrier, 4 no LDS-DMA
+  // (1-4: timing only, WRONG results), 5 = the prefetch's LDS-DMA pieces issued between the MFMA groups (correct results)
   if (const int ex = w4_env_int("CRESTE_W4_EXP", 0)) {
-    static std::atomic<uint64_t> ad1{0}, ad2{0}, ad3{0}, ad4{0};
+    static std::atomic<uint64_t> ad1{0}, ad2{0}, ad3{0}, ad4{0}, ad5{0};
     const unsigned grid = (unsigned)(per_xcd * 8);
-    if (ex == 1) { CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino4_gemm32_kernel<SPLIT, TN, 1>), smem, ad1)); wino4_gemm32_kernel<SPLIT, TN, 1><<<grid, 512, smem, s>>>(a); }
-    if (ex == 2) { CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino4_gemm32_kernel<SPLIT, TN, 2>), smem, ad2)); wino4_gemm32_kernel<SPLIT, TN, 2><<<grid, 512, smem, s>>>(a); }
-    if (ex == 3) { CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino4_gemm32_kernel<SPLIT, TN, 3>), smem, ad3)); wino4_gemm32_kernel<SPLIT, TN, 3><<<grid, 512, smem, s>>>(a); }
-    if (ex == 4) { CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino4_gemm32_kernel<SPLIT, TN, 4>), smem, ad4)); wino4_gemm32_kernel<SPLIT, TN, 4><<<grid, 512, smem, s>>>(a); }
+    if (ex == 1) { CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino4_gemm32_kernel<SPLIT, TN, 1, true>), smem, ad1)); wino4_gemm32_kernel<SPLIT, TN, 1, true><<<grid, 512, smem, s>>>(a); }
+    if (ex == 2) { CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino4_gemm32_kernel<SPLIT, TN, 2, true>), smem, ad2)); wino4_gemm32_kernel<SPLIT, TN, 2, true><<<grid, 512, smem, s>>>(a); }
+    if (ex == 3) { CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino4_gemm32_kernel<SPLIT, TN, 3, true>), smem, ad3)); wino4_gemm32_kernel<SPLIT, TN, 3, true><<<grid, 512, smem, s>>>(a); }
+    if (ex == 4) { CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino4_gemm32_kernel<SPLIT, TN, 4, true>), smem, ad4)); wino4_gemm32_kernel<SPLIT, TN, 4, true><<<grid, 512, smem, s>>>(a); }
+    if (ex == 5) { CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(wino4_gemm32_kernel<SPLIT, TN, 5, true>), smem, ad5)); wino4_gemm32_kernel<SPLIT, TN, 5, true><<<grid, 512, smem, s>>>(a); }
     CRESTE_CHECK_LAUNCH("wino4_gemm32 (experiment)");
     return CRESTE_OK;
   }

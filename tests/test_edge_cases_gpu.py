@@ -262,6 +262,14 @@ def test_value_iteration_is_stream_asynchronous_and_graph_capturable(ops):
     # a solve that cannot converge in max_sweeps reports a negative sweep count instead of blocking the host
     v, q, pi, sw = ops.value_iteration(r, 0.99, 1e-3, max_sweeps=16)
     assert int(sw) == -16 and torch.isfinite(v).all()
+    # ... and nobody has to remember to look: the count was copied to pinned memory behind the solve, and the next check
+    # (the head of a later solve, IRLTrainer before its optimiser step) raises
+    from creste_public_amd._lib import HipLibraryError
+    with pytest.raises(HipLibraryError, match="no convergence within 16"):
+        ops.vi_check()
+    assert ops.vi_poll() == []                     # the failure was reported once
+    ops.value_iteration(r, 0.99, 1e-3)             # a good solve behind it is unaffected
+    assert ops.vi_poll() == [int(out[3])]
 
 
 def test_value_iteration_two_streams_at_once(ops):
