@@ -449,6 +449,7 @@ def irl_step_bench(model_infer, device, variant, steps=5):
             ld, _ = lm(td)
             loss = sum(w * t for w, t in ld.values())
             loss.backward()
+            creste_public_amd.ops.vi_check()       # as IRLTrainer: the solve's sweep count is looked at before the gradients are used
             opt.step()
             return loss.detach(), out
 

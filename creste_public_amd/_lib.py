@@ -87,6 +87,9 @@ SIGNATURES = {
     "creste_bev_splat_mode_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _i, _i, _f, _i, _vp, _vp, _vp,
                                         _vp, _vp]),
     "creste_bev_splat_plan_f32": (_i, [_vp, _i, _i, _f, _f, _f, _f, _i, _i, _vp, _vp, _vp]),
+    "creste_bev_splat_plan_keyed_f32": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
+    "creste_pixel_geometry_keyed_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i,
+                                             _f, _f, _f, _f, _i, _i, _vp, _vp, _vp]),
     "creste_bev_splat_gather_f32": (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "creste_value_iteration_workspace_bytes": (_i64, [_i, _i, _i]),
     "creste_value_iteration_f32": (_i, [_vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

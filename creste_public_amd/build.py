@@ -83,6 +83,29 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_variant(tag: str, pk_sources=(), verbose: bool = True) -> str:
+    """An EXPERIMENT library lib/libcreste_hip_<tag>.so: the same sources, `pk_sources` compiled WITH packed-fp32 VALU allowed
+    (scripts/pk_hazard.sh: is the corruption of round 4 still there, and in which file).  Load it with CRESTE_HIP_LIB=<path>.
+    Never the shipped library: tests/test_abi.py disassembles lib/libcreste_hip.so only."""
+    hipcc = _hipcc()
+    objdir = os.path.join(LIBDIR, "obj_" + tag)
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        op = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+        if src in pk_sources:
+            op = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+            flags = [f for f in FLAGS if f not in NO_PK]
+            cmd = [hipcc, *flags, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", os.path.join(CSRC, src), "-o", op]
+            if verbose:
+                print("[creste build]", " ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        objs.append(op)
+    lib = os.path.join(LIBDIR, f"libcreste_hip_{tag}.so")
+    subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", lib], check=True)
+    return lib
+
+
 def resource_usage() -> dict:
     """{mangled kernel name: {"vgprs", "agprs", "scratch", "occupancy", "lds", "source"}} of the last build (from the
     compiler's kernel-resource-usage remarks; tests/test_abi.py keeps the hot kernels out of scratch with it)."""
@@ -109,4 +132,9 @@ def resource_usage() -> dict:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--variant" in sys.argv:                    # python -m creste_public_amd.build --variant pk mbconv.hip [more.hip ...]
+        i = sys.argv.index("--variant")
+        build()
+        print(build_variant(sys.argv[i + 1], tuple(sys.argv[i + 2:])))
+    else:
+        print(build(force="--force" in sys.argv))

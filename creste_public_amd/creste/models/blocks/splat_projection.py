@@ -96,9 +96,16 @@ class Camera2MapMulti(nn.Module):
             raise Exception("Unknown splat mode:", self.mode)
         g = self._geo.get()
         F = fbuf.cs - self.z_dim
-        xyz, mask = ops.pixel_geometry(depth, p2p, g["bounds"], g["w1"], g["b1"], g["w2"], g["b2"],
-                                       fbuf.slice(F, self.z_dim))
         gh, gw = g["grid"]
+        plan = None
+        if self.NC == 1:
+            # one camera per frame: the points of a frame ARE the pixels of its view, and the binning plan's first kernel
+            # (voxel coordinates, base-cell keys) runs inside the geometry kernel
+            xyz, mask, plan = ops.pixel_geometry_plan(depth, p2p, g["bounds"], g["w1"], g["b1"], g["w2"], g["b2"],
+                                                      fbuf.slice(F, self.z_dim), g["off"], g["vox"], gh, gw)
+        else:
+            xyz, mask = ops.pixel_geometry(depth, p2p, g["bounds"], g["w1"], g["b1"], g["w2"], g["b2"],
+                                           fbuf.slice(F, self.z_dim))
         # NC cameras per frame: views (b, s, c) are consecutive, so the reference's concatenation of the cameras'
         # points ([B*NS, NC*H*W, .], :227-234) is a reshape of the per-view buffers
         BN = xyz.shape[0]
@@ -106,8 +113,9 @@ class Camera2MapMulti(nn.Module):
         if self.scatter_mode not in ops.SPLAT_MODES:
             raise Exception("Unknown splat scatter mode:", self.scatter_mode)
         # the binning plan needs the points only: enqueued here, ahead of the fusion conv whose output the gather reads
-        with ops.shared_rows():
-            plan = ops.bev_splat_plan(xyz.reshape(BN // self.NC, -1, 3), g["off"], g["vox"], gh, gw)
+        if plan is None:
+            with ops.shared_rows():
+                plan = ops.bev_splat_plan(xyz.reshape(BN // self.NC, -1, 3), g["off"], g["vox"], gh, gw)
         whole = Act(fbuf.buf, fbuf.cs, 0)
         if feats_amax is not None and (ops.TRACK_AMAX or hipnn_precision() == "f16x3"):
             whole.amax = ops.max2(feats_amax, ops.absmax(fbuf.slice(F, self.z_dim)))

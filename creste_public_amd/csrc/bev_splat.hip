@@ -503,10 +503,8 @@ extern "C" int64_t creste_bev_splat_workspace_bytes(int B, int P, int GH, int GW
 
 // Binning plan of one batch of points: needs ONLY xyz (reference splat_projection.py:185-187 + the index half of :293-333),
 // so the model enqueues it right behind the pixel geometry, ahead of the 288 -> 96 fusion conv that produces the features.
-extern "C" int creste_bev_splat_plan_f32(const float* xyz, int B, int P, float off_x, float off_y, float vox_x, float vox_y,
-                                         int GH, int GW, float* coords, void* work, void* stream) {
-  CRESTE_REQUIRE(xyz && coords && work, "bev_splat_plan: null pointer");
-  CRESTE_REQUIRE(B > 0 && P > 0 && GH > 0 && GW > 0 && vox_x > 0.f && vox_y > 0.f, "bev_splat_plan: bad dims / grid");
+static int splat_plan(const float* xyz, int B, int P, float off_x, float off_y, float vox_x, float vox_y, int GH, int GW,
+                      float* coords, void* work, void* stream) {      // xyz == nullptr: coords and keys are already there
   const int E = (GH + 1) * (GW + 1);
   const long BP = (long)B * P;
   hipStream_t s = (hipStream_t)stream;
@@ -524,8 +522,10 @@ extern "C" int creste_bev_splat_plan_f32(const float* xyz, int B, int P, float o
     const int Q = (GH + 1 + rpb - 1) / rpb;
     const size_t smem = (size_t)rpb * EW * sizeof(int);
     const int g1 = (int)((BP + 255) / 256 > 8192 ? 8192 : (BP + 255) / 256);
-    splat_key_kernel<<<g1, 256, 0, s>>>(xyz, BP, off_x, off_y, vox_x, vox_y, GH, GW, coords, w.key);
-    CRESTE_CHECK_LAUNCH("splat_key");
+    if (xyz) {
+      splat_key_kernel<<<g1, 256, 0, s>>>(xyz, BP, off_x, off_y, vox_x, vox_y, GH, GW, coords, w.key);
+      CRESTE_CHECK_LAUNCH("splat_key");
+    }
     const int kpt = (P + BUILD_THREADS - 1) / BUILD_THREADS;
     static_assert(BUILD_MAX_CELLS <= 16384, "the packed {rank, cell} word keeps 14 bits for the cell");
     if (P <= 65536 && kpt <= 16)
@@ -543,6 +543,21 @@ extern "C" int creste_bev_splat_plan_f32(const float* xyz, int B, int P, float o
   splat_sort_rec_kernel<<<dim3((E + SORT_CELLS - 1) / SORT_CELLS, B), 256, 0, s>>>(w.offset, w.recu, w.rec, P, E);
   CRESTE_CHECK_LAUNCH("splat_sort_rec");
   return CRESTE_OK;
+}
+
+extern "C" int creste_bev_splat_plan_f32(const float* xyz, int B, int P, float off_x, float off_y, float vox_x, float vox_y,
+                                         int GH, int GW, float* coords, void* work, void* stream) {
+  CRESTE_REQUIRE(xyz && coords && work, "bev_splat_plan: null pointer");
+  CRESTE_REQUIRE(B > 0 && P > 0 && GH > 0 && GW > 0 && vox_x > 0.f && vox_y > 0.f, "bev_splat_plan: bad dims / grid");
+  return splat_plan(xyz, B, P, off_x, off_y, vox_x, vox_y, GH, GW, coords, work, stream);
+}
+
+// The rest of the plan when creste_pixel_geometry_keyed_f32 has already written bev_coords and the keys (the first B*P ints of
+// `work`): CSR build, record fill, per-cell sort.
+extern "C" int creste_bev_splat_plan_keyed_f32(int B, int P, int GH, int GW, const float* coords, void* work, void* stream) {
+  CRESTE_REQUIRE(coords && work, "bev_splat_plan_keyed: null pointer");
+  CRESTE_REQUIRE(B > 0 && P > 0 && GH > 0 && GW > 0, "bev_splat_plan_keyed: bad dims / grid");
+  return splat_plan(nullptr, B, P, 0.f, 0.f, 1.f, 1.f, GH, GW, const_cast<float*>(coords), work, stream);
 }
 
 // The gather over a plan (creste_bev_splat_plan_f32 of the same B, P, GH, GW into the same `work`): every BEV cell's F

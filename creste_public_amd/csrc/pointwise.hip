@@ -682,11 +682,20 @@ __global__ __launch_bounds__(256) void pixel_geometry_kernel(
 // 2048 multiply-adds per pixel need no LDS and no shuffles -- the lane-per-output form above is bound by 64 shuffles per
 // output (220 us per batch of 16; this form: ~70).  Same operations in the same order (geometry fma chain; s = b2[j], then
 // h = 0..63): bit-identical.
+// KEY: the point's BEV voxel coordinates and extended base-cell key as well -- the first kernel of the splat's binning plan
+// (csrc/bev_splat.hip: splat_key_kernel, the same operations on the same floats), one launch and one read of xyz less.
+struct SplatKeyArgs {
+  float off_x, off_y, vox_x, vox_y;
+  int GH, GW;
+  float* coords;
+  int* key;
+};
+template <bool KEY>
 __global__ __launch_bounds__(256) void pixel_geometry_px_kernel(
     const float* __restrict__ depth, const float* __restrict__ p2p, int B, int Hs, int Ws,
     const float* __restrict__ bounds, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ xyz, float* __restrict__ mask,
-    float* __restrict__ zfeat, int z_cs, int z_co) {
+    float* __restrict__ zfeat, int z_cs, int z_co, const SplatKeyArgs sk) {
   const unsigned P32 = (unsigned)Hs * (unsigned)Ws, total = (unsigned)B * P32;
   const unsigned g = blockIdx.x * 256u + threadIdx.x;
   if (g >= total) return;
@@ -704,6 +713,17 @@ __global__ __launch_bounds__(256) void pixel_geometry_px_kernel(
   const bool ok = q[0] >= bounds[0] && q[1] >= bounds[1] && q[2] >= bounds[2] &&
                   q[0] < bounds[3] && q[1] < bounds[4] && q[2] < bounds[5];
   mask[g] = ok ? 1.f : 0.f;
+  if constexpr (KEY) {
+    // map = lidar2map @ [x,y,z,1]: rows (0,-1,0,off_x), (-1,0,0,off_y) -> one rounding each (reference splat_projection.py:185-187)
+    const float mx = __fadd_rn(-q[1], sk.off_x), my = __fadd_rn(-q[0], sk.off_y);
+    const float X = __fdiv_rn(mx, sk.vox_x), Y = __fdiv_rn(my, sk.vox_y);
+    *reinterpret_cast<float2*>(sk.coords + (long)g * 2) = make_float2(X, Y);
+    const float fx = floorf(X), fy = floorf(Y);
+    int k = -1;
+    if (fx >= -1.f && fx <= (float)(sk.GW - 1) && fy >= -1.f && fy <= (float)(sk.GH - 1))
+      k = ((int)fy + 1) * (sk.GW + 1) + ((int)fx + 1);
+    sk.key[g] = k;
+  }
   float hv[64];
 #pragma unroll
   for (int h = 0; h < 64; ++h) hv[h] = fmaxf(__fmaf_rn(w1[h], q[2], b1[h]), 0.f);
@@ -993,8 +1013,8 @@ extern "C" int creste_pixel_geometry_f32(const float* depth, const float* p2p, i
   CRESTE_REQUIRE((long)B * Hs * Ws < (1L << 31), "pixel_geometry: B*Hs*Ws overflows int32");
   const long total = (long)B * Hs * Ws;
   if (zhid == 64 && zdim == 32 && z_cs % 4 == 0 && z_co % 4 == 0 && (reinterpret_cast<uintptr_t>(zfeat) & 15) == 0) {
-    pixel_geometry_px_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        depth, p2p, B, Hs, Ws, bounds6, w1, b1, w2, b2, xyz, mask, zfeat, z_cs, z_co);
+    pixel_geometry_px_kernel<false><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        depth, p2p, B, Hs, Ws, bounds6, w1, b1, w2, b2, xyz, mask, zfeat, z_cs, z_co, SplatKeyArgs{});
     CRESTE_CHECK_LAUNCH("pixel_geometry_px");
     return CRESTE_OK;
   }
@@ -1003,6 +1023,30 @@ extern "C" int creste_pixel_geometry_f32(const float* depth, const float* p2p, i
   pixel_geometry_kernel<<<grid_for(total, per, 256 * 16), 256, smem, (hipStream_t)stream>>>(
       depth, p2p, B, Hs, Ws, bounds6, w1, b1, w2, b2, zhid, zdim, xyz, mask, zfeat, z_cs, z_co);
   CRESTE_CHECK_LAUNCH("pixel_geometry");
+  return CRESTE_OK;
+}
+
+// creste_pixel_geometry_f32 + the key kernel of creste_bev_splat_plan_f32 in one launch: also writes bev_coords [B*P][2] and the
+// points' extended base-cell keys into `splat_work` (its first B*P ints; creste_bev_splat_workspace_bytes(B, Hs*Ws, GH, GW)
+// bytes), for creste_bev_splat_plan_keyed_f32.  Built for the shipped z-MLP (1 -> 64 -> 32) only: CRESTE_ERR_ARG else.
+extern "C" int creste_pixel_geometry_keyed_f32(const float* depth, const float* p2p, int B, int Hs, int Ws,
+                                               const float* bounds6, const float* w1, const float* b1, const float* w2,
+                                               const float* b2, int zhid, int zdim, float* xyz, float* mask, float* zfeat,
+                                               int z_cs, int z_co, float off_x, float off_y, float vox_x, float vox_y, int GH,
+                                               int GW, float* coords, void* splat_work, void* stream) {
+  CRESTE_REQUIRE(depth && p2p && bounds6 && w1 && b1 && w2 && b2 && xyz && mask && zfeat && coords && splat_work,
+                 "pixel_geometry_keyed: null pointer");
+  CRESTE_REQUIRE((long)B * Hs * Ws < (1L << 31), "pixel_geometry: B*Hs*Ws overflows int32");
+  CRESTE_REQUIRE(GH > 0 && GW > 0 && vox_x > 0.f && vox_y > 0.f, "pixel_geometry_keyed: bad grid");
+  if (!(zhid == 64 && zdim == 32 && z_cs % 4 == 0 && z_co % 4 == 0 && (reinterpret_cast<uintptr_t>(zfeat) & 15) == 0)) {
+    set_error("pixel_geometry_keyed: built for the 1 -> 64 -> 32 z-MLP with 16-byte aligned output slices");
+    return CRESTE_ERR_ARG;
+  }
+  const long total = (long)B * Hs * Ws;
+  const SplatKeyArgs sk{off_x, off_y, vox_x, vox_y, GH, GW, coords, (int*)splat_work};
+  pixel_geometry_px_kernel<true><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      depth, p2p, B, Hs, Ws, bounds6, w1, b1, w2, b2, xyz, mask, zfeat, z_cs, z_co, sk);
+  CRESTE_CHECK_LAUNCH("pixel_geometry_px (keyed)");
   return CRESTE_OK;
 }
 

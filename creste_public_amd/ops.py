@@ -950,6 +950,35 @@ def pixel_geometry(depth, p2p, bounds6, w1, b1, w2, b2, zfeat: Act):
 
 
 SPLAT_MODES = {"mean": 0, "sum": 1, "max": 2}
+KEYED_GEOMETRY = True     # the splat plan's key kernel inside the pixel geometry (one launch, one read of xyz less)
+
+
+def pixel_geometry_plan(depth, p2p, bounds6, w1, b1, w2, b2, zfeat: Act, off_xy, vox_xy, GH, GW):
+    """pixel_geometry + bev_splat_plan of the same points (one camera per frame) -> xyz [B,P,3], mask [B,P], SplatPlan.  With
+    the shipped 1 -> 64 -> 32 z-MLP the plan's first kernel (voxel coordinates + base-cell keys, reference
+    splat_projection.py:185-187) runs inside the geometry kernel; any other z-MLP takes the two calls."""
+    zhid, zdim = w1.shape[0], w2.shape[0]
+    if not (KEYED_GEOMETRY and zhid == 64 and zdim == 32 and zfeat.cs % 4 == 0 and zfeat.co % 4 == 0):
+        xyz, mask = pixel_geometry(depth, p2p, bounds6, w1, b1, w2, b2, zfeat)
+        with shared_rows():
+            return xyz, mask, bev_splat_plan(xyz, off_xy, vox_xy, GH, GW)
+    lib = _lib.load()
+    B, Hs, Ws = depth.shape
+    P, dev = Hs * Ws, depth.device
+    xyz = torch.empty((B, P, 3), dtype=torch.float32, device=dev)
+    mask = torch.empty((B, P), dtype=torch.float32, device=dev)
+    with shared_rows():
+        coords = rows_empty((B, P, 2), torch.float32, dev)
+    work = torch.empty(lib.creste_bev_splat_workspace_bytes(B, P, GH, GW), dtype=torch.uint8, device=dev)
+    assert zfeat.C == zdim
+    _lib.check(lib.creste_pixel_geometry_keyed_f32(
+        _chk(depth).data_ptr(), _chk(p2p).data_ptr(), B, Hs, Ws, _chk(bounds6).data_ptr(),
+        _chk(w1).data_ptr(), _chk(b1).data_ptr(), _chk(w2).data_ptr(), _chk(b2).data_ptr(), zhid, zdim,
+        xyz.data_ptr(), mask.data_ptr(), zfeat.buf.data_ptr(), zfeat.cs, zfeat.co, float(off_xy[0]), float(off_xy[1]),
+        float(vox_xy[0]), float(vox_xy[1]), GH, GW, coords.data_ptr(), work.data_ptr(), _stream()), "pixel_geometry_keyed")
+    _lib.check(lib.creste_bev_splat_plan_keyed_f32(B, P, GH, GW, coords.data_ptr(), work.data_ptr(), _stream()),
+               "bev_splat_plan_keyed")
+    return xyz, mask, SplatPlan(coords, work, B, P, GH, GW)
 
 
 class SplatPlan:
@@ -1051,13 +1080,20 @@ def check_vi_sweeps(sweeps: torch.Tensor) -> int:
 
 VI_ABORTED = -2 ** 31
 _vi_pending: list = []          # [(event, pinned int32[1])] of solves whose sweep count has not been looked at yet
+_vi_ring, _vi_ring_pos = None, 0
 
 
 def _vi_note(sweeps: torch.Tensor):
     """queue the asynchronous look at a solve's sweep count: a 4-byte copy into pinned memory behind the solve + an event"""
     if _lib._recorder is not None or torch.cuda.is_current_stream_capturing():
         return
-    host = torch.empty(1, dtype=torch.int32).pin_memory()
+    global _vi_ring, _vi_ring_pos
+    if _vi_ring is None:
+        _vi_ring = torch.empty(16, dtype=torch.int32).pin_memory()       # (one pinned allocation: they cost ~100 us of host time each)
+    if len(_vi_pending) >= 12:                                            # never reuse a slot that is still unlooked-at
+        vi_check(wait=True)
+    host = _vi_ring[_vi_ring_pos:_vi_ring_pos + 1]
+    _vi_ring_pos = (_vi_ring_pos + 1) % 16
     host.copy_(sweeps, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(sweeps.device))

@@ -124,9 +124,12 @@ class ConvG:
         if grads is not None:
             gw, acc = _acc(grads, w)
             side = ops.wgrad_stream(w.device) if x.N * x.H * x.W * max(Cin, Cout) >= WGRAD_STREAM_MIN else None
-            if side is not None and hipnn._precision == ops.PREC_F16X3:
+            f16_wgrad = (hipnn._precision == ops.PREC_F16X3 and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 8 and Cout >= 8
+                         and x.cs % 4 == 0 and gy.cs % 4 == 0 and x.co % 4 == 0 and gy.co % 4 == 0)
+            if side is not None and f16_wgrad:
                 # the |max| bounds are CACHED on the Acts and read again by this stream's input-gradient conv: they are
                 # made here, on the backward's stream (the side stream waits for it below), never on the side stream
+                # (the Winograd-domain weight gradient below does not read them: the cost is one small pass)
                 ops.absmax(x), ops.absmax(gy)
             if side is not None:
                 # the weight gradient reads gy and the saved x and nothing of this backward reads IT: on the side stream,
@@ -150,8 +153,7 @@ class ConvG:
                 else:
                     work = torch.empty(lib.creste_conv_wgrad_strided_workspace_bytes(gy.N, gy.H, gy.W, Cin, Cout, self.K),
                                        dtype=torch.uint8, device=w.device)
-                    if (hipnn._precision == ops.PREC_F16X3 and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 8 and Cout >= 8
-                            and x.cs % 4 == 0 and gy.cs % 4 == 0 and x.co % 4 == 0 and gy.co % 4 == 0):
+                    if f16_wgrad:
                         # f16x3 wgrad: fp16 hi+lo operands from the tensors' |max| bounds, fp32 accumulation
                         _lib.check(lib.creste_conv_wgrad_f16x3(x.ptr, x.cs, gy.ptr, gy.cs, gw.data_ptr(),
                                                                ops.absmax(x).data_ptr(), ops.absmax(gy).data_ptr(), x.N, x.H,

@@ -299,6 +299,16 @@ int creste_pixel_geometry_f32(const float* depth, const float* p2p, int B, int H
                               const float* w2, const float* b2, int zhid, int zdim, float* xyz,
                               float* mask, float* zfeat, int z_cs, int z_co, void* stream);
 
+/* The same launch + the first kernel of the splat's binning plan (reference splat_projection.py:185-187: map = lidar2map @
+ * xyz, / voxel size): also writes bev_coords [B*P][2] and every point's base-cell key into the first B*P ints of `splat_work`
+ * (creste_bev_splat_workspace_bytes(B, Hs*Ws, GH, GW) bytes); creste_bev_splat_plan_keyed_f32 finishes the plan.  Built for the
+ * shipped 1 -> 64 -> 32 z-MLP (CRESTE_ERR_ARG otherwise: use creste_pixel_geometry_f32 + creste_bev_splat_plan_f32). */
+int creste_pixel_geometry_keyed_f32(const float* depth, const float* p2p, int B, int Hs, int Ws,
+                                    const float* bounds6, const float* w1, const float* b1, const float* w2,
+                                    const float* b2, int zhid, int zdim, float* xyz, float* mask, float* zfeat,
+                                    int z_cs, int z_co, float off_x, float off_y, float vox_x, float vox_y, int GH,
+                                    int GW, float* coords, void* splat_work, void* stream);
+
 /* Depth-guided camera->BEV bilinear voxel pooling (mean).  reference splat_projection.py:185-187
  * (lidar2map, /voxel), :293-352 (floor, 4 taps, scatter-add of weights and weighted features,
  * / clamp(density, 1)).  Gather formulation: points are binned by base cell, each BEV cell then
@@ -332,6 +342,7 @@ int creste_bev_splat_mode_f32(const float* xyz, const float* feats, int feats_cs
  * GATHER then reads the plan from the same `work` (same B, P, GH, GW, same stream order) and writes bev / dens once. */
 int creste_bev_splat_plan_f32(const float* xyz, int B, int P, float off_x, float off_y, float vox_x, float vox_y, int GH,
                               int GW, float* coords, void* work, void* stream);
+int creste_bev_splat_plan_keyed_f32(int B, int P, int GH, int GW, const float* coords, void* work, void* stream);
 int creste_bev_splat_gather_f32(const float* feats, int feats_cs, int B, int P, int F, int GH, int GW, float min_weight,
                                 int mode, float* bev, float* dens, void* work, void* stream);
 

@@ -168,3 +168,35 @@ def test_thirty_ssc_steps_with_side_stream_weight_gradients_equal_one_stream_ste
         assert not bad, bad[:10]
     finally:
         creste_public_amd.set_precision("f32")
+
+
+def test_ssc_step_in_f16x3_with_side_stream_weight_gradients(monkeypatch):
+    """f16x3 operands + weight gradients on the side stream: the |max| bounds of x / gy are made on the backward's stream
+    before the side stream is entered -- only for the convs whose weight gradient reads them (the 2- and 6-class
+    projections have gradients with Cout % 4 != 0 and take the exact-fp32 kernel: no bound, no aligned slice to scan)."""
+    from creste_public_amd import harness, train_backbone
+    from creste_public_amd.creste.models.terrainnet import TerrainNet
+    from creste_public_amd.creste.utils.loss_utils import LossManager
+    creste_public_amd.set_precision("f16x3")
+    try:
+        H, W, B = 128, 192, 2
+        cfg = harness.ssc_cfg((H, W), class_weights=[0.5, 0.2, 0.1, 0.1, 0.05, 0.05], freeze_backbone_epochs=0)
+        batch = _ssc_batch(B, H, W, seed=3)
+
+        def run(side):
+            monkeypatch.setattr(ops, "WGRAD_STREAM", side)
+            monkeypatch.setattr(train_backbone, "WGRAD_STREAM_MIN", 0)
+            harness.seed_everything(5)
+            model = TerrainNet(cfg).cuda()
+            synth.randomize_bn(model, seed=2)
+            tr = harness.SSCTrainer(model, LossManager(cfg).cuda(), cfg)
+            losses = torch.stack([tr.training_step(batch)["train/loss"] for _ in range(3)])
+            torch.cuda.synchronize()
+            return losses, {k: v.clone() for k, v in model.state_dict().items()}
+
+        l0, sd0 = run(False)
+        l1, sd1 = run(True)
+        assert torch.isfinite(l0).all() and torch.equal(l0, l1)
+        assert not [k for k in sd0 if not torch.equal(sd0[k], sd1[k])]
+    finally:
+        creste_public_amd.set_precision("f32")
