@@ -112,7 +112,17 @@ class ConvProfiler:
         from creste_public_amd import ops
         self._ops, self._orig = ops, ops.conv2d
         self._orig_plan, self._orig_gather = ops.bev_splat_plan, ops.bev_splat_gather
+        self._orig_plan_keyed = ops.bev_splat_plan_keyed
         prof = self
+
+        def timed_plan_keyed(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            plan = prof._orig_plan_keyed(*a, **kw)
+            e1.record()
+            plan._bench_ev = (e0, e1)
+            return plan
+        ops.bev_splat_plan_keyed = timed_plan_keyed
 
         def timed_plan(xyz, *a, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -148,17 +158,22 @@ class ConvProfiler:
     def uninstall(self):
         self._ops.conv2d = self._orig
         self._ops.bev_splat_plan, self._ops.bev_splat_gather = self._orig_plan, self._orig_gather
+        self._ops.bev_splat_plan_keyed = self._orig_plan_keyed
 
-    def splat_roofline(self):
+    def splat_roofline(self, key_ms: float = 0.0):
+        """key_ms: what the plan's first kernel (voxel coordinates + base-cell keys) adds to the pixel-geometry kernel it now
+        runs inside (keyed_geometry_extra_ms below), charged to the plan"""
         if not self.splat:
             return None
-        plan_ms = [p[0].elapsed_time(p[1]) for p, _, _ in self.splat]
+        plan_ms = [p[0].elapsed_time(p[1]) + key_ms for p, _, _ in self.splat]
         gath_ms = [g[0].elapsed_time(g[1]) for _, g, _ in self.splat]
         ms = [a + b for a, b in zip(plan_ms, gath_ms)]
         by = self.splat[0][2]
         avg = sum(ms) / len(ms)
-        return {"bound": "hbm", "kernel": "creste_bev_splat_plan_f32 (splat_key + splat_build_reg + splat_fill_rec + "
-                                          "splat_sort_rec) + creste_bev_splat_gather_f32 (splat_gather8): every splat kernel of the step",
+        return {"bound": "hbm", "kernel": "the key computation inside pixel_geometry_px_kernel<true> (its measured extra time) + "
+                                          "creste_bev_splat_plan_keyed_f32 (splat_build_reg + splat_fill_rec + splat_sort_rec) + "
+                                          "creste_bev_splat_gather_f32 (splat_gather8): every splat kernel of the step",
+                "key_in_geometry_ms": round(key_ms, 4),
                 "achieved": round(by / (avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(by / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes": by, "avg_call_ms": round(avg, 4),
                 "plan_ms": round(sum(plan_ms) / len(plan_ms), 4), "gather_ms": round(sum(gath_ms) / len(gath_ms), 4),
@@ -568,6 +583,47 @@ def irl_extras(model_infer, device, steps=5):
     return out
 
 
+def keyed_geometry_extra_ms(device, reps=20) -> float:
+    """The splat plan's key kernel runs inside the pixel-geometry kernel: its cost = keyed launch - plain launch of the same
+    geometry (batch 16, the bench's feature-map size), HIP events around `reps` launches each, best of 3; >= 0."""
+    from creste_public_amd import ops
+    Hs, Ws, B = IMG_H // 4, IMG_W // 4, BATCH
+    g = torch.Generator().manual_seed(5)
+    depth = (torch.rand(B, Hs, Ws, generator=g) * 20 + 1).to(device)
+    p2p = torch.eye(4).repeat(B, 1, 1).to(device)
+    bounds = torch.tensor([-12.8, -12.8, -2.0, 12.8, 12.8, 1.0], device=device)
+    w1, b1 = torch.randn(64, generator=g).to(device), torch.randn(64, generator=g).to(device)
+    w2, b2 = torch.randn(32, 64, generator=g).to(device), torch.randn(32, generator=g).to(device)
+    z = ops.Act.empty(B, Hs, Ws, 32, device)
+    lib = ops._lib.load()
+    xyz = torch.empty(B, Hs * Ws, 3, device=device); mask = torch.empty(B, Hs * Ws, device=device)
+    coords = torch.empty(B, Hs * Ws, 2, device=device)
+    work = torch.empty(lib.creste_bev_splat_workspace_bytes(B, Hs * Ws, 256, 256), dtype=torch.uint8, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+    common = (depth.data_ptr(), p2p.data_ptr(), B, Hs, Ws, bounds.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+              b2.data_ptr(), 64, 32, xyz.data_ptr(), mask.data_ptr(), z.buf.data_ptr(), z.cs, z.co)
+
+    def plain():
+        ops._lib.check(lib.creste_pixel_geometry_f32(*common, st), "pixel_geometry")
+
+    def keyed():
+        ops._lib.check(lib.creste_pixel_geometry_keyed_f32(*common, 12.8, 12.8, 0.1, 0.1, 256, 256, coords.data_ptr(),
+                                                           work.data_ptr(), st), "pixel_geometry_keyed")
+
+    def t(fn):
+        best = 1e9
+        for _ in range(3):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / reps)
+        return best
+    return max(0.0, t(keyed) - t(plain))
+
+
 def latency_extras(model, device, iters=30):
     """single-frame latency of the same forward (the deployed robot runs batch 1: scripts/runtime in the reference)"""
     from creste_public_amd import synth
@@ -898,7 +954,7 @@ def main():
         }
         if gemm_probe is not None:
             line["roofline"]["gemm_kernel"] = gemm_probe
-        sr = prof.splat_roofline()
+        sr = prof.splat_roofline(keyed_geometry_extra_ms(device))
         if sr is not None:
             line["roofline_splat"] = sr
         if serial_ms is not None:

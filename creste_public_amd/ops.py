@@ -976,9 +976,14 @@ def pixel_geometry_plan(depth, p2p, bounds6, w1, b1, w2, b2, zfeat: Act, off_xy,
         _chk(w1).data_ptr(), _chk(b1).data_ptr(), _chk(w2).data_ptr(), _chk(b2).data_ptr(), zhid, zdim,
         xyz.data_ptr(), mask.data_ptr(), zfeat.buf.data_ptr(), zfeat.cs, zfeat.co, float(off_xy[0]), float(off_xy[1]),
         float(vox_xy[0]), float(vox_xy[1]), GH, GW, coords.data_ptr(), work.data_ptr(), _stream()), "pixel_geometry_keyed")
-    _lib.check(lib.creste_bev_splat_plan_keyed_f32(B, P, GH, GW, coords.data_ptr(), work.data_ptr(), _stream()),
+    return xyz, mask, bev_splat_plan_keyed(coords, work, B, P, GH, GW)
+
+
+def bev_splat_plan_keyed(coords, work, B, P, GH, GW) -> SplatPlan:
+    """the rest of the binning plan behind a keyed pixel geometry (CSR build, record fill, per-cell sort)"""
+    _lib.check(_lib.load().creste_bev_splat_plan_keyed_f32(B, P, GH, GW, coords.data_ptr(), work.data_ptr(), _stream()),
                "bev_splat_plan_keyed")
-    return xyz, mask, SplatPlan(coords, work, B, P, GH, GW)
+    return SplatPlan(coords, work, B, P, GH, GW)
 
 
 class SplatPlan:
