@@ -592,15 +592,21 @@ static int launch_patch3(const PatchArgs& a, hipStream_t s) {
 //   * the K weight tiles of one kernel row arrive by LDS-DMA, double-buffered; K * 6 * TN MFMAs per wave and barrier
 //     interval; the next chunk's patch is prefetched branch-free during the K row steps and converted once.
 // SPLIT / F16: f16x3 (two fp16 pieces, operands rescaled from their |max| bounds) or bf16x6 (three bf16 pieces, no scaling)
-template <int K, int S, int TN, int SPLIT = 2, bool F16 = true>
+// RP = 2 (stride 2 only; the bf16x6 form of the 7x7/2 BEV stem, whose 21 x 69-pixel patch in three pieces + double-buffered
+// weight rows would need 227 KiB): a 16-channel chunk is done in TWO passes by input-row parity -- kernel rows 0, 2, 4, 6
+// only touch the patch's even rows, rows 1, 3, 5 the odd ones -- so the LDS holds 11 of the 21 patch rows at a time
+// (73.5 + 84 KiB).  Same products, same fp32 accumulation per output element up to the order of the kernel rows.
+template <int K, int S, int TN, int SPLIT = 2, bool F16 = true, int RP = 1>
 __global__ __launch_bounds__(512, 1) void conv_patch_row_kernel(const PatchArgs p) {
   typedef typename Piece<F16>::V8 h8;
   typedef typename Piece<F16>::V4 h4;
   static_assert(S == 1 || S == 2, "stride 1 or 2");
+  static_assert(RP == 1 || (RP == 2 && S == 2), "row-parity passes are for stride 2");
   constexpr int PH = S * PT_TH + K - S, PW = S * PT_TW + K - S;    // input patch extent
+  constexpr int PHL = RP == 2 ? (PH + 1) / 2 : PH;                 // patch rows resident in LDS
   constexpr int PWH = (PW + 1) / 2, PROW = S == 2 ? 2 * PWH : PW;  // slots per column parity / per patch row
-  constexpr int NSLOT = PH * PROW, NSLOTP = (NSLOT + 15) / 16 * 16;
-  constexpr int NPIX = PH * PW;
+  constexpr int NSLOT = PHL * PROW, NSLOTP = (NSLOT + 15) / 16 * 16;
+  constexpr int NPIX = PHL * PW;
   constexpr int BN = 64 * TN;
   constexpr int A_OCT = NSLOTP * 16, A_PLANE = 2 * A_OCT, A_BYTES = SPLIT * A_PLANE;
   constexpr int U_OCT = 64 * 16, U_PLANE = 2 * U_OCT, U_BYTES = SPLIT * U_PLANE;
@@ -633,27 +639,41 @@ __global__ __launch_bounds__(512, 1) void conv_patch_row_kernel(const PatchArgs 
 
   // staging slots: thread = (patch pixel, channel quad); rounds of 128 pixels
   const int cq = tid & 3;
-  int a_yx[ROUNDS];          // (iy << 16) | ix, or -1
+  int a_yx[ROUNDS];          // (iy << 16) | ix, or -1;  RP == 2: ((row of the EVEN pass + 8) << 16) | ix, -1 = column outside
   int a_lofs[ROUNDS];        // LDS byte offset of the pixel's slot (+ octet / half-octet of the quad)
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     const int pix = r * 128 + (tid >> 2);
     const int py = pix / PW, px = pix - py * PW;
-    const int iy = oy0 * S + py - p.pad_t, ix = ox0 * S + px - p.pad_l;
-    const bool ok = pix < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    a_yx[r] = ok ? (iy << 16) | ix : -1;
+    const int iy = oy0 * S + (RP == 2 ? 2 * py : py) - p.pad_t, ix = ox0 * S + px - p.pad_l;
+    if constexpr (RP == 2) {
+      a_yx[r] = (pix < NPIX && (unsigned)ix < (unsigned)p.W) ? ((iy + 8) << 16) | ix : -1;    // pad_t <= 8: iy + 8 >= 0
+    } else {
+      const bool ok = pix < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      a_yx[r] = ok ? (iy << 16) | ix : -1;
+    }
     const int slot = S == 2 ? py * PROW + (px & 1) * PWH + (px >> 1) : py * PROW + px;
     a_lofs[r] = pix < NPIX ? (cq >> 1) * A_OCT + slot * 16 + (cq & 1) * 8 : -1;
   }
+  // c: chunk (RP == 1) or 2 * chunk + row parity (RP == 2)
   auto load_a = [&](int r, int c) __attribute__((always_inline)) -> f32x4 {
-    const int ch = c * PT_CK + cq * 4;
-    const bool ok = a_yx[r] >= 0 && ch < p.Cin;
-    const int iy = a_yx[r] >> 16, ix = a_yx[r] & 0xffff;
-    return *reinterpret_cast<const f32x4*>(ok ? p.in + ((size_t)(img * p.H + iy) * p.W + ix) * p.in_cs + ch : p.in);
+    if constexpr (RP == 2) {
+      const int ch = (c >> 1) * PT_CK + cq * 4;
+      const int iy = (a_yx[r] >> 16) - 8 + (c & 1), ix = a_yx[r] & 0xffff;
+      const bool ok = a_yx[r] >= 0 && (unsigned)iy < (unsigned)p.H && ch < p.Cin;
+      return *reinterpret_cast<const f32x4*>(ok ? p.in + ((size_t)(img * p.H + iy) * p.W + ix) * p.in_cs + ch : p.in);
+    } else {
+      const int ch = c * PT_CK + cq * 4;
+      const bool ok = a_yx[r] >= 0 && ch < p.Cin;
+      const int iy = a_yx[r] >> 16, ix = a_yx[r] & 0xffff;
+      return *reinterpret_cast<const f32x4*>(ok ? p.in + ((size_t)(img * p.H + iy) * p.W + ix) * p.in_cs + ch : p.in);
+    }
   };
   auto store_a = [&](int r, int c, f32x4 v) __attribute__((always_inline)) {
     if (a_lofs[r] < 0) return;
-    const bool ok = a_yx[r] >= 0 && c * PT_CK + cq * 4 < p.Cin;
+    bool ok;
+    if constexpr (RP == 2) ok = a_yx[r] >= 0 && (unsigned)((a_yx[r] >> 16) - 8 + (c & 1)) < (unsigned)p.H && (c >> 1) * PT_CK + cq * 4 < p.Cin;
+    else ok = a_yx[r] >= 0 && c * PT_CK + cq * 4 < p.Cin;
     if constexpr (F16) v *= a_mul;
     if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -665,8 +685,8 @@ __global__ __launch_bounds__(512, 1) void conv_patch_row_kernel(const PatchArgs 
   };
   const size_t nrows_w = (size_t)p.nchunk * K;
   const char* wrow0 = p.wpk + (size_t)tn * TN * nrows_w * UROW_BYTES;
-  auto dma_row = [&](int g) __attribute__((always_inline)) {
-    char* dst = bbase + (g & 1) * ROW_BYTES;
+  auto dma_row = [&](int g, int buf) __attribute__((always_inline)) {       // weight row g = chunk * K + ky -> buffer `buf`
+    char* dst = bbase + buf * ROW_BYTES;
 #pragma unroll
     for (int j = 0; j < (ROW_INSTR + 7) / 8; ++j) {
       const int i = wave + 8 * j;
@@ -687,19 +707,78 @@ __global__ __launch_bounds__(512, 1) void conv_patch_row_kernel(const PatchArgs 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  dma_row(0);
+  dma_row(0, 0);
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) store_a(r, 0, load_a(r, 0));
   __syncthreads();
 
   const int nrows = p.nchunk * K;
+  // RP == 2: one kernel row; `srow` = the resident patch row that output row 0 of the tile reads for it
+  auto row_step = [&](const char* Brow, int srow) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      h8 af[2][SPLIT];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int slot = ((wm * 2 + mt) + srow) * PROW + (kx & 1) * PWH + li + (kx >> 1);
+#pragma unroll
+        for (int pl = 0; pl < SPLIT; ++pl)
+          af[mt][pl] = *reinterpret_cast<const h8*>(abuf + pl * A_PLANE + lh * A_OCT + slot * 16);
+      }
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) {
+        h8 bfr[SPLIT];
+        const int n = (wn * TN + nt) * 32 + li;
+#pragma unroll
+        for (int pl = 0; pl < SPLIT; ++pl)
+          bfr[pl] = *reinterpret_cast<const h8*>(Brow + (n >> 6) * UROW_BYTES + kx * U_BYTES + pl * U_PLANE + lh * U_OCT +
+                                                 (n & 63) * 16);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = split_mfma<SPLIT, h8>(bfr, af[mt], acc[mt][nt]);
+      }
+    }
+  };
+  if constexpr (RP == 2) {
+    // weight rows are consumed in the order ky = 0, 2, 4, 6, 1, 3, 5 of every chunk; buffer = step parity
+    constexpr int KE = (K + 1) / 2, KO = K / 2, RPS2 = (ROUNDS + KO - 1) / KO;
+    int s = 0;
+    for (int c = 0; c < p.nchunk; ++c) {
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const bool more_a = par == 0 || c + 1 < p.nchunk;
+        const int cn = 2 * c + par + 1;                      // the next (chunk, parity) pass
+        f32x4 ra[ROUNDS];
+#pragma unroll
+        for (int i = 0; i < (par ? KO : KE); ++i, ++s) {
+          const int ky = par + 2 * i;
+          // the next step of the sequence
+          const bool last_of_pass = i + 1 == (par ? KO : KE);
+          const int nky = last_of_pass ? (par ? 0 : 1) : ky + 2;
+          const int nc = (last_of_pass && par) ? c + 1 : c;
+          if (nc < p.nchunk) dma_row(nc * K + nky, (s + 1) & 1);
+          if (more_a) {
+#pragma unroll
+            for (int q = 0; q < RPS2; ++q)
+              if (i * RPS2 + q < ROUNDS) ra[i * RPS2 + q] = load_a(i * RPS2 + q, cn);
+          }
+          row_step(bbase + (s & 1) * ROW_BYTES, ky >> 1);
+          __syncthreads();
+        }
+        if (more_a) {
+#pragma unroll
+          for (int r = 0; r < ROUNDS; ++r) store_a(r, cn, ra[r]);
+          __syncthreads();
+        }
+      }
+    }
+  } else {
   int g = 0;
   for (int c = 0; c < p.nchunk; ++c) {
     const bool more_a = c + 1 < p.nchunk;
     f32x4 ra[ROUNDS];
 #pragma unroll
     for (int ky = 0; ky < K; ++ky, ++g) {
-      if (g + 1 < nrows) dma_row(g + 1);
+      if (g + 1 < nrows) dma_row(g + 1, (g + 1) & 1);
       if (more_a) {
 #pragma unroll
         for (int q = 0; q < RPS; ++q)
@@ -737,21 +816,22 @@ __global__ __launch_bounds__(512, 1) void conv_patch_row_kernel(const PatchArgs 
       __syncthreads();
     }
   }
+  }
   const bool vec_ok = (p.Cout & 3) == 0 && (p.out_cs & 3) == 0 && (p.out_co & 3) == 0 && (!p.res || (p.res_cs & 3) == 0);
   if (vec_ok) patch_epilogue_lds<TN>(acc, p, img, oy0, ox0, tn * BN, wm, wn, lane, o_mul, reinterpret_cast<float*>(smem));
   else patch_epilogue<TN, F16>(acc, p, img, oy0, ox0, tn * BN, wm, wn, li, lh, o_mul, reinterpret_cast<float*>(smem));
 }
 
-template <int K, int S, int TN, int SPLIT = 2, bool F16 = true>
+template <int K, int S, int TN, int SPLIT = 2, bool F16 = true, int RP = 1>
 static int launch_patch_row(const PatchArgs& a, hipStream_t s) {
   constexpr int PH = S * PT_TH + K - S, PW = S * PT_TW + K - S, PROW = S == 2 ? 2 * ((PW + 1) / 2) : PW;
-  constexpr int NSLOTP = (PH * PROW + 15) / 16 * 16;
+  constexpr int NSLOTP = ((RP == 2 ? (PH + 1) / 2 : PH) * PROW + 15) / 16 * 16;
   constexpr int smem = SPLIT * 2 * NSLOTP * 16 + 2 * K * (SPLIT * 2 * 64 * TN * 16);
   static_assert(smem <= 160 * 1024, "stride-2 patch does not fit the LDS");
   static std::atomic<uint64_t> attr_devs{0};
-  CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(conv_patch_row_kernel<K, S, TN, SPLIT, F16>), smem, attr_devs));
+  CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(conv_patch_row_kernel<K, S, TN, SPLIT, F16, RP>), smem, attr_devs));
   const int nblk = a.tiles_n * a.tiles_x * a.tiles_y * a.N;
-  conv_patch_row_kernel<K, S, TN, SPLIT, F16><<<nblk, 512, smem, s>>>(a);
+  conv_patch_row_kernel<K, S, TN, SPLIT, F16, RP><<<nblk, 512, smem, s>>>(a);
   CRESTE_CHECK_LAUNCH("conv_patch_row");
   return CRESTE_OK;
 }
@@ -847,8 +927,8 @@ static int launch_patch(const PatchArgs& a, hipStream_t s) {
 bool conv_patch_supported(int prec, int KH, int KW, int stride) {
   if (prec == CRESTE_PREC_F16X3 && KH == KW && (KH == 1 || KH == 3 || KH == 7) && stride == 2) return true;
   if (prec == CRESTE_PREC_F16X3 && KH == KW && (KH == 5 || KH == 7) && stride == 1) return true;
-  // bf16x6 on the row kernel where three pieces of the halo patch fit the LDS (not the 7x7/2 stem: 141 + 86 KiB)
-  if (prec == CRESTE_PREC_BF16X6 && KH == KW && (((KH == 1 || KH == 3) && stride == 2) || ((KH == 5 || KH == 7) && stride == 1))) return true;
+  // bf16x6 on the row kernel: three pieces of the halo patch fit the LDS (the 7x7/2 stem in two row-parity passes per chunk)
+  if (prec == CRESTE_PREC_BF16X6 && KH == KW && (((KH == 1 || KH == 3 || KH == 7) && stride == 2) || ((KH == 5 || KH == 7) && stride == 1))) return true;
   return (prec == CRESTE_PREC_BF16 || prec == CRESTE_PREC_BF16X3 || prec == CRESTE_PREC_BF16X6 ||
           prec == CRESTE_PREC_F16X3) && KH == KW && (KH == 1 || KH == 3) && stride == 1;
 }
@@ -911,6 +991,10 @@ int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
     a.tiles_n = (d->Cout + 63) / 64;
     if (d->stride == 1) return K == 7 ? launch_patch_row<7, 1, 1, 3, false>(a, s) : launch_patch_row<5, 1, 1, 3, false>(a, s);
     if (K == 3) return launch_patch_row<3, 2, 1, 3, false>(a, s);
+    if (K == 7) {
+      CRESTE_REQUIRE(d->pad_t >= 0 && d->pad_t <= 8 && d->H < 32000, "conv2d: 7x7/2 bf16x6 row-parity kernel: pad_t %d / H %d out of its packed range", d->pad_t, d->H);
+      return launch_patch_row<7, 2, 1, 3, false, 2>(a, s);
+    }
     if (d->Cout > 64) { a.tiles_n = (d->Cout + 127) / 128; return launch_patch_row<1, 2, 2, 3, false>(a, s); }
     return launch_patch_row<1, 2, 1, 3, false>(a, s);
   }

@@ -1,5 +1,5 @@
 """Micro-benchmark of one conv shape through the C ABI (tuning aid; run on the GPU box).
-usage: conv_micro.py PREC Cin Cout K H W [N] [iters]"""
+usage: [STRIDE=2] conv_micro.py PREC Cin Cout K H W [N] [iters]   (H, W: input extent)"""
 import sys, os, torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from creste_public_amd import ops
@@ -10,8 +10,11 @@ iters = int(sys.argv[8]) if len(sys.argv) > 8 else 10
 torch.manual_seed(0)
 x = ops.Act((torch.zeros if os.environ.get("ZERO") else torch.randn)(N, H, W, Cin, device="cuda"), Cin)
 w = torch.randn(Cout, Cin, K, K, device="cuda") / (Cin * K * K) ** 0.5
-pc = ops.pack_conv(w, None, None, 1, K // 2, ops.ACT_RELU, prec)
-out = ops.Act.empty(N, H, W, Cout, "cuda")
+S = int(os.environ.get("STRIDE", "1"))
+prec = ops.conv_precision(prec, K, S, Cin)
+pc = ops.pack_conv(w, None, None, S, K // 2, ops.ACT_RELU, prec)
+Ho, Wo = (H + 2 * (K // 2) - K) // S + 1, (W + 2 * (K // 2) - K) // S + 1
+out = ops.Act.empty(N, Ho, Wo, Cout, "cuda")
 for _ in range(2):
     ops.conv2d(x, pc, out=out)
 torch.cuda.synchronize()
@@ -21,5 +24,5 @@ for _ in range(iters):
     ops.conv2d(x, pc, out=out)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
-fl = 2.0 * N * H * W * Cout * Cin * K * K
-print(f"{sys.argv[1]} {Cin}->{Cout} k{K} {H}x{W} N={N}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s (algorithmic)")
+fl = 2.0 * N * Ho * Wo * Cout * Cin * K * K
+print(f"{sys.argv[1]} (engine {prec}) {Cin}->{Cout} k{K}/{S} {H}x{W} N={N}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s (algorithmic)")

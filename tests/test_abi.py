@@ -46,13 +46,14 @@ def test_conv_engine_routing_is_a_host_query():
         assert ops.conv_supported(F16X3, k, s), (k, s)
         assert ops.conv_supported(F32, k, s)
     assert not ops.conv_supported(F16X3, 5, 2) and not ops.conv_supported(F16X3, 9, 1)
-    # bf16x6: every row-kernel shape whose halo patch fits the LDS in three pieces -- all but the 7x7/2 stem
+    # bf16x6: every row-kernel shape (the 7x7/2 stem's halo patch fits the LDS in three pieces as two row-parity passes)
     assert ops.conv_supported(BF16X6, 3, 1) and ops.conv_supported(BF16X6, 3, 2) and ops.conv_supported(BF16X6, 7, 1)
-    assert ops.conv_supported(BF16X6, 5, 1) and ops.conv_supported(BF16X6, 1, 2) and not ops.conv_supported(BF16X6, 7, 2)
+    assert ops.conv_supported(BF16X6, 5, 1) and ops.conv_supported(BF16X6, 1, 2) and ops.conv_supported(BF16X6, 7, 2)
+    assert not ops.conv_supported(BF16X6, 5, 2)
     assert ops.conv_precision(F16X3, 7, 2, 96) == F16X3          # BEV stem
     assert ops.conv_precision(F16X3, 3, 2, 4) == F32             # encoder stem: one mostly-empty channel chunk
     assert ops.conv_precision(F16X3, 5, 1, 40) == F16X3          # reward FCN
-    assert ops.conv_precision(BF16X6, 7, 2, 96) == F32
+    assert ops.conv_precision(BF16X6, 7, 2, 96) == BF16X6        # BEV stem (round 5; exact-fp32 engine before)
     lib = _lib.load()
     assert lib.creste_conv_packed_weight_bytes(64, 96, 7, 7, F16X3) == 4 * 6 * 49 * 2 * 2 * 64 * 16   # 4 padded units
 

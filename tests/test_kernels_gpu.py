@@ -188,13 +188,10 @@ S2_CASES = [c for c in CONV_CASES if c[6] == 2] + [
 @pytest.mark.parametrize("case", S2_CASES)
 def test_conv_patch_stride2_f16x3(ops, case, mode):
     """stride-2 convs (K = 1, 3, 7) and stride-1 5x5 / 7x7 convs on the row kernel vs a float64 conv, fp32-grade: f16x3
-    (two fp16 pieces) and bf16x6 (three bf16 pieces; every shape but the 7x7/2 stem, whose halo patch does not fit the LDS
-    in three pieces and stays on the exact-fp32 engine)"""
+    (two fp16 pieces) and bf16x6 (three bf16 pieces; the 7x7/2 stem, whose halo patch does not fit the LDS in three pieces,
+    in two row-parity passes per channel chunk)"""
     N, Cin, H, W, Cout, K, s, pad, act, use_bias, use_bn, use_res = case
     prec = ops.PREC_F16X3 if mode == "f16x3" else ops.PREC_BF16X6
-    if mode == "bf16x6" and (K, s) == (7, 2):
-        assert not ops.conv_supported(prec, K, s)
-        return
     g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
     x = torch.randn(N, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
