@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libcreste_hip.so")
 
-ABI_VERSION = 9          # creste_abi_version() of the library this binding was written against
+ABI_VERSION = 10         # creste_abi_version() of the library this binding was written against
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
 

@@ -213,7 +213,7 @@ class Up(nn.Module):
 
     def convs_act(self, cat: Act, out: Act = None) -> Act:
         u = self._u()
-        return u[1](u[0](cat), out=out)
+        return ops.conv2d_pair(cat, u[0].packed(), u[1].packed(), out=out)
 
     def forward_act(self, x1: Act, x2: Act, out: Act = None) -> Act:
         return self.convs_act(self.concat_act(x1, x2), out=out)

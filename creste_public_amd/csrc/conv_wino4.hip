@@ -903,6 +903,137 @@ __global__ __launch_bounds__(256) void wino4_out2_kernel(const Wino4OutArgs p) {
   if (p.out_amax) block_amax_update(vmax, p.out_amax, scratch);
 }
 
+// ---- Output transform of conv 1 fused with the input transform of conv 2 (round 5): the conv1 -> conv2 pairs of the
+// reference's Up blocks (effnet.py:15-28: conv3x3 + BN + ReLU twice; DeconvHead.up1, inpainting.py:52-68).  Unfused, conv 1's
+// output Y crosses HBM twice (written by its output transform, read 2.25x -- mostly from L2 -- by conv 2's input transform)
+// between the two 2.25x-sized tensors M1 and V2 that have to cross it anyway.  Here one workgroup = a block of 8 x 16 tiles
+// (32 x 64 pixels) x ONE channel quad:
+//   phase 1  thread = tile of the block PLUS its one-tile ring (10 x 18 tiles: conv 2's 6x6 windows reach one pixel into
+//            the neighbouring tiles): 36 16-byte loads of M1, Y = act(A^T M A + bias) with wino4_out2_kernel's expressions,
+//            the 34 x 66 pixels conv 2 needs go to four LDS planes (pixels outside the image: conv 2's zero padding);
+//   phase 2  thread = (tile, channel): its 6x6 window from the plane, B^T d B with wino4_in1_kernel's expressions, 36 4-byte
+//            stores; lane = (tile of a block row, channel of the quad), so a wave's store is 256 contiguous bytes of V2.
+// The ring tiles are re-read by the neighbouring blocks: blocks walk an XCD's contiguous block range fastest, so those
+// re-reads come from its L2 / the infinity cache.  M1 and V2 are what the unfused kernels read / write, bit for bit; Y is
+// never materialised.  Channel quads past Cout (the padded tail of V2's last 16-channel chunk) are written as zeros.
+struct Wino4OutInArgs {
+  const float* M;
+  const float* bias;
+  char* V;
+  int Ho, Wo, Cout, act;
+  int tiles_y, tiles_x, T;
+  long mplane;
+  int nchunk, m_blocks;      // of V2 (Cin of conv 2 = Cout of conv 1)
+  int by, bx, nblk, q8;      // blocks per image column / row, blocks in all, blocks per XCD
+};
+constexpr int OI_BH = 8, OI_BW = 16;
+constexpr int OI_ROWS = 4 * OI_BH + 2, OI_RS = 4 * OI_BW + 2 + 1;            // 34 rows of 66 (+1) floats
+constexpr int OI_PS = (OI_ROWS * OI_RS + 63) / 64 * 64 + 1;                   // plane stride = 1 mod 64: conflict-free window reads
+__global__ __launch_bounds__(256) void wino4_outin_kernel(const Wino4OutInArgs p) {
+  __shared__ float yb[4 * OI_PS];
+  const int t = threadIdx.x;
+  const int L = blockIdx.x, xcd = L & 7, idx = L >> 3;
+  const int quad = idx / p.q8, blk = xcd * p.q8 + (idx - quad * p.q8);
+  if (blk >= p.nblk) return;
+  const int per_img = p.by * p.bx;
+  const int img = blk / per_img, rem = blk - img * per_img;
+  const int ty0 = (rem / p.bx) * OI_BH, tx0 = (rem % p.bx) * OI_BW;
+  const int Q = p.Cout >> 2;
+  const bool live = quad < Q;
+  if (live) {
+    if (t < (OI_BH + 2) * (OI_BW + 2)) {
+      const int hy = t / (OI_BW + 2), hx = t - hy * (OI_BW + 2);
+      const int ty = ty0 + hy - 1, tx = tx0 + hx - 1;
+      const bool tile_ok = (unsigned)ty < (unsigned)p.tiles_y && (unsigned)tx < (unsigned)p.tiles_x;
+      w4f32x4 y[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) y[a][b] = w4f32x4{0.f, 0.f, 0.f, 0.f};
+      if (tile_ok) {
+        const int tile = (img * p.tiles_y + ty) * p.tiles_x + tx;
+        const float* src = p.M + ((size_t)quad * p.T + tile) * 4;
+        const size_t plane = (size_t)p.mplane;
+        constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          w4f32x4 m[6];
+#pragma unroll
+          for (int j = 0; j < 6; ++j) m[j] = *reinterpret_cast<const w4f32x4*>(src + (i * 6 + j) * plane);
+          const w4f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+          const w4f32x4 r[4] = {(m[0] + s12) + s34, d12 + 2.f * d34, s12 + 4.f * s34, (d12 + 8.f * d34) + m[5]};
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            if (AT[a][i] == 0.f) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) y[a][b] = AT[a][i] == 1.f ? y[a][b] + r[b] : (AT[a][i] == -1.f ? y[a][b] - r[b] : y[a][b] + AT[a][i] * r[b]);
+          }
+        }
+      }
+      const w4f32x4 bs = p.bias ? *reinterpret_cast<const w4f32x4*>(p.bias + quad * 4) : w4f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int py = 4 * hy + a - 3;
+        if ((unsigned)py >= (unsigned)OI_ROWS) continue;
+        const bool yin = tile_ok && 4 * ty + a < p.Ho;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int px = 4 * hx + b - 3;
+          if ((unsigned)px >= (unsigned)(4 * OI_BW + 2)) continue;
+          w4f32x4 v = y[a][b] + bs;
+          const bool in = yin && 4 * tx + b < p.Wo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) yb[e * OI_PS + py * OI_RS + px] = in ? act_apply(v[e], p.act) : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int lane = t & 63, wv = t >> 6;
+  const int bxl = lane >> 2, c = lane & 3;
+  const int chunk = quad >> 2, kq = quad & 3;
+  const size_t pos_stride = (size_t)p.m_blocks * p.nchunk * (size_t)(4 * W4_M * 16);
+#pragma unroll 1
+  for (int rr = 0; rr < 2; ++rr) {
+    const int byl = wv * 2 + rr;
+    const int ty = ty0 + byl, tx = tx0 + bxl;
+    if (ty >= p.tiles_y || tx >= p.tiles_x) continue;
+    const int tile = (img * p.tiles_y + ty) * p.tiles_x + tx;
+    float d[6][6];
+    if (live) {
+      const float* wsrc = yb + c * OI_PS + (4 * byl) * OI_RS + 4 * bxl;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d[i][j] = wsrc[i * OI_RS + j];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+        float o[6];
+        w4_bt1(col, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i][j] = o[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        float o[6];
+        w4_bt1(d[i], o);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d[i][j] = o[j];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d[i][j] = 0.f;
+    }
+    const int mb = tile >> 8, row = tile & (W4_M - 1);
+    char* dst = p.V + (((size_t)mb * p.nchunk + chunk) * 4 + kq) * (size_t)(W4_M * 16) + (size_t)row * 16 + c * 4;
+#pragma unroll
+    for (int pos = 0; pos < 36; ++pos) *reinterpret_cast<float*>(dst + pos * pos_stride) = d[pos / 6][pos % 6];
+  }
+}
+
 // U = G g G^T in float64 from the OIHW fp32 weights (x BatchNorm scale, applied in fp32 as the direct packers do),
 // rounded once to fp32, split into bf16 pieces: [pos][unit][chunk][piece][k-octet][64][8]
 __global__ void wino4_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale, __bf16* __restrict__ out,
@@ -1080,6 +1211,9 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
   CRESTE_REQUIRE(d->work && !d->a_scale, "conv2d: the Winograd path needs its workspace and takes no per-sample input gate");
   CRESTE_REQUIRE(!d->up_src || (d->pad_t == 1 && d->pad_l == 1 && d->H == 2 * d->up_H && d->W == 2 * d->up_W),
                  "conv2d: the fused upsample of the F(4x4,3x3) input transform is the exact 2x one under pad 1");
+  CRESTE_REQUIRE(!(d->flags & CRESTE_CONV_EMIT_NEXT_V) || (!d->res && !d->row_mask && !d->out_amax && d->pad_t == 1 && d->pad_l == 1 &&
+                                                           d->Ho == d->H && d->Wo == d->W && wino4_split(d->prec) == 3),
+                 "conv2d: EMIT_NEXT_V takes a pad-1 bf16x6 conv without residual / row mask / |max| tracking");
   CRESTE_REQUIRE((d->out_cs & 3) == 0 && (d->out_co & 3) == 0 && (!d->res || (d->res_cs & 3) == 0) &&
                      (reinterpret_cast<uintptr_t>(d->out) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->work) & 15) == 0,
                  "conv2d: the Winograd path needs 16-byte aligned output / residual channel slices and workspace");
@@ -1145,6 +1279,21 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
   if (rc != CRESTE_OK) return rc;
   if (probe) CRESTE_HIP(hipEventRecord(g_w4_ev[1], s));
 
+  if (d->flags & CRESTE_CONV_EMIT_NEXT_V) {
+    // `out` is the NEXT conv's workspace: its transformed input V2 is written instead of this conv's output (creste_hip.h)
+    Wino4OutInArgs f;
+    f.M = M; f.bias = d->bias; f.V = reinterpret_cast<char*>(d->out);
+    f.Ho = d->Ho; f.Wo = d->Wo; f.Cout = d->Cout; f.act = d->act;
+    f.tiles_y = tiles_y; f.tiles_x = tiles_x; f.T = (int)T; f.mplane = a.mplane;
+    f.nchunk = (d->Cout + W4_CK - 1) / W4_CK; f.m_blocks = m_blocks;
+    f.by = (tiles_y + OI_BH - 1) / OI_BH; f.bx = (tiles_x + OI_BW - 1) / OI_BW;
+    f.nblk = d->N * f.by * f.bx; f.q8 = (f.nblk + 7) / 8;
+    const long grid = 8L * f.q8 * (f.nchunk * 4);
+    CRESTE_REQUIRE(grid < (1L << 31), "conv2d: fused output -> input transform grid too large");
+    if (only & 4) wino4_outin_kernel<<<(unsigned)grid, 256, 0, s>>>(f);
+    CRESTE_CHECK_LAUNCH("wino4_outin");
+    return CRESTE_OK;
+  }
   Wino4OutArgs o;
   o.M = M; o.bias = d->bias; o.res = d->res; o.row_mask = d->row_mask; o.out = d->out; o.out_amax = d->out_amax;
   o.N = d->N; o.Ho = d->Ho; o.Wo = d->Wo; o.Cout = d->Cout; o.out_cs = d->out_cs; o.out_co = d->out_co; o.res_cs = d->res_cs;

@@ -579,9 +579,43 @@ def pack_conv(weight: torch.Tensor, bias, bn, stride, pad, act, prec=PREC_F32, a
     return PackedConv(wpk, b, Cin, Cout, KH, KW, stride, pad[0], pad[2], pad[1], pad[3], act, prec, unscale)
 
 
+# conv3x3 -> conv3x3 pairs (Up.conv): conv 1's output transform writes conv 2's transformed input (CRESTE_FUSE_PAIRS=0: off)
+FUSE_CONV_PAIRS = os.environ.get("CRESTE_FUSE_PAIRS", "1") != "0"
+FUSE_PAIR_MIN_FILL = 0.5   # ... where the map fills the fused kernel's 8 x 16-tile blocks at least this well (38 x 76: 0.37, slower)
+
+
+class _TransformedInput:
+    """The input of a F(4x4,3x3) conv that only exists as its transformed image V, at the start of the conv's workspace
+    (written by the previous conv's fused output -> input transform, CRESTE_CONV_EMIT_NEXT_V)."""
+    __slots__ = ("work", "N", "H", "W", "C", "device")
+
+    def __init__(self, work, N, H, W, C, device):
+        self.work, self.N, self.H, self.W, self.C, self.device = work, N, H, W, C, device
+
+
+def conv_pair_fusable(pc1: PackedConv, pc2: PackedConv) -> bool:
+    return (FUSE_CONV_PAIRS and not TRACK_AMAX and pc1.algo == ALGO_WINOGRAD4 and pc2.algo == ALGO_WINOGRAD4
+            and pc1.prec == PREC_BF16X6 and pc2.prec == PREC_BF16X6 and pc1.Cout == pc2.Cin
+            and (pc1.pad_t, pc1.pad_l, pc2.pad_t, pc2.pad_l) == (1, 1, 1, 1) and pc1.out_hw(8, 8) == (8, 8)
+            and pc2.out_hw(8, 8) == (8, 8))
+
+
+def conv2d_pair(x, pc1: PackedConv, pc2: PackedConv, out: Act | None = None) -> Act:
+    """conv2(conv1(x)) of a conv3x3 (+BN+ReLU) pair (reference Up.conv, effnet.py:15-28).  Where both run as F(4x4,3x3) in
+    bf16x6, conv 1's output never crosses HBM as a tensor: its output transform writes conv 2's transformed input directly
+    (same values, bit for bit, as the two separate calls)."""
+    ty, tx = (x.H + 3) // 4, (x.W + 3) // 4
+    fill = ty * tx / float(((ty + 7) // 8 * 8) * ((tx + 15) // 16 * 16))
+    if not conv_pair_fusable(pc1, pc2) or fill < FUSE_PAIR_MIN_FILL:
+        return conv2d(conv2d(x, pc1), pc2, out=out)
+    return conv2d(conv2d(x, pc1, _emit_next=pc2), pc2, out=out)
+
+
 def conv2d(x: Act, pc: PackedConv, out: Act | None = None, res: Act | None = None,
-           a_scale: torch.Tensor | None = None, row_mask: torch.Tensor | None = None) -> Act:
+           a_scale: torch.Tensor | None = None, row_mask: torch.Tensor | None = None, _emit_next: PackedConv | None = None) -> Act:
     lib = _lib.load()
+    if isinstance(x, _TransformedInput):
+        return _conv2d_from_v(x, pc, out)
     up, shared = None, None
     if isinstance(x, LazyUpCat):
         if FUSE_UPSAMPLE and pc.algo == ALGO_WINOGRAD4 and x.exact2x and a_scale is None:
@@ -612,9 +646,16 @@ def conv2d(x: Act, pc: PackedConv, out: Act | None = None, res: Act | None = Non
     if cin != pc.Cin:
         raise HipLibraryError(f"conv2d: input has {cin} channels, weights expect {pc.Cin}")
     Ho, Wo = pc.out_hw(H, W)
-    if out is None:
+    nxt = None
+    if _emit_next is not None:
+        if out is not None or res is not None or row_mask is not None or a_scale is not None:
+            raise HipLibraryError("conv2d: the fused conv pair takes no output slice / residual / mask / gate on its first conv")
+        nxt = _TransformedInput(torch.empty(lib.creste_conv_wino4_workspace_bytes(N, Ho, Wo, _emit_next.Cin, _emit_next.Cout,
+                                                                                   _emit_next.prec), dtype=torch.uint8, device=dev),
+                                N, Ho, Wo, pc.Cout, dev)
+    elif out is None:
         out = Act.empty(N, Ho, Wo, pc.Cout, dev)
-    if (out.N, out.H, out.W, out.C) != (N, Ho, Wo, pc.Cout):
+    if nxt is None and (out.N, out.H, out.W, out.C) != (N, Ho, Wo, pc.Cout):
         raise HipLibraryError(f"conv2d: output slice {(out.N, out.H, out.W, out.C)} != "
                               f"{(N, Ho, Wo, pc.Cout)}")
     d = ConvDesc()
@@ -624,7 +665,7 @@ def conv2d(x: Act, pc: PackedConv, out: Act | None = None, res: Act | None = Non
         _chk(up.x1.buf, name="conv upsample source")
         d.in_, in_cs = (up.skip.ptr, up.skip.cs) if up.skip is not None else (None, 0)
         d.up_src, d.up_H, d.up_W, d.up_C, d.up_cs = up.x1.ptr, up.x1.H, up.x1.W, up.x1.C, up.x1.cs
-    d.wpk, d.out = pc.wpk.data_ptr(), out.buf.data_ptr()
+    d.wpk, d.out = pc.wpk.data_ptr(), (out.buf.data_ptr() if nxt is None else nxt.work.data_ptr())
     d.bias = pc.bias.data_ptr() if pc.bias is not None else None
     if res is not None:
         if (res.N, res.H, res.W, res.C) != (out.N, out.H, out.W, out.C):
@@ -643,7 +684,7 @@ def conv2d(x: Act, pc: PackedConv, out: Act | None = None, res: Act | None = Non
             raise HipLibraryError("conv2d: row_mask must have N*Ho*Wo elements")
         d.row_mask = row_mask.data_ptr()
     d.N, d.H, d.W, d.Cin, d.in_cs = N, H, W, pc.Cin, in_cs
-    d.Ho, d.Wo, d.Cout, d.out_cs, d.out_co = Ho, Wo, pc.Cout, out.cs, out.co
+    d.Ho, d.Wo, d.Cout, d.out_cs, d.out_co = (Ho, Wo, pc.Cout, out.cs, out.co) if nxt is None else (Ho, Wo, pc.Cout, pc.Cout, 0)
     d.KH, d.KW, d.stride, d.pad_t, d.pad_l = pc.KH, pc.KW, pc.stride, pc.pad_t, pc.pad_l
     d.act, d.prec, d.algo = pc.act, pc.prec, pc.algo
     work = None
@@ -661,11 +702,39 @@ def conv2d(x: Act, pc: PackedConv, out: Act | None = None, res: Act | None = Non
             if shared is not None:
                 shared._w4 = (key, work)
         d.work = work.data_ptr()
+    if nxt is not None:
+        d.flags = d.flags | 2                  # CRESTE_CONV_EMIT_NEXT_V
+        _lib.check(lib.creste_conv2d_nhwc(C.byref(d), _stream()), "conv2d_nhwc")
+        return nxt
     if pc.prec == PREC_F16X3:
         d.a_amax, d.w_unscale = absmax(x).data_ptr(), pc.w_unscale.data_ptr()
     if TRACK_AMAX or pc.prec == PREC_F16X3:     # also into a caller's slice: the bound of THAT slice (its Act object)
         out.amax = _AmaxPool.slot(dev)
         d.out_amax = out.amax.data_ptr()
+    _lib.check(lib.creste_conv2d_nhwc(C.byref(d), _stream()), "conv2d_nhwc")
+    return out
+
+
+def _conv2d_from_v(x: "_TransformedInput", pc: PackedConv, out: Act | None) -> Act:
+    """the second conv of a fused pair: its workspace already holds the transformed input (CRESTE_CONV_V_VALID)"""
+    lib = _lib.load()
+    N, H, W = x.N, x.H, x.W
+    if pc.algo != ALGO_WINOGRAD4 or x.C != pc.Cin:
+        raise HipLibraryError("conv2d: a transformed input feeds the F(4x4,3x3) conv it was made for")
+    Ho, Wo = pc.out_hw(H, W)
+    if out is None:
+        out = Act.empty(N, Ho, Wo, pc.Cout, x.device)
+    if (out.N, out.H, out.W, out.C) != (N, Ho, Wo, pc.Cout):
+        raise HipLibraryError(f"conv2d: output slice {(out.N, out.H, out.W, out.C)} != {(N, Ho, Wo, pc.Cout)}")
+    d = ConvDesc()
+    d.in_, d.wpk, d.out = x.work.data_ptr(), pc.wpk.data_ptr(), out.buf.data_ptr()      # `in` is not read
+    d.bias = pc.bias.data_ptr() if pc.bias is not None else None
+    d.res, d.res_cs = None, 0
+    d.N, d.H, d.W, d.Cin, d.in_cs = N, H, W, pc.Cin, pc.Cin
+    d.Ho, d.Wo, d.Cout, d.out_cs, d.out_co = Ho, Wo, pc.Cout, out.cs, out.co
+    d.KH, d.KW, d.stride, d.pad_t, d.pad_l = pc.KH, pc.KW, pc.stride, pc.pad_t, pc.pad_l
+    d.act, d.prec, d.algo = pc.act, pc.prec, pc.algo
+    d.work, d.flags = x.work.data_ptr(), 1
     _lib.check(lib.creste_conv2d_nhwc(C.byref(d), _stream()), "conv2d_nhwc")
     return out
 

@@ -54,6 +54,13 @@ extern "C" {
  * tensor (same N, H, W, Cin, padding, precision) from a previous call on the same stream -- several convs that read one
  * tensor (the three BEV heads' first conv, inpainting.py:141-146) run the input transform once. */
 #define CRESTE_CONV_V_VALID 1
+/* EMIT_NEXT_V (CRESTE_ALGO_WINOGRAD4, CRESTE_PREC_BF16X6, pad 1, no residual / row mask / out_amax): this conv is the first of
+ * a conv3x3 -> conv3x3 pair (reference Up.conv, effnet.py:15-28; DeconvHead.up1, inpainting.py:52-68).  Its output
+ * act(conv + bias) is NOT written: `out` must point to the `work` buffer of the SECOND conv (3x3, stride 1, pad 1, Cin == this
+ * Cout, same N / H / W, same precision), and the output transform writes that conv's transformed input there -- bit for bit
+ * what the second conv's own input transform would have produced from the materialised tensor.  The second call passes
+ * CRESTE_CONV_V_VALID (its `in` is not read).  out_cs / out_co are ignored. */
+#define CRESTE_CONV_EMIT_NEXT_V 2
 #define CRESTE_ALGO_WINOGRAD4 2 /* F(4x4,3x3): the same convs, transformed input materialised, see creste_conv_wino4_* */
 
 const char* creste_last_error(void);

@@ -618,6 +618,46 @@ def test_conv_winograd4_fused_upsample_concat(ops, N, C1, C2, H1, W1, Cout):
     assert lazy._mat is not None and ops.conv2d(lazy, pcd).buf.shape == y.buf.shape
 
 
+@pytest.mark.parametrize("N,Cin,Cmid,Cout,H,W,up", [
+    (2, 128, 256, 128, 20, 28, False),     # one partial block in both directions (5 x 7 tiles)
+    (1, 320, 496, 496, 37, 41, False),     # partial tiles (37 x 41 pixels), 31 chunks, two cout tiles
+    (3, 144, 136, 132, 70, 132, False),    # several blocks per image (18 x 33 tiles), Cmid = 8.5 chunks: the padded channel quads
+    (2, 256, 128, 256, 32, 64, True),      # exactly one block; conv 1 with the fused upsample input
+    (1, 128, 256, 128, 152, 304, False),   # the up3 map: 38 x 76 tiles, 5 x 5 blocks with ragged right / bottom blocks
+])
+def test_conv_pair_fused_output_input_transform_is_bit_identical(ops, monkeypatch, N, Cin, Cmid, Cout, H, W, up):
+    """conv3x3+ReLU -> conv3x3+ReLU (reference Up.conv, effnet.py:15-28) with conv 1's output transform writing conv 2's
+    transformed input (CRESTE_CONV_EMIT_NEXT_V / V_VALID, csrc/conv_wino4.hip: wino4_outin_kernel) == the two separate
+    calls, bit for bit: the intermediate tensor never exists, its values are formed with the same expressions."""
+    g = torch.Generator().manual_seed(Cin + Cmid + H)
+    w1 = torch.randn(Cmid, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    w2 = torch.randn(Cout, Cmid, 3, 3, generator=g) / (Cmid * 9) ** 0.5
+    b1, b2 = torch.randn(Cmid, generator=g), torch.randn(Cout, generator=g)
+    pc1 = ops.pack_conv(dev(w1), dev(b1), None, 1, 1, ops.ACT_RELU, ops.PREC_BF16X6, algo=ops.ALGO_WINOGRAD4)
+    pc2 = ops.pack_conv(dev(w2), dev(b2), None, 1, 1, ops.ACT_RELU, ops.PREC_BF16X6, algo=ops.ALGO_WINOGRAD4)
+    if up:
+        x1 = to_act(ops, torch.randn(N, Cin - 64, H // 2, W // 2, generator=g))
+        skip = to_act(ops, torch.randn(N, 64, H, W, generator=g))
+        make = lambda: ops.upsample_concat_lazy(x1, skip, H, W, 0.5, 0.5)
+    else:
+        x = to_act(ops, torch.randn(N, Cin, H, W, generator=g))
+        make = lambda: x
+    assert ops.conv_pair_fusable(pc1, pc2)
+    monkeypatch.setattr(ops, "FUSE_PAIR_MIN_FILL", 0.0)        # every case through the fused kernel, however ragged
+    fused = ops.conv2d_pair(make(), pc1, pc2)
+    monkeypatch.setattr(ops, "FUSE_CONV_PAIRS", False)
+    assert not ops.conv_pair_fusable(pc1, pc2)
+    plain = ops.conv2d_pair(make(), pc1, pc2)
+    assert torch.equal(fused.buf, plain.buf)
+    # and into a channel slice of a wider buffer, as the encoder's last Up block writes (effnet.py: the 288-channel fusion buffer)
+    monkeypatch.setattr(ops, "FUSE_CONV_PAIRS", True)
+    wide = ops.Act.empty(N, H, W, Cout + 32, "cuda")
+    wide.buf.zero_()
+    sl = ops.Act(wide.buf, Cout, 16)
+    ops.conv2d_pair(make(), pc1, pc2, out=sl)
+    assert torch.equal(wide.buf[..., 16:16 + Cout], plain.buf) and float(wide.buf[..., :16].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("prec", ["bf16x6", "bf16x3"])
 @pytest.mark.parametrize("N,Cin,Cout,H,W,up", [
     (2, 128, 256, 20, 28, False),      # 8 chunks, one ragged tile block
