@@ -941,27 +941,31 @@ __global__ __launch_bounds__(256) void wino4_outin_kernel(const Wino4OutInArgs p
   const int Q = p.Cout >> 2;
   const bool live = quad < Q;
   if (live) {
-    if (t < (OI_BH + 2) * (OI_BW + 2)) {
-      const int hy = t / (OI_BW + 2), hx = t - hy * (OI_BW + 2);
+    // thread = (tile of the 10 x 18 ring block, channel PAIR): two lanes share a quad's 16 bytes; 360 items in two rounds
+    // (rolled: 80 registers, so that the kernel fits beside another stream's GEMM workgroup like the transforms above)
+#pragma unroll 1
+    for (int item = t; item < 2 * (OI_BH + 2) * (OI_BW + 2); item += 256) {
+      const int ht = item >> 1, pr = item & 1;
+      const int hy = ht / (OI_BW + 2), hx = ht - hy * (OI_BW + 2);
       const int ty = ty0 + hy - 1, tx = tx0 + hx - 1;
       const bool tile_ok = (unsigned)ty < (unsigned)p.tiles_y && (unsigned)tx < (unsigned)p.tiles_x;
-      w4f32x4 y[4][4];
+      w4f32x2 y[4][4];
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) y[a][b] = w4f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < 4; ++b) y[a][b] = w4f32x2{0.f, 0.f};
       if (tile_ok) {
         const int tile = (img * p.tiles_y + ty) * p.tiles_x + tx;
-        const float* src = p.M + ((size_t)quad * p.T + tile) * 4;
+        const float* src = p.M + ((size_t)quad * p.T + tile) * 4 + pr * 2;
         const size_t plane = (size_t)p.mplane;
         constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          w4f32x4 m[6];
+          w4f32x2 m[6];
 #pragma unroll
-          for (int j = 0; j < 6; ++j) m[j] = *reinterpret_cast<const w4f32x4*>(src + (i * 6 + j) * plane);
-          const w4f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-          const w4f32x4 r[4] = {(m[0] + s12) + s34, d12 + 2.f * d34, s12 + 4.f * s34, (d12 + 8.f * d34) + m[5]};
+          for (int j = 0; j < 6; ++j) m[j] = *reinterpret_cast<const w4f32x2*>(src + (i * 6 + j) * plane);
+          const w4f32x2 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+          const w4f32x2 r[4] = {(m[0] + s12) + s34, d12 + 2.f * d34, s12 + 4.f * s34, (d12 + 8.f * d34) + m[5]};
 #pragma unroll
           for (int a = 0; a < 4; ++a) {
             if (AT[a][i] == 0.f) continue;
@@ -970,7 +974,7 @@ __global__ __launch_bounds__(256) void wino4_outin_kernel(const Wino4OutInArgs p
           }
         }
       }
-      const w4f32x4 bs = p.bias ? *reinterpret_cast<const w4f32x4*>(p.bias + quad * 4) : w4f32x4{0.f, 0.f, 0.f, 0.f};
+      const w4f32x2 bs = p.bias ? *reinterpret_cast<const w4f32x2*>(p.bias + quad * 4 + pr * 2) : w4f32x2{0.f, 0.f};
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         const int py = 4 * hy + a - 3;
@@ -980,10 +984,10 @@ __global__ __launch_bounds__(256) void wino4_outin_kernel(const Wino4OutInArgs p
         for (int b = 0; b < 4; ++b) {
           const int px = 4 * hx + b - 3;
           if ((unsigned)px >= (unsigned)(4 * OI_BW + 2)) continue;
-          w4f32x4 v = y[a][b] + bs;
+          const w4f32x2 v = y[a][b] + bs;
           const bool in = yin && 4 * tx + b < p.Wo;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) yb[e * OI_PS + py * OI_RS + px] = in ? act_apply(v[e], p.act) : 0.f;
+          for (int e = 0; e < 2; ++e) yb[(pr * 2 + e) * OI_PS + py * OI_RS + px] = in ? act_apply(v[e], p.act) : 0.f;
         }
       }
     }
