@@ -78,7 +78,8 @@ def kernel_symbol(pc, N, Ho, Wo):
     if getattr(pc, "algo", 0) == 2:             # Winograd F(4x4,3x3): input transform + GEMM over the 36 positions + output transform
         split = {2: 2, 3: 3}[pc.prec]
         return (PREC_NAME[pc.prec] + "+winograd4",
-                f"wino4_in1_kernel<UP> + wino4_gemm32_kernel<{split}, {4 if pc.Cout > 128 else 2}> + wino4_out2_kernel")
+                f"wino4_in1_kernel<UP> + wino4_gemm32_kernel<{split}, {4 if pc.Cout > 128 else 2}, 0, true> + wino4_out2_kernel"
+                " (conv3x3 -> conv3x3 pairs: wino4_outin_kernel in place of the first conv's output and the second conv's input transform)")
     if pc.prec == 0:
         return ("f32", "conv_igemm_f32_kernel<2, 2, 2, 2>" if pc.Cout > 64 else
                 "conv_igemm_f32_kernel<2, 2, 2, 1>" if pc.Cout > 32 else "conv_igemm_f32_kernel<4, 1, 1, 1>")
@@ -179,7 +180,7 @@ class ConvProfiler:
                 "plan_ms": round(sum(plan_ms) / len(plan_ms), 4), "gather_ms": round(sum(gath_ms) / len(gath_ms), 4),
                 "min_call_ms": round(min(ms), 4), "calls": len(ms), "traffic": None,
                 "note": "HIP events around the binning plan (enqueued right after the pixel geometry, ahead of the fusion "
-                        "conv) and around the gather, inside the one-stream steps run right after the timed region (the "
+                        "conv) and around the gather, in the one-stream steps run right AFTER the timed region, not inside it (the "
                         "network's own predicted depths and fused features, batch 16); time = plan_ms + gather_ms; bytes = 4*(F*P + 2*P + F*G + G) per frame "
                         "(SURVEY 8d: F=96, P=46208, G=65536), one read of the inputs and one write of the outputs"}
 
@@ -239,7 +240,7 @@ def gemm_kernel_probe(step):
             "algorithmic_tflops": round(alg / (ms_tot * 1e-3) / 1e12, 1),
             "note": "HIP events around the GEMM kernel alone (library probe), one untimed step after the timed ones; "
                     "piece products = 36 positions x padded tiles x padded Cin x padded Cout x 2 x pieces, issued on "
-                    "v_mfma_f32_32x32x16_bf16 (dense peak 2500 TFLOP/s); PMC of the pre-split form of this kernel: profiles/r03_pmc_wino4_496.txt"}
+                    "v_mfma_f32_32x32x16_bf16 (dense peak 2500 TFLOP/s); SQ_VALU_MFMA_BUSY_CYCLES of this kernel: roofline.mfma_busy_gemm (profiles/r05_pmc_encoder.txt)"}
 
 
 def cpu_baseline(batches=(1, 16), runs=5, budget_s=210.0):
@@ -902,23 +903,29 @@ def main():
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         dprec, kname = dom
         conv_ms = sum(v["ms"] for v in by.values())
-        traffic = None
+        traffic, traffic_note, mfma_busy = None, None, None
         pj = os.path.join(ROOT, "profiles", "roofline_counters.json")
         if os.path.exists(pj):
             try:
-                # a Winograd call is several kernels ("a + b + c"): HBM bytes of one call = the sum over its kernels
+                # HBM bytes of one F(4x4,3x3) conv call = the PMC bytes of EVERY kernel of the family (both input-transform
+                # instantiations, the GEMM, the output transform and the fused output -> input transform of the conv pairs)
+                # over the profiled run / the family's GEMM launches (every call launches exactly one GEMM)
                 cnt = json.load(open(pj))
-                def per_launch(k):
-                    if ", UP" in k:       # the input transform has two instantiations (plain / fused upsample + concat input)
-                        es = [cnt.get(k.replace("UP", v)) for v in ("false", "true")]
-                        es = [e for e in es if e]
-                        n = sum(e["launches"] for e in es)
-                        return sum(e["hbm_bytes_per_launch"] * e["launches"] for e in es) / n if n else None
-                    return cnt.get(k, {}).get("hbm_bytes_per_launch")
-                parts = [per_launch(k.strip()) for k in kname.split(" + ")]
-                traffic = sum(parts) if all(v is not None for v in parts) else None
+                fam = {k: v for k, v in cnt.items() if isinstance(v, dict) and k.startswith("wino4_") and "wg_" not in k and "pack" not in k}
+                gemms = sum(v["launches"] for k, v in fam.items() if "gemm32" in k)
+                if gemms:
+                    traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fam.values()) / gemms
+                    traffic_note = (f"PMC (profiles/roofline_counters.json: {cnt.get('_source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --parts 1')}): "
+                                    f"HBM bytes of all {len(fam)} kernels of the F(4x4,3x3) family / {gemms} conv calls, i.e. the average over "
+                                    "the step's 19 calls of both GEMM tile widths")
             except Exception:
                 traffic = None
+        pm = os.path.join(ROOT, "profiles", "r05_pmc_encoder.json")
+        if os.path.exists(pm):
+            try:
+                mfma_busy = json.load(open(pm))
+            except Exception:
+                mfma_busy = None
         line = {
             "metric": "frames/sec (RGB+LiDAR->BEV costmap)",
             "value": round(frames / elapsed, 3),
@@ -942,7 +949,10 @@ def main():
                                  "with every 214 MB batch copied from pinned host memory inside the timed region"},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": round(PEAK[dprec], 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK[dprec], 4), "traffic": traffic,
+                         "frac": round(achieved / PEAK[dprec], 4), "traffic": traffic, "traffic_note": traffic_note,
+                         "mfma_busy_gemm": (mfma_busy or {}).get("gemm"), "mfma_busy_encoder": (mfma_busy or {}).get("encoder"),
+                         "mfma_busy_whole_step": (mfma_busy or {}).get("whole_step"),
+                         "mfma_busy_note": (mfma_busy or {}).get("note"),
                          "mfma_products_per_multiply": round(PRODUCTS[dprec], 3),
                          "mfma_issue_util": round(PRODUCTS[dprec] * achieved / PEAK[dprec], 4),
                          "launches": d["n"], "avg_launch_ms": round(d["ms"] / d["n"], 4),
@@ -956,6 +966,17 @@ def main():
             line["roofline"]["gemm_kernel"] = gemm_probe
         sr = prof.splat_roofline(keyed_geometry_extra_ms(device))
         if sr is not None:
+            try:      # PMC bytes of the step's splat kernels (profiles/roofline_counters.json, calibrated WRITE_SIZE / FETCH_SIZE)
+                cnt = json.load(open(os.path.join(ROOT, "profiles", "roofline_counters.json")))
+                ks = [k for k in cnt if isinstance(cnt[k], dict) and k.startswith("splat_") and "launches" in cnt[k]]
+                if any("splat_gather8" in k for k in ks):
+                    sr["traffic"] = round(sum(cnt[k]["hbm_bytes_per_launch"] for k in ks), 1)
+                    sr["traffic_kernels"] = {k: round(cnt[k]["hbm_bytes_per_launch"] / 1e6, 1) for k in ks}
+                    sr["traffic_note"] = ("PMC MB per launch of every splat kernel of a step; " + str(cnt.get("_note", "")) +
+                                          " -- the gather's 402.7 MB of BEV rows leave as nontemporal stores, which WRITE_SIZE "
+                                          "under-reports (calibrated against an empty plan: profiles/r05_pmc_calibration.json)")
+            except Exception:
+                pass
             line["roofline_splat"] = sr
         if serial_ms is not None:
             line["ms_per_step_one_stream"] = round(serial_ms, 3)
@@ -993,7 +1014,23 @@ def main():
                                    "note": "r ~ U[0,1) [8,256,256], gamma 0.99, threshold 1e-3; bytes = B*H*W*(12*sweeps + 72) "
                                            "(SURVEY 8d: the HBM-streaming figure of a sweep-per-launch solver; the state is "
                                            "LDS / L2 resident here, so the fraction may exceed 1)"}
+            # The solver keeps its state in registers / LDS: what bounds a sweep is VALU issue (117 VALU instructions per
+            # 1 x 4 strip and sweep, counted in the ISA of vi_spec_kernel; a wave64 instruction holds a SIMD for 4 cycles)
+            # and LDS traffic (two 16-byte reads + one 16-byte write per strip and sweep), not HBM
+            def vi_onchip(ms, sweeps, nwg, waves, strips):
+                clk, simds, cus = 2.4e9, 1024, 256
+                t = ms * 1e-3
+                valu = nwg * waves * 117 * 4.0 * sweeps / (simds * clk * t)
+                lds_bytes = nwg * strips * 48.0 * sweeps
+                return {"valu_issue_frac": round(valu, 4), "lds_GBps": round(lds_bytes / t / 1e9, 1),
+                        "lds_frac": round(lds_bytes / t / (cus * 128 * clk), 4)}
+            line["roofline_vi"]["on_chip"] = dict(vi_onchip(vi["ms"], vi["sweeps"], 256, 16, 48 * 20),
+                note="8x256x256: 256 workgroups (32 x 64 tiles + 8-cell halo = 48 x 80 cells), 16 waves each; valu_issue_frac = "
+                     "waves x 117 VALU instructions x 4 cycles x sweeps / (1024 SIMDs x 2.4 GHz x time): the bound a sweep is "
+                     "closest to (the rest: barrier / LDS / DPP latency inside a sweep and the halo exchange, profiles/r04_value_iteration.md); "
+                     "lds_frac against 256 CUs x 128 B/clk")
             vr = line["irl"]["vi_8x64x128"]
+            line["roofline_vi"]["on_chip_8x64x128"] = vi_onchip(vr["ms"], vr["sweeps"], 256, 4, 32 * 8)
             line["roofline_vi"]["reference_grid_8x64x128"] = {"achieved": vr["algorithmic_GBps"], "frac": vr["frac_of_hbm_peak"],
                                                               "ms": vr["ms"], "sweeps": vr["sweeps"]}
             line["distill"] = distill_extras(device)

@@ -6,6 +6,6 @@ OUT=gpurun_out/pmc_encoder; mkdir -p $OUT
 CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-irl --no-modes --no-host-fed --parts 1"
 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $OUT/sq -o pmc -- $CMD > $OUT/sq.log 2>&1
 timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/grbm -o pmc -- $CMD > $OUT/grbm.log 2>&1
-python scripts/pmc_encoder_summary.py $OUT > gpurun_out/r05_pmc_encoder.txt
+python scripts/pmc_encoder_summary.py $OUT gpurun_out/r05_pmc_encoder.json > gpurun_out/r05_pmc_encoder.txt
 cat gpurun_out/r05_pmc_encoder.txt
 find $OUT -name "*.db" -delete

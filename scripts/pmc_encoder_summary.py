@@ -55,3 +55,15 @@ for k, d in rows:
     if d["simd_cycles"] <= 0:
         continue
     print(f"  {k:62s} {int(d['n']):5d} {d['gui'] / 1e6:9.2f} {d['mfma_busy'] / d['simd_cycles']:10.3f} {d['mfma_insts']:12.4g}")
+
+import json
+def _frac(name):
+    d = next((v for k, v in tot.items() if k.startswith(name)), None)
+    return round(d["mfma_busy"] / d["simd_cycles"], 4) if d and d["simd_cycles"] > 0 else None
+json.dump({"gemm": _frac("wino4_gemm32_kernel<3, 4"), "gemm_128_cout_tile": _frac("wino4_gemm32_kernel<3, 2"),
+           "encoder": _frac("ENCODER"), "whole_step": _frac("WHOLE STEP"),
+           "note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) per kernel family of ONE inference step of "
+                   "bench.py --parts 1 (batch 16, bf16x6), two rocprofv3 --pmc passes (scripts/pmc_encoder.sh, table: "
+                   "profiles/r05_pmc_encoder.txt); gemm = wino4_gemm32_kernel<3, 4> (256-cout tiles, 15 of the 19 calls), encoder = "
+                   "every kernel from nchw4_to_nhwc to pixel_geometry"},
+          open(sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/r05_pmc_encoder.json", "w"), indent=1)

@@ -38,19 +38,35 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 per[k][1] += 1
     pmc[c] = per
 
-# rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB (hbm_bytes = (FETCH+WRITE)*1024); on gfx950 FETCH_SIZE
-# counts 64 B per 128-B request of wide coalesced reads -> x2 (MI355X_MICROARCH.md section HBM).
+# rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  On gfx950 FETCH_SIZE counts 64 B per 128-B request of wide coalesced
+# reads -> x2 (MI355X_MICROARCH.md section HBM); WRITE_SIZE is "uncalibrated" there: scripts/pmc_calib.sh measures both
+# against known byte counts on the same box (1 GiB fill / copy, the gather's nontemporal stores over an empty plan) and the
+# factors found replace the defaults.
+ff, wf, wf_nt, calib = 2.0, 1.0, 1.0, None
+cj = os.path.join(ROOT, "gpurun_out", "pmc_calib", "calib.json")
+if os.path.exists(cj):
+    calib = json.load(open(cj))
+    f = calib.get("factors", {})
+    if f.get("fetch_copy_1GiB"): ff = 1.0 / f["fetch_copy_1GiB"]
+    if f.get("write_fill_1GiB"): wf = 1.0 / f["write_fill_1GiB"]
+    if f.get("write_gather_nt_stores"): wf_nt = 1.0 / f["write_gather_nt_stores"]
 counters = {}
 for k in set(pmc["FETCH_SIZE"]) | set(pmc["WRITE_SIZE"]):
     fk, fn = pmc["FETCH_SIZE"].get(k, [0, 0])
     wk, wn = pmc["WRITE_SIZE"].get(k, [0, 0])
     n = max(fn, wn, 1)
+    w = wf_nt if "splat_gather" in k else wf
     counters[k] = dict(launches=n, fetch_kib_raw=fk, write_kib_raw=wk,
-                       hbm_bytes_per_launch=(2.0 * fk + wk) * 1024.0 / n,
+                       hbm_bytes_per_launch=(ff * fk + w * wk) * 1024.0 / n,
                        hbm_bytes_per_launch_uncorrected=(fk + wk) * 1024.0 / n)
 out = dict(counters)
-out["_note"] = ("per-launch averages over one bench step (batch 16); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, "
-                "the x2 is the gfx950 FETCH_SIZE correction for 16-B/lane coalesced reads")
+out["_note"] = (f"per-launch averages over the profiled run of bench.py --parts 1 (batch 16); hbm_bytes = ({ff:.3f} * FETCH_SIZE + "
+                f"{wf:.3f} * WRITE_SIZE) * 1024 ({wf_nt:.3f} for the nontemporal stores of splat_gather8); factors "
+                + ("calibrated on this box against known byte counts (scripts/pmc_calib.sh)" if calib else
+                   "defaults: the gfx950 FETCH_SIZE x2 correction of the guide, WRITE_SIZE as reported"))
+out["_source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --parts 1, tag {tag}"
+if calib:
+    out["_calibration"] = calib
 json.dump(out, open(os.path.join(dst, "roofline_counters.json"), "w"), indent=1, sort_keys=True)
 
 tot = sum(float(r["TotalDurationNs"]) for r in stats)
