@@ -26,15 +26,26 @@ def short(name):
     return n.split("(")[0]
 
 
+# PMC rows of ONE steady-state step only: the dispatches between the last two lidar_depth_kernel launches (a kernel name's
+# launches elsewhere in the run -- the batch-2 BatchNorm calibration forward, warm-ups -- have other sizes and would skew a
+# per-launch average: round 4's table showed the batch-16 gather at 325 MB for that reason)
 pmc = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     per = defaultdict(lambda: [0.0, 0])
     f = os.path.join(src, f"pmc_{c}", "pmc_counter_collection.csv")
     if os.path.exists(f):
+        disp = {}
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] == c:
-                k = short(row["Kernel_Name"])
-                per[k][0] += float(row["Counter_Value"])
+                d = disp.setdefault(int(row["Dispatch_Id"]), [row["Kernel_Name"], 0.0])
+                d[1] += float(row["Counter_Value"])
+        ids = sorted(disp)
+        marks = [i for i in ids if "lidar_depth_kernel" in disp[i][0]]
+        lo, hi = (marks[-2], marks[-1]) if len(marks) >= 2 else (ids[0], ids[-1] + 1)
+        for i in ids:
+            if lo <= i < hi:
+                k = short(disp[i][0])
+                per[k][0] += disp[i][1]
                 per[k][1] += 1
     pmc[c] = per
 
@@ -57,10 +68,10 @@ for k in set(pmc["FETCH_SIZE"]) | set(pmc["WRITE_SIZE"]):
     n = max(fn, wn, 1)
     w = wf_nt if "splat_gather" in k else wf
     counters[k] = dict(launches=n, fetch_kib_raw=fk, write_kib_raw=wk,
-                       hbm_bytes_per_launch=(ff * fk + w * wk) * 1024.0 / n,
-                       hbm_bytes_per_launch_uncorrected=(fk + wk) * 1024.0 / n)
+                       hbm_bytes_per_launch=(ff * fk / max(fn, 1) + w * wk / max(wn, 1)) * 1024.0,
+                       hbm_bytes_per_launch_uncorrected=(fk / max(fn, 1) + wk / max(wn, 1)) * 1024.0)
 out = dict(counters)
-out["_note"] = (f"per-launch averages over the profiled run of bench.py --parts 1 (batch 16); hbm_bytes = ({ff:.3f} * FETCH_SIZE + "
+out["_note"] = (f"per-launch averages over ONE step of bench.py --parts 1 (batch 16; `launches` = launches of the kernel in that step); hbm_bytes = ({ff:.3f} * FETCH_SIZE + "
                 f"{wf:.3f} * WRITE_SIZE) * 1024 ({wf_nt:.3f} for the nontemporal stores of splat_gather8); factors "
                 + ("calibrated on this box against known byte counts (scripts/pmc_calib.sh)" if calib else
                    "defaults: the gfx950 FETCH_SIZE x2 correction of the guide, WRITE_SIZE as reported"))
