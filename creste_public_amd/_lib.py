@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libcreste_hip.so")
 
-ABI_VERSION = 10         # creste_abi_version() of the library this binding was written against
+ABI_VERSION = 11         # creste_abi_version() of the library this binding was written against
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
 
@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
                                          "out_co", "res_cs", "KH", "KW", "stride", "pad_t", "pad_l",
                                          "act", "prec", "algo", "flags")] + \
                [("a_amax", C.c_void_p), ("out_amax", C.c_void_p), ("w_unscale", C.c_void_p), ("up_src", C.c_void_p)] + \
-               [(n, C.c_int32) for n in ("up_H", "up_W", "up_C", "up_cs")]
+               [(n, C.c_int32) for n in ("up_H", "up_W", "up_C", "up_cs")] + [("out_stats", C.c_void_p)]
 
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
@@ -38,6 +38,7 @@ SIGNATURES = {
     "creste_last_error": (C.c_char_p, []),
     "creste_abi_version": (_i, []),
     "creste_conv2d_nhwc": (_i, [C.POINTER(ConvDesc), _vp]),
+    "creste_conv_stat_rows": (_i, [C.POINTER(ConvDesc)]),
     "creste_conv_supported": (_i, [_i, _i, _i, _i]),
     "creste_conv_wino_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "creste_conv_wino_weight_bytes": (_i64, [_i, _i, _i]),
@@ -99,6 +100,8 @@ SIGNATURES = {
     "creste_bn_workspace_bytes": (_i64, [_i]),
     "creste_bn_train_forward_f32": (_i, [_vp, _i, _i64, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
                                          _vp, _vp, _vp]),
+    "creste_bn_train_forward_stats_f32": (_i, [_vp, _i, _i64, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
+                                               _vp, _vp, _i, _vp]),
     "creste_bn_train_tangent_f32": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "creste_bn_train_backward_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp,
                                           _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),

@@ -236,6 +236,7 @@ int64_t conv_patch_weight_bytes(int Cout, int Cin, int K, int prec);
 int conv_patch_pack(const float* w, const float* scale, void* wpk, float* w_unscale, int Cout, int Cin, int K,
                     int prec, hipStream_t s);
 int conv_patch_run(const creste_conv_desc* d, hipStream_t s);
+int conv_patch_stat_rows(const creste_conv_desc* d);
 }  // namespace creste
 namespace creste {   // conv_wino.hip
 bool conv_wino_supported(int prec, int KH, int KW, int stride, int Cin, int Cout);
@@ -249,6 +250,7 @@ bool conv_wino4_supported(int prec, int KH, int KW, int stride, int Cin, int Cou
 int64_t conv_wino4_weight_bytes(int Cout, int Cin, int prec);
 int conv_wino4_pack(const float* w, const float* scale, void* wpk, int Cout, int Cin, int prec, hipStream_t s);
 int64_t conv_wino4_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int prec);
+int conv_wino4_stat_rows(const creste_conv_desc* d);
 int conv_wino4_run(const creste_conv_desc* d, hipStream_t s);
 }  // namespace creste
 
@@ -257,6 +259,13 @@ size_t conv_desc_bytes() { return sizeof(creste_conv_desc); }     // csrc/plan_r
 }
 
 using namespace creste;
+
+extern "C" int creste_conv_stat_rows(const creste_conv_desc* d) {
+  if (!d || d->Cout <= 0 || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0) return -1;
+  if (d->algo == CRESTE_ALGO_WINOGRAD4) return conv_wino4_stat_rows(d);
+  if (d->algo == CRESTE_ALGO_DIRECT && d->prec != CRESTE_PREC_F32) return conv_patch_stat_rows(d);
+  return -1;
+}
 
 extern "C" int creste_conv_supported(int prec, int KH, int KW, int stride) {
   if (prec == CRESTE_PREC_F32) return KH > 0 && KW > 0 && stride > 0;
@@ -369,6 +378,7 @@ extern "C" int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream) {
                  "conv2d: %dx%d input exceeds the row kernel's packed coordinate range", d->H, d->W);
   CRESTE_REQUIRE(d->prec != CRESTE_PREC_F16X3 || (d->a_amax && d->w_unscale),
                  "conv2d: F16X3 needs a_amax (device bound of |in|) and w_unscale (from creste_conv_pack_weight_f16)");
+  CRESTE_REQUIRE(!d->out_stats || creste_conv_stat_rows(d) > 0, "conv2d: this kernel keeps no out_stats (creste_conv_stat_rows)");
   if (d->algo == CRESTE_ALGO_WINOGRAD) return conv_wino_run(d, (hipStream_t)stream);
   if (d->algo == CRESTE_ALGO_WINOGRAD4) return conv_wino4_run(d, (hipStream_t)stream);
   if (d->prec != CRESTE_PREC_F32) return conv_patch_run(d, (hipStream_t)stream);

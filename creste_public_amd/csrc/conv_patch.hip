@@ -87,6 +87,7 @@ struct PatchArgs {
   int nchunk;
   int tiles_x, tiles_y, tiles_n;
   int gate_hw;               // > 0: pixels were re-tiled as one flat image; a_scale row = linear pixel / gate_hw
+  float* stats;              // creste_conv_desc.out_stats ([pixel tiles][2][Cout]; 1x1 bf16-split kernels only), or nullptr
 };
 
 // Epilogue.  The MFMAs are issued with the WEIGHT fragment as the first operand, so D = W * X^T: in the
@@ -94,11 +95,18 @@ struct PatchArgs {
 // (row = (r&3) + 8*(r>>2) + 4*(lane>>5)): registers 4g..4g+3 are 4 CONSECUTIVE output channels of one
 // pixel -> one 16-byte store (and one 16-byte residual / bias load) instead of four dword stores; the
 // store tail of a conv is issue-bound, not bandwidth-bound (cdna_hip_programming.md T21).
-template <int TN, bool F16>
+template <int TN, bool F16, bool STATS = false>
 __device__ __forceinline__ void patch_epilogue(const f32x16 (&acc)[2][TN], const PatchArgs& p, int img,
                                                int oy0, int ox0, int nbase, int wm, int wn, int li, int lh,
-                                               float o_mul, float* scratch) {
+                                               float o_mul, float* scratch, int stat_row = 0) {
   float vmax = 0.f;
+  f32x4 st1[TN][4], st2[TN][4];                    // STATS: this lane's pixel(s), per channel quad of its registers
+  if constexpr (STATS) {
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) st1[nt][g] = st2[nt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const bool vec_ok = (p.Cout & 3) == 0 && (p.out_cs & 3) == 0 && (p.out_co & 3) == 0 &&
                       (!p.res || (p.res_cs & 3) == 0);
   const int ox = ox0 + li;
@@ -125,6 +133,7 @@ __device__ __forceinline__ void patch_epilogue(const f32x16 (&acc)[2][TN], const
             vmax = fmaxf(vmax, fabsf(v[j]));
           }
           CRESTE_OUT_STORE(reinterpret_cast<f32x4*>(p.out + m * p.out_cs + p.out_co + n), v);
+          if constexpr (STATS) { st1[nt][g] += v; st2[nt][g] += v * v; }
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -140,6 +149,48 @@ __device__ __forceinline__ void patch_epilogue(const f32x16 (&acc)[2][TN], const
           }
         }
       }
+    }
+  }
+  if constexpr (STATS) {
+    if (p.stats) {
+      // channel sums over the tile's 8 x 32 pixels in a fixed order: the 32 lanes of a half-wave (pixels of a row) by xor
+      // shuffles, then the four row-pair waves through LDS (scratch: [4 wm][2 wn][TN][4 g][2 lh][8] floats)
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int o = 1; o < 32; o <<= 1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              st1[nt][g][j] += __shfl_xor(st1[nt][g][j], o);
+              st2[nt][g][j] += __shfl_xor(st2[nt][g][j], o);
+            }
+      __syncthreads();                               // the operand buffers `scratch` aliases are free
+      if (li == 0) {
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float* dst = scratch + ((((wm * 2 + wn) * TN + nt) * 4 + g) * 2 + lh) * 8;
+            *reinterpret_cast<f32x4*>(dst) = st1[nt][g];
+            *reinterpret_cast<f32x4*>(dst + 4) = st2[nt][g];
+          }
+      }
+      __syncthreads();
+      // thread = (k, channel of the tile): n = (wn * TN + nt) * 32 + 8 g + 4 lh + j
+      for (int i = threadIdx.x; i < 2 * 64 * TN; i += blockDim.x) {
+        const int k = i / (64 * TN), cn = i - k * (64 * TN);
+        const int wn2 = cn / (32 * TN), r = cn - wn2 * (32 * TN), nt = r >> 5, g = (r >> 3) & 3, lh2 = (r >> 2) & 1, j = r & 3;
+        const int n = nbase + cn;
+        if (n < p.Cout) {
+          float a = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) a += scratch[((((w * 2 + wn2) * TN + nt) * 4 + g) * 2 + lh2) * 8 + k * 4 + j];
+          p.stats[((size_t)stat_row * 2 + k) * p.Cout + n] = a;
+        }
+      }
+      __syncthreads();
     }
   }
   if (p.out_amax) block_amax_update(vmax, p.out_amax, scratch);
@@ -200,8 +251,10 @@ __device__ __forceinline__ void patch_epilogue_lds(const f32x16 (&acc)[2][TN], c
 
 // FG: the squeeze-excite gate row is looked up per staged PIXEL (flat re-tiling of a gated 1x1 conv, gate_hw > 0) -- its
 // own instantiation: the per-round gate registers pushed the common 128-register kernels into scratch
-template <int K, int SPLIT, int TN, bool F16, bool FG = false>
-__global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) void conv_patch_kernel(const PatchArgs p) {
+// ST: the epilogue also keeps per-channel sums of what it writes (PatchArgs.stats, training) -- its own instantiation, the
+// sums' registers would push the inference kernels into scratch
+template <int K, int SPLIT, int TN, bool F16, bool FG = false, bool ST = false>
+__global__ __launch_bounds__(512, (SPLIT * TN >= 6 || (ST && TN == 2)) ? 2 : PATCH_WAVES_PER_SIMD) void conv_patch_kernel(const PatchArgs p) {
   typedef typename Piece<F16>::V8 V8;
   typedef typename Piece<F16>::V4 V4;
   constexpr int T = K * K;
@@ -386,7 +439,14 @@ __global__ __launch_bounds__(512, SPLIT * TN >= 6 ? 2 : PATCH_WAVES_PER_SIMD) vo
       return;
     }
   }
-  patch_epilogue<TN, F16>(acc, p, img, oy0, ox0, tn * BN, wm, wn, li, lh, o_mul, reinterpret_cast<float*>(smem));
+  if constexpr (ST) {
+    static_assert(K == 1 && !F16 && TN <= 2, "statistics epilogue: 1x1 convs of the bf16 split modes, tiles of <= 128 channels");
+    __syncthreads();                                   // (the statistics' LDS scratch aliases the operand buffers)
+    patch_epilogue<TN, F16, true>(acc, p, img, oy0, ox0, tn * BN, wm, wn, li, lh, o_mul, reinterpret_cast<float*>(smem),
+                                  (img * p.tiles_y + ty) * p.tiles_x + tx);
+  } else {
+    patch_epilogue<TN, F16>(acc, p, img, oy0, ox0, tn * BN, wm, wn, li, lh, o_mul, reinterpret_cast<float*>(smem));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -913,6 +973,17 @@ static int launch_patch(const PatchArgs& a, hipStream_t s) {
   constexpr int smem = 2 * (SPLIT * 2 * NPIXP * 16) + 2 * (SPLIT * 2 * 64 * TN * 16);
   static std::atomic<uint64_t> attr_devs{0}, attr_devs_fg{0};
   const int nblk = a.tiles_n * a.tiles_x * a.tiles_y * a.N;
+  if constexpr (K == 1 && !F16 && TN <= 2) {
+    if (a.stats) {
+      CRESTE_REQUIRE(a.gate_hw == 0, "conv2d: out_stats with a per-sample gate on a flat re-tiled 1x1 conv is not built");
+      static std::atomic<uint64_t> attr_devs_st{0};
+      if (smem > 64 * 1024) CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(conv_patch_kernel<K, SPLIT, TN, F16, false, true>), smem, attr_devs_st));
+      conv_patch_kernel<K, SPLIT, TN, F16, false, true><<<nblk, 512, smem, s>>>(a);
+      CRESTE_CHECK_LAUNCH("conv_patch (statistics)");
+      return CRESTE_OK;
+    }
+  }
+  CRESTE_REQUIRE(!a.stats, "conv2d: out_stats on a kernel that keeps none");
   if (K == 1 && a.gate_hw > 0) {
     if (smem > 64 * 1024) CRESTE_HIP(ensure_dyn_smem(reinterpret_cast<const void*>(conv_patch_kernel<K, SPLIT, TN, F16, true>), smem, attr_devs_fg));
     conv_patch_kernel<K, SPLIT, TN, F16, true><<<nblk, 512, smem, s>>>(a);
@@ -957,15 +1028,9 @@ int conv_patch_pack(const float* w, const float* scale, void* wpk, float* w_unsc
   return CRESTE_OK;
 }
 
-int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
-  PatchArgs a;
-  a.in = d->in; a.wpk = (const char*)d->wpk; a.bias = d->bias; a.res = d->res; a.a_scale = d->a_scale;
-  a.row_mask = d->row_mask; a.out = d->out;
-  a.a_amax = d->a_amax; a.out_amax = d->out_amax; a.w_unscale = d->w_unscale;
-  a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_cs = d->in_cs;
-  a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.out_cs = d->out_cs; a.out_co = d->out_co;
-  a.res_cs = d->res_cs; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.act = d->act;
-  a.nchunk = (d->Cin + PT_CK - 1) / PT_CK;
+// geometry of a launch: pixel tiles (with the flat re-tiling of a halo-free 1x1 conv, below)
+static void patch_geometry(const creste_conv_desc* d, PatchArgs& a) {
+  a.N = d->N; a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo;
   a.tiles_x = (d->Wo + PT_TW - 1) / PT_TW;
   a.tiles_y = (d->Ho + PT_TH - 1) / PT_TH;
   a.gate_hw = 0;
@@ -983,7 +1048,35 @@ int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
       a.tiles_x = 1; a.tiles_y = (a.Ho + PT_TH - 1) / PT_TH;
     }
   }
-  const int bn = 64 * patch_tn(d->Cout, d->prec, d->Cin, d->KH, (long)a.tiles_x * a.tiles_y * a.N);
+}
+
+// rows of creste_conv_desc.out_stats (one per pixel tile), or -1: only the stride-1 1x1 kernels of the bf16 split modes keep them
+int conv_patch_stat_rows(const creste_conv_desc* d) {
+  const bool bf = d->prec == CRESTE_PREC_BF16 || d->prec == CRESTE_PREC_BF16X3 || d->prec == CRESTE_PREC_BF16X6;
+  if (!bf || d->KH != 1 || d->KW != 1 || d->stride != 1 || d->res || d->row_mask || (d->Cout & 3) || (d->out_cs & 3) || (d->out_co & 3))
+    return -1;
+  PatchArgs a;
+  patch_geometry(d, a);
+  if (a.gate_hw > 0) return -1;                    // gated AND flat re-tiled: the per-pixel-gate instantiation keeps none
+  const long rows = (long)a.tiles_x * a.tiles_y * a.N;
+  return rows < (1L << 30) ? (int)rows : -1;
+}
+
+int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
+  PatchArgs a;
+  a.in = d->in; a.wpk = (const char*)d->wpk; a.bias = d->bias; a.res = d->res; a.a_scale = d->a_scale;
+  a.row_mask = d->row_mask; a.out = d->out;
+  a.a_amax = d->a_amax; a.out_amax = d->out_amax; a.w_unscale = d->w_unscale;
+  a.Cin = d->Cin; a.in_cs = d->in_cs;
+  a.Cout = d->Cout; a.out_cs = d->out_cs; a.out_co = d->out_co;
+  a.res_cs = d->res_cs; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.act = d->act;
+  a.nchunk = (d->Cin + PT_CK - 1) / PT_CK;
+  patch_geometry(d, a);
+  a.stats = d->out_stats;
+  CRESTE_REQUIRE(!d->out_stats || conv_patch_stat_rows(d) > 0, "conv2d: out_stats is kept by the stride-1 1x1 kernels of the bf16 split modes "
+                                                               "(Cout and the output slice multiples of 4, no residual / row mask)");
+  int bn = 64 * patch_tn(d->Cout, d->prec, d->Cin, d->KH, (long)a.tiles_x * a.tiles_y * a.N);
+  if (a.stats && bn > 128) bn = 128;               // the statistics epilogue is built for tiles of <= 128 channels
   a.tiles_n = (d->Cout + bn - 1) / bn;
   const int split = patch_split(d->prec);
   const int K = d->KH;

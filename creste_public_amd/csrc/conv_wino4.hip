@@ -817,6 +817,7 @@ struct Wino4OutArgs {
   int tiles_y, tiles_x, T;
   long mplane;
   int order, ncg, ntg8;      // order 1: 1-D grid, cout groups fastest inside an XCD's range of ntg8 tile groups
+  float* stats;              // creste_conv_desc.out_stats: [ceil(T / 16)][2][Cout] sums of what this workgroup writes, or nullptr
 };
 
 constexpr int W4O_TILES = 16;
@@ -878,6 +879,7 @@ __global__ __launch_bounds__(256) void wino4_out2_kernel(const Wino4OutArgs p) {
   const int per = p.tiles_y * p.tiles_x;
   const bool nok = quad0 + cq < Q;
   const w4f32x4 bs = (nok && p.bias) ? *reinterpret_cast<const w4f32x4*>(p.bias + n) : w4f32x4{0.f, 0.f, 0.f, 0.f};
+  w4f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
   if (nok) {
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
@@ -898,6 +900,31 @@ __global__ __launch_bounds__(256) void wino4_out2_kernel(const Wino4OutArgs p) {
         vmax = fmaxf(vmax, fabsf(v[e]));
       }
       *reinterpret_cast<w4f32x4*>(p.out + mrow * p.out_cs + p.out_co + n) = v;
+      s1 += v; s2 += v * v;
+    }
+  }
+  if (p.stats) {
+    // per-channel sums over the workgroup's 16 tiles: the 32 threads that share a channel quad (8 lanes apart) in a fixed
+    // order -- within a wave by xor shuffles, across the four waves through the (now free) tile buffer
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[e] += __shfl_xor(s1[e], o); s2[e] += __shfl_xor(s2[e], o); }
+    __syncthreads();                                   // every thread is done reading tilebuf
+    if ((t & 63) < 8) {
+      float* dst = tilebuf + ((t >> 6) * 8 + cq) * 8;
+      *reinterpret_cast<w4f32x4*>(dst) = s1;
+      *reinterpret_cast<w4f32x4*>(dst + 4) = s2;
+    }
+    __syncthreads();
+    if (t < 64) {                                      // thread = (channel quad t >> 3, k = (t >> 2) & 1, element t & 3)
+      const int q = t >> 3, k = (t >> 2) & 1, e = t & 3, c = (quad0 + q) * 4 + e;
+      if (quad0 + q < Q) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) a += tilebuf[(w * 8 + q) * 8 + k * 4 + e];
+        p.stats[((size_t)(tile0 / W4O_TILES) * 2 + k) * p.Cout + c] = a;
+      }
     }
   }
   if (p.out_amax) block_amax_update(vmax, p.out_amax, scratch);
@@ -1209,13 +1236,19 @@ static int launch_wino4_gemm32(const Wino4GemmArgs& a, hipStream_t s) {
   return w4_chain_record(s);
 }
 
+int conv_wino4_stat_rows(const creste_conv_desc* d) {
+  if (!conv_wino4_supported(d->prec, d->KH, d->KW, d->stride, d->Cin, d->Cout) || d->res || d->row_mask ||
+      (d->flags & CRESTE_CONV_EMIT_NEXT_V)) return -1;
+  return (int)((wino4_tiles(d->N, d->Ho, d->Wo) + W4O_TILES - 1) / W4O_TILES);
+}
+
 int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
   CRESTE_REQUIRE(conv_wino4_supported(d->prec, d->KH, d->KW, d->stride, d->Cin, d->Cout),
                  "conv2d: the F(4x4,3x3) path is built for stride-1 3x3 convs in the bf16 split modes, Cout a multiple of 4");
   CRESTE_REQUIRE(d->work && !d->a_scale, "conv2d: the Winograd path needs its workspace and takes no per-sample input gate");
   CRESTE_REQUIRE(!d->up_src || (d->pad_t == 1 && d->pad_l == 1 && d->H == 2 * d->up_H && d->W == 2 * d->up_W),
                  "conv2d: the fused upsample of the F(4x4,3x3) input transform is the exact 2x one under pad 1");
-  CRESTE_REQUIRE(!(d->flags & CRESTE_CONV_EMIT_NEXT_V) || (!d->res && !d->row_mask && !d->out_amax && d->pad_t == 1 && d->pad_l == 1 &&
+  CRESTE_REQUIRE(!(d->flags & CRESTE_CONV_EMIT_NEXT_V) || (!d->res && !d->row_mask && !d->out_amax && !d->out_stats && d->pad_t == 1 && d->pad_l == 1 &&
                                                            d->Ho == d->H && d->Wo == d->W && wino4_split(d->prec) == 3),
                  "conv2d: EMIT_NEXT_V takes a pad-1 bf16x6 conv without residual / row mask / |max| tracking");
   CRESTE_REQUIRE((d->out_cs & 3) == 0 && (d->out_co & 3) == 0 && (!d->res || (d->res_cs & 3) == 0) &&
@@ -1302,6 +1335,8 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
   o.M = M; o.bias = d->bias; o.res = d->res; o.row_mask = d->row_mask; o.out = d->out; o.out_amax = d->out_amax;
   o.N = d->N; o.Ho = d->Ho; o.Wo = d->Wo; o.Cout = d->Cout; o.out_cs = d->out_cs; o.out_co = d->out_co; o.res_cs = d->res_cs;
   o.act = d->act; o.tiles_y = tiles_y; o.tiles_x = tiles_x; o.T = (int)T; o.mplane = a.mplane;
+  o.stats = d->out_stats;
+  CRESTE_REQUIRE(!d->out_stats || (!d->res && !d->row_mask), "conv2d: out_stats takes a conv without residual / row mask");
   o.order = (order >> 1) & 1; o.ncg = (d->Cout / 4 + W4O2_QUADS - 1) / W4O2_QUADS;
   o.ntg8 = (int)(((T + W4O_TILES - 1) / W4O_TILES + 7) / 8);
   const dim3 ogrid = o.order ? dim3((unsigned)(o.ntg8 * 8 * o.ncg))

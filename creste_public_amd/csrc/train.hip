@@ -1040,6 +1040,49 @@ extern "C" int creste_bn_train_forward_f32(const float* x, int x_cs, int64_t P, 
   return CRESTE_OK;
 }
 
+// statistics from the producing conv's per-workgroup sums ([rows][2][C]: sum x, sum x^2): one wave per channel, lane l adds
+// rows l, l + 64, ... in float64, fixed xor tree -> mean, biased variance, 1/sqrt(var + eps), running statistics
+__global__ __launch_bounds__(64) void bn_stats_from_partials_kernel(const float* __restrict__ partial, int rows, int C, long P,
+                                                                    float* __restrict__ mean, float* __restrict__ var,
+                                                                    float* __restrict__ invstd, float* running_mean,
+                                                                    float* running_var, float eps, float momentum, float unbias) {
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = threadIdx.x; r < rows; r += 64) {
+    s1 += (double)partial[((size_t)r * 2 + 0) * C + c];
+    s2 += (double)partial[((size_t)r * 2 + 1) * C + c];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  if (threadIdx.x == 0) {
+    const double m = s1 / (double)P, v = fmax(s2 / (double)P - m * m, 0.0);
+    const float mu = (float)m, vf = (float)v;
+    mean[c] = mu; var[c] = vf; invstd[c] = 1.f / sqrtf(vf + eps);
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (vf * unbias);
+  }
+}
+
+extern "C" int creste_bn_train_forward_stats_f32(const float* x, int x_cs, int64_t P, int C, const float* gamma,
+                                                 const float* beta, float eps, float momentum, float* running_mean,
+                                                 float* running_var, float* mean, float* invstd, float* var_scratch,
+                                                 float* y, int y_cs, int relu, float* out_amax, const float* stat_partial,
+                                                 int stat_rows, void* stream) {
+  CRESTE_REQUIRE(x && mean && invstd && var_scratch && y && stat_partial && stat_rows > 0 && P > 1 && C > 0,
+                 "bn_train_forward_stats: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  bn_stats_from_partials_kernel<<<C, 64, 0, s>>>(stat_partial, stat_rows, C, P, mean, var_scratch, invstd, running_mean,
+                                                 running_var, eps, momentum, (float)P / (float)(P - 1));
+  CRESTE_CHECK_LAUNCH("bn_stats_from_partials");
+  EwArgs e = {};
+  e.x = x; e.x_cs = x_cs; e.gamma = gamma; e.beta = beta; e.mean = mean; e.invstd = invstd;
+  e.o0 = y; e.o0_cs = y_cs; e.P = P; e.C = C; e.act = relu; e.amax = out_amax;
+  if (ew_vec_ok(e)) bn_elementwise4_kernel<0><<<grid1d(P * C / 4, 1024), 256, 0, s>>>(e);
+  else bn_elementwise_kernel<0><<<grid1d(P * C), 256, 0, s>>>(e);
+  CRESTE_CHECK_LAUNCH("bn_forward");
+  return CRESTE_OK;
+}
+
 extern "C" int creste_bn_train_tangent_f32(const float* x, int x_cs, const float* xd, int xd_cs, int64_t P, int C,
                                            const float* gamma, const float* mean, const float* invstd,
                                            float* mom_t, float* yd, int yd_cs, void* work, void* stream) {

@@ -401,6 +401,7 @@ class Act:
     C: int                 # channels in the slice
     co: int = 0            # channel offset of the slice
     amax: torch.Tensor | None = None   # device float >= max|slice| when known (see TRACK_AMAX)
+    stats: tuple | None = None         # (per-workgroup channel sums [rows, 2, C], rows) left by the producing conv (conv2d want_stats)
 
     @property
     def N(self): return self.buf.shape[0]
@@ -611,8 +612,15 @@ def conv2d_pair(x, pc1: PackedConv, pc2: PackedConv, out: Act | None = None) -> 
     return conv2d(conv2d(x, pc1, _emit_next=pc2), pc2, out=out)
 
 
+CONV_STATS = os.environ.get("CRESTE_CONV_STATS", "1") != "0"     # training: BatchNorm statistics from the producing conv's epilogue
+
+
 def conv2d(x: Act, pc: PackedConv, out: Act | None = None, res: Act | None = None,
-           a_scale: torch.Tensor | None = None, row_mask: torch.Tensor | None = None, _emit_next: PackedConv | None = None) -> Act:
+           a_scale: torch.Tensor | None = None, row_mask: torch.Tensor | None = None, _emit_next: PackedConv | None = None,
+           want_stats: bool = False) -> Act:
+    """want_stats: where the kernel this conv dispatches to keeps them (creste_conv_stat_rows), the returned Act carries
+    `.stats = (partial [rows, 2, Cout], rows)`: per-workgroup sums of the output, the training-mode BatchNorm's batch
+    statistics without another pass (creste_bn_train_forward_stats_f32); otherwise `.stats` stays None."""
     lib = _lib.load()
     if isinstance(x, _TransformedInput):
         return _conv2d_from_v(x, pc, out)
@@ -702,6 +710,12 @@ def conv2d(x: Act, pc: PackedConv, out: Act | None = None, res: Act | None = Non
             if shared is not None:
                 shared._w4 = (key, work)
         d.work = work.data_ptr()
+    stats = None
+    if want_stats and CONV_STATS and nxt is None and res is None and row_mask is None:
+        rows = lib.creste_conv_stat_rows(C.byref(d))
+        if rows > 0:
+            stats = (torch.empty((rows, 2, pc.Cout), dtype=torch.float32, device=dev), rows)
+            d.out_stats = stats[0].data_ptr()
     if nxt is not None:
         d.flags = d.flags | 2                  # CRESTE_CONV_EMIT_NEXT_V
         _lib.check(lib.creste_conv2d_nhwc(C.byref(d), _stream()), "conv2d_nhwc")
@@ -712,6 +726,7 @@ def conv2d(x: Act, pc: PackedConv, out: Act | None = None, res: Act | None = Non
         out.amax = _AmaxPool.slot(dev)
         d.out_amax = out.amax.data_ptr()
     _lib.check(lib.creste_conv2d_nhwc(C.byref(d), _stream()), "conv2d_nhwc")
+    out.stats = stats
     return out
 
 

@@ -112,9 +112,9 @@ class ConvG:
             self._bw = ops.pack_conv(wt, None, None, 1, (k1 - t, k1 - b_, k1 - l, k1 - r), ops.ACT_NONE, prec)
         return self._fw, self._bw
 
-    def fwd(self, x: Act, out=None) -> Act:
+    def fwd(self, x: Act, out=None, want_stats=False) -> Act:
         self.x = x
-        return ops.conv2d(x, self._packed(False)[0], out=out)
+        return ops.conv2d(x, self._packed(False)[0], out=out, want_stats=want_stats)
 
     def bwd(self, gy: Act, grads, need_input=True):
         lib = _lib_()
@@ -338,7 +338,12 @@ class Seq:
 
     def fwd(self, x, out=None):
         for i, o in enumerate(self.ops):
-            x = o.fwd(x, out=out if i == len(self.ops) - 1 else None)
+            last = i == len(self.ops) - 1
+            if isinstance(o, ConvG) and not last and isinstance(self.ops[i + 1], BN):
+                # the BatchNorm that follows takes its batch statistics from this conv's epilogue (ops.conv2d want_stats)
+                x = o.fwd(x, want_stats=True)
+            else:
+                x = o.fwd(x, out=out if last else None)
         return x
 
     def bwd(self, gy, grads, need_input=True):

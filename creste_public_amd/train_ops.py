@@ -203,6 +203,17 @@ class BNT:
         var = torch.empty(Cn, device=dev)
         y = out or _new(x)
         y.amax = _amax_slot(dev)               # max|y| for an f16x3 conv consuming it (None outside that mode)
+        st = getattr(x, "stats", None)
+        if st is not None and st[0].shape[2] == Cn and x.co == 0:
+            # the producing conv left per-workgroup channel sums of x: no statistics pass over the tensor
+            _lib.check(_lib_().creste_bn_train_forward_stats_f32(
+                x.ptr, x.cs, _px(x), Cn, bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), float(bn.momentum),
+                bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.mean.data_ptr(), self.invstd.data_ptr(),
+                var.data_ptr(), y.ptr, y.cs, self.act, y.amax.data_ptr() if y.amax is not None else None,
+                st[0].data_ptr(), st[1], _stream()), "bn_train_forward_stats")
+            bn.num_batches_tracked += 1
+            self.y = y
+            return y
         _lib.check(_lib_().creste_bn_train_forward_f32(
             x.ptr, x.cs, _px(x), Cn, bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), float(bn.momentum),
             bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.mean.data_ptr(), self.invstd.data_ptr(),

@@ -111,9 +111,18 @@ typedef struct creste_conv_desc {
    * up_src [N, up_H, up_W, up_cs] with H == 2 up_H, W == 2 up_W, up_C % 4 == 0. */
   const float* up_src;
   int32_t up_H, up_W, up_C, up_cs;
+  /* Optional (training): per-channel partial sums of the values this call WRITES -- [rows][2][Cout] fp32, row r =
+   * (sum x, sum x^2) over one workgroup's pixels, rows = creste_conv_stat_rows(d) -- so that the training-mode BatchNorm that
+   * follows the conv (reference train_pefree.py / train_ssc.py: nn.Conv2d -> nn.BatchNorm2d) gets its batch statistics without
+   * another pass over the tensor: creste_bn_train_forward_stats_f32.  Deterministic (one row per workgroup, no atomics).
+   * Built for CRESTE_ALGO_WINOGRAD4 and for the stride-1 1x1 convs of the bf16 split modes; no residual / row mask. */
+  float* out_stats;
 } creste_conv_desc;
 
 int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream);
+/* rows of creste_conv_desc.out_stats this call would write (host query; `out_stats` itself is not read), or -1 when the
+ * kernel this descriptor dispatches to does not produce statistics */
+int creste_conv_stat_rows(const creste_conv_desc* d);
 /* 1 when (precision, kernel, stride) is built: F32 covers everything; BF16 / BF16X3 / BF16X6 cover stride-1 1x1 and
  * 3x3; F16X3 covers stride-1 1x1, 3x3, 5x5, 7x7 and stride-2 1x1, 3x3, 7x7 (every dense conv of the reference path:
  * effnet.py / inpainting.py / conv.py). */
@@ -412,6 +421,12 @@ int creste_conv_flip_weight_f32(const float* w, float* wt, int Cout, int Cin, in
  *             the f16x3 convs consuming the tensor need (creste_conv_desc.a_amax), without a separate pass.
  *   work: creste_bn_workspace_bytes(C). */
 int64_t creste_bn_workspace_bytes(int C);
+/* creste_bn_train_forward_f32 without its statistics pass: mean / variance from the producing conv's partial sums
+ * (creste_conv_desc.out_stats, [stat_rows][2][C]: summed per channel in float64, fixed order), then the same apply pass. */
+int creste_bn_train_forward_stats_f32(const float* x, int x_cs, int64_t P, int C, const float* gamma, const float* beta,
+                                      float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                                      float* invstd, float* var_scratch, float* y, int y_cs, int relu, float* out_amax,
+                                      const float* stat_partial, int stat_rows, void* stream);
 int creste_bn_train_forward_f32(const float* x, int x_cs, int64_t P, int C, const float* gamma, const float* beta,
                                 float eps, float momentum, float* running_mean, float* running_var, float* mean,
                                 float* invstd, float* var_scratch, float* y, int y_cs, int relu /* 0 none, 1 ReLU, 2 swish */,

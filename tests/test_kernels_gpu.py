@@ -618,6 +618,40 @@ def test_conv_winograd4_fused_upsample_concat(ops, N, C1, C2, H1, W1, Cout):
     assert lazy._mat is not None and ops.conv2d(lazy, pcd).buf.shape == y.buf.shape
 
 
+@pytest.mark.parametrize("case", [
+    ("wino4", 2, 128, 256, 20, 28),        # F(4x4) output transform: ragged tile groups
+    ("wino4", 1, 144, 132, 37, 41),        # partial tiles in both directions, Cout = 33 quads (4 + 1/8 cout groups)
+    ("1x1", 2, 96, 24, 40, 72),            # 64-channel tile, partial in x and y
+    ("1x1", 3, 40, 240, 19, 38),           # flat re-tiled map, two 128-channel tiles
+    ("1x1", 1, 496, 256, 24, 64),          # 256-wide tiles are narrowed to 128 for the statistics epilogue
+])
+def test_conv_output_statistics_for_batchnorm(ops, case):
+    """creste_conv_desc.out_stats (ops.conv2d want_stats): the per-workgroup channel sums a conv leaves of its output give the
+    training-mode BatchNorm's batch mean / variance without another pass (reference: nn.Conv2d -> nn.BatchNorm2d in train mode,
+    train_pefree.py / train_ssc.py); the conv's own output is unchanged, bit for bit."""
+    kind, N, Cin, Cout, H, W = case
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    x = to_act(ops, torch.randn(N, Cin, H, W, generator=g) + 0.3)
+    K = 3 if kind == "wino4" else 1
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    pc = ops.pack_conv(dev(w), dev(b), None, 1, K // 2, ops.ACT_NONE, ops.PREC_BF16X6,
+                       algo=ops.ALGO_WINOGRAD4 if kind == "wino4" else ops.ALGO_DIRECT)
+    plain = ops.conv2d(x, pc)
+    assert plain.stats is None
+    y = ops.conv2d(x, pc, want_stats=True)
+    assert y.stats is not None and torch.equal(y.buf, plain.buf)
+    part, rows = y.stats
+    assert part.shape == (rows, 2, Cout)
+    yd = y.buf.double().reshape(-1, Cout)
+    s = part.double().sum(0).cpu()
+    assert torch.allclose(s[0], yd.sum(0).cpu(), rtol=1e-6, atol=1e-4 * yd.shape[0] ** 0.5)
+    assert torch.allclose(s[1], (yd * yd).sum(0).cpu(), rtol=2e-6)
+    # two runs leave the same partial sums (one row per workgroup, fixed order: no atomics)
+    y2 = ops.conv2d(x, pc, want_stats=True)
+    assert torch.equal(y2.stats[0], part)
+
+
 @pytest.mark.parametrize("N,Cin,Cmid,Cout,H,W,up", [
     (2, 128, 256, 128, 20, 28, False),     # one partial block in both directions (5 x 7 tiles)
     (1, 320, 496, 496, 37, 41, False),     # partial tiles (37 x 41 pixels), 31 chunks, two cout tiles

@@ -549,3 +549,35 @@ def test_weight_gradients_on_the_side_stream_are_the_same_gradients(monkeypatch)
             assert g.keys() == ref.keys()
             for n in ref:
                 assert torch.equal(g[n], ref[n]), f"{n} (arena {arena}, step {i})"
+
+
+@pytest.mark.parametrize("Cin,Cout,K,H,W", [(128, 256, 3, 40, 56), (96, 24, 1, 40, 72), (40, 240, 1, 19, 38)])
+def test_batchnorm_statistics_from_the_conv_epilogue(monkeypatch, Cin, Cout, K, H, W):
+    """nn.Conv2d -> nn.BatchNorm2d (train mode) in a `Seq`: the BatchNorm takes its batch statistics from the per-workgroup channel
+    sums the conv's epilogue leaves (creste_conv_desc.out_stats, creste_bn_train_forward_stats_f32) instead of a pass over the
+    tensor (reference train_pefree.py:71-99 / train_ssc.py:92-129 run the same modules in train mode).  Same outputs, batch
+    statistics and running statistics as the separate pass to fp32 round-off; the backward is untouched."""
+    import torch.nn as nn
+    from creste_public_amd import ops
+    from creste_public_amd.train_backbone import BN, ConvG, Seq
+    torch.manual_seed(Cin + Cout)
+    conv = nn.Conv2d(Cin, Cout, K, padding=K // 2, bias=False).to("cuda")
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "CONV_STATS", flag)
+        bn = nn.BatchNorm2d(Cout).to("cuda")
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, Cout)); bn.bias.copy_(torch.linspace(-0.2, 0.2, Cout))
+        seq = Seq([ConvG(conv), BN(bn, relu=True)])
+        x = ops.Act(torch.randn(4, H, W, Cin, device="cuda", generator=torch.Generator("cuda").manual_seed(1)) + 0.5, Cin)
+        y = seq.fwd(x)
+        gx = seq.bwd(ops.Act(torch.ones_like(y.buf), Cout), None)
+        res[flag] = (y.buf.clone(), seq.ops[1].op.mean.clone(), seq.ops[1].op.invstd.clone(), bn.running_mean.clone(),
+                     bn.running_var.clone(), gx.buf.clone())
+    a, b = res[True], res[False]
+    scale = float(b[0].abs().max())
+    assert float((a[0] - b[0]).abs().max()) < 1e-5 * scale
+    assert float((a[1] - b[1]).abs().max()) < 1e-5 * float(b[1].abs().max() + 1e-3)
+    assert float(((a[2] - b[2]).abs() / b[2]).max()) < 2e-6
+    assert torch.allclose(a[3], b[3], rtol=1e-5, atol=1e-7) and torch.allclose(a[4], b[4], rtol=1e-5, atol=1e-8)
+    assert float((a[5] - b[5]).abs().max()) < 1e-4 * float(b[5].abs().max() + 1e-6)
