@@ -658,7 +658,96 @@ def self_launch(n: int, argv=None) -> int:
     #                                                                                throttle the rank-0 CPU baseline)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
-    return subprocess.call(cmd, env=env)
+    # The parent is the outer watchdog: it passes the children's stdout through, notes whether rank 0's JSON line went by, and
+    # when the launcher dies / a rank fails (torch.distributed.run then tears the others down) / CRESTE_BENCH_TIMEOUT_S passes
+    # (default 1700 s, below the driver's 1800 s limit) without one, prints a line with an `error` field itself instead of
+    # leaving the caller with nothing
+    import threading
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1, start_new_session=True)
+    seen = {"line": False}
+
+    def pump():
+        for ln in proc.stdout:
+            if ln.lstrip().startswith("{") and '"metric"' in ln:
+                seen["line"] = True
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    limit = float(os.environ.get("CRESTE_BENCH_TIMEOUT_S", "1700"))
+    err = None
+    try:
+        rc = proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        err = f"no result within {limit:.0f} s: the {n}-rank job was killed (a rank hung?)"
+        try:
+            os.killpg(proc.pid, 15)                  # our own process group (start_new_session): launcher + every rank
+            proc.wait(timeout=20)
+        except Exception:
+            try:
+                os.killpg(proc.pid, 9)
+            except Exception:
+                pass
+        rc = 124
+    th.join(timeout=10)
+    if not seen["line"]:
+        print(json.dumps(error_line(n, err or f"torch.distributed.run exited with code {rc} before rank 0 printed its line "
+                                               f"(a rank failed; see stderr)")), flush=True)
+        rc = rc or 1
+    return rc
+
+
+def error_line(n_gpus: int, message: str, **extra) -> dict:
+    """the ONE JSON line of a run that could not produce a measurement: same leading keys, value null, an `error` field"""
+    line = {"metric": "frames/sec (RGB+LiDAR->BEV costmap)", "value": None, "unit": "frames/s", "n_gpus": n_gpus,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "error": message}
+    line.update(extra)
+    return line
+
+
+class RankWatchdog:
+    """In-rank half of the watchdog (the driver starts N > 1 ranks under ITS OWN torch.distributed.run, no parent of ours):
+    every collective / barrier of the bench is bracketed by arm() / disarm(); a deadline that passes means a peer is dead or
+    hung -- rank 0 prints the error line (once; never after the real line), every rank leaves with os._exit so that nothing
+    waits in a destructor.  SIGTERM (torch.distributed.run tearing the job down after a peer's failure) does the same."""
+
+    def __init__(self, rank: int, world: int):
+        import threading
+        self.rank, self.world, self.done, self.timer, self._lock = rank, world, False, None, threading.Lock()
+        self.default_s = float(os.environ.get("CRESTE_BENCH_BARRIER_TIMEOUT_S", "600"))
+        if world > 1 or os.environ.get("CRESTE_BENCH_LAUNCHED") == "1":
+            import signal
+            signal.signal(signal.SIGTERM, lambda *_: self.fail("terminated by the launcher (a peer rank failed or the job timed out)", 143))
+
+    def arm(self, what: str, seconds: float | None = None):
+        import threading
+        self.disarm()
+        secs = self.default_s if seconds is None else seconds
+        self.timer = threading.Timer(secs, self.fail, (f"rank {self.rank}: '{what}' did not complete within {secs:.0f} s "
+                                                       f"(a peer rank is dead or hung)", 124))
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+    def fail(self, message: str, code: int):
+        with self._lock:
+            if self.done:
+                os._exit(code)
+            self.done = True
+        if self.rank == 0:
+            print(json.dumps(error_line(self.world, message)), flush=True)
+        else:
+            print(f"[bench rank {self.rank}] {message}", file=sys.stderr, flush=True)
+        os._exit(code)
+
+    def printed(self):
+        with self._lock:
+            self.done = True
+        self.disarm()
 
 
 def dry_run(args) -> int:
@@ -672,15 +761,25 @@ def dry_run(args) -> int:
     if "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
+    dog = RankWatchdog(rank, world)
+    die = os.environ.get("CRESTE_BENCH_TEST_DIE", "")            # (tests: a rank that dies / hangs before its first barrier)
+    if dist.is_initialized() and die == str(rank):
+        os._exit(17)
+    if dist.is_initialized() and die == f"sleep:{rank}":
+        time.sleep(3600)
     for _ in range(args.warmup):
         time.sleep(0.002)
     if dist.is_initialized():
+        dog.arm("barrier before the timed steps")
         dist.barrier()
+        dog.disarm()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.002 * (rank + 1))
     if dist.is_initialized():
+        dog.arm("barrier behind the timed steps")
         dist.barrier()
+        dog.disarm()
     el = dist_utils.max_over_ranks(time.perf_counter() - t0)
     if rank == 0:
         print(json.dumps({"metric": "frames/sec (RGB+LiDAR->BEV costmap)", "value": round(args.batch * world * args.steps / el, 3),
@@ -688,6 +787,7 @@ def dry_run(args) -> int:
                           "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "data": "dry-run", "launched_by": "self" if os.environ.get("CRESTE_BENCH_LAUNCHED") else "external",
                           "note": "NOT a measurement: launcher check, a step is a sleep"}), flush=True)
+    dog.printed()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -739,6 +839,9 @@ def main():
         _du.init_rccl(torch.device("cuda", local_rank))       # (collectives on a high-priority stream: see its docstring)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    dog = RankWatchdog(rank, world)
+    if os.environ.get("CRESTE_BENCH_TEST_DIE") == str(rank) and dist is not None:      # (tests: a rank that dies before its first barrier)
+        os._exit(17)
 
     import creste_public_amd
     from creste_public_amd import synth
@@ -776,7 +879,9 @@ def main():
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
+            dog.arm("barrier around the timed steps")
             dist.barrier()
+            dog.disarm()
         torch.cuda.synchronize()
 
     fence()
@@ -1038,10 +1143,14 @@ def main():
     train_dp = None
     if dist is not None and not args.no_train_dp:
         # every rank takes part (synchronous SGD); rank 0 reports
+        dog.arm("data-parallel training legs", 900)
         train_dp = train_dp_extras(model, device, rank)
+        dog.disarm()
     if dist is not None:
         torch.cuda.synchronize()
+        dog.arm("host-side gloo group")
         host_group = dist.new_group(backend="gloo") if world > 1 else None
+        dog.disarm()
     if rank == 0:
         if train_dp is not None:
             line["train_dp"] = train_dp
@@ -1050,10 +1159,14 @@ def main():
             # kernel spins on their GPUs meanwhile); `cores` says how many host threads the baseline used
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
+        dog.printed()
     if dist is not None:
+        if rank != 0:
+            dog.arm("waiting for rank 0's CPU baseline", 1200)       # (~250 s of oracle forwards on rank 0's host cores)
         if host_group is not None:
             dist.barrier(group=host_group)
         dist.barrier()
+        dog.printed()
         dist.destroy_process_group()
 
 

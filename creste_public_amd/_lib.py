@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libcreste_hip.so")
 
-ABI_VERSION = 11         # creste_abi_version() of the library this binding was written against
+ABI_VERSION = 12         # creste_abi_version() of the library this binding was written against
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3, 4
 
@@ -94,6 +94,7 @@ SIGNATURES = {
     "creste_bev_splat_gather_f32": (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "creste_value_iteration_workspace_bytes": (_i64, [_i, _i, _i]),
     "creste_value_iteration_f32": (_i, [_vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "creste_value_iteration_chunked_f32": (_i, [_vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "creste_conv_wgrad_workspace_bytes": (_i64, [_i] * 6),
     "creste_conv_wgrad_f32": (_i, [_vp, _i, _vp, _i, _vp] + [_i] * 8 + [_vp, _vp]),
     "creste_conv_flip_weight_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -184,9 +185,18 @@ class PlanRecorder(list):
         super().__init__()
         self.pipelined = bool(pipelined)
         self._events = {}
+        self._keep = []          # every event seen stays alive for the trace: id() of a freed event is handed out again
+
+    MAX_STREAMS, MAX_EVENTS = 16, 4096      # what csrc/plan_runtime.cpp's loader accepts (deploy.export_plan checks before writing)
 
     def event_id(self, ev) -> int:
-        return self._events.setdefault(id(ev), len(self._events))
+        k = id(ev)
+        if k not in self._events:
+            self._events[k] = len(self._events)
+            self._keep.append(ev)
+        return self._events[k]
+
+    num_events = property(lambda self: len(self._events))
 
 
 def event_record(ev, stream):

@@ -1276,6 +1276,8 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
   const dim3 igrid1 = ia.order ? dim3((unsigned)(m_blocks * 32 * ia.ncp)) : dim3((unsigned)(m_blocks * 32), (unsigned)((nchunk + 1) / 2));
   const char* f32_env = getenv("CRESTE_W4_F32V");
   const bool f32v = f32_env ? atoi(f32_env) != 0 : true;
+  CRESTE_REQUIRE(f32v || !(d->flags & CRESTE_CONV_EMIT_NEXT_V),
+                 "conv2d: EMIT_NEXT_V writes the next conv's transformed input as fp32; CRESTE_W4_F32V=0 (bf16-piece V) cannot consume it");
   // experiment knob (scripts/coresidency_probe.py): CRESTE_W4_ONLY = bit mask of the kernels of the call that run
   // (1 input transform, 2 GEMM, 4 output transform); results are only meaningful with all three
   const int only = w4_env_int("CRESTE_W4_ONLY", 7);

@@ -15,4 +15,4 @@ void set_error(const char* fmt, ...) {
 }  // namespace creste
 
 extern "C" const char* creste_last_error(void) { return creste::g_err; }
-extern "C" int creste_abi_version(void) { return 11; }
+extern "C" int creste_abi_version(void) { return 12; }

@@ -1041,8 +1041,15 @@ extern "C" int creste_bn_train_forward_f32(const float* x, int x_cs, int64_t P, 
 }
 
 // statistics from the producing conv's per-workgroup sums ([rows][2][C]: sum x, sum x^2): one wave per channel, lane l adds
-// rows l, l + 64, ... in float64, fixed xor tree -> mean, biased variance, 1/sqrt(var + eps), running statistics
+// rows l, l + 64, ... in float64, fixed xor tree -> mean, biased variance, 1/sqrt(var + eps), running statistics.
+// The epilogues add RAW x and x^2 in fp32 (a few hundred values per row), so E[x^2] - E[x]^2 loses about mean^2 / var x 1e-6 of
+// the variance: harmless while |mean| is a few standard deviations, wrong for a channel that sits far from zero
+// (large bias, late training).  A channel whose sums say mean^2 > BN_CANCEL_RATIO x var therefore does not trust them: the
+// same wave re-reads its channel of x and takes the shifted two-moment sums about the (accurate) mean in float64 -- the
+// statistics pass for that channel only, fixed order, so the result stays reproducible.
+constexpr double BN_CANCEL_RATIO = 64.0;
 __global__ __launch_bounds__(64) void bn_stats_from_partials_kernel(const float* __restrict__ partial, int rows, int C, long P,
+                                                                    const float* __restrict__ x, int x_cs,
                                                                     float* __restrict__ mean, float* __restrict__ var,
                                                                     float* __restrict__ invstd, float* running_mean,
                                                                     float* running_var, float eps, float momentum, float unbias) {
@@ -1054,8 +1061,24 @@ __global__ __launch_bounds__(64) void bn_stats_from_partials_kernel(const float*
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  double m = s1 / (double)P, v = fmax(s2 / (double)P - m * m, 0.0);          // (every lane holds the same sums)
+  if (m * m > BN_CANCEL_RATIO * v) {
+    const float pivot = (float)m;
+    double d1 = 0.0, d2 = 0.0;
+    for (long p0 = threadIdx.x; p0 < P; p0 += 256) {
+      float t[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const long p = p0 + 64 * k; t[k] = p < P ? x[p * x_cs + c] - pivot : 0.f; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { d1 += (double)t[k]; d2 += (double)t[k] * (double)t[k]; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o, 64); d2 += __shfl_xor(d2, o, 64); }
+    const double dm = d1 / (double)P;
+    m = (double)pivot + dm;
+    v = fmax(d2 / (double)P - dm * dm, 0.0);
+  }
   if (threadIdx.x == 0) {
-    const double m = s1 / (double)P, v = fmax(s2 / (double)P - m * m, 0.0);
     const float mu = (float)m, vf = (float)v;
     mean[c] = mu; var[c] = vf; invstd[c] = 1.f / sqrtf(vf + eps);
     if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
@@ -1071,7 +1094,7 @@ extern "C" int creste_bn_train_forward_stats_f32(const float* x, int x_cs, int64
   CRESTE_REQUIRE(x && mean && invstd && var_scratch && y && stat_partial && stat_rows > 0 && P > 1 && C > 0,
                  "bn_train_forward_stats: bad args");
   hipStream_t s = (hipStream_t)stream;
-  bn_stats_from_partials_kernel<<<C, 64, 0, s>>>(stat_partial, stat_rows, C, P, mean, var_scratch, invstd, running_mean,
+  bn_stats_from_partials_kernel<<<C, 64, 0, s>>>(stat_partial, stat_rows, C, P, x, x_cs, mean, var_scratch, invstd, running_mean,
                                                  running_var, eps, momentum, (float)P / (float)(P - 1));
   CRESTE_CHECK_LAUNCH("bn_stats_from_partials");
   EwArgs e = {};

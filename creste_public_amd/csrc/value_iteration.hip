@@ -842,9 +842,24 @@ extern "C" int64_t creste_value_iteration_workspace_bytes(int B, int H, int W) {
                    vi_align(sizeof(VmState) + 4u * ((1u << 20) + 256)));
 }
 
+static int value_iteration_run(const float* r, int B, int H, int W, float discount, float threshold, int max_sweeps, float* v,
+                               float* q, float* policy, int32_t* sweeps_out, void* work, void* stream, bool chunked);
+
 extern "C" int creste_value_iteration_f32(const float* r, int B, int H, int W, float discount,
                                           float threshold, int max_sweeps, float* v, float* q,
                                           float* policy, int32_t* sweeps_out, void* work, void* stream) {
+  return value_iteration_run(r, B, H, W, discount, threshold, max_sweeps, v, q, policy, sweeps_out, work, stream, false);
+}
+
+// the launch-per-chunk form on request (the retry of a persistent solve that reported INT32_MIN; creste_hip.h)
+extern "C" int creste_value_iteration_chunked_f32(const float* r, int B, int H, int W, float discount,
+                                                  float threshold, int max_sweeps, float* v, float* q,
+                                                  float* policy, int32_t* sweeps_out, void* work, void* stream) {
+  return value_iteration_run(r, B, H, W, discount, threshold, max_sweeps, v, q, policy, sweeps_out, work, stream, true);
+}
+
+static int value_iteration_run(const float* r, int B, int H, int W, float discount, float threshold, int max_sweeps, float* v,
+                               float* q, float* policy, int32_t* sweeps_out, void* work, void* stream, bool chunked) {
   CRESTE_REQUIRE(r && v && q && policy && sweeps_out && work, "value_iteration: null pointer");
   CRESTE_REQUIRE(B > 0 && H > 0 && W > 0, "value_iteration: bad dims");
   CRESTE_REQUIRE(max_sweeps > 0 && max_sweeps <= (1 << 20), "value_iteration: max_sweeps out of range");
@@ -899,7 +914,7 @@ extern "C" int creste_value_iteration_f32(const float* r, int B, int H, int W, f
       if (spec && per_cu > 1) per_cu = 1;          // the barrier-free solver is built and tuned for one workgroup per CU
     }
     const char* force_multi = getenv("CRESTE_VI_MULTI");
-    if (nwg <= (long)per_cu * cus && !(force_multi && force_multi[0] == '1')) {
+    if (nwg <= (long)per_cu * cus && !chunked && !(force_multi && force_multi[0] == '1')) {
       const int max_chunks = (max_sweeps + PS - 1) / PS;
       // Two solves at once (two streams of this process) could each end up partially resident and wait for each other
       // until the bounded spins give up: launches of the persistent solver are chained through one event per device, so

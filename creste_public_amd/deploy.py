@@ -243,6 +243,10 @@ def export_plan(model: torch.nn.Module, example_inputs, path: str, warmup: int =
     def s_(b: bytes):
         return struct.pack("<I", len(b)) + b
 
+    if len(stream_ids) > rec.MAX_STREAMS or rec.num_events > rec.MAX_EVENTS or len(used_segments) > 4096:
+        raise ops.HipLibraryError(f"export_plan: {len(stream_ids)} streams / {rec.num_events} events / {len(used_segments)} segments exceed "
+                              f"the plan loader's limits ({rec.MAX_STREAMS} / {rec.MAX_EVENTS} / 4096, csrc/plan_runtime.cpp)")
+
     info = (f"{type(model).__name__} precision={hipnn.get_precision()} inputs="
             f"{[tuple(t.shape) for t in static_in]} calls={len(calls)} streams={len(stream_ids)} abi={_lib.ABI_VERSION}").encode()
     seg_sizes = [None] * len(used_segments)

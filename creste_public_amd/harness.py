@@ -104,11 +104,26 @@ class IRLTrainer:
             # in the launch-per-chunk form; no convergence raises.
             if any(n == ops.VI_ABORTED for n in self._vi_counts()):
                 self.optimizer.zero_grad()
-                with ops.vi_launch_per_chunk():
-                    outputs = self.model._forward_trainable(inputs, None) if hasattr(self.model, "_forward_trainable") \
-                        else self.model(inputs)
+                # the retry re-runs the trainable forward in training mode: its BatchNorms must not fold this batch into
+                # their running statistics a second time -- momentum 0 leaves them bit-unchanged
+                bns = [m for m in self.model.modules()
+                       if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training and m.momentum]
+                saved = [m.momentum for m in bns]
+                for m in bns:
+                    m.momentum = 0.0
+                try:
+                    with ops.vi_launch_per_chunk():
+                        outputs = self.model._forward_trainable(inputs, None) if hasattr(self.model, "_forward_trainable") \
+                            else self.model(inputs)
+                finally:
+                    for m, mom in zip(bns, saved):
+                        m.momentum = mom
+                        if m.num_batches_tracked is not None:
+                            m.num_batches_tracked -= 1
                 loss_dict, meta, loss = self._loss_and_backward(task, data, outputs)
-                self._vi_counts()
+                if any(n == ops.VI_ABORTED for n in self._vi_counts()):       # (no convergence already raised in there)
+                    raise ops.HipLibraryError("IRLTrainer: the MDP solve was aborted again in its launch-per-chunk retry; "
+                                              "the gradients of this step are invalid")
                 self.vi_retries += 1
             dist_utils.allreduce_mean_grads(self.params)          # one flat all-reduce (no-op on 1 GPU)
             self.optimizer.step()
@@ -143,8 +158,13 @@ class IRLTrainer:
         return counts
 
     def on_train_epoch_end(self):
+        ops.vi_check(wait=True)            # the epoch's last solve: nothing later would look at its sweep count
         self.scheduler.step()
         self.epoch += 1
+
+    def on_validation_epoch_end(self):
+        """call at the end of an evaluation loop (Lightning's hook name): the LAST solve of a loop is checked by nobody else"""
+        ops.vi_check(wait=True)
 
     # ---- Lightning-layout checkpoints
     def checkpoint(self) -> dict:

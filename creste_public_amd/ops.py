@@ -595,7 +595,10 @@ class _TransformedInput:
 
 
 def conv_pair_fusable(pc1: PackedConv, pc2: PackedConv) -> bool:
-    return (FUSE_CONV_PAIRS and not TRACK_AMAX and pc1.algo == ALGO_WINOGRAD4 and pc2.algo == ALGO_WINOGRAD4
+    # (the fused kernel writes conv 2's transformed input as fp32: with the bf16-piece form forced -- CRESTE_W4_F32V=0, the
+    # bit-exact twin the tests compare against -- the second GEMM would read it as pieces: never fuse there)
+    return (FUSE_CONV_PAIRS and not TRACK_AMAX and os.environ.get("CRESTE_W4_F32V", "1") != "0"
+            and pc1.algo == ALGO_WINOGRAD4 and pc2.algo == ALGO_WINOGRAD4
             and pc1.prec == PREC_BF16X6 and pc2.prec == PREC_BF16X6 and pc1.Cout == pc2.Cin
             and (pc1.pad_t, pc1.pad_l, pc2.pad_t, pc2.pad_l) == (1, 1, 1, 1) and pc1.out_hw(8, 8) == (8, 8)
             and pc2.out_hw(8, 8) == (8, 8))
@@ -623,6 +626,8 @@ def conv2d(x: Act, pc: PackedConv, out: Act | None = None, res: Act | None = Non
     statistics without another pass (creste_bn_train_forward_stats_f32); otherwise `.stats` stays None."""
     lib = _lib.load()
     if isinstance(x, _TransformedInput):
+        if res is not None or a_scale is not None or row_mask is not None or want_stats or _emit_next is not None:
+            raise HipLibraryError("conv2d: the second conv of a fused pair takes no residual / gate / row mask / statistics request")
         return _conv2d_from_v(x, pc, out)
     up, shared = None, None
     if isinstance(x, LazyUpCat):
@@ -1168,77 +1173,100 @@ def check_vi_sweeps(sweeps: torch.Tensor) -> int:
 
 
 VI_ABORTED = -2 ** 31
-_vi_pending: list = []          # [(event, pinned int32[1])] of solves whose sweep count has not been looked at yet
-_vi_ring, _vi_ring_pos = None, 0
+# per DEVICE: [(event, pinned int32[1])] of solves whose sweep count has not been looked at yet, and the ring of pinned slots
+# (one shared list would hand device 1's check to whoever polls on device 0, and two threads driving two devices
+# would race on the ring position)
+_vi_state: dict = {}
+_vi_lock = threading.Lock()
+_vi_tls = threading.local()      # .chunked > 0: solves of THIS thread take the launch-per-chunk form (vi_launch_per_chunk)
+
+
+def _vi_dev(device) -> dict:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    with _vi_lock:
+        st = _vi_state.get(idx)
+        if st is None:
+            # (one pinned allocation per device: they cost ~100 us of host time each)
+            st = _vi_state[idx] = {"pending": [], "ring": torch.empty(16, dtype=torch.int32).pin_memory(), "pos": 0,
+                                   "lock": threading.Lock()}
+    return st
 
 
 def _vi_note(sweeps: torch.Tensor):
     """queue the asynchronous look at a solve's sweep count: a 4-byte copy into pinned memory behind the solve + an event"""
     if _lib._recorder is not None or torch.cuda.is_current_stream_capturing():
         return
-    global _vi_ring, _vi_ring_pos
-    if _vi_ring is None:
-        _vi_ring = torch.empty(16, dtype=torch.int32).pin_memory()       # (one pinned allocation: they cost ~100 us of host time each)
-    if len(_vi_pending) >= 12:                                            # never reuse a slot that is still unlooked-at
-        vi_check(wait=True)
-    host = _vi_ring[_vi_ring_pos:_vi_ring_pos + 1]
-    _vi_ring_pos = (_vi_ring_pos + 1) % 16
-    host.copy_(sweeps, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(sweeps.device))
-    _vi_pending.append((ev, host))
+    st = _vi_dev(sweeps.device)
+    if len(st["pending"]) >= 12:                                          # never reuse a slot that is still unlooked-at
+        vi_check(wait=True, device=sweeps.device)
+    with st["lock"]:
+        host = st["ring"][st["pos"]:st["pos"] + 1]
+        st["pos"] = (st["pos"] + 1) % 16
+        host.copy_(sweeps, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(sweeps.device))
+        st["pending"].append((ev, host))
 
 
-def vi_poll(wait: bool = True) -> list:
-    """The sweep counts of the solves issued since the last poll whose result has arrived (all of them with wait=True: waits
-    for the LAST SOLVE's event, not for the stream -- work queued behind the solves keeps the device busy; wait=False
-    waits only while more than four solves are unlooked-at).  The caller decides what a negative count means for it;
-    `vi_check()` raises."""
+def vi_poll(wait: bool = True, device=None) -> list:
+    """The sweep counts of the solves issued since the last poll (on `device`; None: on every device) whose result has arrived
+    (all of them with wait=True: waits for the LAST SOLVE's event, not for the stream -- work queued behind the solves keeps
+    the device busy; wait=False waits only while more than four solves are unlooked-at).  The caller decides what a negative
+    count means for it; `vi_check()` raises."""
     out = []
-    while _vi_pending and (wait or len(_vi_pending) > 4 or _vi_pending[0][0].query()):
-        ev, host = _vi_pending.pop(0)
-        ev.synchronize()
-        out.append(int(host[0]))
+    if device is None:
+        with _vi_lock:
+            states = list(_vi_state.values())
+    else:
+        states = [_vi_dev(device)]
+    for st in states:
+        with st["lock"]:
+            pend = st["pending"]
+            while pend and (wait or len(pend) > 4 or pend[0][0].query()):
+                ev, host = pend.pop(0)
+                ev.synchronize()
+                out.append(int(host[0]))
     return out
 
 
-def vi_check(wait: bool = True):
+def vi_check(wait: bool = True, device=None):
     """Raise if a solve issued since the last poll failed (see check_vi_sweeps).  Runs by itself at the head of every
-    `value_iteration` (wait=False there: back-to-back solves stay asynchronous, at most four behind) and, waiting, in
-    IRLTrainer before every optimiser step."""
-    for n in vi_poll(wait):
+    `value_iteration` (wait=False there: back-to-back solves stay asynchronous, at most four behind), waiting in IRLTrainer
+    before every optimiser step and at the end of its validation / epoch hooks, and in `VIN.last_sweeps` -- call it with
+    wait=True after the LAST solve of a loop of your own (nothing else looks at that one)."""
+    for n in vi_poll(wait, device):
         check_vi_sweeps(torch.tensor([n], dtype=torch.int32))
 
 
-def value_iteration(r: torch.Tensor, discount: float, threshold: float = 1e-3, max_sweeps: int = 100000):
+def value_iteration(r: torch.Tensor, discount: float, threshold: float = 1e-3, max_sweeps: int = 100000, chunked: bool = False):
     """r [B,H,W] -> v [B,H,W], q [B,8,H,W], policy [B,8,H,W], sweeps (device int32 tensor).  The call is asynchronous:
-    failures are reported in the SIGN of `sweeps` (see `check_vi_sweeps`).  Nobody has to remember to look: every solve's
-    count is copied to pinned memory behind it and checked at the head of a later solve (`vi_check`; IRLTrainer checks
-    before each optimiser step and redoes a step whose solve was aborted through the launch-per-chunk form); `VIN.last_sweeps`
-    checks on demand; under CRESTE_CHECK_VI=1 every call checks at once (one host sync per solve) and an aborted persistent
-    solve is redone in the launch-per-chunk form before returning."""
+    failures are reported in the SIGN of `sweeps` (see `check_vi_sweeps`).  Every solve's count is copied to pinned memory
+    behind it and checked at the head of a later solve on the same device (`vi_check`; IRLTrainer checks before each optimiser
+    step and redoes a step whose solve was aborted through the launch-per-chunk form); `VIN.last_sweeps` checks on demand;
+    the last solve of a loop is only checked by an explicit `vi_check()`.  Under CRESTE_CHECK_VI=1 every call checks at once
+    (one host sync per solve) and an aborted persistent solve is redone in the launch-per-chunk form before returning.
+    chunked (or inside `vi_launch_per_chunk()`): the launch-per-chunk form (creste_value_iteration_chunked_f32)."""
     lib = _lib.load()
     B, H, W = r.shape
     dev = r.device
     eager = _lib._recorder is None and not torch.cuda.is_current_stream_capturing()
     if eager:
-        vi_check(wait=False)
+        vi_check(wait=False, device=dev)
     v = torch.empty((B, H, W), dtype=torch.float32, device=dev)
     q = torch.empty((B, 8, H, W), dtype=torch.float32, device=dev)
     pi = torch.empty((B, 8, H, W), dtype=torch.float32, device=dev)
     sweeps = torch.zeros(1, dtype=torch.int32, device=dev)
     work = torch.empty(lib.creste_value_iteration_workspace_bytes(B, H, W), dtype=torch.uint8, device=dev)
 
-    def solve():
-        _lib.check(lib.creste_value_iteration_f32(_chk(r).data_ptr(), B, H, W, float(discount),
-                                                  float(threshold), int(max_sweeps), v.data_ptr(),
-                                                  q.data_ptr(), pi.data_ptr(), sweeps.data_ptr(),
-                                                  work.data_ptr(), _stream()), "value_iteration")
-    solve()
+    def solve(per_chunk: bool):
+        fn = lib.creste_value_iteration_chunked_f32 if per_chunk else lib.creste_value_iteration_f32
+        _lib.check(fn(_chk(r).data_ptr(), B, H, W, float(discount), float(threshold), int(max_sweeps), v.data_ptr(),
+                      q.data_ptr(), pi.data_ptr(), sweeps.data_ptr(), work.data_ptr(), _stream()), "value_iteration")
+    per_chunk = bool(chunked) or getattr(_vi_tls, "chunked", 0) > 0
+    solve(per_chunk)
     if eager and os.environ.get("CRESTE_CHECK_VI") == "1":
-        if int(sweeps.item()) == VI_ABORTED:
-            with vi_launch_per_chunk():
-                solve()
+        if int(sweeps.item()) == VI_ABORTED and not per_chunk:
+            solve(True)
         check_vi_sweeps(sweeps)
     elif eager:
         _vi_note(sweeps)
@@ -1246,18 +1274,15 @@ def value_iteration(r: torch.Tensor, discount: float, threshold: float = 1e-3, m
 
 
 class vi_launch_per_chunk:
-    """`with vi_launch_per_chunk():` -- solves inside take the launch-per-chunk form (host-synchronous, needs no co-residency):
-    the retry path of a persistent solve that reported VI_ABORTED."""
+    """`with vi_launch_per_chunk():` -- solves THIS THREAD issues inside take the launch-per-chunk form (host-synchronous, needs
+    no co-residency): the retry path of a persistent solve that reported VI_ABORTED.  (A thread-local flag handed to the C call
+    as its entry point -- not the process environment)"""
 
     def __enter__(self):
-        self.prev = os.environ.get("CRESTE_VI_MULTI")
-        os.environ["CRESTE_VI_MULTI"] = "1"
+        _vi_tls.chunked = getattr(_vi_tls, "chunked", 0) + 1
 
     def __exit__(self, *exc):
-        if self.prev is None:
-            os.environ.pop("CRESTE_VI_MULTI", None)
-        else:
-            os.environ["CRESTE_VI_MULTI"] = self.prev
+        _vi_tls.chunked -= 1
         return False
 
 

@@ -378,6 +378,12 @@ int64_t creste_value_iteration_workspace_bytes(int B, int H, int W);
 int creste_value_iteration_f32(const float* r, int B, int H, int W, float discount, float threshold,
                                int max_sweeps, float* v, float* q, float* policy, int32_t* sweeps_out,
                                void* work, void* stream);
+/* The same solve in the launch-per-chunk form whatever the grid size (host-synchronous peeks, no co-residency needed): what a
+ * caller retries with when the persistent launch reported *sweeps_out = INT32_MIN (its workgroups could not all become resident
+ * beside another stream's kernels).  Same arguments, same results. */
+int creste_value_iteration_chunked_f32(const float* r, int B, int H, int W, float discount, float threshold,
+                                       int max_sweeps, float* v, float* q, float* policy, int32_t* sweeps_out,
+                                       void* work, void* stream);
 
 /* Expected state-visitation frequency + greedy rollout.  reference lfd.py:156-277,
  * train_utils.py:765-803.

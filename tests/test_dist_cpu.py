@@ -393,3 +393,32 @@ def test_bench_launches_itself_for_more_than_one_gpu():
                           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"],
                          env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0
+
+
+def test_bench_dead_rank_yields_a_line_with_an_error_field():
+    """a rank that dies must not leave the job hanging at a barrier or the caller without a line.
+    (a) self-launched: rank 1 exits before its first barrier -> torch.distributed.run tears the job down, and whichever of
+    rank 0's SIGTERM handler / the launching parent gets there first prints ONE JSON line with `error`, rc != 0;
+    (b) the in-rank deadline alone (the driver's own torch.distributed.run at N > 1, no parent of ours): rank 0 waits at a
+    barrier its peer never reaches and prints the error line when CRESTE_BENCH_BARRIER_TIMEOUT_S passes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["CRESTE_BENCH_TEST_DIE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and lines[0]["value"] is None and lines[0]["error"] and lines[0]["n_gpus"] == 2, r.stdout + r.stderr[-1500:]
+    # (b) rank 0 alone in a 2-rank world whose rank 1 never shows up at the barrier: the rendezvous itself needs both, so rank 1
+    # joins and then sleeps (CRESTE_BENCH_TEST_DIE=sleep:1)
+    env["CRESTE_BENCH_TEST_DIE"] = "sleep:1"
+    env["CRESTE_BENCH_BARRIER_TIMEOUT_S"] = "5"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--dry-run"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and "did not complete within 5 s" in lines[0]["error"], r.stdout + r.stderr[-1500:]

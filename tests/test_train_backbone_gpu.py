@@ -581,3 +581,33 @@ def test_batchnorm_statistics_from_the_conv_epilogue(monkeypatch, Cin, Cout, K, 
     assert float(((a[2] - b[2]).abs() / b[2]).max()) < 2e-6
     assert torch.allclose(a[3], b[3], rtol=1e-5, atol=1e-7) and torch.allclose(a[4], b[4], rtol=1e-5, atol=1e-8)
     assert float((a[5] - b[5]).abs().max()) < 1e-4 * float(b[5].abs().max() + 1e-6)
+
+
+@pytest.mark.parametrize("Cin,Cout,K,H,W,ratio", [(128, 256, 3, 40, 56, 300.0), (96, 24, 1, 40, 72, 1000.0), (40, 240, 1, 19, 38, 30.0)])
+def test_batchnorm_statistics_from_the_conv_epilogue_far_from_zero(monkeypatch, Cin, Cout, K, H, W, ratio):
+    """the epilogue sums are RAW (sum x, sum x^2) in fp32, so channels whose |mean| is hundreds of standard deviations
+    would lose their variance to cancellation.  The finisher (bn_stats_from_partials_kernel) notices mean^2 >> var and takes the
+    shifted sums of that channel itself: mean / invstd / outputs still equal the separate shifted-moments pass."""
+    import torch.nn as nn
+    from creste_public_amd import ops
+    from creste_public_amd.train_backbone import BN, ConvG, Seq
+    g = torch.Generator("cuda").manual_seed(Cin + 7)
+    conv = nn.Conv2d(Cin, Cout, K, padding=K // 2, bias=False).to("cuda")
+    with torch.no_grad():
+        # every output channel = (a large constant) + (a small random part): |mean| / std of about `ratio` in the interior
+        conv.weight.copy_(1.0 / (Cin * K * K) + torch.randn(conv.weight.shape, device="cuda", generator=g) / (ratio * (Cin * K * K) ** 0.5))
+    x0 = 1.0 + torch.randn(4, H, W, Cin, device="cuda", generator=g) / ratio
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "CONV_STATS", flag)
+        bn = nn.BatchNorm2d(Cout).to("cuda")
+        seq = Seq([ConvG(conv), BN(bn, relu=False)])
+        y = seq.fwd(ops.Act(x0.clone(), Cin))
+        res[flag] = (y.buf.clone(), seq.ops[1].op.mean.clone(), seq.ops[1].op.invstd.clone(), bn.running_var.clone())
+    if K == 1:      # (3x3: the zero-padded border widens the spread; the 1x1 channels really sit `ratio` deviations from zero)
+        assert float((res[False][1].abs() * res[False][2]).min()) > 0.5 * ratio
+    a, b = res[True], res[False]
+    assert float(((a[1] - b[1]).abs() / b[1].abs()).max()) < 1e-6
+    assert float(((a[2] - b[2]).abs() / b[2]).max()) < 2e-5
+    assert torch.allclose(a[3], b[3], rtol=1e-4, atol=1e-9)
+    assert float((a[0] - b[0]).abs().max()) < 2e-4 * float(b[0].abs().max())
