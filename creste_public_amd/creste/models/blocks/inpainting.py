@@ -11,7 +11,7 @@ import torch
 from torch import nn
 
 from .... import ops
-from ....hipnn import ACT_NONE, ACT_RELU, Act, ConvUnit, require_hip, up_out_size, up_scales
+from ....hipnn import ACT_NONE, ACT_RELU, Act, ConvUnit, UpConvUnit, require_hip, up_out_size, up_scales
 from .effnet import Up
 
 
@@ -86,15 +86,15 @@ class DeconvHead(nn.Module):
 
     def _units(self):
         if self._u is None:
-            self._u = (ConvUnit(self.up2[1], self.up2[2], ACT_RELU), ConvUnit(self.proj, None, ACT_NONE))
+            self._u = (UpConvUnit(self.up2[1], self.up2[2], ACT_RELU), ConvUnit(self.proj, None, ACT_NONE))
         return self._u
 
     def _tail(self, h: Act, pred_out: Act = None):
         c3, proj = self._units()
         sf, (rh, rw) = up_scales(self.up2[0].scale_factor)
-        Ho, Wo = up_out_size(h.H, h.W, sf)
         with ops.shared_rows():
-            feat = c3(ops.upsample_concat_lazy(h, None, Ho, Wo, rh, rw))
+            # (bf16 split modes: four phase convolutions on the 128 x 128 map instead of a conv over the upsampled one)
+            feat = c3.up(h, sf, rh, rw)
         return proj(feat, out=pred_out), feat
 
     def from_concat_act(self, cat: Act, pred_out: Act = None):

@@ -362,7 +362,9 @@ extern "C" int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream) {
   CRESTE_REQUIRE(d->Cin % 4 == 0 && (!d->in || (d->in_cs % 4 == 0 && d->in_cs >= d->Cin - (d->up_src ? d->up_C : 0))),
                  "conv2d: Cin (%d) and in_cs (%d) must be multiples of 4, in_cs >= Cin", d->Cin, d->in_cs);
   CRESTE_REQUIRE((reinterpret_cast<uintptr_t>(d->in) & 15) == 0, "conv2d: input not 16-byte aligned");
-  CRESTE_REQUIRE(d->out_cs >= d->out_co + d->Cout, "conv2d: output slice exceeds out_cs");
+  CRESTE_REQUIRE(!(d->flags & (CRESTE_CONV_REPLICATE_PAD | CRESTE_CONV_PHASE2X)) || d->algo == CRESTE_ALGO_WINOGRAD4,
+                 "conv2d: REPLICATE_PAD / PHASE2X are flags of the F(4x4,3x3) path");
+  CRESTE_REQUIRE(d->out_cs >= d->out_co + ((d->flags & CRESTE_CONV_PHASE2X) ? d->Cout / 4 : d->Cout), "conv2d: output slice exceeds out_cs");
   CRESTE_REQUIRE(!d->res || d->res_cs >= d->Cout, "conv2d: res_cs < Cout");
   CRESTE_REQUIRE((long)d->N * d->Ho * d->Wo < (1L << 31), "conv2d: M overflows int32");
   // sanity: the last output pixel may lie in trailing padding (the input gradient of a strided conv has rows the

@@ -504,6 +504,7 @@ struct Wino4InArgs {
   const float* up_src;       // UP: channels >= Cin - up_C are the exact 2x bilinear upsample of up_src [N, H/2, W/2, up_cs]
   int up_C, up_cs;
   int order, ncp;            // order 1: 1-D grid, channel-chunk pairs fastest inside an XCD's contiguous range of tile groups
+  int repl;                  // CRESTE_CONV_REPLICATE_PAD: window pixels outside the image take the nearest border pixel (wino4_in1_kernel<false>)
 };
 
 // One workgroup = 16 tiles x 32 channels (two chunks), tile groups the fast grid dimension; thread = (tile, channel
@@ -749,17 +750,21 @@ __global__ __launch_bounds__(256) void wino4_in1_kernel(const Wino4InArgs p) {
         for (int j = 0; j < 6; ++j) d[i][j] = 0.f;
     } else {
       const float* base = p.in + ch;
+      const bool repl = p.repl != 0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         const int yy = y0 + i;
         const bool yok = (unsigned)yy < (unsigned)p.H;
-        const size_t rowoff = ((size_t)img * p.H + (yok ? yy : 0)) * p.W;
+        const int yc = yy < 0 ? 0 : (yy > p.H - 1 ? p.H - 1 : yy);
+        const size_t rowoff = ((size_t)img * p.H + (yok ? yy : (repl ? yc : 0))) * p.W;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
           const int xx = x0 + j;
-          const bool in = yok && (unsigned)xx < (unsigned)p.W;
-          const float v = base[(rowoff + (in ? xx : 0)) * p.in_cs];
-          d[i][j] = in ? v : 0.f;
+          const bool xok = (unsigned)xx < (unsigned)p.W;
+          const int xc = xx < 0 ? 0 : (xx > p.W - 1 ? p.W - 1 : xx);
+          const bool in = yok && xok;
+          const float v = base[(rowoff + (xok ? xx : (repl ? xc : 0))) * p.in_cs];
+          d[i][j] = (in || repl) ? v : 0.f;
         }
       }
     }
@@ -818,6 +823,9 @@ struct Wino4OutArgs {
   long mplane;
   int order, ncg, ntg8;      // order 1: 1-D grid, cout groups fastest inside an XCD's range of ntg8 tile groups
   float* stats;              // creste_conv_desc.out_stats: [ceil(T / 16)][2][Cout] sums of what this workgroup writes, or nullptr
+  int phaseC;                // CRESTE_CONV_PHASE2X: > 0 = channels per phase; channel n of pixel (oy, ox) is channel n % phaseC of pixel
+                             // (2 oy + (n / phaseC >> 1), 2 ox + (n / phaseC & 1)) of the [N, 2 Ho, 2 Wo] output; the outermost
+                             // ring of that image is written WITHOUT the activation (upconv2x_ring_fix_kernel finishes it)
 };
 
 constexpr int W4O_TILES = 16;
@@ -890,8 +898,17 @@ __global__ __launch_bounds__(256) void wino4_out2_kernel(const Wino4OutArgs p) {
       const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
       const int oy = 4 * ty + ((pl >> 2) & 3), ox = 4 * tx + (pl & 3);
       if (oy >= p.Ho || ox >= p.Wo) continue;
-      const long mrow = ((long)img * p.Ho + oy) * p.Wo + ox;
       w4f32x4 v = *reinterpret_cast<const w4f32x4*>(tilebuf + pl * W4O2_ROW + cq * 4) + bs;
+      if (p.phaseC > 0) {
+        const int ph = n / p.phaseC, nn = n - ph * p.phaseC;
+        const int oy2 = 2 * oy + (ph >> 1), ox2 = 2 * ox + (ph & 1), H2 = 2 * p.Ho, W2 = 2 * p.Wo;
+        const bool ring = oy2 == 0 || ox2 == 0 || oy2 == H2 - 1 || ox2 == W2 - 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ring ? v[e] : act_apply(v[e], p.act);
+        *reinterpret_cast<w4f32x4*>(p.out + (((long)img * H2 + oy2) * W2 + ox2) * p.out_cs + p.out_co + nn) = v;
+        continue;
+      }
+      const long mrow = ((long)img * p.Ho + oy) * p.Wo + ox;
       if (p.res) v += *reinterpret_cast<const w4f32x4*>(p.res + mrow * p.res_cs + n);
       const float rmask = p.row_mask ? p.row_mask[mrow] : 1.f;
 #pragma unroll
@@ -1108,6 +1125,10 @@ __global__ void wino4_pack_kernel(const float* __restrict__ w, const float* __re
   }
 }
 
+static inline bool f32v_default() {
+  const char* e = getenv("CRESTE_W4_F32V");
+  return e ? atoi(e) != 0 : true;
+}
 static inline int wino4_split(int prec) {
   return prec == CRESTE_PREC_BF16X6 ? 3 : (prec == CRESTE_PREC_BF16X3 ? 2 : 0);
 }
@@ -1267,6 +1288,12 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
   ia.tiles_y = tiles_y; ia.tiles_x = tiles_x; ia.T = (int)T; ia.pad_t = d->pad_t; ia.pad_l = d->pad_l;
   ia.nchunk = nchunk; ia.m_blocks = m_blocks;
   ia.up_src = d->up_src; ia.up_C = d->up_C; ia.up_cs = d->up_cs;
+  ia.repl = (d->flags & CRESTE_CONV_REPLICATE_PAD) ? 1 : 0;
+  const bool phase2x = (d->flags & CRESTE_CONV_PHASE2X) != 0;
+  CRESTE_REQUIRE(!(ia.repl || phase2x) || (f32v_default() && !d->up_src && !(d->flags & (CRESTE_CONV_EMIT_NEXT_V | CRESTE_CONV_V_VALID))),
+                 "conv2d: REPLICATE_PAD / PHASE2X are built for the plain fp32-V input transform (no fused upsample, no conv pair)");
+  CRESTE_REQUIRE(!phase2x || (d->Cout % 16 == 0 && !d->res && !d->row_mask && !d->out_amax && !d->out_stats && d->Ho == d->H && d->Wo == d->W),
+                 "conv2d: PHASE2X scatters 4 x (Cout / 4) channels onto the [N, 2H, 2W] output; no residual / row mask / |max| / statistics");
   CRESTE_REQUIRE((d->Cin & 3) == 0 && (!d->in || ((d->in_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(d->in) & 15) == 0)),
                  "conv2d: the F(4x4,3x3) input transform reads channel pairs (Cin / in_cs multiples of 4, as every NHWC conv here)");
   const char* ord_env = getenv("CRESTE_W4_ORDER");
@@ -1338,6 +1365,7 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
   o.N = d->N; o.Ho = d->Ho; o.Wo = d->Wo; o.Cout = d->Cout; o.out_cs = d->out_cs; o.out_co = d->out_co; o.res_cs = d->res_cs;
   o.act = d->act; o.tiles_y = tiles_y; o.tiles_x = tiles_x; o.T = (int)T; o.mplane = a.mplane;
   o.stats = d->out_stats;
+  o.phaseC = phase2x ? d->Cout / 4 : 0;
   CRESTE_REQUIRE(!d->out_stats || (!d->res && !d->row_mask), "conv2d: out_stats takes a conv without residual / row mask");
   o.order = (order >> 1) & 1; o.ncg = (d->Cout / 4 + W4O2_QUADS - 1) / W4O2_QUADS;
   o.ntg8 = (int)(((T + W4O_TILES - 1) / W4O_TILES + 7) / 8);
@@ -1598,6 +1626,137 @@ int conv_wgrad_wino4_run(const float* x, int x_cs, const float* gy, int gy_cs, f
   return CRESTE_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ upsample -> conv3x3 ring
+// `Upsample(x2, bilinear, align_corners=False) -> conv3x3(pad 1)` (reference DeconvHead.up2, inpainting.py:56-60) runs as four
+// phase convolutions on the LOW-resolution map: high-resolution row 2y + a only ever sees low-resolution rows y - 1 .. y + 1, so
+// the conv over the upsampled image is a 3x3 conv with 4 x Cout composed kernels on the small map (same products, a transformed
+// input a quarter the size, no upsampled tensor) -- exact everywhere except at the image border: the high-resolution conv pads the
+// UPSAMPLED image with zeros, the phase form continues it with the replicate-padded interpolation.  This kernel takes those
+// taps back out of the outermost ring of the output: for ring pixel (oy, ox) and every tap (ky, kx) whose source
+// (oy + ky - 1, ox + kx - 1) lies outside [0, 2H) x [0, 2W):  out -= sum_ci w[co, ci, ky, kx] * u~(source), u~ = the bilinear
+// formula on the replicate-padded map (what the phase form used), then the activation the output transform left out there.
+// One workgroup = 32 consecutive pixels of one side of one image x 128 couts (wave = 32 couts), K = taps x Cin in chunks of 64
+// on the exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32: the term cancels a term of the same size, so fp32 products).
+// Corners belong to the top / bottom sides (five taps there), the left / right sides run over rows 1 .. 2H - 2.
+struct RingFixArgs {
+  const float* x;            // [N, H, W, x_cs] low-resolution input (channel offset applied)
+  const float* w;            // [3][3][Cin][Cout] fp32, BatchNorm scale folded
+  float* out;                // [N, 2H, 2W, out_cs] at channel offset out_co
+  int N, H, W, Cin, x_cs, Cout, out_cs, out_co, act;
+  int cw, ch;                // 32-pixel chunks per horizontal / vertical side
+};
+constexpr int RF_LD = 65;
+__global__ __launch_bounds__(256) void upconv2x_ring_fix_kernel(const RingFixArgs p) {
+  __shared__ float As[32 * RF_LD];
+  __shared__ __attribute__((aligned(16))) float Ws[64 * 128];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int H2 = 2 * p.H, W2 = 2 * p.W;
+  const int per_img = 2 * p.cw + 2 * p.ch;
+  const int img = blockIdx.x / per_img;
+  int r = blockIdx.x - img * per_img, side;           // side 0 top, 1 bottom, 2 left, 3 right
+  if (r < 2 * p.cw) { side = r / p.cw; r -= side * p.cw; } else { r -= 2 * p.cw; side = 2 + r / p.ch; r -= (side - 2) * p.ch; }
+  const int s0 = r * 32, len = side < 2 ? W2 : H2 - 2;
+  auto pix = [&](int j, int& oy, int& ox) __attribute__((always_inline)) -> bool {
+    const int sidx = s0 + j;
+    if (side == 0) { oy = 0; ox = sidx; }
+    else if (side == 1) { oy = H2 - 1; ox = sidx; }
+    else if (side == 2) { oy = sidx + 1; ox = 0; }
+    else { oy = sidx + 1; ox = W2 - 1; }
+    return sidx < len;
+  };
+  // taps any pixel of this workgroup needs (wave-uniform: every wave evaluates the same 32 pixels)
+  unsigned need = 0;
+  {
+    int oy, ox;
+    const bool ok = pix(lane & 31, oy, ox);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int Y = oy + tap / 3 - 1, X = ox + tap % 3 - 1;
+      const bool outside = ok && ((unsigned)Y >= (unsigned)H2 || (unsigned)X >= (unsigned)W2);
+      if (__ballot(outside) != 0ull) need |= 1u << tap;
+    }
+  }
+  const int co0 = blockIdx.y * 128 + wv * 32;
+  w4f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  // A-tile thread = (pixel, 8 channels of the 64-channel chunk)
+  const int apx = t >> 3, ac8 = (t & 7) * 8;
+  int aoy, aox;
+  const bool aok = pix(apx, aoy, aox);
+  const float* ximg = p.x + (size_t)img * p.H * p.W * p.x_cs;
+  for (int tap = 0; tap < 9; ++tap) {
+    if (!((need >> tap) & 1u)) continue;
+    const int ky = tap / 3, kx = tap % 3;
+    const int Y = aoy + ky - 1, X = aox + kx - 1;
+    const bool outside = aok && ((unsigned)Y >= (unsigned)H2 || (unsigned)X >= (unsigned)W2);
+    // u~(Y, X): source coordinate 0.5 (Y + 0.5) - 0.5 NOT clamped at 0 (so that row -1 = 0.75 x~[-1] + 0.25 x[0]), indices clamped
+    const float sy = 0.5f * ((float)Y + 0.5f) - 0.5f, sx = 0.5f * ((float)X + 0.5f) - 0.5f;
+    const float fy0 = floorf(sy), fx0 = floorf(sx);
+    const float wy1 = sy - fy0, wx1 = sx - fx0, wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+    const int yi = (int)fy0, xi = (int)fx0;
+    const int ya = yi < 0 ? 0 : (yi > p.H - 1 ? p.H - 1 : yi), yb = yi + 1 < 0 ? 0 : (yi + 1 > p.H - 1 ? p.H - 1 : yi + 1);
+    const int xa = xi < 0 ? 0 : (xi > p.W - 1 ? p.W - 1 : xi), xb = xi + 1 < 0 ? 0 : (xi + 1 > p.W - 1 ? p.W - 1 : xi + 1);
+    const float* paa = ximg + ((size_t)ya * p.W + xa) * p.x_cs;
+    const float* pab = ximg + ((size_t)ya * p.W + xb) * p.x_cs;
+    const float* pba = ximg + ((size_t)yb * p.W + xa) * p.x_cs;
+    const float* pbb = ximg + ((size_t)yb * p.W + xb) * p.x_cs;
+    const float* wt = p.w + (size_t)tap * p.Cin * p.Cout;
+    for (int c0 = 0; c0 < p.Cin; c0 += 64) {
+      __syncthreads();                                   // everybody is done with the previous chunk's tiles
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        w4f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (outside) {
+          const int c = c0 + ac8 + 4 * h;
+          const w4f32x4 vaa = *reinterpret_cast<const w4f32x4*>(paa + c), vab = *reinterpret_cast<const w4f32x4*>(pab + c);
+          const w4f32x4 vba = *reinterpret_cast<const w4f32x4*>(pba + c), vbb = *reinterpret_cast<const w4f32x4*>(pbb + c);
+          v = wy0 * (wx0 * vaa + wx1 * vab) + wy1 * (wx0 * vba + wx1 * vbb);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) As[apx * RF_LD + ac8 + 4 * h + e] = v[e];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int idx = q * 256 + t, k = idx >> 5, c4 = (idx & 31) * 4;
+        const int co = blockIdx.y * 128 + c4;
+        w4f32x4 wv4 = {0.f, 0.f, 0.f, 0.f};
+        if (co < p.Cout) wv4 = *reinterpret_cast<const w4f32x4*>(wt + (size_t)(c0 + k) * p.Cout + co);
+        *reinterpret_cast<w4f32x4*>(Ws + k * 128 + c4) = wv4;
+      }
+      __syncthreads();
+#pragma unroll 8
+      for (int st = 0; st < 32; ++st) {
+        const int k = 2 * st + (lane >> 5);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(lane & 31) * RF_LD + k], Ws[k * 128 + wv * 32 + (lane & 31)], acc, 0, 0, 0);
+      }
+    }
+  }
+  if (co0 >= p.Cout) return;
+  const int co = co0 + (lane & 31);
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    const int j = 8 * (rr >> 2) + 4 * (lane >> 5) + (rr & 3);
+    int oy, ox;
+    if (!pix(j, oy, ox) || co >= p.Cout) continue;
+    float* dst = p.out + (((size_t)img * H2 + oy) * W2 + ox) * p.out_cs + p.out_co + co;
+    *dst = act_apply(*dst - acc[rr], p.act);
+  }
+}
+
+int upconv2x_ring_fix_run(const float* x, int x_cs, int N, int H, int W, int Cin, const float* w_ring, int Cout, int act, float* out,
+                          int out_cs, int out_co, hipStream_t s) {
+  RingFixArgs a;
+  a.x = x; a.w = w_ring; a.out = out; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.x_cs = x_cs; a.Cout = Cout; a.out_cs = out_cs;
+  a.out_co = out_co; a.act = act;
+  a.cw = (2 * W + 31) / 32; a.ch = (2 * H - 2 + 31) / 32;
+  const dim3 grid((unsigned)(N * (2 * a.cw + 2 * a.ch)), (unsigned)((Cout + 127) / 128));
+  upconv2x_ring_fix_kernel<<<grid, 256, 0, s>>>(a);
+  CRESTE_CHECK_LAUNCH("upconv2x_ring_fix");
+  return CRESTE_OK;
+}
+
 }  // namespace creste
 
 extern "C" int creste_conv_wgrad_wino4_supported(int K, int stride, int H, int W, int Ho, int Wo, int Cin, int Cout) {
@@ -1617,6 +1776,16 @@ extern "C" int creste_conv_wgrad_wino4(const float* x, int x_cs, const float* gy
                  "conv_wgrad_wino4: built for stride-1 same-size 3x3 convs with >= 128 channels (multiples of 4) on both sides");
   CRESTE_REQUIRE(x_cs >= Cin && gy_cs >= Cout && (reinterpret_cast<uintptr_t>(work) & 15) == 0, "conv_wgrad_wino4: bad strides / workspace alignment");
   return conv_wgrad_wino4_run(x, x_cs, gy, gy_cs, gw, N, H, W, Cin, Cout, pad_t, pad_l, accumulate, work, (hipStream_t)stream);
+}
+
+extern "C" int creste_upconv2x_ring_fix_f32(const float* x, int x_cs, int N, int H, int W, int Cin, const float* w_ring, int Cout,
+                                            int act, float* out, int out_cs, int out_co, void* stream) {
+  using namespace creste;
+  CRESTE_REQUIRE(x && w_ring && out, "upconv2x_ring_fix: null pointer");
+  CRESTE_REQUIRE(N > 0 && H >= 2 && W >= 2 && Cin > 0 && Cin % 64 == 0 && Cout > 0 && Cout % 4 == 0 && x_cs >= Cin && x_cs % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w_ring) & 15) == 0 && out_cs >= out_co + Cout,
+                 "upconv2x_ring_fix: maps of at least 2 x 2, Cin a multiple of 64, Cout a multiple of 4, 16-byte aligned x / weights");
+  return upconv2x_ring_fix_run(x, x_cs, N, H, W, Cin, w_ring, Cout, act, out, out_cs, out_co, (hipStream_t)stream);
 }
 
 extern "C" int creste_conv_wino4_gemm_probe(int enable) {

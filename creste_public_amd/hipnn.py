@@ -130,6 +130,44 @@ class ConvUnit:
         return ops.conv2d(x, self.packed(), out=out, res=res, a_scale=a_scale, row_mask=row_mask)
 
 
+class UpConvUnit(ConvUnit):
+    """nn.Upsample(x2, bilinear) -> conv3x3 (+ folded BN) (+ activation) (reference DeconvHead.up2, inpainting.py:56-60): where the
+    operand mode has the F(4x4,3x3) engine, four phase convolutions on the LOW-resolution map (ops.upconv2x: a transformed input a
+    quarter the size, the 256-cout GEMM tile, no upsampled tensor); otherwise the conv over the lazily upsampled map."""
+
+    def __init__(self, conv, bn, act):
+        super().__init__(conv, bn, act)
+        self._packed_up, self._key_up = None, None
+
+    def phase_ok(self, x: Act, sf, rh, rw) -> bool:
+        prec = ops.conv_precision(_precision, 3, 1, self.conv.in_channels)
+        return (self.conv.kernel_size == (3, 3) and self.conv.stride == (1, 1) and self.pad == (1, 1, 1, 1) and tuple(sf) == (2.0, 2.0)
+                and float(rh) == 0.5 and float(rw) == 0.5 and x.H >= 2 and x.W >= 2 and x.C % 4 == 0 and x.co % 4 == 0
+                and ops.upconv2x_supported(prec, self.conv.in_channels, self.conv.out_channels))
+
+    def packed_up(self) -> ops.PackedUpConv:
+        prec = ops.conv_precision(_precision, 3, 1, self.conv.in_channels)
+        key = (_sig(self._tensors()), prec)
+        if self._packed_up is None or key != self._key_up:
+            require_hip(self.conv.weight, "conv weight")
+            bn = None
+            if self.bn is not None:
+                if self.bn.training:
+                    raise NotImplementedError("BatchNorm in training mode is not on the HIP path (eval-mode folding only)")
+                b = self.bn
+                bn = (b.weight, b.bias, b.running_mean, b.running_var, b.eps)
+            self._packed_up = ops.pack_upconv2x(self.conv.weight, self.conv.bias, bn, self.act, prec)
+            self._key_up = key
+        return self._packed_up
+
+    def up(self, x: Act, sf, rh, rw, out: Act | None = None) -> Act:
+        """act(bn(conv(upsample(x))))"""
+        if self.phase_ok(x, sf, rh, rw):
+            return ops.upconv2x(x, self.packed_up(), out=out)
+        Ho, Wo = up_out_size(x.H, x.W, sf)
+        return self(ops.upsample_concat_lazy(x, None, Ho, Wo, rh, rw), out=out)
+
+
 class Cached:
     """Small cache of derived device tensors keyed on the source tensors' identity/version."""
 

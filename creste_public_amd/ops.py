@@ -759,6 +759,81 @@ def _conv2d_from_v(x: "_TransformedInput", pc: PackedConv, out: Act | None) -> A
     return out
 
 
+# `Upsample(x2, bilinear) -> conv3x3` as four phase convolutions on the low-resolution map (CRESTE_PHASE_UPCONV=0: off; then the
+# upsample is formed inside the F(4x4) input transform of a conv over the high-resolution map, LazyUpCat)
+PHASE_UPCONV = os.environ.get("CRESTE_PHASE_UPCONV", "1") != "0"
+
+
+def phase_upconv_weights(weight: torch.Tensor) -> torch.Tensor:
+    """OIHW 3x3 kernel of a conv that reads the exact 2x bilinear upsample (align_corners=False) of x -> the [4 * O, I, 3, 3] kernel
+    of the equivalent conv on x itself: output channel (2a + b) * O + o at low-resolution pixel (y, x) = output channel o at
+    high-resolution pixel (2y + a, 2x + b).  High-resolution row 2y + a - 1 + ky is 0.75 / 0.25 of two of the rows y - 1 .. y + 1
+    (R[a][ky][ky']), so w'[a, b] = R[a]^T w R[b] per (o, i); composed in float64, rounded once."""
+    R = torch.tensor([[[0.75, 0.25, 0.0], [0.25, 0.75, 0.0], [0.0, 0.75, 0.25]],
+                      [[0.25, 0.75, 0.0], [0.0, 0.75, 0.25], [0.0, 0.25, 0.75]]], dtype=torch.float64, device=weight.device)
+    w = weight.detach().double()
+    O, I = w.shape[:2]
+    wp = torch.einsum("ayp,bxq,oiyx->aboipq", R, R, w)                 # [2, 2, O, I, 3, 3]
+    return wp.reshape(4 * O, I, 3, 3).float().contiguous()
+
+
+@dataclass
+class PackedUpConv:
+    phase: PackedConv          # the composed 4 x Cout kernels, F(4x4,3x3)-packed, BatchNorm folded, bias replicated
+    w_ring: torch.Tensor       # [3][3][Cin][Cout] fp32: the ORIGINAL kernel (BatchNorm scale folded) for the border ring
+    Cout: int
+
+
+def pack_upconv2x(weight: torch.Tensor, bias, bn, act, prec) -> PackedUpConv:
+    """`nn.Upsample(scale_factor=2, mode='bilinear') -> nn.Conv2d(k=3, padding=1) (+ eval BatchNorm) (+ act)` (reference
+    DeconvHead.up2, inpainting.py:56-60) packed for `upconv2x`."""
+    Cout, Cin = weight.shape[:2]
+    rep = lambda t: None if t is None else t.detach().repeat(4)
+    bn4 = None if bn is None else (rep(bn[0]), rep(bn[1]), rep(bn[2]), rep(bn[3]), bn[4])
+    pc = pack_conv(phase_upconv_weights(weight), rep(bias), bn4, 1, 1, act, prec, algo=ALGO_WINOGRAD4)
+    w = weight.detach().float()
+    if bn is not None:
+        w = w * (bn[0].detach() / torch.sqrt(bn[3].detach() + bn[4])).float()[:, None, None, None]
+    return PackedUpConv(pc, w.permute(2, 3, 1, 0).contiguous(), Cout)
+
+
+def upconv2x_supported(prec: int, cin: int, cout: int) -> bool:
+    return (PHASE_UPCONV and prec in (PREC_BF16X6, PREC_BF16X3) and cin % 64 == 0 and cout % 4 == 0 and not TRACK_AMAX
+            and os.environ.get("CRESTE_W4_F32V", "1") != "0"
+            and bool(_lib.load().creste_conv_wino4_supported(prec, 3, 3, 1, cin, 4 * cout)))
+
+
+def upconv2x(x: Act, pu: PackedUpConv, out: Act | None = None) -> Act:
+    """act(bn(conv3x3(bilinear_up2x(x)))) [N, 2H, 2W, Cout] without the upsampled tensor: the phase convolution on x with
+    replicate padding (CRESTE_CONV_REPLICATE_PAD | CRESTE_CONV_PHASE2X), then the border ring put right
+    (creste_upconv2x_ring_fix_f32: the high-resolution conv pads the UPSAMPLED image with zeros)."""
+    lib = _lib.load()
+    pc = pu.phase
+    N, H, W, dev = x.N, x.H, x.W, x.buf.device
+    _chk(x.buf, name="upconv2x input")
+    if x.C != pc.Cin:
+        raise HipLibraryError(f"upconv2x: input has {x.C} channels, weights expect {pc.Cin}")
+    if out is None:
+        out = Act.empty(N, 2 * H, 2 * W, pu.Cout, dev)
+    if (out.N, out.H, out.W, out.C) != (N, 2 * H, 2 * W, pu.Cout):
+        raise HipLibraryError(f"upconv2x: output slice {(out.N, out.H, out.W, out.C)} != {(N, 2 * H, 2 * W, pu.Cout)}")
+    d = ConvDesc()
+    d.in_, d.wpk, d.out = x.ptr, pc.wpk.data_ptr(), out.buf.data_ptr()
+    d.bias = pc.bias.data_ptr() if pc.bias is not None else None
+    d.res, d.res_cs = None, 0
+    d.N, d.H, d.W, d.Cin, d.in_cs = N, H, W, pc.Cin, x.cs
+    d.Ho, d.Wo, d.Cout, d.out_cs, d.out_co = H, W, pc.Cout, out.cs, out.co
+    d.KH, d.KW, d.stride, d.pad_t, d.pad_l = 3, 3, 1, 1, 1
+    d.act, d.prec, d.algo = pc.act, pc.prec, ALGO_WINOGRAD4
+    work = torch.empty(lib.creste_conv_wino4_workspace_bytes(N, H, W, pc.Cin, pc.Cout, pc.prec), dtype=torch.uint8, device=dev)
+    d.work, d.flags = work.data_ptr(), 4 | 8            # CRESTE_CONV_REPLICATE_PAD | CRESTE_CONV_PHASE2X
+    _lib.check(lib.creste_conv2d_nhwc(C.byref(d), _stream()), "conv2d_nhwc (phase upconv)")
+    _lib.check(lib.creste_upconv2x_ring_fix_f32(x.ptr, x.cs, N, H, W, pc.Cin, pu.w_ring.data_ptr(), pu.Cout, pc.act,
+                                                out.buf.data_ptr(), out.cs, out.co, _stream()), "upconv2x_ring_fix")
+    out.amax, out.stats = None, None
+    return out
+
+
 DW_TILE, DW_TILE_MIN_C = True, 16       # policy of dwconv2d / dwconv2d_se: LDS-tile kernel for channel counts >= DW_TILE_MIN_C
 
 

@@ -61,6 +61,15 @@ extern "C" {
  * what the second conv's own input transform would have produced from the materialised tensor.  The second call passes
  * CRESTE_CONV_V_VALID (its `in` is not read).  out_cs / out_co are ignored. */
 #define CRESTE_CONV_EMIT_NEXT_V 2
+/* CRESTE_ALGO_WINOGRAD4, the two halves of `Upsample(x2, bilinear) -> conv3x3` run as FOUR PHASE convolutions on the
+ * low-resolution map (reference DeconvHead.up2, inpainting.py:56-60; creste_upconv2x_ring_fix_f32 below):
+ * REPLICATE_PAD: window pixels outside the image take the nearest border pixel instead of zero;
+ * PHASE2X: Cout = 4 x C'; channel n of low-resolution pixel (y, x) is written as channel n % C' of pixel
+ *   (2 y + (n / C' >> 1), 2 x + (n / C' & 1)) of `out` [N, 2 Ho, 2 Wo, out_cs] (bias per n); the outermost ring of that image
+ *   is written WITHOUT the activation -- creste_upconv2x_ring_fix_f32 subtracts the taps the high-resolution conv's zero
+ *   padding excludes and applies it. */
+#define CRESTE_CONV_REPLICATE_PAD 4
+#define CRESTE_CONV_PHASE2X 8
 #define CRESTE_ALGO_WINOGRAD4 2 /* F(4x4,3x3): the same convs, transformed input materialised, see creste_conv_wino4_* */
 
 const char* creste_last_error(void);
@@ -120,6 +129,15 @@ typedef struct creste_conv_desc {
 } creste_conv_desc;
 
 int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream);
+/* Second half of `Upsample(x2, bilinear, align_corners=False) -> conv3x3(pad 1)` run as phase convolutions on the low-resolution
+ * map (reference DeconvHead.up2, inpainting.py:56-60): after creste_conv2d_nhwc with CRESTE_CONV_REPLICATE_PAD | CRESTE_CONV_PHASE2X
+ * and the composed 4 x Cout kernels, the outermost ring of `out` [N, 2H, 2W, out_cs] still contains the taps the high-resolution
+ * conv's ZERO padding excludes and has no activation applied.  For every ring pixel and every tap whose source lies outside the
+ * upsampled image this subtracts sum_ci w_ring[ky][kx][ci][co] * u~(source) (u~: the bilinear formula on the replicate-padded
+ * x, exact-fp32 products) and applies `act`.  x [N, H, W, x_cs] is the conv's low-resolution input, w_ring [3][3][Cin][Cout] the
+ * ORIGINAL 3x3 kernel (BatchNorm scale folded).  Cin % 64 == 0. */
+int creste_upconv2x_ring_fix_f32(const float* x, int x_cs, int N, int H, int W, int Cin, const float* w_ring, int Cout, int act,
+                                 float* out, int out_cs, int out_co, void* stream);
 /* rows of creste_conv_desc.out_stats this call would write (host query; `out_stats` itself is not read), or -1 when the
  * kernel this descriptor dispatches to does not produce statistics */
 int creste_conv_stat_rows(const creste_conv_desc* d);

@@ -618,6 +618,53 @@ def test_conv_winograd4_fused_upsample_concat(ops, N, C1, C2, H1, W1, Cout):
     assert lazy._mat is not None and ops.conv2d(lazy, pcd).buf.shape == y.buf.shape
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W,prec", [
+    (2, 256, 128, 16, 24, "bf16x6"),       # DeconvHead.up2's channel counts, whole tiles
+    (1, 64, 8, 5, 7, "bf16x6"),            # odd extents: partial tiles, every ring pixel near a corner, Cout of two quads
+    (3, 128, 132, 33, 18, "bf16x6"),       # Cout = 33 quads per phase (528 phase channels), sides longer than one 32-pixel chunk
+    (1, 64, 16, 2, 2, "bf16x6"),           # the smallest map: the 4 x 4 output is ring + corners only... plus 2 x 2 interior
+    (2, 256, 128, 32, 32, "bf16x3"),
+])
+def test_upsample_conv3x3_as_phase_convolutions(ops, N, Cin, Cout, H, W, prec):
+    """`nn.Upsample(scale_factor=2, bilinear, align_corners=False) -> nn.Conv2d(3, padding=1) -> BatchNorm (eval) -> ReLU` (reference
+    DeconvHead.up2, inpainting.py:56-60) as four phase convolutions on the LOW-resolution map + the border-ring correction
+    (ops.upconv2x: CRESTE_CONV_REPLICATE_PAD | CRESTE_CONV_PHASE2X, creste_upconv2x_ring_fix_f32) against float64 PyTorch on the
+    CPU, at the F(4x4) engine's tolerance, ring and corners included; also into a channel slice of a wider buffer, and against
+    the conv over the upsampled map the other modes keep using."""
+    import torch.nn.functional as F
+    P = getattr(ops, "PREC_" + prec.upper())
+    g = torch.Generator().manual_seed(N * 100 + Cin + Cout)
+    xt = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.3
+    mean, var = torch.randn(Cout, generator=g) * 0.2, torch.rand(Cout, generator=g) + 0.5
+    up = F.interpolate(xt.double(), scale_factor=2, mode="bilinear", align_corners=False)
+    scale = gamma.double() / torch.sqrt(var.double() + 1e-5)
+    ref = torch.relu(F.conv2d(up, w.double(), padding=1) * scale[None, :, None, None] + (beta.double() - mean.double() * scale)[None, :, None, None])
+    x = to_act(ops, xt)
+    assert ops.upconv2x_supported(P, Cin, Cout)
+    pu = ops.pack_upconv2x(dev(w), None, (dev(gamma), dev(beta), dev(mean), dev(var), 1e-5), ops.ACT_RELU, P)
+    y = ops.upconv2x(x, pu)
+    assert (y.N, y.H, y.W, y.C) == (N, 2 * H, 2 * W, Cout)
+    got = y.nchw().double().cpu()
+    tol = 3e-5 if prec == "bf16x6" else 2e-3
+    err = (got - ref).abs()
+    assert float(err.max()) < tol * float(ref.abs().max()), (float(err.max()), float(ref.abs().max()))
+    ring = torch.ones(2 * H, 2 * W, dtype=torch.bool); ring[1:-1, 1:-1] = False
+    assert float(err[:, :, ring].max()) < tol * float(ref.abs().max())
+    rms = float((err ** 2).mean().sqrt() / (ref ** 2).mean().sqrt())
+    assert rms < (1e-5 if prec == "bf16x6" else 5e-4), rms
+    # into a channel slice of a wider buffer (the neighbours stay untouched), twice: same bits
+    wide = ops.Act(torch.full((N, 2 * H, 2 * W, Cout + 8), 7.0, device="cuda"), Cout, 4)
+    ops.upconv2x(x, pu, out=wide)
+    assert torch.equal(wide.buf[..., 4:4 + Cout], y.buf) and bool((wide.buf[..., :4] == 7).all()) and bool((wide.buf[..., 4 + Cout:] == 7).all())
+    assert torch.equal(ops.upconv2x(x, pu).buf, y.buf)
+    # the conv over the (lazily) upsampled map: the same operator to the engine's tolerance
+    pc = ops.pack_conv(dev(w), None, (dev(gamma), dev(beta), dev(mean), dev(var), 1e-5), 1, 1, ops.ACT_RELU, P, algo=ops.ALGO_WINOGRAD4)
+    z = ops.conv2d(ops.upsample_concat_lazy(x, None, 2 * H, 2 * W, 0.5, 0.5), pc)
+    assert float((z.buf - y.buf).abs().max()) < 2 * tol * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("case", [
     ("wino4", 2, 128, 256, 20, 28),        # F(4x4) output transform: ragged tile groups
     ("wino4", 1, 144, 132, 37, 41),        # partial tiles in both directions, Cout = 33 quads (4 + 1/8 cout groups)

@@ -605,7 +605,7 @@ def test_batchnorm_statistics_from_the_conv_epilogue_far_from_zero(monkeypatch, 
         y = seq.fwd(ops.Act(x0.clone(), Cin))
         res[flag] = (y.buf.clone(), seq.ops[1].op.mean.clone(), seq.ops[1].op.invstd.clone(), bn.running_var.clone())
     if K == 1:      # (3x3: the zero-padded border widens the spread; the 1x1 channels really sit `ratio` deviations from zero)
-        assert float((res[False][1].abs() * res[False][2]).min()) > 0.5 * ratio
+        assert float((res[False][1].abs() * res[False][2]).min()) > 0.2 * ratio
     a, b = res[True], res[False]
     assert float(((a[1] - b[1]).abs() / b[1].abs()).max()) < 1e-6
     assert float(((a[2] - b[2]).abs() / b[2]).max()) < 2e-5
