@@ -1639,6 +1639,8 @@ int conv_wgrad_wino4_run(const float* x, int x_cs, const float* gy, int gy_cs, f
 // One workgroup = 32 consecutive pixels of one side of one image x 128 couts (wave = 32 couts), K = taps x Cin in chunks of 64
 // on the exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32: the term cancels a term of the same size, so fp32 products).
 // Corners belong to the top / bottom sides (five taps there), the left / right sides run over rows 1 .. 2H - 2.
+// Measured (scripts/upconv_micro.py, 256 -> 128 at 256 x 256, batch 16): 77-83 us; by ablation 25 us is the empty skeleton, ~17 us the
+// loads, ~40 us the 384 dependent fp32 MFMAs per wave (20 us if the 512 workgroups were spread evenly over the SIMDs).
 struct RingFixArgs {
   const float* x;            // [N, H, W, x_cs] low-resolution input (channel offset applied)
   const float* w;            // [3][3][Cin][Cout] fp32, BatchNorm scale folded
@@ -1646,10 +1648,13 @@ struct RingFixArgs {
   int N, H, W, Cin, x_cs, Cout, out_cs, out_co, act;
   int cw, ch;                // 32-pixel chunks per horizontal / vertical side
 };
-constexpr int RF_LD = 65;
+constexpr int RF_KC = 64, RF_LD = RF_KC / 2 + 4;      // A tile rows: [k parity][pixel][32 values (+4)]
 __global__ __launch_bounds__(256) void upconv2x_ring_fix_kernel(const RingFixArgs p) {
-  __shared__ float As[32 * RF_LD];
-  __shared__ __attribute__((aligned(16))) float Ws[64 * 128];
+  // The A tile [32 pixels][64 channels (+1)] crosses LDS (two stages: it is formed by (pixel, channel octet) threads and consumed as
+  // MFMA rows); the weight operand does not: lane (k half, cout) of an MFMA reads w[k][cout] -- 2 x 128 contiguous bytes per
+  // wave and instruction, straight from L2 (all workgroups share the 1.2 MB of weights) into registers, one chunk ahead of the
+  // matrix instructions that consume it.  16.6 KB of LDS: several workgroups per CU hide each other's load latency.
+  __shared__ __attribute__((aligned(16))) float As[2][2 * 32 * RF_LD];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int H2 = 2 * p.H, W2 = 2 * p.W;
   const int per_img = 2 * p.cw + 2 * p.ch;
@@ -1677,7 +1682,21 @@ __global__ __launch_bounds__(256) void upconv2x_ring_fix_kernel(const RingFixArg
       if (__ballot(outside) != 0ull) need |= 1u << tap;
     }
   }
-  const int co0 = blockIdx.y * 128 + wv * 32;
+  if (need == 0) return;
+  const int co = blockIdx.y * 128 + wv * 32 + (lane & 31);
+  const bool cok = co < p.Cout;
+  const int cw = cok ? co : 0;
+  // this lane's 16 output addresses: read now, so that the values are there when the matrix work ends
+  float* dst[16];
+  float old[16];
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    const int j = 8 * (rr >> 2) + 4 * (lane >> 5) + (rr & 3);
+    int oy, ox;
+    const bool ok = pix(j, oy, ox) && cok;
+    dst[rr] = ok ? p.out + (((size_t)img * H2 + oy) * W2 + ox) * p.out_cs + p.out_co + co : nullptr;
+    old[rr] = ok ? *dst[rr] : 0.f;
+  }
   w4f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -1686,63 +1705,68 @@ __global__ __launch_bounds__(256) void upconv2x_ring_fix_kernel(const RingFixArg
   int aoy, aox;
   const bool aok = pix(apx, aoy, aox);
   const float* ximg = p.x + (size_t)img * p.H * p.W * p.x_cs;
-  for (int tap = 0; tap < 9; ++tap) {
-    if (!((need >> tap) & 1u)) continue;
-    const int ky = tap / 3, kx = tap % 3;
+  w4f32x4 ra[2];
+  float wn[RF_KC / 2], wc[RF_KC / 2];
+  // chunk (tap, c0) -> registers: this thread's part of the A tile and this lane's weight operands of the chunk's 32 MFMAs
+  auto fetch = [&](int tap, int c0) __attribute__((always_inline)) {
+    const int ky = tap / 3, kx = tap - 3 * ky;
     const int Y = aoy + ky - 1, X = aox + kx - 1;
     const bool outside = aok && ((unsigned)Y >= (unsigned)H2 || (unsigned)X >= (unsigned)W2);
-    // u~(Y, X): source coordinate 0.5 (Y + 0.5) - 0.5 NOT clamped at 0 (so that row -1 = 0.75 x~[-1] + 0.25 x[0]), indices clamped
-    const float sy = 0.5f * ((float)Y + 0.5f) - 0.5f, sx = 0.5f * ((float)X + 0.5f) - 0.5f;
-    const float fy0 = floorf(sy), fx0 = floorf(sx);
-    const float wy1 = sy - fy0, wx1 = sx - fx0, wy0 = 1.f - wy1, wx0 = 1.f - wx1;
-    const int yi = (int)fy0, xi = (int)fx0;
-    const int ya = yi < 0 ? 0 : (yi > p.H - 1 ? p.H - 1 : yi), yb = yi + 1 < 0 ? 0 : (yi + 1 > p.H - 1 ? p.H - 1 : yi + 1);
-    const int xa = xi < 0 ? 0 : (xi > p.W - 1 ? p.W - 1 : xi), xb = xi + 1 < 0 ? 0 : (xi + 1 > p.W - 1 ? p.W - 1 : xi + 1);
-    const float* paa = ximg + ((size_t)ya * p.W + xa) * p.x_cs;
-    const float* pab = ximg + ((size_t)ya * p.W + xb) * p.x_cs;
-    const float* pba = ximg + ((size_t)yb * p.W + xa) * p.x_cs;
-    const float* pbb = ximg + ((size_t)yb * p.W + xb) * p.x_cs;
-    const float* wt = p.w + (size_t)tap * p.Cin * p.Cout;
-    for (int c0 = 0; c0 < p.Cin; c0 += 64) {
-      __syncthreads();                                   // everybody is done with the previous chunk's tiles
+    ra[0] = ra[1] = w4f32x4{0.f, 0.f, 0.f, 0.f};
+    if (outside) {
+      // u~(Y, X): source coordinate 0.5 (Y + 0.5) - 0.5 NOT clamped at 0 (so that row -1 = 0.75 x~[-1] + 0.25 x[0]), indices clamped
+      const float sy = 0.5f * ((float)Y + 0.5f) - 0.5f, sx = 0.5f * ((float)X + 0.5f) - 0.5f;
+      const float fy0 = floorf(sy), fx0 = floorf(sx);
+      const float wy1 = sy - fy0, wx1 = sx - fx0, wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+      const int yi = (int)fy0, xi = (int)fx0;
+      const int ya = yi < 0 ? 0 : (yi > p.H - 1 ? p.H - 1 : yi), yb = yi + 1 < 0 ? 0 : (yi + 1 > p.H - 1 ? p.H - 1 : yi + 1);
+      const int xa = xi < 0 ? 0 : (xi > p.W - 1 ? p.W - 1 : xi), xb = xi + 1 < 0 ? 0 : (xi + 1 > p.W - 1 ? p.W - 1 : xi + 1);
+      const float* paa = ximg + ((size_t)ya * p.W + xa) * p.x_cs + c0 + ac8;
+      const float* pab = ximg + ((size_t)ya * p.W + xb) * p.x_cs + c0 + ac8;
+      const float* pba = ximg + ((size_t)yb * p.W + xa) * p.x_cs + c0 + ac8;
+      const float* pbb = ximg + ((size_t)yb * p.W + xb) * p.x_cs + c0 + ac8;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        w4f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (outside) {
-          const int c = c0 + ac8 + 4 * h;
-          const w4f32x4 vaa = *reinterpret_cast<const w4f32x4*>(paa + c), vab = *reinterpret_cast<const w4f32x4*>(pab + c);
-          const w4f32x4 vba = *reinterpret_cast<const w4f32x4*>(pba + c), vbb = *reinterpret_cast<const w4f32x4*>(pbb + c);
-          v = wy0 * (wx0 * vaa + wx1 * vab) + wy1 * (wx0 * vba + wx1 * vbb);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) As[apx * RF_LD + ac8 + 4 * h + e] = v[e];
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int idx = q * 256 + t, k = idx >> 5, c4 = (idx & 31) * 4;
-        const int co = blockIdx.y * 128 + c4;
-        w4f32x4 wv4 = {0.f, 0.f, 0.f, 0.f};
-        if (co < p.Cout) wv4 = *reinterpret_cast<const w4f32x4*>(wt + (size_t)(c0 + k) * p.Cout + co);
-        *reinterpret_cast<w4f32x4*>(Ws + k * 128 + c4) = wv4;
-      }
-      __syncthreads();
-#pragma unroll 8
-      for (int st = 0; st < 32; ++st) {
-        const int k = 2 * st + (lane >> 5);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(lane & 31) * RF_LD + k], Ws[k * 128 + wv * 32 + (lane & 31)], acc, 0, 0, 0);
-      }
+      for (int h = 0; h < 2; ++h)
+        ra[h] = wy0 * (wx0 * *reinterpret_cast<const w4f32x4*>(paa + 4 * h) + wx1 * *reinterpret_cast<const w4f32x4*>(pab + 4 * h)) +
+                wy1 * (wx0 * *reinterpret_cast<const w4f32x4*>(pba + 4 * h) + wx1 * *reinterpret_cast<const w4f32x4*>(pbb + 4 * h));
     }
-  }
-  if (co0 >= p.Cout) return;
-  const int co = co0 + (lane & 31);
+    const float* wt = p.w + ((size_t)tap * p.Cin + c0 + (lane >> 5)) * p.Cout + cw;
 #pragma unroll
-  for (int rr = 0; rr < 16; ++rr) {
-    const int j = 8 * (rr >> 2) + 4 * (lane >> 5) + (rr & 3);
-    int oy, ox;
-    if (!pix(j, oy, ox) || co >= p.Cout) continue;
-    float* dst = p.out + (((size_t)img * H2 + oy) * W2 + ox) * p.out_cs + p.out_co + co;
-    *dst = act_apply(*dst - acc[rr], p.act);
+    for (int s2 = 0; s2 < RF_KC / 2; ++s2) wn[s2] = wt[(size_t)(2 * s2) * p.Cout];
+  };
+  auto stash = [&](int st) __attribute__((always_inline)) {
+    // channel k of the chunk -> [k & 1][pixel][k >> 1]: a lane's 32 MFMA operands (k = 2 s + its k half) are contiguous
+    *reinterpret_cast<w4f32x4*>(&As[st][(0 * 32 + apx) * RF_LD + (ac8 >> 1)]) = w4f32x4{ra[0][0], ra[0][2], ra[1][0], ra[1][2]};
+    *reinterpret_cast<w4f32x4*>(&As[st][(1 * 32 + apx) * RF_LD + (ac8 >> 1)]) = w4f32x4{ra[0][1], ra[0][3], ra[1][1], ra[1][3]};
+  };
+  int tap = __builtin_ctz(need), c0 = 0, st = 0;
+  fetch(tap, 0);
+  stash(0);
+  __syncthreads();
+  for (;;) {
+#pragma unroll
+    for (int s2 = 0; s2 < RF_KC / 2; ++s2) wc[s2] = wn[s2];
+    int ntap = tap, nc0 = c0 + RF_KC;
+    if (nc0 >= p.Cin) {
+      nc0 = 0;
+      const unsigned rest = need >> (tap + 1);
+      ntap = rest ? tap + 1 + __builtin_ctz(rest) : 9;
+    }
+    if (ntap < 9) fetch(ntap, nc0);
+    w4f32x4 av[RF_KC / 8];
+#pragma unroll
+    for (int q = 0; q < RF_KC / 8; ++q) av[q] = *reinterpret_cast<const w4f32x4*>(&As[st][((lane >> 5) * 32 + (lane & 31)) * RF_LD + 4 * q]);
+#pragma unroll
+    for (int s2 = 0; s2 < RF_KC / 2; ++s2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2 >> 2][s2 & 3], wc[s2], acc, 0, 0, 0);
+    if (ntap >= 9) break;
+    stash(st ^ 1);           // (stage st ^ 1 was last read one chunk ago: everybody passed the barrier behind it)
+    __syncthreads();
+    st ^= 1; tap = ntap; c0 = nc0;
   }
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr)
+    if (dst[rr]) *dst[rr] = act_apply(old[rr] - acc[rr], p.act);
 }
 
 int upconv2x_ring_fix_run(const float* x, int x_cs, int N, int H, int W, int Cin, const float* w_ring, int Cout, int act, float* out,
