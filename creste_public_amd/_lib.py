@@ -92,6 +92,8 @@ SIGNATURES = {
     "creste_pixel_geometry_keyed_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i,
                                              _f, _f, _f, _f, _i, _i, _vp, _vp, _vp]),
     "creste_bev_splat_gather_f32": (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "creste_conv1x1_chain3_weight_bytes": (_i64, [_i, _i]),
+    "creste_conv1x1_chain3_f32": (_i, [_vp, _i, _i64, _i, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "creste_upconv2x_ring_fix_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
     "creste_value_iteration_workspace_bytes": (_i64, [_i, _i, _i]),
     "creste_value_iteration_f32": (_i, [_vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -46,9 +46,31 @@ class _ConvStack(nn.Module):
         setattr(self, self._attr, nn.Sequential(*layers))
         self._units = None
 
+    def _chain(self):
+        """the fused form of a stack of three 1x1 conv + BN + ReLU layers of 128 channels (the distillation head,
+        reference distillation.py:179): ops.conv1x1_chain3, or None when the stack / operand mode is not that shape"""
+        from .... import hipnn
+        us = self._units
+        prec = ops.conv_precision(hipnn._precision, 1, 1, us[0].conv.in_channels) if us else None
+        ok = (len(us) == 3 and all(u.conv.kernel_size == (1, 1) and u.conv.stride == (1, 1) and u.pad == (0, 0, 0, 0) and u.act == ACT_RELU
+                                   and (u.bn is None or not u.bn.training) for u in us)
+              and ops.conv1x1_chain3_supported(prec, [us[0].conv.in_channels] + [u.conv.out_channels for u in us]))
+        if not ok:
+            return None
+        key = (tuple(hipnn._sig(u._tensors()) for u in us), prec)
+        if getattr(self, "_chain_pk", None) is None or self._chain_key != key:
+            layers = [(u.conv.weight, u.conv.bias, None if u.bn is None else (u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var, u.bn.eps))
+                      for u in us]
+            self._chain_pk, self._chain_key = ops.pack_conv1x1_chain3(layers, prec), key
+        return self._chain_pk
+
     def forward_act(self, x: Act, out: Act = None, row_mask=None) -> Act:
         if self._units is None:
             self._units = _units_from_sequential(getattr(self, self._attr))
+        if row_mask is None and isinstance(x, Act) and x.co % 4 == 0:
+            pk = self._chain()
+            if pk is not None:
+                return ops.conv1x1_chain3(x, pk, out=out)
         for i, u in enumerate(self._units):
             last = i == len(self._units) - 1
             x = u(x, out=out if last else None, row_mask=row_mask if last else None)

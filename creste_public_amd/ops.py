@@ -759,6 +759,77 @@ def _conv2d_from_v(x: "_TransformedInput", pc: PackedConv, out: Act | None) -> A
     return out
 
 
+# three 1x1 conv + BN + ReLU layers of 128 channels as one kernel (the distillation head; CRESTE_CHAIN_1X1=0: three conv launches)
+CHAIN_1X1 = os.environ.get("CRESTE_CHAIN_1X1", "1") != "0"
+
+
+@dataclass
+class PackedChain3:
+    wimg: torch.Tensor         # MFMA operand tiles of the three weight matrices (bf16 pieces, uint8 storage)
+    bias: torch.Tensor         # [3][128] fp32
+    Cin: int
+    prec: int
+
+
+def conv1x1_chain3_supported(prec: int, dims) -> bool:
+    return (CHAIN_1X1 and not TRACK_AMAX and prec in (PREC_BF16X6, PREC_BF16X3) and len(dims) == 4 and tuple(dims[1:]) == (128, 128, 128)
+            and dims[0] % 32 == 0 and dims[0] <= 1024)
+
+
+def pack_conv1x1_chain3(layers, prec) -> PackedChain3:
+    """layers: three (weight [128, C, 1, 1], bias or None, bn = None | (gamma, beta, mean, var, eps)) of 1x1 convs each followed by ReLU
+    (reference MultiLayerConv, blocks/conv.py:5-32) -> the operand tiles of creste_conv1x1_chain3_f32: BatchNorm folded as pack_conv
+    does, every fp32 weight split into its bf16 pieces (round to nearest, the remainder again), layer 1 in channel order, layers 2 / 3
+    in the order of the accumulator layout (MFMA step 2t + j, k-octet h: channels 32t + 16j + {4h + e, 8 + 4h + e}, e < 4)."""
+    note_cache_build()
+    split = 3 if prec == PREC_BF16X6 else 2
+    dev = layers[0][0].device
+    tiles, biases = [], []
+    for li, (weight, bias, bn) in enumerate(layers):
+        w = _chk(weight.detach().contiguous(), name="conv weight").reshape(weight.shape[0], weight.shape[1]).float()
+        b = torch.zeros(128, dtype=torch.float32, device=dev) if bias is None else bias.detach().float()
+        if bn is not None:
+            gamma, beta, mean, var, eps = bn
+            scale = (gamma.detach() / torch.sqrt(var.detach() + eps)).float()
+            w = w * scale[:, None]
+            b = b * scale + (beta.detach() - mean.detach() * scale)
+        K = w.shape[1]
+        if li == 0:
+            idx = torch.arange(K, device=dev).reshape(K // 16, 2, 8)                          # [step][k-octet][e]
+        else:
+            t, j, h, e = torch.meshgrid(torch.arange(4, device=dev), torch.arange(2, device=dev), torch.arange(2, device=dev),
+                                        torch.arange(8, device=dev), indexing="ij")
+            idx = (32 * t + 16 * j + torch.where(e < 4, 4 * h + e, 8 + 4 * h + e - 4)).reshape(8, 2, 8)
+        g = w[:, idx].permute(1, 2, 0, 3).contiguous()                                       # [step][k-octet][128 couts][8]
+        pieces, r = [], g
+        for _ in range(split):
+            pc = r.to(torch.bfloat16)
+            pieces.append(pc)
+            r = r - pc.float()
+        tiles.append(torch.stack(pieces, dim=1))                                             # [step][piece][k-octet][128][8]
+        biases.append(b)
+    wimg = torch.cat([t.reshape(-1) for t in tiles]).contiguous().view(torch.uint8)
+    need = _lib.load().creste_conv1x1_chain3_weight_bytes(layers[0][0].shape[1], prec)
+    if wimg.numel() != need:
+        raise HipLibraryError(f"pack_conv1x1_chain3: {wimg.numel()} bytes of operand tiles, the kernel expects {need}")
+    return PackedChain3(wimg, torch.stack(biases).contiguous(), int(layers[0][0].shape[1]), prec)
+
+
+def conv1x1_chain3(x: Act, pk: PackedChain3, out: Act | None = None) -> Act:
+    """relu(W3 relu(W2 relu(W1 x + b1) + b2) + b3) per pixel, 128 channels out; the hidden layers never leave the registers"""
+    _chk(x.buf, name="conv input")
+    if x.C != pk.Cin:
+        raise HipLibraryError(f"conv1x1_chain3: input has {x.C} channels, weights expect {pk.Cin}")
+    if out is None:
+        out = Act.empty(x.N, x.H, x.W, 128, x.buf.device)
+    if (out.N, out.H, out.W, out.C) != (x.N, x.H, x.W, 128):
+        raise HipLibraryError(f"conv1x1_chain3: output slice {(out.N, out.H, out.W, out.C)} != {(x.N, x.H, x.W, 128)}")
+    _lib.check(_lib.load().creste_conv1x1_chain3_f32(x.ptr, x.cs, x.N * x.H * x.W, pk.Cin, pk.wimg.data_ptr(), pk.bias.data_ptr(), pk.prec,
+                                                     out.buf.data_ptr(), out.cs, out.co, _stream()), "conv1x1_chain3")
+    out.amax, out.stats = None, None
+    return out
+
+
 # `Upsample(x2, bilinear) -> conv3x3` as four phase convolutions on the low-resolution map (CRESTE_PHASE_UPCONV=0: off; then the
 # upsample is formed inside the F(4x4) input transform of a conv over the high-resolution map, LazyUpCat)
 PHASE_UPCONV = os.environ.get("CRESTE_PHASE_UPCONV", "1") != "0"

@@ -129,6 +129,16 @@ typedef struct creste_conv_desc {
 } creste_conv_desc;
 
 int creste_conv2d_nhwc(const creste_conv_desc* d, void* stream);
+/* Three 1x1 convolutions with 128 output channels each, every one followed by a folded eval-mode BatchNorm and ReLU, as ONE launch:
+ * the distillation head MultiLayerConv(kernels [1,1,1], dims [Cin, 128, 128, 128]) of reference creste/models/distillation.py:179
+ * (blocks/conv.py:5-32).  out[p, out_co + n] = relu(W3 relu(W2 relu(W1 in[p] + b1) + b2) + b3): the hidden activations stay in the
+ * accumulator registers of the wave that owns the pixel, split-operand bf16 products as creste_conv2d_nhwc (CRESTE_PREC_BF16X6 /
+ * _BF16X3; Cin a multiple of 32).  wimg: the three weight matrices as MFMA operand tiles, [Cin / 16 + 16 steps][pieces][2][128][8] bf16 -- first layer in
+ * channel order, layers two and three in the channel order of the accumulator layout (step 2t + j, k-octet h: channels
+ * 32t + 16j + {4h + e, 8 + 4h + e}, e < 4); creste_conv1x1_chain3_weight_bytes(Cin, prec) bytes.  bias [3][128] fp32. */
+int64_t creste_conv1x1_chain3_weight_bytes(int Cin, int prec);
+int creste_conv1x1_chain3_f32(const float* in, int in_cs, int64_t P, int Cin, const void* wimg, const float* bias, int prec, float* out,
+                              int out_cs, int out_co, void* stream);
 /* Second half of `Upsample(x2, bilinear, align_corners=False) -> conv3x3(pad 1)` run as phase convolutions on the low-resolution
  * map (reference DeconvHead.up2, inpainting.py:56-60): after creste_conv2d_nhwc with CRESTE_CONV_REPLICATE_PAD | CRESTE_CONV_PHASE2X
  * and the composed 4 x Cout kernels, the outermost ring of `out` [N, 2H, 2W, out_cs] still contains the taps the high-resolution

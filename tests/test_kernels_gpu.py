@@ -618,6 +618,50 @@ def test_conv_winograd4_fused_upsample_concat(ops, N, C1, C2, H1, W1, Cout):
     assert lazy._mat is not None and ops.conv2d(lazy, pcd).buf.shape == y.buf.shape
 
 
+@pytest.mark.parametrize("N,Cin,H,W,prec", [
+    (2, 256, 19, 38, "bf16x6"),            # the distillation head's widths (reference distillation.py:179), ragged last workgroup
+    (1, 96, 16, 16, "bf16x6"),             # a narrow first layer: three steps (a partial group of the four-deep input prefetch)
+    (3, 256, 8, 32, "bf16x3"),
+])
+def test_conv1x1_chain_of_three_layers_in_one_kernel(ops, N, Cin, H, W, prec):
+    """MultiLayerConv(kernels [1,1,1], dims [Cin,128,128,128]): three 1x1 conv(+bias) + BatchNorm(eval) + ReLU layers as ONE launch whose
+    hidden activations stay in the accumulator registers (creste_conv1x1_chain3_f32) -- against float64, against the three launches
+    of the 1x1 engine it replaces (same piece products, another summation order), and into a channel slice."""
+    import torch.nn.functional as F
+    P = getattr(ops, "PREC_" + prec.upper())
+    g = torch.Generator().manual_seed(Cin + H)
+    xt = torch.randn(N, Cin, H, W, generator=g)
+    dims = [Cin, 128, 128, 128]
+    layers, ref = [], xt.double()
+    for i in range(3):
+        w = torch.randn(dims[i + 1], dims[i], 1, 1, generator=g) / dims[i] ** 0.5
+        b = torch.randn(128, generator=g) * 0.2
+        gamma, beta = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.3
+        mean, var = torch.randn(128, generator=g) * 0.2, torch.rand(128, generator=g) + 0.5
+        layers.append((dev(w), dev(b), (dev(gamma), dev(beta), dev(mean), dev(var), 1e-5)))
+        scale = gamma.double() / torch.sqrt(var.double() + 1e-5)
+        ref = torch.relu((F.conv2d(ref, w.double(), b.double()) - mean.double()[None, :, None, None]) * scale[None, :, None, None]
+                         + beta.double()[None, :, None, None])
+    x = to_act(ops, xt)
+    assert ops.conv1x1_chain3_supported(P, dims)
+    pk = ops.pack_conv1x1_chain3(layers, P)
+    y = ops.conv1x1_chain3(x, pk)
+    got = y.nchw().double().cpu()
+    tol = 1e-5 if prec == "bf16x6" else 2e-3
+    assert float((got - ref).abs().max()) < tol * float(ref.abs().max()), float((got - ref).abs().max())
+    z = x
+    for (w, b, bn) in layers:
+        z = ops.conv2d(z, ops.pack_conv(w, b, bn, 1, 0, ops.ACT_RELU, P))
+    assert float((z.buf - y.buf).abs().max()) < 2 * tol * float(ref.abs().max())
+    wide = ops.Act(torch.full((N, H, W, 140), 5.0, device="cuda"), 128, 8)
+    ops.conv1x1_chain3(x, pk, out=wide)
+    assert torch.equal(wide.buf[..., 8:136], y.buf) and bool((wide.buf[..., :8] == 5).all()) and bool((wide.buf[..., 136:] == 5).all())
+    # the input as a channel slice of a wider buffer (the encoder's 288-channel fusion buffer holds the head's input)
+    xw = ops.Act(torch.randn(N, H, W, Cin + 32, device="cuda"), Cin, 16)
+    xw.buf[..., 16:16 + Cin] = x.buf
+    assert torch.equal(ops.conv1x1_chain3(xw, pk).buf, y.buf)
+
+
 @pytest.mark.parametrize("N,Cin,Cout,H,W,prec", [
     (2, 256, 128, 16, 24, "bf16x6"),       # DeconvHead.up2's channel counts, whole tiles
     (1, 64, 8, 5, 7, "bf16x6"),            # odd extents: partial tiles, every ring pixel near a corner, Cout of two quads
