@@ -1020,13 +1020,16 @@ def main():
                 gemms = sum(v["launches"] for k, v in fam.items() if "gemm32" in k)
                 if gemms:
                     traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fam.values()) / gemms
-                    traffic_note = (f"PMC (profiles/roofline_counters.json: {cnt.get('_source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --parts 1')}): "
+                    traffic_note = (f"CONSTANT of the committed profile, not of this run: PMC (profiles/roofline_counters.json: {cnt.get('_source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --parts 1')}; "
+                                    f"commit {cnt.get('_commit')}, box {cnt.get('_box')}; {cnt.get('_launch_check', 'launch counts unchecked')}): "
                                     f"HBM bytes of all {len(fam)} kernels of the F(4x4,3x3) family / {gemms} conv calls, i.e. the average over "
-                                    "the step's 19 calls of both GEMM tile widths")
+                                    "the step's calls of both GEMM tile widths")
             except Exception:
                 traffic = None
-        pm = os.path.join(ROOT, "profiles", "r05_pmc_encoder.json")
-        if os.path.exists(pm):
+        import glob
+        pms = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_encoder.json")))      # the newest round's table
+        pm = pms[-1] if pms else ""
+        if pm and os.path.exists(pm):
             try:
                 mfma_busy = json.load(open(pm))
             except Exception:

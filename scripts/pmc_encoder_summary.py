@@ -64,6 +64,6 @@ json.dump({"gemm": _frac("wino4_gemm32_kernel<3, 4"), "gemm_128_cout_tile": _fra
            "encoder": _frac("ENCODER"), "whole_step": _frac("WHOLE STEP"),
            "note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) per kernel family of ONE inference step of "
                    "bench.py --parts 1 (batch 16, bf16x6), two rocprofv3 --pmc passes (scripts/pmc_encoder.sh, table: "
-                   "profiles/r05_pmc_encoder.txt); gemm = wino4_gemm32_kernel<3, 4> (256-cout tiles, 15 of the 19 calls), encoder = "
-                   "every kernel from nchw4_to_nhwc to pixel_geometry"},
-          open(sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/r05_pmc_encoder.json", "w"), indent=1)
+                   "profiles/<tag>_pmc_encoder.txt); gemm = wino4_gemm32_kernel<3, 4> (256-cout tiles, 18 of the 19 calls), encoder = "
+                   "every kernel from nchw4_to_nhwc to pixel_geometry; a CONSTANT of the committed profile, not of the run that prints it"},
+          open(sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/r06_pmc_encoder.json", "w"), indent=1)

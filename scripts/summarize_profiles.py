@@ -41,7 +41,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 d[1] += float(row["Counter_Value"])
         ids = sorted(disp)
         marks = [i for i in ids if "lidar_depth_kernel" in disp[i][0]]
-        lo, hi = (marks[-2], marks[-1]) if len(marks) >= 2 else (ids[0], ids[-1] + 1)
+        assert len(marks) >= 2, f"{c}: fewer than two steps in the PMC run -- no steady-state step to take (scripts/profile_gpu.sh)"
+        lo, hi = marks[-2], marks[-1]
         for i in ids:
             if lo <= i < hi:
                 k = short(disp[i][0])
@@ -76,6 +77,31 @@ out["_note"] = (f"per-launch averages over ONE step of bench.py --parts 1 (batch
                 + ("calibrated on this box against known byte counts (scripts/pmc_calib.sh)" if calib else
                    "defaults: the gfx950 FETCH_SIZE x2 correction of the guide, WRITE_SIZE as reported"))
 out["_source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --parts 1, tag {tag}"
+# the counters must be those of exactly the step scripts/step_table.sh tabulated: same kernels, same launch counts (VERDICT r05
+# item 7: the r05 file carried the pack / calibration launches of a one-step run)
+import re
+import subprocess
+st = os.path.join(ROOT, "gpurun_out", f"step_{tag}", "step_table.md")
+if os.path.exists(st):
+    table = {}
+    for ln in open(st):
+        m = re.match(r"\| `([^`]+)` \| (\d+) \|", ln)
+        if m:
+            table[m.group(1)] = int(m.group(2))
+    fam = lambda k: re.match(r"([\w:]+(?:<[^(]*>)?)", k).group(1)[:70]
+    got = {}
+    for k, v in counters.items():
+        got[fam(k)] = got.get(fam(k), 0) + v["launches"]
+    # (the table lists the step's top 40 kernels; a kernel below its cut -- one tiny launch -- is only in the PMC pass)
+    bad = {k: (table.get(k), got.get(k)) for k in table if table.get(k) != got.get(k) and not k.startswith(("at::", "__amd_rocclr"))}
+    assert not bad, f"PMC step and step table disagree on launches (table, PMC): {bad}"
+    out["_launch_check"] = f"launch counts of the {len(table)} kernel families of the step table equal gpurun_out/step_{tag}/step_table.md (profiles/{tag}_step_table.md)"
+try:
+    out["_commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+except Exception:
+    out["_commit"] = None
+bx = os.path.join(src, "box.txt")
+out["_box"] = " / ".join(l.strip() for l in open(bx)) if os.path.exists(bx) else None
 if calib:
     out["_calibration"] = calib
 json.dump(out, open(os.path.join(dst, "roofline_counters.json"), "w"), indent=1, sort_keys=True)
