@@ -83,7 +83,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
-def build_variant(tag: str, pk_sources=(), verbose: bool = True) -> str:
+def build_variant(tag: str, pk_sources=(), verbose: bool = True, extra_flags=()) -> str:
     """An EXPERIMENT library lib/libcreste_hip_<tag>.so: the same sources, `pk_sources` compiled WITH packed-fp32 VALU allowed
     (scripts/pk_hazard.sh: is the corruption of round 4 still there, and in which file).  Load it with CRESTE_HIP_LIB=<path>.
     Never the shipped library: tests/test_abi.py disassembles lib/libcreste_hip.so only."""
@@ -96,7 +96,7 @@ def build_variant(tag: str, pk_sources=(), verbose: bool = True) -> str:
         if src in pk_sources:
             op = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
             flags = [f for f in FLAGS if f not in NO_PK]
-            cmd = [hipcc, *flags, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", os.path.join(CSRC, src), "-o", op]
+            cmd = [hipcc, *flags, *EXTRA_FLAGS.get(src, []), *extra_flags, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", op]
             if verbose:
                 print("[creste build]", " ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

@@ -31,6 +31,28 @@ struct MbArgs {
 // these kernels are VALU-bound -- a * b + c as two instructions doubled their arithmetic
 __device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x4 fma4(f32x4 a, float b, f32x4 c) { return __builtin_elementwise_fma(a, f32x4{b, b, b, b}, c); }
+// CRESTE_MB_BISECT (scripts/micro/pk_pair.sh, a build WITH packed fp32, experiment only): 1 = the expand stage's FMAs as four scalar
+// fmaf (the packed build then has v_pk_fma_f32 with a broadcast operand -- op_sel -- nowhere in the fused kernel), 2 = the depthwise
+// stage's, 3 = the swish's multiply; which stage's packed instructions are the ones that go wrong beside another kernel's MFMAs
+#ifndef CRESTE_MB_BISECT
+#define CRESTE_MB_BISECT 0
+#endif
+// 4: the expand stage's FMAs stay PACKED but without operand-half selection: the broadcast pair {b, b} is materialised in a register pair
+// (opaque to the optimiser) and the instruction is a plain v_pk_fma_f32 -- op_sel or not is then the only difference to variant 0
+typedef float mbf32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 fma4b(f32x4 a, float b, f32x4 c) {
+  mbf32x2 bb = {b, b};
+  asm volatile("" : "+v"(bb));
+  const mbf32x2 lo = __builtin_elementwise_fma(mbf32x2{a[0], a[1]}, bb, mbf32x2{c[0], c[1]});
+  const mbf32x2 hi = __builtin_elementwise_fma(mbf32x2{a[2], a[3]}, bb, mbf32x2{c[2], c[3]});
+  return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ f32x4 fma4s(f32x4 a, f32x4 b, f32x4 c) {
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { float t; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(a[i]), "v"(b[i]), "v"(c[i])); r[i] = t; }
+  return r;
+}
 
 // swish on the hardware transcendentals: v * rcp(1 + exp2(-v * log2 e)) -- v_exp_f32 and v_rcp_f32 are 1-ulp
 // instructions; expf + an IEEE division cost ~25 VALU instructions per value, and this kernel is VALU-bound (the two
@@ -104,7 +126,8 @@ __global__ __launch_bounds__(256, MINB) void mbconv_expand_dw_kernel(const MbArg
           for (int kq = 0; kq < CQ; ++kq) {
             const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + 4 * kq);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = fma4(wq[4 * kq + j], xv[j], acc);
+            for (int j = 0; j < 4; ++j) acc = (CRESTE_MB_BISECT & 1) ? fma4s(wq[4 * kq + j], f32x4{xv[j], xv[j], xv[j], xv[j]}, acc)
+                                                                  : (CRESTE_MB_BISECT & 4) ? fma4b(wq[4 * kq + j], xv[j], acc) : fma4(wq[4 * kq + j], xv[j], acc);
           }
           acc = swish4(acc);
         }
@@ -123,7 +146,9 @@ __global__ __launch_bounds__(256, MINB) void mbconv_expand_dw_kernel(const MbArg
         for (int ky = 0; ky < K; ++ky) {
           const float* rp = ring + (((r0 + ky) % K) * IW + ox * S) * Cexp + 4 * q;
 #pragma unroll
-          for (int kx = 0; kx < K; ++kx) acc = fma4(*reinterpret_cast<const f32x4*>(rp + kx * Cexp), dwq[ky * K + kx], acc);
+          for (int kx = 0; kx < K; ++kx)
+            acc = (CRESTE_MB_BISECT & 2) ? fma4s(*reinterpret_cast<const f32x4*>(rp + kx * Cexp), dwq[ky * K + kx], acc)
+                                         : fma4(*reinterpret_cast<const f32x4*>(rp + kx * Cexp), dwq[ky * K + kx], acc);
         }
         acc = swish4(acc);
 #pragma unroll
