@@ -155,9 +155,33 @@ class ConvProfiler:
         import creste_public_amd.hipnn as hipnn
         ops.conv2d = timed
         hipnn.ops.conv2d = timed
+        self._orig_up, self._orig_chain = ops.upconv2x, ops.conv1x1_chain3
+
+        def timed_up(x, pu, **kw):
+            # Upsample(x2) -> conv3x3 as phase convolutions: one F(4x4,3x3) call of the same kernels (+ the ring fix); FLOPs = the
+            # reference operator's, a direct 3x3 conv over the UPSAMPLED map
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = prof._orig_up(x, pu, **kw)
+            e1.record()
+            flops = 2.0 * y.N * y.H * y.W * pu.Cout * pu.phase.Cin * 9
+            prof.records.append((e0, e1, flops, kernel_symbol(pu.phase, x.N, x.H, x.W), (pu.phase.Cin, pu.Cout, 3, y.H, y.W)))
+            return y
+
+        def timed_chain(x, pk, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = prof._orig_chain(x, pk, **kw)
+            e1.record()
+            flops = 2.0 * y.N * y.H * y.W * 128 * (pk.Cin + 256)
+            prof.records.append((e0, e1, flops, (PREC_NAME[pk.prec], f"conv1x1_chain3_kernel<{3 if pk.prec == 3 else 2}>"),
+                                 (pk.Cin, 128, 1, y.H, y.W)))
+            return y
+        ops.upconv2x, ops.conv1x1_chain3 = timed_up, timed_chain
 
     def uninstall(self):
         self._ops.conv2d = self._orig
+        self._ops.upconv2x, self._ops.conv1x1_chain3 = self._orig_up, self._orig_chain
         self._ops.bev_splat_plan, self._ops.bev_splat_gather = self._orig_plan, self._orig_gather
         self._ops.bev_splat_plan_keyed = self._orig_plan_keyed
 
@@ -223,14 +247,33 @@ def gemm_kernel_probe(step):
         alg += 2.0 * y.N * y.H * y.W * pc.Cout * pc.Cin * 9
         calls += 1
         return y
+    orig_up = ops.upconv2x
+
+    def probed_up(x, pu, **kw):
+        nonlocal ms_tot, raw, alg, calls
+        lib.creste_conv_wino4_gemm_probe(1)
+        y = orig_up(x, pu, **kw)
+        lib.creste_conv_wino4_gemm_probe(0)
+        ms = C.c_float(0.0)
+        _lib.check(lib.creste_conv_wino4_gemm_last_ms(C.byref(ms)), "gemm_last_ms")
+        pc = pu.phase
+        T = x.N * ((x.H + 3) // 4) * ((x.W + 3) // 4)
+        mp, kp, np_ = (T + 255) // 256 * 256, (pc.Cin + 15) // 16 * 16, (pc.Cout + 255) // 256 * 256
+        ms_tot += ms.value
+        raw += 36.0 * mp * kp * np_ * 2.0 * {2: 3, 3: 6}[pc.prec]
+        alg += 2.0 * y.N * y.H * y.W * pu.Cout * pc.Cin * 9
+        calls += 1
+        return y
     ops.conv2d = probed
     hipnn.ops.conv2d = probed
+    ops.upconv2x = probed_up
     try:
         step()
         torch.cuda.synchronize()
     finally:
         ops.conv2d = orig
         hipnn.ops.conv2d = orig
+        ops.upconv2x = orig_up
     if not calls:
         return None
     return {"kernel": "wino4_gemm32_kernel<SPLIT, TN> (the GEMM kernel of every F(4x4,3x3) conv call of one step)",
@@ -240,7 +283,7 @@ def gemm_kernel_probe(step):
             "algorithmic_tflops": round(alg / (ms_tot * 1e-3) / 1e12, 1),
             "note": "HIP events around the GEMM kernel alone (library probe), one untimed step after the timed ones; "
                     "piece products = 36 positions x padded tiles x padded Cin x padded Cout x 2 x pieces, issued on "
-                    "v_mfma_f32_32x32x16_bf16 (dense peak 2500 TFLOP/s); SQ_VALU_MFMA_BUSY_CYCLES of this kernel: roofline.mfma_busy_gemm (profiles/r05_pmc_encoder.txt)"}
+                    "v_mfma_f32_32x32x16_bf16 (dense peak 2500 TFLOP/s); SQ_VALU_MFMA_BUSY_CYCLES of this kernel: roofline.mfma_busy_gemm (profiles/r06_pmc_encoder.txt)"}
 
 
 def cpu_baseline(batches=(1, 16), runs=5, budget_s=210.0):
