@@ -556,7 +556,10 @@ def test_value_iteration(ops, golden, name):
     r = g.t("r")[:, 0]
     v, q, pi, sweeps = ops.value_iteration(dev(r), float(g["discount"]), float(g["threshold"]))
     n = int(sweeps.item())
-    assert abs(n - int(g["sweeps"])) <= 1, (n, int(g["sweeps"]))
+    # EXACTLY the reference loop's count (vin.py:68-74) on the reference-generated reward maps: 683 / 688 sweeps.  (The count is an
+    # integer the rounding can move: the same loop in float64 stops after 682 / 686, scripts/vi_golden_sweeps.py -- which is why the
+    # end-to-end model test, whose reward map itself differs from the oracle's at float-noise level, accepts +-1.)
+    assert n == int(g["sweeps"]), (n, int(g["sweeps"]))
     torch.testing.assert_close(v.cpu(), g.t("v")[:, 0], rtol=2e-5, atol=2e-3)
     torch.testing.assert_close(q.cpu(), g.t("q"), rtol=2e-5, atol=2e-3)
     torch.testing.assert_close(pi.cpu(), g.t("policy"), rtol=0, atol=1e-4)
