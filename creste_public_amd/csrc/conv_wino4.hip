@@ -73,12 +73,18 @@ struct Wino4GemmArgs {
   int nchunk, m_blocks, tiles_n, units;
   int npos;                  // 36 (forward) or 36 x K-segments (weight gradient)
   long mplane;               // floats between the product planes of two positions (>= Cout * T)
+  int mbg;                   // tile blocks per unit: min(W4_MBG, m_blocks) -- see the item comment below
 };
 
-// Item = (tile block, position, cout tile).  Items are dealt in UNITS of 32 = 8 panels (position, cout tile) x W4_MBG
-// tile blocks; unit u goes to XCD u % 8 (workgroup b sits on XCD b % 8) and its 32 items to that XCD's workgroups, so a
-// weight panel streams through the XCD's L2 once for four tile blocks and a V tile once for its cout tiles.  Placement
-// is speed only.
+// Item = (tile block, position, cout tile).  Items are dealt in UNITS of 8 panels (position, cout tile) x mbg tile blocks
+// (mbg = W4_MBG = 4 for every map with at least four tile blocks); unit u goes to XCD u % 8 (workgroup b sits on XCD b % 8) and
+// its items to that XCD's workgroups, so a weight panel streams through the XCD's L2 once for four tile blocks and a V tile once
+// for its cout tiles.  Placement is speed only.
+// Round 6: with FEWER than four tile blocks -- the weight gradient's GEMMs, whose rows are the <= 496 input CHANNELS = two blocks,
+// and batch-1 maps -- units of 32 slots left (4 - m_blocks) / 4 of the slots as holes, and because a workgroup's slot advances by a
+// multiple of 32 it met the SAME hole every time: with two blocks half of the chip's workgroups never received an item (the
+// weight-gradient GEMMs ran at half speed: 1.93 ms per call against 0.95 for the forward's same products).  The unit now has
+// 8 x min(4, m_blocks) slots, none of them a hole.
 //
 // AF32: the A operand (transformed input) arrives as fp32, [k-quad][256 rows][4 floats] per chunk (2/3 of the bytes of the
 // three bf16 pieces, in HBM and through the LDS-DMA), and every wave splits its own 64 rows into the bf16 pieces in
@@ -109,7 +115,8 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_kernel(const Wino4GemmArgs 
 
   const int cus = gridDim.x >> 3;
   const int xcd = blockIdx.x & 7, P = p.npos * p.tiles_n;
-  const int units_pg = (P + 7) >> 3, nunits = units_pg * ((p.m_blocks + W4_MBG - 1) / W4_MBG);
+  const int mbg = p.mbg, us = 8 * mbg;
+  const int units_pg = (P + 7) >> 3, nunits = units_pg * ((p.m_blocks + mbg - 1) / mbg);
   int slot = blockIdx.x >> 3;
 
   int mb, pos, tn;
@@ -117,11 +124,11 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm_kernel(const Wino4GemmArgs 
   // -> true when `slot` names an item (advancing over the holes of ragged units), false at the end
   auto setup = [&]() __attribute__((always_inline)) -> bool {
     for (;; slot += cus) {
-      const int unit = (slot >> 5) * 8 + xcd, w = slot & 31;
+      const int su = slot / us, unit = su * 8 + xcd, w = slot - su * us;
       if (unit >= nunits) return false;
       const int mg = unit / units_pg, pg = unit - mg * units_pg;   // panel groups fastest: neighbouring XCDs share V tiles in the MALL
       const int pnl = pg * 8 + (w & 7);
-      mb = mg * W4_MBG + (w >> 3);
+      mb = mg * mbg + (w >> 3);
       if (pnl >= P || mb >= p.m_blocks) continue;
       pos = pnl / p.tiles_n; tn = pnl - pos * p.tiles_n;
       abase_g = p.V + ((size_t)pos * p.m_blocks + mb) * p.nchunk * A_BYTES;
@@ -290,18 +297,19 @@ __global__ __launch_bounds__(512, 2) void wino4_gemm32_kernel(const Wino4GemmArg
 
   const int cus = gridDim.x >> 3;
   const int xcd = blockIdx.x & 7, P = p.npos * p.tiles_n;
-  const int units_pg = (P + 7) >> 3, nunits = units_pg * ((p.m_blocks + W4_MBG - 1) / W4_MBG);
+  const int mbg = p.mbg, us = 8 * mbg;
+  const int units_pg = (P + 7) >> 3, nunits = units_pg * ((p.m_blocks + mbg - 1) / mbg);
   int slot = blockIdx.x >> 3;
 
   struct Item { int mb, pos, tn; const char* a; const char* w; };
   // -> true when `slot` names an item (advancing over the holes of ragged units), false at the end
   auto setup = [&](Item& it) __attribute__((always_inline)) -> bool {
     for (;; slot += cus) {
-      const int unit = (slot >> 5) * 8 + xcd, w = slot & 31;
+      const int su = slot / us, unit = su * 8 + xcd, w = slot - su * us;
       if (unit >= nunits) return false;
       const int mg = unit / units_pg, pg = unit - mg * units_pg;   // panel groups fastest: neighbouring XCDs share V tiles in the MALL
       const int pnl = pg * 8 + (w & 7);
-      it.mb = mg * W4_MBG + (w >> 3);
+      it.mb = mg * mbg + (w >> 3);
       if (pnl >= P || it.mb >= p.m_blocks) continue;
       it.pos = pnl / p.tiles_n; it.tn = pnl - it.pos * p.tiles_n;
       it.a = p.V + ((size_t)it.pos * p.m_blocks + it.mb) * p.nchunk * A_BYTES;
@@ -1324,6 +1332,7 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
   a.V = V; a.wpk = (const char*)d->wpk; a.M = M; a.T = (int)T; a.Cout = d->Cout;
   a.nchunk = nchunk; a.m_blocks = m_blocks; a.units = wino4_units(d->Cout); a.npos = W4_POS;
   a.mplane = wino4_mplane(T, d->Cout);
+  a.mbg = m_blocks < W4_MBG ? m_blocks : W4_MBG;
   const int tn = d->Cout > 128 ? 4 : 2;
   a.tiles_n = (d->Cout + 64 * tn - 1) / (64 * tn);
   int rc;
@@ -1617,6 +1626,7 @@ int conv_wgrad_wino4_run(const float* x, int x_cs, const float* gy, int gy_cs, f
   Wino4GemmArgs a;
   a.V = Aimg; a.wpk = Bimg; a.M = M; a.T = Cin; a.Cout = Cout; a.nchunk = nchunk; a.m_blocks = mbl; a.units = units;
   a.npos = W4_POS * seg; a.mplane = (long)Cout * Cin;
+  a.mbg = mbl < W4_MBG ? mbl : W4_MBG;
   const int tn = Cout > 128 ? 4 : 2;
   a.tiles_n = (Cout + 64 * tn - 1) / (64 * tn);
   const int rc = tn == 4 ? launch_wino4_gemm<3, 4>(a, s) : launch_wino4_gemm<3, 2>(a, s);
