@@ -625,6 +625,7 @@ def test_conv_winograd4_fused_upsample_concat(ops, N, C1, C2, H1, W1, Cout):
     (2, 256, 19, 38, "bf16x6"),            # the distillation head's widths (reference distillation.py:179), ragged last workgroup
     (1, 96, 16, 16, "bf16x6"),             # a narrow first layer: three steps (a partial group of the four-deep input prefetch)
     (3, 256, 8, 32, "bf16x3"),
+    (16, 256, 152, 304, "bf16x6"),         # BASELINE configs[1]: the distillation head at batch 16 of 608 x 1216 (152 x 304 maps)
 ])
 def test_conv1x1_chain_of_three_layers_in_one_kernel(ops, N, Cin, H, W, prec):
     """MultiLayerConv(kernels [1,1,1], dims [Cin,128,128,128]): three 1x1 conv(+bias) + BatchNorm(eval) + ReLU layers as ONE launch whose
@@ -671,6 +672,7 @@ def test_conv1x1_chain_of_three_layers_in_one_kernel(ops, N, Cin, H, W, prec):
     (3, 128, 132, 33, 18, "bf16x6"),       # Cout = 33 quads per phase (528 phase channels), sides longer than one 32-pixel chunk
     (1, 64, 16, 2, 2, "bf16x6"),           # the smallest map: the 4 x 4 output is ring + corners only... plus 2 x 2 interior
     (2, 256, 128, 32, 32, "bf16x3"),
+    (16, 256, 128, 128, 128, "bf16x6"),    # BASELINE configs[1]: the three BEV heads' up2 at batch 16 (128 x 128 -> 256 x 256)
 ])
 def test_upsample_conv3x3_as_phase_convolutions(ops, N, Cin, Cout, H, W, prec):
     """`nn.Upsample(scale_factor=2, bilinear, align_corners=False) -> nn.Conv2d(3, padding=1) -> BatchNorm (eval) -> ReLU` (reference
