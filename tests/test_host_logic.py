@@ -266,3 +266,53 @@ def test_value_iteration_sweep_count_contract_and_prefetch_key():
     assert not MaxEntIRL._same_inputs(key, (b, p))
     a.add_(1.0)                                    # same tensor, written since the prefetch
     assert not MaxEntIRL._same_inputs(key, (a, p))
+
+
+def test_upsample_conv_as_phase_convolutions_identity_in_float64():
+    """The algebra behind ops.upconv2x (reference DeconvHead.up2, inpainting.py:56-60: Upsample(x2, bilinear, align_corners=False) ->
+    Conv2d(3, padding=1)), in float64 on the CPU, no kernels:
+    (a) ops.phase_upconv_weights: the conv over the upsampled image == the 3x3 conv with the composed 4 x Cout kernels on the
+        replicate-padded low-resolution image, phase (a, b) of pixel (y, x) being pixel (2y + a, 2x + b) -- exactly, away from the border;
+    (b) on the outermost ring the two differ by the taps whose source lies outside the upsampled image (zero there, the replicate-padded
+        interpolation in the phase form): subtracting w[ky, kx] * u~(source) for exactly those taps -- what
+        creste_upconv2x_ring_fix_f32 does, u~ = the bilinear formula with an UNCLAMPED source coordinate on clamped indices -- restores
+        equality everywhere, corners included."""
+    import math
+    import torch.nn.functional as F
+    from creste_public_amd import ops
+    torch.manual_seed(0)
+    H, W, Cin, Cout = 5, 6, 2, 3
+    x = torch.randn(1, Cin, H, W, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, 3, 3, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False), w, padding=1)
+    R = torch.tensor([[[0.75, 0.25, 0.0], [0.25, 0.75, 0.0], [0.0, 0.75, 0.25]],
+                      [[0.25, 0.75, 0.0], [0.0, 0.75, 0.25], [0.0, 0.25, 0.75]]], dtype=torch.float64)
+    wp = torch.einsum("ayp,bxq,oiyx->aboipq", R, R, w).reshape(4 * Cout, Cin, 3, 3)
+    # the packer composes the same kernels (in float64, rounded once to fp32)
+    assert torch.allclose(ops.phase_upconv_weights(w.float()).double(), wp, rtol=0, atol=2e-7 * float(wp.abs().max()))
+    ph = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="replicate"), wp)
+    out = torch.zeros_like(ref)
+    for a in range(2):
+        for b in range(2):
+            out[:, :, a::2, b::2] = ph[:, (2 * a + b) * Cout:(2 * a + b + 1) * Cout]
+    d = (out - ref).abs()
+    assert float(d[:, :, 1:-1, 1:-1].max()) < 1e-12 and float(d.max()) > 1e-3          # exact inside, wrong on the ring
+
+    def u_tilde(Y, X):
+        sy, sx = 0.5 * (Y + 0.5) - 0.5, 0.5 * (X + 0.5) - 0.5
+        y0, x0 = math.floor(sy), math.floor(sx)
+        fy, fx = sy - y0, sx - x0
+        cl = lambda v, n: min(max(v, 0), n - 1)
+        ya, yb, xa, xb = cl(y0, H), cl(y0 + 1, H), cl(x0, W), cl(x0 + 1, W)
+        return (1 - fy) * ((1 - fx) * x[0, :, ya, xa] + fx * x[0, :, ya, xb]) + fy * ((1 - fx) * x[0, :, yb, xa] + fx * x[0, :, yb, xb])
+
+    H2, W2 = 2 * H, 2 * W
+    for oy in range(H2):
+        for ox in range(W2):
+            if oy in (0, H2 - 1) or ox in (0, W2 - 1):
+                for ky in range(3):
+                    for kx in range(3):
+                        Y, X = oy + ky - 1, ox + kx - 1
+                        if not (0 <= Y < H2 and 0 <= X < W2):
+                            out[0, :, oy, ox] -= w[:, :, ky, kx] @ u_tilde(Y, X)
+    assert float((out - ref).abs().max()) < 1e-12
