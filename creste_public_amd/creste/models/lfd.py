@@ -218,9 +218,10 @@ class MaxEntIRL(nn.Module):
 
     def prefetch_backbone(self, inputs):
         """Enqueue the frozen half of `forward(inputs)` on a side stream; the next `forward` with the SAME input tensors
-        (same storage, same version) picks the result up instead of recomputing it.  Returns immediately.  Call it AFTER
-        the current batch's forward (i.e. behind its value iteration, as IRLTrainer does): the persistent MDP solver
-        needs all of its workgroups resident and must not share the device with a stream of full-chip kernels."""
+        (same storage, same version) picks the result up instead of recomputing it.  Returns immediately.  IRLTrainer calls it
+        right after it has picked up the CURRENT batch's prefetched half, ahead of the reward forward and the MDP solve (round 6:
+        the barrier-free solver only waits for its halo neighbours, with bounded polls, and was never seen to abort beside the
+        backbone's kernels -- 0 of 276 solves; a solve that reports INT32_MIN is redone in the launch-per-chunk form)."""
         image, p2p = inputs[0], inputs[1]
         require_hip(image, "MaxEntIRL")
         main = torch.cuda.current_stream(image.device)

@@ -16,6 +16,8 @@ from __future__ import annotations
 import random
 
 import numpy as np
+import os
+
 import torch
 
 from . import dist_utils, ops
@@ -89,12 +91,21 @@ class IRLTrainer:
                 if getattr(self.model, "_prefetched", None) is None:          # first step: nothing in flight yet
                     self.model.prefetch_backbone(inputs)
                 pf = self.model._take_prefetched(inputs)                      # (waits for the side stream's event)
+                # Where the next frozen half is enqueued.  Round 3 put it BEHIND the value iteration: its solver met at a
+                # device-scope rendezvous and, next to a stream of full-chip conv kernels, its unscheduled workgroups starved
+                # while the resident ones spun (a 57 ms step took minutes).  The barrier-free solver of round 4 only waits for
+                # its halo neighbours, with bounded polls, and gets its CUs as the backbone's workgroups retire.  Round 6
+                # (scripts/irl_early.py): enqueued right HERE, before the reward forward and the solve, the backbone also
+                # runs under those and the step becomes the backbone's own time -- reference grid 21.4 -> 20.45 ms, cf-IRL
+                # 512^2 32.25 -> 31.3, 256^2 MDP grid 34.6 -> 34.4, with or without the priority stream, 0 aborted solves of
+                # 276.  A solve that does report INT32_MIN is redone below in the launch-per-chunk form, which needs no
+                # co-residency.  CRESTE_IRL_LATE_PREFETCH=1 restores the old order.
+                early = os.environ.get("CRESTE_IRL_LATE_PREFETCH") != "1"
+                if early:
+                    self.model.prefetch_backbone((nxt["image"], nxt["p2p"]))
                 outputs = self.model._forward_trainable(inputs, pf)           # reward forward, value iteration, SVF
-                # the next frozen half is enqueued BEHIND the value iteration (the side stream waits for this point of the
-                # main stream): the persistent solver synchronises its workgroups on the device and needs them all
-                # resident -- next to a stream of full-chip conv kernels its unscheduled workgroups starve while the
-                # resident ones spin (measured: a 57 ms step took minutes).  It overlaps loss / backward / Adam instead.
-                self.model.prefetch_backbone((nxt["image"], nxt["p2p"]))
+                if not early:
+                    self.model.prefetch_backbone((nxt["image"], nxt["p2p"]))
             else:
                 outputs = self.model(inputs)
             loss_dict, meta, loss = self._loss_and_backward(task, data, outputs)

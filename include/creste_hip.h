@@ -396,10 +396,12 @@ int creste_bev_splat_gather_f32(const float* feats, int feats_cs, int B, int P, 
  *   work: creste_value_iteration_workspace_bytes(B,H,W) bytes.
  * Asynchronous on `stream` like every other entry point: the whole iteration is ONE persistent launch that decides
  * convergence on the device (hipGraph-capturable).  A solve that hits max_sweeps therefore cannot come back as a return
- * code: it leaves *sweeps_out = -(sweeps run) and the last iterate in v / q / policy.  The persistent launch synchronises
- * its workgroups on the device, so they must all become resident: do NOT overlap this call with long-running full-chip
- * kernels on another stream (its unscheduled workgroups starve while the resident ones spin; CRESTE_VI_MULTI=1 selects
- * the launch-per-chunk form, which has no such requirement).  Only grids too large for all their
+ * code: it leaves *sweeps_out = -(sweeps run) and the last iterate in v / q / policy.  The persistent launch's workgroups exchange
+ * their halos on the device, so they must all become resident.  Every wait is bounded: a launch that cannot get its workgroups
+ * resident in time (the device held by long-running full-chip kernels of another stream) leaves *sweeps_out = INT32_MIN and invalid
+ * outputs -- redo such a solve with creste_value_iteration_chunked_f32 (launch per chunk, no co-residency needed).  Beside the
+ * conv kernels of this library's own backbone on another stream the persistent form was never seen to give up (0 of 276 solves,
+ * scripts/irl_early.py): its workgroups take the CUs as the other kernels' workgroups retire.  Only grids too large for all their
  * 32 x 32 tiles to be resident at once (beyond about 2000 x 2000 cells per sample at batch 1) fall back to one launch per
  * chunk with host peeks, which can return CRESTE_ERR_NOCONV. */
 int64_t creste_value_iteration_workspace_bytes(int B, int H, int W);
