@@ -19,6 +19,7 @@
 // planes are a multiple of 256 B apart, so the 16-lane service groups of ds_read_b128 (which mix both
 // octets but always cover 16 row indices distinct mod 16) are conflict-free for any tap shift.
 #include "common.h"
+#include <stdlib.h>
 
 // (nontemporal output stores were measured here and LOSE: f16x3 unchanged, bf16x6 -4 %, bf16 -18 % -- the next layer finds
 // part of the map in the 256 MB Infinity Cache, which streaming stores bypass; plain stores it is)
@@ -87,6 +88,7 @@ struct PatchArgs {
   int nchunk;
   int tiles_x, tiles_y, tiles_n;
   int gate_hw;               // > 0: pixels were re-tiled as one flat image; a_scale row = linear pixel / gate_hw
+  long flat_P;               // > 0: conv1x1_deep_kernel's flat tiling -- the N*H*W pixels as one image of width 32, flat_P of them real
   float* stats;              // creste_conv_desc.out_stats ([pixel tiles][2][Cout]; 1x1 bf16-split kernels only), or nullptr
 };
 
@@ -95,10 +97,11 @@ struct PatchArgs {
 // (row = (r&3) + 8*(r>>2) + 4*(lane>>5)): registers 4g..4g+3 are 4 CONSECUTIVE output channels of one
 // pixel -> one 16-byte store (and one 16-byte residual / bias load) instead of four dword stores; the
 // store tail of a conv is issue-bound, not bandwidth-bound (cdna_hip_programming.md T21).
-template <int TN, bool F16, bool STATS = false>
-__device__ __forceinline__ void patch_epilogue(const f32x16 (&acc)[2][TN], const PatchArgs& p, int img,
+template <int TN, bool F16, bool STATS = false, int MT = 2>
+__device__ __forceinline__ void patch_epilogue(const f32x16 (&acc)[MT][TN], const PatchArgs& p, int img,
                                                int oy0, int ox0, int nbase, int wm, int wn, int li, int lh,
                                                float o_mul, float* scratch, int stat_row = 0) {
+  static_assert(!STATS || MT == 2, "statistics epilogue: 8 x 32 pixel tiles");
   float vmax = 0.f;
   f32x4 st1[TN][4], st2[TN][4];                    // STATS: this lane's pixel(s), per channel quad of its registers
   if constexpr (STATS) {
@@ -111,10 +114,11 @@ __device__ __forceinline__ void patch_epilogue(const f32x16 (&acc)[2][TN], const
                       (!p.res || (p.res_cs & 3) == 0);
   const int ox = ox0 + li;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int oy = oy0 + wm * 2 + mt;
+  for (int mt = 0; mt < MT; ++mt) {
+    const int oy = oy0 + wm * MT + mt;
     if (oy >= p.Ho || ox >= p.Wo) continue;
     const long m = ((long)img * p.Ho + oy) * p.Wo + ox;
+    if (p.flat_P && m >= p.flat_P) continue;             // flat tiling (conv1x1_deep_kernel): the last row of 32 pixels may be partial
     const float rmask = p.row_mask ? p.row_mask[m] : 1.f;
 #pragma unroll
     for (int nt = 0; nt < TN; ++nt) {
@@ -447,6 +451,151 @@ __global__ __launch_bounds__(512, (SPLIT * TN >= 6 || (ST && TN == 2)) ? 2 : PAT
   } else {
     patch_epilogue<TN, F16>(acc, p, img, oy0, ox0, tn * BN, wm, wn, li, lh, o_mul, reinterpret_cast<float*>(smem));
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1x1 convs whose launch has FEW workgroups (the MBConv expand / project convs on the 19 x 38 and 38 x 76 maps: 23 .. 180 pixel
+// tiles on 256 CUs): at most one workgroup per CU, so nothing hides a step's load latency -- conv_patch_kernel<1, ...> prefetches
+// ONE 16-channel chunk, i.e. every step of the K loop waits a full L2 / HBM round trip (72 steps for the 1152-channel project
+// convs).  Here chunk c + D is requested while chunk c is multiplied: a ring of D = 4 chunks of the A tile, of the squeeze-excite
+// gate and of the weight tile in REGISTERS (plain loads only: the compiler counts vmcnt exactly for in-order returns; beside an
+// LDS-DMA it would wait for vmcnt(0)), landed in the same double-buffered LDS images as conv_patch_kernel one step ahead of
+// their use.  Tiling is FLAT: the N*H*W pixels are one run of NHWC rows (a stride-1 1x1 conv has no halo), a tile is 128 * MT
+// consecutive pixels whatever the map's shape (19 x 38 maps pad an 8 x 32 tiling by 2.1x), and MT = 1 halves the tile where even
+// that leaves most CUs idle.  Same pieces, same MFMA order per output: results are conv_patch_kernel's bit for bit.
+// GATED: a squeeze-excite gate row per staged pixel (the pixel's image = linear pixel / gate_hw).
+template <int SPLIT, int TN, int MT, bool GATED>
+__global__ __launch_bounds__(512, 2) void conv1x1_deep_kernel(const PatchArgs p) {
+  typedef bf16x8 V8;
+  typedef bf16x4 V4;
+  constexpr int D = 4;
+  constexpr int NPIX = 128 * MT;
+  constexpr int A_OCT = NPIX * 16, A_PLANE = 2 * A_OCT, A_BYTES = SPLIT * A_PLANE;
+  constexpr int U_OCT = 64 * 16, U_PLANE = 2 * U_OCT, U_BYTES = SPLIT * U_PLANE;
+  constexpr int B_BYTES = TN * U_BYTES, B_SLOTS = B_BYTES / 16, RB = (B_SLOTS + 511) / 512;
+  constexpr int ROUNDS = MT;                    // 128 MT pixels x 4 channel quads / 512 threads
+  constexpr int NG = GATED ? ROUNDS : 0;
+  constexpr int BN = 64 * TN;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const abase = smem;
+  char* const bbase = smem + 2 * A_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;      // 4 (rows of 32 MT pixels) x 2 (channel halves)
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int nblk = p.tiles_n * p.tiles_y;
+  int id = xcd_remap(blockIdx.x, nblk);
+  const int tn = id % p.tiles_n;
+  const int ty = id / p.tiles_n;
+  const long lin0 = (long)ty * NPIX;            // first pixel of the tile
+
+  const int cq = tid & 3;
+  const int a_lofs0 = (cq >> 1) * A_OCT + (tid >> 2) * 16 + (cq & 1) * 8;
+  const float* a_src[ROUNDS];                   // the round's pixel (channel 0), or nullptr beyond the last pixel
+  const float* g_src[NG > 0 ? NG : 1];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const long lin = lin0 + r * 128 + (tid >> 2);
+    const bool ok = lin < p.flat_P;
+    a_src[r] = ok ? p.in + lin * p.in_cs : nullptr;
+    if constexpr (GATED) g_src[r] = p.a_scale + (ok ? lin / p.gate_hw : 0) * p.Cin;
+  }
+
+  const size_t nsteps_w = (size_t)p.nchunk;
+  const char* wbase = p.wpk + (size_t)tn * TN * nsteps_w * U_BYTES;
+  const char* b_src[RB];                        // this thread's 16 bytes of the step-0 weight tile; a step is U_BYTES further
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int slot = r * 512 + tid, sl = slot < B_SLOTS ? slot : 0;
+    b_src[r] = wbase + (size_t)(sl / (U_BYTES / 16)) * nsteps_w * U_BYTES + (sl % (U_BYTES / 16)) * 16;
+  }
+
+  f32x4 ra[D][ROUNDS], rg[D][NG > 0 ? NG : 1], rb[D][RB];
+  // branch-free requests (a predicated load compiles to a branch with a full vmcnt wait behind it): what lies beyond the last
+  // pixel / beyond Cin reads the tensor's first quad and is zeroed at the split
+  auto request = [&](int slot, int c) __attribute__((always_inline)) {
+    const int ch = c * PT_CK + cq * 4;
+    const bool chok = ch < p.Cin;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
+      ra[slot][r] = *reinterpret_cast<const f32x4*>(a_src[r] && chok ? a_src[r] + ch : p.in);
+#pragma unroll
+    for (int r = 0; r < NG; ++r) rg[slot][r] = *reinterpret_cast<const f32x4*>(g_src[r] + (chok ? ch : 0));
+#pragma unroll
+    for (int r = 0; r < RB; ++r) rb[slot][r] = *reinterpret_cast<const f32x4*>(b_src[r] + (size_t)c * U_BYTES);
+  };
+  auto land = [&](int slot, int c, int buf) __attribute__((always_inline)) {
+    const bool chok = c * PT_CK + cq * 4 < p.Cin;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      f32x4 v = ra[slot][r];
+      if constexpr (GATED) v *= rg[slot][r];
+      if (!(a_src[r] && chok)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      char* dst = abase + buf * A_BYTES + a_lofs0 + r * (128 * 16);
+      f32x4 rem = v;
+#pragma unroll
+      for (int pl = 0; pl < SPLIT; ++pl) {
+        const V4 piece = __builtin_convertvector(rem, V4);
+        *reinterpret_cast<V4*>(dst + pl * A_PLANE) = piece;
+        if (pl + 1 < SPLIT) rem -= __builtin_convertvector(piece, f32x4);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+      if (r * 512 + tid < B_SLOTS) *reinterpret_cast<f32x4*>(bbase + buf * B_BYTES + (r * 512 + tid) * 16) = rb[slot][r];
+  };
+
+  f32x16 acc[MT][TN];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int last = p.nchunk - 1;
+#pragma unroll
+  for (int j = 0; j < D; ++j) request(j, j < last ? j : last);
+  land(0, 0, 0);
+  __syncthreads();
+
+  for (int c0 = 0; c0 < p.nchunk; c0 += D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const int c = c0 + j;
+      if (c >= p.nchunk) break;
+      request(j, c + D < last ? c + D : last);        // slot j held chunk c, landed one step ago
+      const char* A = abase + (j & 1) * A_BYTES;
+      const char* B = bbase + (j & 1) * B_BYTES;
+      V8 af[MT][SPLIT], bfr[TN][SPLIT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int idx = (wm * MT + mt) * PT_TW + li;
+#pragma unroll
+        for (int pl = 0; pl < SPLIT; ++pl)
+          af[mt][pl] = *reinterpret_cast<const V8*>(A + pl * A_PLANE + lh * A_OCT + idx * 16);
+      }
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) {
+        const int n = (wn * TN + nt) * 32 + li;
+#pragma unroll
+        for (int pl = 0; pl < SPLIT; ++pl)
+          bfr[nt][pl] = *reinterpret_cast<const V8*>(B + (n >> 6) * U_BYTES + pl * U_PLANE + lh * U_OCT + (n & 63) * 16);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) acc[mt][nt] = split_mfma<SPLIT, V8>(bfr[nt], af[mt], acc[mt][nt]);
+      if (c + 1 < p.nchunk) land((j + 1) % D, c + 1, (j + 1) & 1);
+      __syncthreads();
+    }
+  }
+  // (flat geometry set by the launcher: one image of width 32, row = linear pixel / 32)
+  patch_epilogue<TN, false, false, MT>(acc, p, 0, (int)(lin0 / PT_TW), 0, tn * BN, wm, wn, li, lh, 1.f, reinterpret_cast<float*>(smem));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -995,6 +1144,32 @@ static int launch_patch(const PatchArgs& a, hipStream_t s) {
   return CRESTE_OK;
 }
 
+// conv1x1_deep_kernel: flat tiles of 128 * MT pixels.  Chosen (conv_patch_run) for stride-1 1x1 convs of the bf16 split modes whose
+// 256-pixel tiling leaves the chip under one workgroup per CU; MT = 1 where even that fills under half of it.
+template <int SPLIT, int TN, int MT>
+static int launch_deep(PatchArgs a, const creste_conv_desc* d, hipStream_t s) {
+  constexpr int smem = 2 * (SPLIT * 2 * 128 * MT * 16) + 2 * (SPLIT * 2 * 64 * TN * 16);
+  const long P = (long)d->N * d->H * d->W;
+  a.flat_P = P;
+  a.gate_hw = d->H * d->W;
+  a.N = 1; a.W = a.Wo = PT_TW; a.H = a.Ho = (int)((P + PT_TW - 1) / PT_TW);
+  a.tiles_x = 1; a.tiles_y = (int)((P + 128 * MT - 1) / (128 * MT));
+  const int nblk = a.tiles_n * a.tiles_y;
+  static std::atomic<uint64_t> attr_devs[2] = {{0}, {0}};
+  const void* fn = a.a_scale ? reinterpret_cast<const void*>(conv1x1_deep_kernel<SPLIT, TN, MT, true>)
+                             : reinterpret_cast<const void*>(conv1x1_deep_kernel<SPLIT, TN, MT, false>);
+  if (smem > 64 * 1024) CRESTE_HIP(ensure_dyn_smem(fn, smem, attr_devs[a.a_scale ? 1 : 0]));
+  if (a.a_scale) conv1x1_deep_kernel<SPLIT, TN, MT, true><<<nblk, 512, smem, s>>>(a);
+  else conv1x1_deep_kernel<SPLIT, TN, MT, false><<<nblk, 512, smem, s>>>(a);
+  CRESTE_CHECK_LAUNCH("conv1x1_deep");
+  return CRESTE_OK;
+}
+template <int SPLIT>
+static int launch_deep_tn(const PatchArgs& a, const creste_conv_desc* d, int bn, hipStream_t s) {
+  // 128-pixel tiles (MT = 1) were at least as fast as 256-pixel ones on every layer of the encoder (scripts/conv1x1_deep_ab.sh)
+  return bn == 128 ? launch_deep<SPLIT, 2, 1>(a, d, s) : launch_deep<SPLIT, 1, 1>(a, d, s);
+}
+
 bool conv_patch_supported(int prec, int KH, int KW, int stride) {
   if (prec == CRESTE_PREC_F16X3 && KH == KW && (KH == 1 || KH == 3 || KH == 7) && stride == 2) return true;
   if (prec == CRESTE_PREC_F16X3 && KH == KW && (KH == 5 || KH == 7) && stride == 1) return true;
@@ -1034,6 +1209,7 @@ static void patch_geometry(const creste_conv_desc* d, PatchArgs& a) {
   a.tiles_x = (d->Wo + PT_TW - 1) / PT_TW;
   a.tiles_y = (d->Ho + PT_TH - 1) / PT_TH;
   a.gate_hw = 0;
+  a.flat_P = 0;
   // A stride-1 1x1 conv has no halo: when the 8 x 32 pixel tiles pad the map by more than 12 % (19 x 38: 24 x 64 =
   // 2.1x the pixels, 38 x 76: 1.33x), its N*H*W pixels are re-tiled as ONE image of width 32 -- every tile is 256
   // consecutive pixels of the NHWC buffer, every linear pixel index (input, output, residual, row mask) is unchanged;
@@ -1115,6 +1291,17 @@ int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
                         : split == 2 ? launch_patch3<2, 2, false>(a, s) : launch_patch3<1, 2, false>(a, s);
     return split == 3 ? launch_patch3<3, 1, false>(a, s)
                       : split == 2 ? launch_patch3<2, 1, false>(a, s) : launch_patch3<1, 1, false>(a, s);
+  }
+  if (bn <= 128 && !a.stats && d->pad_t == 0 && d->pad_l == 0 && d->Ho == d->H && d->Wo == d->W && a.nchunk >= 4) {
+    // few workgroups and a K loop worth pipelining: the deep-prefetch form on flat tiles (conv1x1_deep_kernel)
+    // (same box, batch 8, old -> deep: 1152->192 @19x38 76 -> 38 us, 192->1152 48 -> 28, 672->112 @38x76 58 -> 43; batch 1: 72 -> 34, 44 -> 21;
+    // the write-bound 24-channel projections on the 152 x 304 map, thousands of workgroups two to a CU, stay: 69 -> 77)
+    static const int deep_mode = [] { const char* e = getenv("CRESTE_CONV1X1_DEEP"); return e ? atoi(e) : 1; }();     // 0 off, 2 always
+    static const int deep_max = [] { const char* e = getenv("CRESTE_CONV1X1_DEEP_MAX"); return e ? atoi(e) : 1024; }();
+    const long P = (long)d->N * d->H * d->W;
+    const long nblk2 = (P + 255) / 256 * a.tiles_n;
+    if (P < (1L << 30) && (deep_mode == 2 || (deep_mode == 1 && nblk2 <= deep_max)))
+      return split == 3 ? launch_deep_tn<3>(a, d, bn, s) : split == 2 ? launch_deep_tn<2>(a, d, bn, s) : launch_deep_tn<1>(a, d, bn, s);
   }
   if (bn == 256) return launch_patch<1, 3, 4, false>(a, s);          // bf16x6 only (patch_tn)
   if (bn == 128)
