@@ -1292,16 +1292,22 @@ int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
     return split == 3 ? launch_patch3<3, 1, false>(a, s)
                       : split == 2 ? launch_patch3<2, 1, false>(a, s) : launch_patch3<1, 1, false>(a, s);
   }
-  if (bn <= 128 && !a.stats && d->pad_t == 0 && d->pad_l == 0 && d->Ho == d->H && d->Wo == d->W && a.nchunk >= 4) {
-    // few workgroups and a K loop worth pipelining: the deep-prefetch form on flat tiles (conv1x1_deep_kernel)
-    // (same box, batch 8, old -> deep: 1152->192 @19x38 76 -> 38 us, 192->1152 48 -> 28, 672->112 @38x76 58 -> 43; batch 1: 72 -> 34, 44 -> 21;
-    // the write-bound 24-channel projections on the 152 x 304 map, thousands of workgroups two to a CU, stay: 69 -> 77)
+  if (!a.stats && d->pad_t == 0 && d->pad_l == 0 && d->Ho == d->H && d->Wo == d->W && a.nchunk >= 4) {
+    // a K loop worth pipelining: the deep-prefetch form on flat 128-pixel tiles (conv1x1_deep_kernel).  Same box, batch 8, old -> deep:
+    // 1152->192 @19x38 76 -> 38 us, 192->1152 48 -> 28, 672->112 @38x76 58 -> 43, 256->128 @152x304 202 -> 186; batch 1: 72 -> 34, 44 -> 21.
+    // Tile width: 128 channels where that still leaves >= 4 workgroups per CU, else 64 (more, lighter workgroups).  The write-bound
+    // thin projections on large maps (144->24 @152x304: thousands of workgroups, two to a CU) stay on conv_patch_kernel: 69 -> 77.
     static const int deep_mode = [] { const char* e = getenv("CRESTE_CONV1X1_DEEP"); return e ? atoi(e) : 1; }();     // 0 off, 2 always
-    static const int deep_max = [] { const char* e = getenv("CRESTE_CONV1X1_DEEP_MAX"); return e ? atoi(e) : 1024; }();
-    const long P = (long)d->N * d->H * d->W;
-    const long nblk2 = (P + 255) / 256 * a.tiles_n;
-    if (P < (1L << 30) && (deep_mode == 2 || (deep_mode == 1 && nblk2 <= deep_max)))
+    static const int deep_bn = [] { const char* e = getenv("CRESTE_CONV1X1_DEEP_BN"); return e ? atoi(e) : 0; }();       // 64 / 128: forced
+    const long P = (long)d->N * d->H * d->W, pt = (P + 255) / 256;
+    const long n128 = pt * ((d->Cout + 127) / 128), n64 = pt * ((d->Cout + 63) / 64);
+    int dbn = d->Cout > 64 && n128 >= 1024 ? 128 : 64;
+    if (deep_bn == 64 || (deep_bn == 128 && d->Cout > 64)) dbn = deep_bn;
+    const bool take = d->Cout > 64 ? (bn <= 128 || deep_mode == 2) : n64 <= 1024;
+    if (P < (1L << 30) && deep_mode != 0 && (deep_mode == 2 || take)) {
+      bn = dbn; a.tiles_n = (d->Cout + bn - 1) / bn;
       return split == 3 ? launch_deep_tn<3>(a, d, bn, s) : split == 2 ? launch_deep_tn<2>(a, d, bn, s) : launch_deep_tn<1>(a, d, bn, s);
+    }
   }
   if (bn == 256) return launch_patch<1, 3, 4, false>(a, s);          // bf16x6 only (patch_tn)
   if (bn == 128)

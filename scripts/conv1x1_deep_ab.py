@@ -16,9 +16,9 @@ def timeit(fn, n=40):
     return e0.elapsed_time(e1) / n * 1e3
 SHAPES = [(19, 38, 1152, 192, 1), (19, 38, 192, 1152, 0), (19, 38, 1152, 320, 1), (19, 38, 672, 192, 1), (38, 76, 112, 672, 0), (38, 76, 672, 112, 1),
           (38, 76, 80, 480, 0), (38, 76, 480, 80, 1), (38, 76, 480, 112, 1), (38, 76, 240, 80, 1), (76, 152, 40, 240, 0), (76, 152, 240, 40, 1),
-          (76, 152, 144, 40, 1), (152, 304, 144, 24, 1), (152, 304, 96, 24, 1), (152, 304, 288, 96, 0), (152, 304, 128, 128, 0), (152, 304, 256, 128, 0)]
+          (76, 152, 144, 40, 1), (152, 304, 144, 24, 1), (152, 304, 96, 24, 1), (152, 304, 288, 96, 0), (152, 304, 128, 128, 0), (152, 304, 256, 128, 0), (152, 304, 496, 256, 0), (128, 128, 512, 256, 0), (256, 256, 128, 32, 0)]
 torch.manual_seed(0)
-for N in (8, 1):
+for N in (8, 16):
     for (H, W, Cin, Cout, gated) in SHAPES:
         xs = [ops.Act(torch.randn(N, H, W, Cin, device=dev), Cin, 0) for _ in range(4)]
         w = torch.randn(Cout, Cin, 1, 1, device=dev) / Cin ** 0.5
