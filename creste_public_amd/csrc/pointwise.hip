@@ -192,8 +192,13 @@ __global__ __launch_bounds__(512) void dwconv_se_kernel(const float* __restrict_
   if (amax) block_amax_update(vmax, amax, sm);
 }
 
-// one 1024-thread block per sample: mean -> FC1 + swish -> FC2 -> sigmoid
+// mean -> FC1 + swish -> FC2 -> sigmoid.  Grid (sample, channel slice): every workgroup forms the sample's mean and the Cse hidden
+// units itself (a few microseconds of L2 reads) and then only ITS slice of the C gates -- one workgroup per sample left the
+// chip idle behind three dependent load phases (36 us for C = 1152 at batch 8, 16 such launches per forward).  Summation orders
+// are those of the one-workgroup form, so the gates are the same bits: chunk sums in G interleaved groups of (even, odd) pairs,
+// FC1 per lane over c = lane + 64 i then an xor butterfly, FC2 serially over the hidden units.
 constexpr int SEG_T = 1024;
+constexpr int SEG_SLICE = 128;                           // gates per workgroup
 __global__ __launch_bounds__(SEG_T) void se_gate_kernel(const float* __restrict__ partial,
                                                         const float* __restrict__ w1,
                                                         const float* __restrict__ b1,
@@ -213,13 +218,18 @@ __global__ __launch_bounds__(SEG_T) void se_gate_kernel(const float* __restrict_
     const int c = c0 + (G > 1 ? threadIdx.x % C : threadIdx.x);
     const int g = G > 1 ? threadIdx.x / C : 0;
     if (c < C && g < G) {
+      const float* pp = partial + (long)n * nchunk * C + c;
       float s0 = 0.f, s1 = 0.f;
       int k = g;
-      for (; k + G < nchunk; k += 2 * G) {                // two independent loads in flight
-        s0 += partial[((long)n * nchunk + k) * C + c];
-        s1 += partial[((long)n * nchunk + k + G) * C + c];
+      for (; k + 3 * G < nchunk; k += 4 * G) {            // four independent loads in flight, summed as two (even, odd) steps
+        const float a0 = pp[(long)k * C], a1 = pp[(long)(k + G) * C], a2 = pp[(long)(k + 2 * G) * C], a3 = pp[(long)(k + 3 * G) * C];
+        s0 += a0; s1 += a1; s0 += a2; s1 += a3;
       }
-      if (k < nchunk) s0 += partial[((long)n * nchunk + k) * C + c];
+      for (; k + G < nchunk; k += 2 * G) {
+        const float a0 = pp[(long)k * C], a1 = pp[(long)(k + G) * C];
+        s0 += a0; s1 += a1;
+      }
+      if (k < nchunk) s0 += pp[(long)k * C];
       gsum[g * C + c] = s0 + s1;
     }
   }
@@ -233,15 +243,41 @@ __global__ __launch_bounds__(SEG_T) void se_gate_kernel(const float* __restrict_
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int j = wave; j < Cse; j += SEG_T / 64) {         // one wave per squeezed channel
     float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += w1[(long)j * C + c] * mean[c];
+    int c = lane;
+    for (; c + 192 < C; c += 256) {                      // four loads in flight, added in the order of c
+      const float a0 = w1[(long)j * C + c], a1 = w1[(long)j * C + c + 64], a2 = w1[(long)j * C + c + 128], a3 = w1[(long)j * C + c + 192];
+      s += a0 * mean[c]; s += a1 * mean[c + 64]; s += a2 * mean[c + 128]; s += a3 * mean[c + 192];
+    }
+    for (; c < C; c += 64) s += w1[(long)j * C + c] * mean[c];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) hid[j] = act_apply(s + b1[j], CRESTE_ACT_SWISH);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += SEG_T) {
+  const int c_lo = blockIdx.y * SEG_SLICE, c_hi = c_lo + SEG_SLICE < C ? c_lo + SEG_SLICE : C;
+  for (int c = c_lo + threadIdx.x; c < c_hi; c += SEG_T) {
     float s = b2[c];
-    for (int j = 0; j < Cse; ++j) s += w2[(long)c * Cse + j] * hid[j];
+    const float* wr = w2 + (long)c * Cse;
+    int j = 0;
+    if ((Cse & 3) == 0) {                                // rows of w2 are 16-byte aligned: the row in float4 loads, four in flight
+      for (; j + 16 <= Cse; j += 16) {
+        const f32x4 q0 = ld4(wr + j), q1 = ld4(wr + j + 4), q2 = ld4(wr + j + 8), q3 = ld4(wr + j + 12);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += q0[i] * hid[j + i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += q1[i] * hid[j + 4 + i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += q2[i] * hid[j + 8 + i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += q3[i] * hid[j + 12 + i];
+      }
+      for (; j + 4 <= Cse; j += 4) {
+        const f32x4 q0 = ld4(wr + j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += q0[i] * hid[j + i];
+      }
+    }
+    for (; j < Cse; ++j) s += wr[j] * hid[j];
     gate[(long)n * C + c] = 1.f / (1.f + expf(-s));
   }
 }
@@ -838,7 +874,7 @@ extern "C" int creste_se_gate_f32(const float* x, float* partial, const float* w
     se_partial_kernel<<<dim3(nchunk, N), 256, (size_t)slices * C * sizeof(float), s>>>(x, partial, HW, C, nchunk);
     CRESTE_CHECK_LAUNCH("se_partial");
   }
-  se_gate_kernel<<<N, SEG_T, (size_t)(C + Cse + (C < SEG_T ? (SEG_T / C) * C : C)) * sizeof(float), s>>>(partial, w1, b1, w2, b2, gate, HW, C, Cse, nchunk);
+  se_gate_kernel<<<dim3(N, (C + SEG_SLICE - 1) / SEG_SLICE), SEG_T, (size_t)(C + Cse + (C < SEG_T ? (SEG_T / C) * C : C)) * sizeof(float), s>>>(partial, w1, b1, w2, b2, gate, HW, C, Cse, nchunk);
   CRESTE_CHECK_LAUNCH("se_gate");
   return CRESTE_OK;
 }
@@ -848,7 +884,7 @@ extern "C" int creste_se_gate_partial_f32(const float* partial, int nchunk, cons
                                           void* stream) {
   CRESTE_REQUIRE(partial && w1 && b1 && w2 && b2 && gate, "se_gate_partial: null pointer");
   CRESTE_REQUIRE(C % 4 == 0 && C > 0 && Cse > 0 && N > 0 && HW > 0 && nchunk > 0, "se_gate_partial: bad dims");
-  se_gate_kernel<<<N, SEG_T, (size_t)(C + Cse + (C < SEG_T ? (SEG_T / C) * C : C)) * sizeof(float), (hipStream_t)stream>>>(
+  se_gate_kernel<<<dim3(N, (C + SEG_SLICE - 1) / SEG_SLICE), SEG_T, (size_t)(C + Cse + (C < SEG_T ? (SEG_T / C) * C : C)) * sizeof(float), (hipStream_t)stream>>>(
       partial, w1, b1, w2, b2, gate, HW, C, Cse, nchunk);
   CRESTE_CHECK_LAUNCH("se_gate");
   return CRESTE_OK;
