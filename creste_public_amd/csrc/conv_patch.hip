@@ -1297,8 +1297,10 @@ int conv_patch_run(const creste_conv_desc* d, hipStream_t s) {
     // 1152->192 @19x38 76 -> 38 us, 192->1152 48 -> 28, 672->112 @38x76 58 -> 43, 256->128 @152x304 202 -> 186; batch 1: 72 -> 34, 44 -> 21.
     // Tile width: 128 channels where that still leaves >= 4 workgroups per CU, else 64 (more, lighter workgroups).  The write-bound
     // thin projections on large maps (144->24 @152x304: thousands of workgroups, two to a CU) stay on conv_patch_kernel: 69 -> 77.
-    static const int deep_mode = [] { const char* e = getenv("CRESTE_CONV1X1_DEEP"); return e ? atoi(e) : 1; }();     // 0 off, 2 always
-    static const int deep_bn = [] { const char* e = getenv("CRESTE_CONV1X1_DEEP_BN"); return e ? atoi(e) : 0; }();       // 64 / 128: forced
+    // (experiment / test knobs, read per call: CRESTE_CONV1X1_DEEP = 0 never, 2 wherever it is built; CRESTE_CONV1X1_DEEP_BN = 64 / 128)
+    const char* e_mode = getenv("CRESTE_CONV1X1_DEEP");
+    const char* e_bn = getenv("CRESTE_CONV1X1_DEEP_BN");
+    const int deep_mode = e_mode ? atoi(e_mode) : 1, deep_bn = e_bn ? atoi(e_bn) : 0;
     const long P = (long)d->N * d->H * d->W, pt = (P + 255) / 256;
     const long n128 = pt * ((d->Cout + 127) / 128), n64 = pt * ((d->Cout + 63) / 64);
     int dbn = d->Cout > 64 && n128 >= 1024 ? 128 : 64;

@@ -1337,7 +1337,7 @@ int conv_wino4_run(const creste_conv_desc* d, hipStream_t s) {
   // small maps (the BEV trunk's 256 -> 256 convs at 32 x 32: 2 tile blocks x 36 positions = 72 items of a 256-wide tile on 256
   // CUs): 128-wide tiles double the items; an item is a latency chain of Cin / 16 steps, not MFMA-bound, so the halved item
   // costs nearly its full time and the launch shortens (same K order per output: same bits)
-  static const int small_items = w4_env_int("CRESTE_W4_SMALL_ITEMS", 512);
+  const int small_items = w4_env_int("CRESTE_W4_SMALL_ITEMS", 512);
   if (tn == 4 && (long)m_blocks * W4_POS * ((d->Cout + 255) / 256) <= small_items) tn = 2;
   a.tiles_n = (d->Cout + 64 * tn - 1) / (64 * tn);
   int rc;

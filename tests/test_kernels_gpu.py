@@ -305,6 +305,52 @@ def test_conv1x1_flat_retiling(ops, prec, tol, N, H, W, Cin, Cout, gated):
     assert float(out.amax) >= float(ref.abs().max()) * (1 - 1e-5)
 
 
+@pytest.mark.parametrize("prec", ["bf16x6", "bf16x3", "bf16"])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,gated", [(8, 19, 38, 1152, 192, True), (3, 19, 38, 192, 1152, False), (1, 38, 76, 672, 112, True),
+                                                  (2, 5, 7, 72, 30, True), (2, 9, 13, 100, 66, False), (5, 19, 38, 64, 130, True)])
+def test_conv1x1_deep_prefetch_kernel_is_bit_identical(ops, monkeypatch, prec, N, H, W, Cin, Cout, gated):
+    """conv1x1_deep_kernel (flat 128-pixel tiles, a 4-chunk register ring of A / gate / weight tiles; csrc/conv_patch.hip) forms the
+    same pieces and adds them in the same order as conv_patch_kernel<1, ...>: outputs are equal bit for bit -- pixel counts that
+    are no multiple of 128 or 32, Cin no multiple of 16 (a partial last chunk), Cout no multiple of 4 (scalar epilogue) or of 64,
+    squeeze-excite gates of tiles that straddle images, residual, bias, activation; both tile widths."""
+    g = torch.Generator().manual_seed(N * H + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g)
+    gate = torch.rand(N, Cin, generator=g) + 0.25 if gated else None
+    res = torch.randn(N, Cout, H, W, generator=g)
+    P = {"bf16x6": ops.PREC_BF16X6, "bf16x3": ops.PREC_BF16X3, "bf16": ops.PREC_BF16}[prec]
+    pc = ops.pack_conv(dev(w), dev(b), None, 1, 0, ops.ACT_SWISH, P)
+    xa, ra = to_act(ops, x), to_act(ops, res)
+    outs = {}
+    for mode, bn in (("0", "0"), ("2", "64"), ("2", "128"), ("1", "0")):
+        monkeypatch.setenv("CRESTE_CONV1X1_DEEP", mode)
+        monkeypatch.setenv("CRESTE_CONV1X1_DEEP_BN", bn)
+        outs[mode, bn] = ops.conv2d(xa, pc, res=ra, a_scale=dev(gate) if gated else None).buf.clone()
+    ref = outs["0", "0"]
+    for k, v in outs.items():
+        assert torch.equal(v, ref), k
+    want = F.silu(F.conv2d(x.double() * (gate.double().view(N, Cin, 1, 1) if gated else 1.0), w.double(), b.double()) + res.double())
+    got = from_act(ops.Act(ref, Cout, 0)).double()
+    tol = {"bf16x6": 1e-5, "bf16x3": 3e-4, "bf16": 2e-2}[prec]
+    assert float((got - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()) < tol
+
+
+def test_conv_winograd4_narrow_tiles_on_small_maps_are_bit_identical(ops, monkeypatch):
+    """F(4x4,3x3) GEMM: where the 256-wide tiling leaves <= 512 items (the BEV trunk's 256 -> 256 convs at 32 x 32), 128-wide tiles
+    double the workgroups (CRESTE_W4_SMALL_ITEMS); per output the K order is unchanged: same bits."""
+    g = torch.Generator().manual_seed(5)
+    x = to_act(ops, torch.randn(2, 256, 32, 32, generator=g))
+    w = torch.randn(256, 256, 3, 3, generator=g) / (256 * 9) ** 0.5
+    pc = ops.pack_conv(dev(w), None, None, 1, 1, ops.ACT_RELU, ops.PREC_BF16X6, algo=ops.ALGO_WINOGRAD4)
+    outs = []
+    for items in ("0", "512"):
+        monkeypatch.setenv("CRESTE_W4_SMALL_ITEMS", items)
+        outs.append(ops.conv2d(x, pc).buf.clone())
+    assert float(outs[0].abs().max()) > 0.1
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("K,s,pad", [(3, 1, (1, 1, 1, 1)), (3, 2, (0, 1, 0, 1)), (5, 2, (1, 2, 1, 2)),
                                      (5, 1, (2, 2, 2, 2))])
 def test_dwconv(ops, K, s, pad):
