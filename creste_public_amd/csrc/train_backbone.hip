@@ -868,57 +868,63 @@ __global__ __launch_bounds__(256) void sample_reduce_finalize_kernel(const float
 }
 
 // ------------------------------------------------------------------------------------ squeeze-excite FCs
-// forward (one block per sample): hpre = W1 s + b1 ; h = swish(hpre) ; z = W2 h + b2 ; gate = sigmoid(z)
-__global__ __launch_bounds__(256) void se_fc_forward_kernel(const float* __restrict__ s, const float* __restrict__ w1,
-                                                            const float* __restrict__ b1, const float* __restrict__ w2,
-                                                            const float* __restrict__ b2, float* __restrict__ hpre,
-                                                            float* __restrict__ hact, float* __restrict__ gate, int C,
-                                                            int Cse) {
+// Grid (sample, 128-channel slice), 1024 threads: every workgroup computes the Cse hidden units itself (a few microseconds of L2
+// reads) and then only ITS slice of the C outputs -- one 256-thread workgroup per sample walked 12 rounds of the first FC and
+// C / 256 passes of Cse dependent loads of the second (36 / 31 us per launch, 32 launches per step, 8 workgroups on the chip).
+constexpr int SEFC_T = 1024, SEFC_SLICE = 128;
+// forward: hpre = W1 s + b1 ; h = swish(hpre) ; z = W2 h + b2 ; gate = sigmoid(z)
+__global__ __launch_bounds__(SEFC_T) void se_fc_forward_kernel(const float* __restrict__ s, const float* __restrict__ w1,
+                                                               const float* __restrict__ b1, const float* __restrict__ w2,
+                                                               const float* __restrict__ b2, float* __restrict__ hpre,
+                                                               float* __restrict__ hact, float* __restrict__ gate, int C,
+                                                               int Cse) {
   extern __shared__ float sm[];   // s[C] | h[Cse]
   float* ss = sm; float* hh = sm + C;
   const int n = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += 256) ss[c] = s[(size_t)n * C + c];
+  for (int c = threadIdx.x; c < C; c += SEFC_T) ss[c] = s[(size_t)n * C + c];
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int j = wave; j < Cse; j += 4) {
+  for (int j = wave; j < Cse; j += SEFC_T / 64) {
     float acc = 0.f;
     for (int c = lane; c < C; c += 64) acc += w1[(size_t)j * C + c] * ss[c];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if (lane == 0) {
       const float hp = acc + b1[j];
-      hpre[(size_t)n * Cse + j] = hp;
       hh[j] = hp / (1.f + expf(-hp));
-      hact[(size_t)n * Cse + j] = hh[j];
+      if (blockIdx.y == 0) { hpre[(size_t)n * Cse + j] = hp; hact[(size_t)n * Cse + j] = hh[j]; }
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  const int c_lo = blockIdx.y * SEFC_SLICE, c_hi = c_lo + SEFC_SLICE < C ? c_lo + SEFC_SLICE : C;
+  for (int c = c_lo + threadIdx.x; c < c_hi; c += SEFC_T) {
     float z = b2[c];
     for (int j = 0; j < Cse; ++j) z += w2[(size_t)c * Cse + j] * hh[j];
     gate[(size_t)n * C + c] = 1.f / (1.f + expf(-z));
   }
 }
 
-// backward (one block per sample): gg = d loss / d gate ->
+// backward: gg = d loss / d gate ->
 //   gz = gg*gate*(1-gate) ; gh = W2^T gz ; ghpre = gh * swish'(hpre) ; gs = W1^T ghpre
 // gz and ghpre are kept for the weight gradients (summed over the batch by se_fc_wgrad_kernel).
-__global__ __launch_bounds__(256) void se_fc_backward_kernel(const float* __restrict__ gg, const float* __restrict__ gate,
-                                                             const float* __restrict__ hpre,
-                                                             const float* __restrict__ w1, const float* __restrict__ w2,
-                                                             float* __restrict__ gz, float* __restrict__ ghpre,
-                                                             float* __restrict__ gs, int C, int Cse) {
+__global__ __launch_bounds__(SEFC_T) void se_fc_backward_kernel(const float* __restrict__ gg, const float* __restrict__ gate,
+                                                                const float* __restrict__ hpre,
+                                                                const float* __restrict__ w1, const float* __restrict__ w2,
+                                                                float* __restrict__ gz, float* __restrict__ ghpre,
+                                                                float* __restrict__ gs, int C, int Cse) {
   extern __shared__ float sm[];   // gz[C] | ghpre[Cse]
   float* sz = sm; float* sh = sm + C;
   const int n = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += 256) {
+  const bool first = blockIdx.y == 0;
+  for (int c = threadIdx.x; c < C; c += SEFC_T) {
     const float g = gate[(size_t)n * C + c];
     const float v = gg[(size_t)n * C + c] * g * (1.f - g);
-    sz[c] = v; gz[(size_t)n * C + c] = v;
+    sz[c] = v;
+    if (first) gz[(size_t)n * C + c] = v;
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int j = wave; j < Cse; j += 4) {
+  for (int j = wave; j < Cse; j += SEFC_T / 64) {
     float acc = 0.f;
     for (int c = lane; c < C; c += 64) acc += w2[(size_t)c * Cse + j] * sz[c];
 #pragma unroll
@@ -926,11 +932,13 @@ __global__ __launch_bounds__(256) void se_fc_backward_kernel(const float* __rest
     if (lane == 0) {
       const float x = hpre[(size_t)n * Cse + j], sg = 1.f / (1.f + expf(-x));
       const float v = acc * (sg + x * sg * (1.f - sg));
-      sh[j] = v; ghpre[(size_t)n * Cse + j] = v;
+      sh[j] = v;
+      if (first) ghpre[(size_t)n * Cse + j] = v;
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  const int c_lo = blockIdx.y * SEFC_SLICE, c_hi = c_lo + SEFC_SLICE < C ? c_lo + SEFC_SLICE : C;
+  for (int c = c_lo + threadIdx.x; c < c_hi; c += SEFC_T) {
     float acc = 0.f;
     for (int j = 0; j < Cse; ++j) acc += w1[(size_t)j * C + c] * sh[j];
     gs[(size_t)n * C + c] = acc;
@@ -1077,13 +1085,16 @@ __global__ void mse_finish_kernel(const float* __restrict__ sums, float* __restr
   out2[1] = sums[1];
 }
 
-// out[k] = sum_b partial[b][k], k < nk (single block, ordered)
+// out[k] = sum_b partial[b][k], k < nk <= 4: one wave per output (launch <<<1, 256>>>), lane l adds blocks l, l + 64, ... in order,
+// then a fixed xor tree (one thread per output walked up to 1024 dependent loads: 68 us for a scalar)
 __global__ void reduce_small_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblocks, int nk) {
-  const int k = threadIdx.x;
+  const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (k >= nk) return;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * nk + k];
-  out[k] = s;
+  for (int b = lane; b < nblocks; b += 64) s += partial[(size_t)b * nk + k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) out[k] = s;
 }
 
 }  // namespace creste
@@ -1319,8 +1330,14 @@ extern "C" int creste_train_pointwise_f32(int op, const float* a, int a_cs, cons
   return CRESTE_OK;
 }
 
+// chunks per sample: SR_CHUNKS, or more when there are few samples (N = 1: the whole batch as one sample -- 256 workgroups of four
+// waves streamed a 140 MB tensor pair at 1.35 TB/s) so that about 2048 workgroups are in flight either way
+static inline int sr_chunk_cap(int N) {
+  const int c = 2048 / (N > 0 ? N : 1);
+  return c > SR_CHUNKS ? c : SR_CHUNKS;
+}
 extern "C" int64_t creste_sample_reduce_workspace_bytes(int N, int C) {
-  return N > 0 && C > 0 ? (int64_t)N * SR_CHUNKS * C * 4 : -1;
+  return N > 0 && C > 0 ? (int64_t)N * sr_chunk_cap(N) * C * 4 : -1;
 }
 
 extern "C" int creste_sample_reduce_f32(const float* a, int a_cs, const float* b, int b_cs, float* out, int N,
@@ -1328,7 +1345,8 @@ extern "C" int creste_sample_reduce_f32(const float* a, int a_cs, const float* b
   CRESTE_REQUIRE(a && out && work && N > 0 && HW > 0 && C > 0, "sample_reduce: bad args");
   const int rows = 256 / C > 0 ? 256 / C : 1;
   const long per = (HW + rows - 1) / rows;
-  const int chunks = (int)(per < SR_CHUNKS ? per : SR_CHUNKS);
+  const int cap = sr_chunk_cap(N);
+  const int chunks = (int)(per < cap ? per : cap);
   const size_t smem = (size_t)rows * (C >= 256 ? 256 : C) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   sample_reduce_kernel<<<dim3(chunks, N), 256, smem, s>>>(a, a_cs, b, b_cs, (float*)work, HW, C);
@@ -1343,8 +1361,8 @@ extern "C" int creste_se_fc_forward_f32(const float* s, const float* w1, const f
                                         void* stream) {
   CRESTE_REQUIRE(s && w1 && b1 && w2 && b2 && hpre && hact && gate && N > 0 && C > 0 && Cse > 0,
                  "se_fc_forward: bad args");
-  se_fc_forward_kernel<<<N, 256, (size_t)(C + Cse) * 4, (hipStream_t)stream>>>(s, w1, b1, w2, b2, hpre, hact, gate, C,
-                                                                              Cse);
+  se_fc_forward_kernel<<<dim3(N, (C + SEFC_SLICE - 1) / SEFC_SLICE), SEFC_T, (size_t)(C + Cse) * 4, (hipStream_t)stream>>>(
+      s, w1, b1, w2, b2, hpre, hact, gate, C, Cse);
   CRESTE_CHECK_LAUNCH("se_fc_forward");
   return CRESTE_OK;
 }
@@ -1354,8 +1372,8 @@ extern "C" int creste_se_fc_backward_f32(const float* gg, const float* gate, con
                                          void* stream) {
   CRESTE_REQUIRE(gg && gate && hpre && w1 && w2 && gz && ghpre && gs && N > 0 && C > 0 && Cse > 0,
                  "se_fc_backward: bad args");
-  se_fc_backward_kernel<<<N, 256, (size_t)(C + Cse) * 4, (hipStream_t)stream>>>(gg, gate, hpre, w1, w2, gz, ghpre, gs,
-                                                                               C, Cse);
+  se_fc_backward_kernel<<<dim3(N, (C + SEFC_SLICE - 1) / SEFC_SLICE), SEFC_T, (size_t)(C + Cse) * 4, (hipStream_t)stream>>>(
+      gg, gate, hpre, w1, w2, gz, ghpre, gs, C, Cse);
   CRESTE_CHECK_LAUNCH("se_fc_backward");
   return CRESTE_OK;
 }
@@ -1380,13 +1398,13 @@ extern "C" int creste_depth_ce_loss_f32(const float* logits, int cs, const float
   const int b1 = grid1d(P, 1024);
   depth_count_valid_kernel<<<b1, 256, 0, s>>>(gt_mm, P, depth_min, bin_size, num_bins, wk);
   CRESTE_CHECK_LAUNCH("depth_count_valid");
-  reduce_small_kernel<<<1, 64, 0, s>>>(wk, out3 + 2, b1, 1);
+  reduce_small_kernel<<<1, 256, 0, s>>>(wk, out3 + 2, b1, 1);
   CRESTE_CHECK_LAUNCH("depth_count_reduce");
   const int b2 = grid1d(P * 32, 1024);
   depth_ce_kernel<<<b2, 256, 0, s>>>(logits, cs, gt_mm, P, depth_min, bin_size, num_bins, out3 + 2, weight, g_logits, g_cs,
                                      wk + 1024);
   CRESTE_CHECK_LAUNCH("depth_ce");
-  reduce_small_kernel<<<1, 64, 0, s>>>(wk + 1024, wk + 1024 + 2048, b2, 2);
+  reduce_small_kernel<<<1, 256, 0, s>>>(wk + 1024, wk + 1024 + 2048, b2, 2);
   CRESTE_CHECK_LAUNCH("depth_ce_reduce");
   depth_ce_finish_kernel<<<1, 1, 0, s>>>(wk + 1024 + 2048, out3);   // loss_sum / n_valid, hits / n_valid
   CRESTE_CHECK_LAUNCH("depth_ce_finish");
@@ -1404,7 +1422,7 @@ extern "C" int creste_mse_loss_f32(const float* pred, int p_cs, const float* gt,
   const int b = grid1d(P * C, 1024);
   mse_partial_kernel<<<b, 256, 0, s>>>(pred, p_cs, gt, g_cs, P, C, wk);
   CRESTE_CHECK_LAUNCH("mse_partial");
-  reduce_small_kernel<<<1, 64, 0, s>>>(wk, wk + 2048, b, 2);
+  reduce_small_kernel<<<1, 256, 0, s>>>(wk, wk + 2048, b, 2);
   CRESTE_CHECK_LAUNCH("mse_reduce");
   if (g_pred) {
     mse_grad_kernel<<<grid1d(P * C), 256, 0, s>>>(pred, p_cs, gt, g_cs, P, C, wk + 2048, weight, g_pred, o_cs);
