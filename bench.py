@@ -77,8 +77,12 @@ def kernel_symbol(pc, N, Ho, Wo):
         return (PREC_NAME[pc.prec] + "+winograd", f"wino_gemm_kernel<{split}, {4 if pc.Cout > 128 else 2}> + wino_out_kernel")
     if getattr(pc, "algo", 0) == 2:             # Winograd F(4x4,3x3): input transform + GEMM over the 36 positions + output transform
         split = {2: 2, 3: 3}[pc.prec]
+        w4tn = 4 if pc.Cout > 128 else 2
+        m_blocks = (N * ((Ho + 3) // 4) * ((Wo + 3) // 4) + 255) // 256
+        if w4tn == 4 and m_blocks * 36 * ((pc.Cout + 255) // 256) <= 512:       # small maps: narrow tiles (conv_wino4_run)
+            w4tn = 2
         return (PREC_NAME[pc.prec] + "+winograd4",
-                f"wino4_in1_kernel<UP> + wino4_gemm32_kernel<{split}, {4 if pc.Cout > 128 else 2}, 0, true> + wino4_out2_kernel"
+                f"wino4_in1_kernel<UP> + wino4_gemm32_kernel<{split}, {w4tn}, 0, true> + wino4_out2_kernel"
                 " (conv3x3 -> conv3x3 pairs: wino4_outin_kernel in place of the first conv's output and the second conv's input transform)")
     if pc.prec == 0:
         return ("f32", "conv_igemm_f32_kernel<2, 2, 2, 2>" if pc.Cout > 64 else
@@ -94,9 +98,18 @@ def kernel_symbol(pc, N, Ho, Wo):
     if pc.KH == 1 and pc.Cin < 256 and tn == 4:
         tn = 2
     px_tiles = N * ((Ho + 7) // 8) * ((Wo + 31) // 32)
-    while tn > 1 and px_tiles * ((pc.Cout + 64 * tn - 1) // (64 * tn)) < 400:
+    thr = (1600 if pc.Cin < 256 else 800) if pc.KH == 1 else 400
+    while tn > 1 and px_tiles * ((pc.Cout + 64 * tn - 1) // (64 * tn)) < thr:
         tn //= 2
     f16 = "true" if pc.prec == 4 else "false"
+    if pc.KH == 1 and pc.prec != 4 and (pc.Cin + 15) // 16 >= 4 and pc.pad_t == 0 and pc.pad_l == 0 and pc.stride == 1:
+        # the deep-prefetch form on flat 128-pixel tiles (conv_patch_run): every such conv with > 64 output channels that is
+        # not on the 256-wide tile, and the narrow ones while <= 1024 workgroups of 256 pixels
+        pt = (N * Ho * Wo + 255) // 256
+        n128, n64 = pt * ((pc.Cout + 127) // 128), pt * ((pc.Cout + 63) // 64)
+        if (tn <= 2) if pc.Cout > 64 else n64 <= 1024:
+            dtn = 2 if (pc.Cout > 64 and n128 >= 1024) else 1
+            return (PREC_NAME[pc.prec], f"conv1x1_deep_kernel<{split}, {dtn}, 1, GATED>")
     name = (f"conv_patch3_kernel<{split}, {tn}, {f16}, false>" if pc.KH == 3
             else f"conv_patch_kernel<1, {split}, {tn}, {f16}>")
     return (PREC_NAME[pc.prec], name)
