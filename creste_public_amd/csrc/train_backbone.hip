@@ -9,6 +9,7 @@
 //     accuracy, gradient w.r.t. the logits) and the masked MSE of the distilled features.
 // NHWC fp32 with explicit pixel strides; fixed-order reductions (block partials + ordered finalisation).
 #include "common.h"
+#include <stdlib.h>
 
 namespace creste {
 
