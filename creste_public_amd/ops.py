@@ -504,7 +504,14 @@ def conv_precision(prec: int, k: int, stride: int, cin: int) -> int:
     """The engine a conv of this shape runs on under the requested operand mode: `prec` where the split-operand
     engine is built for it, the exact-fp32 engine otherwise -- and for strided convs with fewer than 16 input channels
     (the 4 -> 32 encoder stem: one mostly-empty 16-channel chunk per 90 KB halo patch; measured 0.74 vs 0.42 ms)."""
-    if not conv_supported(prec, k, stride) or (stride > 1 and cin < 16):
+    if stride > 1 and cin < 16:
+        return PREC_F32
+    if not conv_supported(prec, k, stride):
+        # the narrower bf16 modes are built for the stride-1 1x1 / 3x3 kernels only: their strided / 5x5 / 7x7 convs take the
+        # bf16x6 row kernels (more operand bits than asked for, on the bf16 matrix instruction) rather than the exact-fp32 engine
+        # on the 16x slower fp32 one (cf-IRL step at configs[4]'s per-GPU shape: 7.4 of 35 ms of kernels were those convs)
+        if prec in (PREC_BF16, PREC_BF16X3) and conv_supported(PREC_BF16X6, k, stride):
+            return PREC_BF16X6
         return PREC_F32
     return prec
 

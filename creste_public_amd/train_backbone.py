@@ -106,7 +106,7 @@ class ConvG:
                                                            self.K, cpad, _stream()), "conv_flip_weight")
             t, b_, l, r = self.pad
             k1 = self.K - 1
-            prec = hipnn._precision if ops.conv_supported(hipnn._precision, self.K, 1) else ops.PREC_F32
+            prec = ops.conv_precision(hipnn._precision, self.K, 1, cpad)
             # stride s: the same stride-1 conv, applied to the zero-inserted cotangent; the far-side pads then depend
             # on the input extent (how many trailing rows the strided conv never reached) and are set per call
             self._bw = ops.pack_conv(wt, None, None, 1, (k1 - t, k1 - b_, k1 - l, k1 - r), ops.ACT_NONE, prec)
